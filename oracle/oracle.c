@@ -1,0 +1,740 @@
+/*
+ * oracle.c -- CPU restatement of the PhantomFHE RNS polynomial-arithmetic hot path.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h header).  Plain C11 + unsigned __int128.
+ * "parity unpinned against an executed reference" -- see oracle.h for how it is pinned instead.
+ *
+ * Style: every routine is the straightforward scalar statement of the reference semantics
+ * (SURVEY.md Appendix A).  Lazy ranges inside the transforms follow include/butterfly.cuh:10-37;
+ * every stored output is canonical [0,q) at the points listed in SURVEY.md A.2.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+/* ------------------------------------------------------------------------------------------------
+ * modular primitives (include/uintmodmath.cuh:18-242)
+ * ---------------------------------------------------------------------------------------------- */
+static inline u64 mulhi64(u64 a, u64 b) { return (u64)(((u128)a * b) >> 64); }
+
+/* csub_q uintmodmath.cuh:18-21 */
+static inline u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+static inline u64 addmod(u64 a, u64 b, u64 q) { return csub(a + b, q); }       /* :32-38 */
+static inline u64 submod(u64 a, u64 b, u64 q) { return csub(a + q - b, q); }   /* :43-49 */
+static inline u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }               /* :24-28 */
+
+/* multiply_and_reduce_shoup_lazy :223-231, result in [0,2q) */
+static inline u64 shoup_lazy(u64 a, u64 w, u64 ws, u64 q) { return a * w - mulhi64(a, ws) * q; }
+/* multiply_and_reduce_shoup :207-215, canonical */
+static inline u64 shoup(u64 a, u64 w, u64 ws, u64 q) { return csub(shoup_lazy(a, w, ws, q), q); }
+
+/* barrett_reduce_uint128_uint64 :96-136 -- canonical 128-bit -> [0,q).
+ * Restated exactly as the SEAL-lineage algorithm (only the needed partial products of p*mu >> 128,
+ * one conditional subtraction); checked against p % q in tests. */
+static inline u64 barrett128(u128 p, u64 q, const u64 mu[2]) {
+    u64 lo = (u64)p, hi = (u64)(p >> 64);
+    u64 carry = mulhi64(lo, mu[0]);
+    u128 t = (u128)lo * mu[1];
+    u64 tmp2lo = (u64)t, tmp2hi = (u64)(t >> 64);
+    u64 tmp1 = tmp2lo + carry;
+    u64 tmp3 = tmp2hi + (tmp1 < tmp2lo);
+    t = (u128)hi * mu[0];
+    tmp2lo = (u64)t; tmp2hi = (u64)(t >> 64);
+    u64 s = tmp1 + tmp2lo;
+    carry = tmp2hi + (s < tmp1);
+    u64 quo = hi * mu[1] + tmp3 + carry;
+    return csub(lo - quo * q, q);
+}
+/* barrett_reduce_uint64_uint64 :144-151 */
+static inline u64 barrett64(u64 x, u64 q, u64 mu_hi) { return csub(x - mulhi64(x, mu_hi) * q, q); }
+
+u64 orc_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+u64 orc_powmod(u64 a, u64 e, u64 q) {
+    u64 r = 1 % q;
+    a %= q;
+    while (e) {
+        if (e & 1) r = orc_mulmod(r, a, q);
+        a = orc_mulmod(a, a, q);
+        e >>= 1;
+    }
+    return r;
+}
+/* try_invert_uint_mod (src/host/numth.cu xgcd): q is prime on this path, so Fermat is equivalent. */
+u64 orc_invmod(u64 a, u64 q) { return orc_powmod(a % q, q - 2, q); }
+
+u64 orc_compute_shoup(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+
+void orc_const_ratio(u64 q, u64 ratio[2]) {
+    /* floor(2^128/q): q is never a power of two here, so floor((2^128-1)/q) is the same value */
+    u128 r = (~(u128)0) / q;
+    ratio[0] = (u64)r;
+    ratio[1] = (u64)(r >> 64);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * primes and roots (src/host/numth.cu:150-233,260-331; src/host/modulus.cu:82-111)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_is_prime(u64 n) {
+    /* deterministic Miller-Rabin for 64-bit (reference uses 40 random rounds, numth.cu:150-205;
+     * same answer on every input up to negligible error) */
+    static const u64 bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    if (n < 2) return 0;
+    for (size_t i = 0; i < 12; i++) {
+        if (n == bases[i]) return 1;
+        if (n % bases[i] == 0) return 0;
+    }
+    u64 d = n - 1;
+    int r = 0;
+    while (!(d & 1)) { d >>= 1; r++; }
+    for (size_t i = 0; i < 12; i++) {
+        u64 x = orc_powmod(bases[i], d, n);
+        if (x == 1 || x == n - 1) continue;
+        int comp = 1;
+        for (int j = 1; j < r; j++) {
+            x = orc_mulmod(x, x, n);
+            if (x == n - 1) { comp = 0; break; }
+        }
+        if (comp) return 0;
+    }
+    return 1;
+}
+
+int orc_get_primes(u64 ntt_size, int bit_size, size_t count, u64 *out) {
+    u64 factor = 2 * ntt_size;
+    u64 value = ((u64)1 << bit_size);
+    if (value < factor) return -1;
+    value = value - factor + 1;
+    u64 lower = (u64)1 << (bit_size - 1);
+    size_t k = 0;
+    while (k < count && value > lower) {
+        if (orc_is_prime(value)) out[k++] = value;
+        value -= factor;
+    }
+    return k == count ? 0 : -1;
+}
+
+int orc_coeff_modulus_create(u64 n, const int *bit_sizes, size_t count, u64 *out) {
+    /* count_table / prime_table of modulus.cu:98-109: for each distinct size, find as many primes as
+     * requested (descending), then hand them out from the BACK of that list in request order. */
+    int sizes[64];
+    size_t need[64], used[64];
+    u64 *tabs[64];
+    size_t nd = 0;
+    for (size_t i = 0; i < count; i++) {
+        size_t j = 0;
+        for (; j < nd; j++) if (sizes[j] == bit_sizes[i]) break;
+        if (j == nd) { sizes[nd] = bit_sizes[i]; need[nd] = 0; used[nd] = 0; nd++; }
+        need[j]++;
+    }
+    int rc = 0;
+    for (size_t j = 0; j < nd; j++) {
+        tabs[j] = (u64 *)malloc(sizeof(u64) * need[j]);
+        if (orc_get_primes(n, sizes[j], need[j], tabs[j])) rc = -1;
+    }
+    if (!rc)
+        for (size_t i = 0; i < count; i++) {
+            size_t j = 0;
+            for (; j < nd; j++) if (sizes[j] == bit_sizes[i]) break;
+            out[i] = tabs[j][need[j] - 1 - used[j]];
+            used[j]++;
+        }
+    for (size_t j = 0; j < nd; j++) free(tabs[j]);
+    return rc;
+}
+
+int orc_minimal_primitive_root(u64 degree, u64 q, u64 *root_out) {
+    /* numth.cu:260-331.  Any primitive degree-th root generates the same set of primitive roots
+     * (its odd powers), so the minimum over that set does not depend on the random start. */
+    if ((q - 1) % degree) return -1;
+    u64 quotient = (q - 1) / degree;
+    u64 root = 0;
+    for (u64 g = 2; g < 1000; g++) {
+        u64 r = orc_powmod(g, quotient, q);
+        if (orc_powmod(r, degree >> 1, q) == q - 1) { root = r; break; }
+    }
+    if (!root) return -1;
+    u64 gen_sq = orc_mulmod(root, root, q);
+    u64 cur = root;
+    for (u64 i = 0; i < degree; i++) {
+        if (cur < root) root = cur;
+        cur = orc_mulmod(cur, gen_sq, q);
+    }
+    *root_out = root;
+    return 0;
+}
+
+static uint32_t brev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+int orc_ntt_tables(int log_n, u64 q, u64 *tw, u64 *tws, u64 *itw, u64 *itws, u64 *n_inv, u64 *n_inv_s) {
+    /* src/host/ntt.cu:11-56 */
+    size_t n = (size_t)1 << log_n;
+    u64 root;
+    if (orc_minimal_primitive_root(2 * n, q, &root)) return -1;
+    u64 inv_root = orc_invmod(root, q);
+    u64 power = root;
+    for (size_t i = 1; i < n; i++) {
+        size_t k = brev((uint32_t)i, log_n);
+        tw[k] = power;
+        tws[k] = orc_compute_shoup(power, q);
+        power = orc_mulmod(power, root, q);
+    }
+    tw[0] = 1;
+    tws[0] = orc_compute_shoup(1, q);
+    power = inv_root;
+    for (size_t i = 1; i < n; i++) {
+        size_t k = brev((uint32_t)i, log_n);
+        itw[k] = power;
+        itws[k] = orc_compute_shoup(power, q);
+        power = orc_mulmod(power, inv_root, q);
+    }
+    itw[0] = 1;
+    itws[0] = orc_compute_shoup(1, q);
+    *n_inv = orc_invmod(n % q, q);
+    *n_inv_s = orc_compute_shoup(*n_inv, q);
+    /* :53-55 fold n^-1 into slot 1 */
+    itw[1] = orc_mulmod(itw[1], *n_inv, q);
+    itws[1] = orc_compute_shoup(itw[1], q);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * transforms.  The reference's 2-phase radix-8 kernels (fntt_2d.cu:9-198) evaluate exactly the
+ * SEAL-order Cooley-Tukey loop below: stage with m groups uses tw[m+i]
+ * (ntt_1d.cu:50), butterflies are include/butterfly.cuh:10-22 (CT) / :28-37 (GS).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_ntt_forward(u64 *x, int log_n, u64 q, const u64 *tw, const u64 *tws) {
+    size_t n = (size_t)1 << log_n;
+    u64 two_q = q << 1;
+    size_t t = n;
+    for (size_t m = 1; m < n; m <<= 1) {
+        t >>= 1;
+        for (size_t i = 0; i < m; i++) {
+            u64 w = tw[m + i], ws = tws[m + i];
+            size_t j1 = 2 * i * t;
+            for (size_t j = j1; j < j1 + t; j++) {
+                /* ct_butterfly: x in [0,4q) -> csub 2q ; t = y*w lazy [0,2q) ; (x+t, x+2q-t) */
+                u64 X = csub(x[j], two_q);
+                u64 T = shoup_lazy(x[j + t], w, ws, q);
+                x[j] = X + T;
+                x[j + t] = X + two_q - T;
+            }
+        }
+    }
+    /* final canonicalisation fntt_2d.cu:187-193 */
+    for (size_t j = 0; j < n; j++) x[j] = csub(csub(x[j], two_q), q);
+}
+
+void orc_ntt_inverse(u64 *x, int log_n, u64 q, const u64 *itw, const u64 *itws, u64 n_inv, u64 n_inv_s) {
+    /* GS loop, itw[1] already carries n^-1 (ntt.cu:53-55); first half is scaled explicitly
+     * (intt_2d.cu:195-198); final csub q (:201-205). */
+    size_t n = (size_t)1 << log_n;
+    u64 two_q = q << 1;
+    size_t t = 1;
+    for (size_t m = n >> 1; m >= 1; m >>= 1) {
+        for (size_t i = 0; i < m; i++) {
+            u64 w = itw[m + i], ws = itws[m + i];
+            size_t j1 = 2 * i * t;
+            for (size_t j = j1; j < j1 + t; j++) {
+                /* gs_butterfly: (csub2q(x+y), (x+2q-y)*w lazy) */
+                u64 X = x[j], Y = x[j + t];
+                u64 S = csub(X + Y, two_q);
+                u64 D = shoup_lazy(X + two_q - Y, w, ws, q);
+                if (m == 1) S = shoup_lazy(S, n_inv, n_inv_s, q);
+                x[j] = S;
+                x[j + t] = D;
+            }
+        }
+        t <<= 1;
+    }
+    for (size_t j = 0; j < n; j++) x[j] = csub(csub(x[j], two_q), q);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * context: per-prime tables for the whole QP chain (include/ntt.cuh:34-129; context.cu:170-183)
+ * ---------------------------------------------------------------------------------------------- */
+struct orc_ctx {
+    int log_n;
+    size_t n, size_qp, size_p, size_q;
+    u64 *q;          /* [size_qp] */
+    u64 (*mu)[2];    /* const_ratio */
+    u64 *tw, *tws, *itw, *itws; /* [size_qp][n] */
+    u64 *n_inv, *n_inv_s;
+};
+
+orc_ctx *orc_ctx_create(int log_n, const u64 *primes, size_t size_qp, size_t size_p) {
+    orc_ctx *c = (orc_ctx *)calloc(1, sizeof(*c));
+    c->log_n = log_n;
+    c->n = (size_t)1 << log_n;
+    c->size_qp = size_qp;
+    c->size_p = size_p;
+    c->size_q = size_qp - size_p;
+    c->q = (u64 *)malloc(sizeof(u64) * size_qp);
+    c->mu = malloc(sizeof(u64[2]) * size_qp);
+    c->tw = (u64 *)malloc(sizeof(u64) * size_qp * c->n);
+    c->tws = (u64 *)malloc(sizeof(u64) * size_qp * c->n);
+    c->itw = (u64 *)malloc(sizeof(u64) * size_qp * c->n);
+    c->itws = (u64 *)malloc(sizeof(u64) * size_qp * c->n);
+    c->n_inv = (u64 *)malloc(sizeof(u64) * size_qp);
+    c->n_inv_s = (u64 *)malloc(sizeof(u64) * size_qp);
+    for (size_t i = 0; i < size_qp; i++) {
+        c->q[i] = primes[i];
+        orc_const_ratio(primes[i], c->mu[i]);
+        if (orc_ntt_tables(log_n, primes[i], c->tw + i * c->n, c->tws + i * c->n, c->itw + i * c->n,
+                           c->itws + i * c->n, &c->n_inv[i], &c->n_inv_s[i])) {
+            orc_ctx_destroy(c);
+            return NULL;
+        }
+    }
+    return c;
+}
+void orc_ctx_destroy(orc_ctx *c) {
+    if (!c) return;
+    free(c->q); free(c->mu); free(c->tw); free(c->tws); free(c->itw); free(c->itws);
+    free(c->n_inv); free(c->n_inv_s); free(c);
+}
+size_t orc_ctx_n(const orc_ctx *c) { return c->n; }
+const u64 *orc_ctx_twiddle(const orc_ctx *c, size_t p, int which) {
+    const u64 *b = which == 0 ? c->tw : which == 1 ? c->tws : which == 2 ? c->itw : c->itws;
+    return b + p * c->n;
+}
+u64 orc_ctx_n_inv(const orc_ctx *c, size_t p) { return c->n_inv[p]; }
+
+static void fwd1(const orc_ctx *c, u64 *x, size_t p) {
+    orc_ntt_forward(x, c->log_n, c->q[p], c->tw + p * c->n, c->tws + p * c->n);
+}
+static void inv1(const orc_ctx *c, u64 *x, size_t p) {
+    orc_ntt_inverse(x, c->log_n, c->q[p], c->itw + p * c->n, c->itws + p * c->n, c->n_inv[p], c->n_inv_s[p]);
+}
+void orc_nwt_forward(const orc_ctx *c, u64 *d, size_t limbs, size_t start) {
+    for (size_t i = 0; i < limbs; i++) fwd1(c, d + i * c->n, start + i);
+}
+void orc_nwt_backward(const orc_ctx *c, u64 *d, size_t limbs, size_t start) {
+    for (size_t i = 0; i < limbs; i++) inv1(c, d + i * c->n, start + i);
+}
+void orc_nwt_forward_map(const orc_ctx *c, u64 *d, const uint32_t *map, size_t limbs) {
+    for (size_t i = 0; i < limbs; i++) fwd1(c, d + i * c->n, map[i]);
+}
+void orc_nwt_backward_map(const orc_ctx *c, u64 *d, const uint32_t *map, size_t limbs) {
+    for (size_t i = 0; i < limbs; i++) inv1(c, d + i * c->n, map[i]);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * dyadic kernels (src/polymath.cu)
+ * ---------------------------------------------------------------------------------------------- */
+#define FOR_LIMB_COEFF                                     \
+    for (size_t l = 0; l < limbs; l++) {                   \
+        const u64 q = c->q[start + l];                     \
+        const u64 *mu = c->mu[start + l];                  \
+        (void)mu;                                          \
+        for (size_t k = 0; k < c->n; k++) {                \
+            const size_t id = l * c->n + k;
+
+#define END_LIMB_COEFF }}
+
+void orc_add_rns_poly(const orc_ctx *c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t start) {
+    FOR_LIMB_COEFF r[id] = addmod(a[id], b[id], q); END_LIMB_COEFF
+}
+void orc_sub_rns_poly(const orc_ctx *c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t start) {
+    FOR_LIMB_COEFF r[id] = submod(a[id], b[id], q); END_LIMB_COEFF
+}
+void orc_negate_rns_poly(const orc_ctx *c, const u64 *a, u64 *r, size_t limbs, size_t start) {
+    FOR_LIMB_COEFF r[id] = negmod(a[id], q); END_LIMB_COEFF
+}
+void orc_multiply_rns_poly(const orc_ctx *c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t start) {
+    FOR_LIMB_COEFF r[id] = barrett128((u128)a[id] * b[id], q, mu); END_LIMB_COEFF
+}
+void orc_multiply_and_add_rns_poly(const orc_ctx *c, const u64 *a, const u64 *b, const u64 *d, u64 *r,
+                                   size_t limbs, size_t start) {
+    /* polymath.cu:225-244: r = a*b + d, 128-bit sum then one Barrett */
+    FOR_LIMB_COEFF r[id] = barrett128((u128)a[id] * b[id] + d[id], q, mu); END_LIMB_COEFF
+}
+void orc_multiply_scalar_rns_poly(const orc_ctx *c, const u64 *a, const u64 *scalar, u64 *r, size_t limbs,
+                                  size_t start) {
+    /* Shoup overload polymath.cu:198-213: scalar[l] per limb */
+    FOR_LIMB_COEFF
+        u64 s = scalar[l];
+        r[id] = shoup(a[id], s, orc_compute_shoup(s, q), q);
+    END_LIMB_COEFF
+}
+void orc_tensor_prod_2x2(const orc_ctx *c, const u64 *op1, const u64 *op2, u64 *res, size_t limbs) {
+    const size_t start = 0, rc = limbs * c->n;
+    FOR_LIMB_COEFF
+        u64 c00 = op1[id], c01 = op1[id + rc], c10 = op2[id], c11 = op2[id + rc];
+        u64 d0 = barrett128((u128)c00 * c10, q, mu);
+        u64 d2 = barrett128((u128)c01 * c11, q, mu);
+        /* (c0+c1) is NOT reduced before the multiply (polymath.cu:487) */
+        u64 d1 = barrett128((u128)(c00 + c01) * (c10 + c11), q, mu);
+        d1 = d1 + 2 * q - d0 - d2;
+        d1 = csub(csub(d1, q), q);
+        res[id] = d0; res[id + rc] = d1; res[id + 2 * rc] = d2;
+    END_LIMB_COEFF
+}
+void orc_tensor_square_2x2(const orc_ctx *c, const u64 *op, u64 *res, size_t limbs) {
+    const size_t start = 0, rc = limbs * c->n;
+    FOR_LIMB_COEFF
+        u64 c0 = op[id], c1 = op[id + rc];
+        res[id] = barrett128((u128)c0 * c0, q, mu);
+        res[id + rc] = barrett128(((u128)c0 * c1) << 1, q, mu);
+        res[id + 2 * rc] = barrett128((u128)c1 * c1, q, mu);
+    END_LIMB_COEFF
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * fast base conversion (src/host/rns.cu:282-337 RNSBase::initialize, :438-497 BaseConverter;
+ * src/rns_bconv.cu:22-60 bconv_mult, :109-170 bconv_matmul, :212-229 bConv_BEHZ)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    size_t isz, osz;
+    u64 *ib, *ob;
+    u64 (*omu)[2];
+    u64 *hat_inv, *hat_inv_s; /* qhat_i^-1 mod q_i  [isz] */
+    u64 *mat;                 /* qhat_i mod p_j     [osz][isz] */
+} bconv_t;
+
+static void bconv_init(bconv_t *b, const u64 *ib, size_t isz, const u64 *ob, size_t osz) {
+    b->isz = isz; b->osz = osz;
+    b->ib = (u64 *)malloc(sizeof(u64) * isz);
+    b->ob = (u64 *)malloc(sizeof(u64) * osz);
+    b->omu = malloc(sizeof(u64[2]) * osz);
+    b->hat_inv = (u64 *)malloc(sizeof(u64) * isz);
+    b->hat_inv_s = (u64 *)malloc(sizeof(u64) * isz);
+    b->mat = (u64 *)malloc(sizeof(u64) * isz * osz);
+    memcpy(b->ib, ib, sizeof(u64) * isz);
+    memcpy(b->ob, ob, sizeof(u64) * osz);
+    for (size_t i = 0; i < isz; i++) {
+        /* punctured product mod q_i, then its inverse (rns.cu:307-320); size-1 base -> 1 (:329-334) */
+        u64 h = 1;
+        for (size_t k = 0; k < isz; k++) if (k != i) h = orc_mulmod(h, ib[k] % ib[i], ib[i]);
+        b->hat_inv[i] = orc_invmod(h, ib[i]);
+        b->hat_inv_s[i] = orc_compute_shoup(b->hat_inv[i], ib[i]);
+    }
+    for (size_t j = 0; j < osz; j++) {
+        orc_const_ratio(ob[j], b->omu[j]);
+        for (size_t i = 0; i < isz; i++) {
+            u64 h = 1;
+            for (size_t k = 0; k < isz; k++) if (k != i) h = orc_mulmod(h, ib[k] % ob[j], ob[j]);
+            b->mat[j * isz + i] = h; /* QHatModp_[j][i] rns.cu:448-457 */
+        }
+    }
+}
+static void bconv_free(bconv_t *b) {
+    free(b->ib); free(b->ob); free(b->omu); free(b->hat_inv); free(b->hat_inv_s); free(b->mat);
+}
+/* phase 1: y_i = x_i * qhat_i^-1 mod q_i, canonical (bconv_mult_kernel) */
+static void bconv_mult(const bconv_t *b, const u64 *src, u64 *tmp, size_t n) {
+    for (size_t i = 0; i < b->isz; i++)
+        for (size_t k = 0; k < n; k++)
+            tmp[i * n + k] = shoup(src[i * n + k], b->hat_inv[i], b->hat_inv_s[i], b->ib[i]);
+}
+/* phase 2: out_j = Barrett128(sum_i y_i * (qhat_i mod p_j)); dst limb stride given so that the
+ * "padded" variant (rns_bconv.cu:455-485) can leap over the digit's own range */
+static void bconv_matmul(const bconv_t *b, const u64 *tmp, u64 *dst, size_t n, size_t pad_start, size_t pad_len) {
+    for (size_t j = 0; j < b->osz; j++) {
+        size_t jo = j + (j >= pad_start ? pad_len : 0);
+        for (size_t k = 0; k < n; k++) {
+            u128 acc = 0;
+            for (size_t i = 0; i < b->isz; i++) acc += (u128)tmp[i * n + k] * b->mat[j * b->isz + i];
+            dst[jo * n + k] = barrett128(acc, b->ob[j], b->omu[j]);
+        }
+    }
+}
+void orc_bconv(const u64 *ibase, size_t isz, const u64 *obase, size_t osz, const u64 *src, u64 *dst, size_t n) {
+    bconv_t b;
+    bconv_init(&b, ibase, isz, obase, osz);
+    u64 *tmp = (u64 *)malloc(sizeof(u64) * isz * n);
+    bconv_mult(&b, src, tmp, n);
+    bconv_matmul(&b, tmp, dst, n, osz, 0);
+    free(tmp);
+    bconv_free(&b);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * DRNSTool at one data level (src/rns.cu:11-200)
+ * ---------------------------------------------------------------------------------------------- */
+struct orc_tool {
+    const orc_ctx *c;
+    size_t n, size_ql, size_p, size_qlp, size_q, size_qp, alpha, beta;
+    u64 *qlp;            /* primes of [Ql || P] */
+    uint32_t *qlp_idx;   /* their index in the QP table (twr remap fntt_2d.cu:434-437) */
+    u64 *part_hat_inv, *part_hat_inv_s; /* partQlHatInv_mod_Ql_concat rns.cu:152-182 */
+    bconv_t *digit_conv;                /* part Ql -> complement of QlP, per digit */
+    bconv_t p_to_ql;                    /* base_P_to_Ql_conv rns.cu:196-198 */
+    u64 *pinv, *pinv_s;                 /* bigPInv_mod_q rns.cu:110-123 */
+    u64 *inv_q_last, *inv_q_last_s;     /* rns.cu:66-80 */
+};
+
+orc_tool *orc_tool_create(const orc_ctx *c, size_t size_ql) {
+    orc_tool *t = (orc_tool *)calloc(1, sizeof(*t));
+    t->c = c; t->n = c->n; t->size_ql = size_ql; t->size_p = c->size_p; t->alpha = c->size_p;
+    t->size_q = c->size_q; t->size_qp = c->size_qp; t->size_qlp = size_ql + c->size_p;
+    t->qlp = (u64 *)malloc(sizeof(u64) * t->size_qlp);
+    t->qlp_idx = (uint32_t *)malloc(sizeof(uint32_t) * t->size_qlp);
+    for (size_t i = 0; i < size_ql; i++) { t->qlp[i] = c->q[i]; t->qlp_idx[i] = (uint32_t)i; }
+    for (size_t i = 0; i < t->size_p; i++) {
+        t->qlp[size_ql + i] = c->q[t->size_q + i];
+        t->qlp_idx[size_ql + i] = (uint32_t)(t->size_q + i);
+    }
+    /* rescale constants */
+    if (size_ql > 1) {
+        t->inv_q_last = (u64 *)malloc(sizeof(u64) * (size_ql - 1));
+        t->inv_q_last_s = (u64 *)malloc(sizeof(u64) * (size_ql - 1));
+        for (size_t i = 0; i + 1 < size_ql; i++) {
+            t->inv_q_last[i] = orc_invmod(c->q[size_ql - 1] % c->q[i], c->q[i]);
+            t->inv_q_last_s[i] = orc_compute_shoup(t->inv_q_last[i], c->q[i]);
+        }
+    }
+    if (t->size_p) {
+        t->pinv = (u64 *)malloc(sizeof(u64) * size_ql);
+        t->pinv_s = (u64 *)malloc(sizeof(u64) * size_ql);
+        for (size_t i = 0; i < size_ql; i++) {
+            u64 p = 1;
+            for (size_t k = 0; k < t->size_p; k++) p = orc_mulmod(p, c->q[t->size_q + k] % c->q[i], c->q[i]);
+            t->pinv[i] = orc_invmod(p, c->q[i]);
+            t->pinv_s[i] = orc_compute_shoup(t->pinv[i], c->q[i]);
+        }
+        t->beta = (size_ql + t->alpha - 1) / t->alpha; /* rns.cu:152 */
+        t->digit_conv = (bconv_t *)calloc(t->beta, sizeof(bconv_t));
+        t->part_hat_inv = (u64 *)malloc(sizeof(u64) * size_ql);
+        t->part_hat_inv_s = (u64 *)malloc(sizeof(u64) * size_ql);
+        u64 *compl = (u64 *)malloc(sizeof(u64) * t->size_qlp);
+        for (size_t b = 0; b < t->beta; b++) {
+            size_t s = t->alpha * b;
+            size_t len = (b == t->beta - 1) ? size_ql - t->alpha * (t->beta - 1) : t->alpha;
+            size_t nc = 0;
+            for (size_t j = 0; j < t->size_qlp; j++) if (j < s || j >= s + len) compl[nc++] = t->qlp[j];
+            bconv_init(&t->digit_conv[b], t->qlp + s, len, compl, nc);
+            for (size_t i = 0; i < len; i++) {
+                t->part_hat_inv[s + i] = t->digit_conv[b].hat_inv[i];
+                t->part_hat_inv_s[s + i] = t->digit_conv[b].hat_inv_s[i];
+            }
+        }
+        free(compl);
+        bconv_init(&t->p_to_ql, c->q + t->size_q, t->size_p, c->q, size_ql);
+    }
+    return t;
+}
+void orc_tool_destroy(orc_tool *t) {
+    if (!t) return;
+    free(t->qlp); free(t->qlp_idx); free(t->inv_q_last); free(t->inv_q_last_s);
+    if (t->size_p) {
+        free(t->pinv); free(t->pinv_s); free(t->part_hat_inv); free(t->part_hat_inv_s);
+        for (size_t b = 0; b < t->beta; b++) bconv_free(&t->digit_conv[b]);
+        free(t->digit_conv);
+        bconv_free(&t->p_to_ql);
+    }
+    free(t);
+}
+size_t orc_tool_beta(const orc_tool *t) { return t->beta; }
+
+void orc_modup(const orc_tool *t, u64 *dst, const u64 *cks, int scheme) {
+    /* DRNSTool::modup rns_bconv.cu:530-627 */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp, alpha = t->alpha;
+    u64 *t_cks = (u64 *)malloc(sizeof(u64) * ql * n);
+    memcpy(t_cks, cks, sizeof(u64) * ql * n);
+    if (scheme == ORC_CKKS || scheme == ORC_BGV) {
+        orc_nwt_backward(c, t_cks, ql, 0);
+        if (alpha != 1) /* nwt_2d_radix8_backward_scale: x partQlHatInv, full Shoup reduce (:558-559) */
+            for (size_t i = 0; i < ql; i++)
+                for (size_t k = 0; k < n; k++)
+                    t_cks[i * n + k] = shoup(t_cks[i * n + k], t->part_hat_inv[i], t->part_hat_inv_s[i], c->q[i]);
+    }
+    for (size_t b = 0; b < t->beta; b++) {
+        const size_t s = alpha * b;
+        const size_t len = (b == t->beta - 1) ? ql - alpha * (t->beta - 1) : alpha;
+        u64 *out = dst + b * qlp * n;
+        if (alpha == 1) {
+            /* modup_bconv_single_p_kernel :432-453 */
+            const u64 *normal = (scheme == ORC_BFV) ? cks + s * n : t_cks + s * n;
+            for (size_t j = 0; j < qlp; j++)
+                for (size_t k = 0; k < n; k++) {
+                    if (j == s) out[j * n + k] = cks[s * n + k];
+                    else {
+                        u64 ip = t->qlp[s], op = t->qlp[j], v = normal[k];
+                        out[j * n + k] = ip > op ? barrett64(v, op, c->mu[t->qlp_idx[j]][1]) : v;
+                    }
+                }
+        } else {
+            /* own limbs copied verbatim (:522-528) */
+            memcpy(out + s * n, cks + s * n, sizeof(u64) * len * n);
+            const bconv_t *bc = &t->digit_conv[b];
+            u64 *tmp = t_cks + s * n;
+            u64 *scaled = NULL;
+            if (scheme == ORC_BFV) { /* bconv_mult_kernel :603-607 */
+                scaled = (u64 *)malloc(sizeof(u64) * len * n);
+                bconv_mult(bc, cks + s * n, scaled, n);
+                tmp = scaled;
+            }
+            bconv_matmul(bc, tmp, out, n, s, len);
+            free(scaled);
+        }
+        /* forward NTT: ckks/bgv skip the digit's own range (ntt_modup.cu:422), bfv does all limbs */
+        for (size_t j = 0; j < qlp; j++) {
+            if ((scheme == ORC_CKKS || scheme == ORC_BGV) && j >= s && j < s + len) continue;
+            fwd1(c, out + j * n, t->qlp_idx[j]);
+        }
+    }
+    free(t_cks);
+}
+
+void orc_key_switch_inner_prod(const orc_tool *t, u64 *cx, const u64 *mu_in, const u64 *const *evks) {
+    /* key_switch_inner_prod_c2_and_evk eval_key_switch.cu:14-69.  128-bit accumulate, one Barrett. */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, qlp = t->size_qlp, qp_n = t->size_qp * n, qlp_n = qlp * n;
+    for (size_t nid = 0; nid < qlp; nid++) {
+        size_t twr = t->qlp_idx[nid];
+        for (size_t k = 0; k < n; k++) {
+            u128 a0 = 0, a1 = 0;
+            for (size_t i = 0; i < t->beta; i++) {
+                u64 v = mu_in[i * qlp_n + nid * n + k];
+                a0 += (u128)v * evks[i][twr * n + k];
+                a1 += (u128)v * evks[i][twr * n + k + qp_n];
+            }
+            cx[nid * n + k] = barrett128(a0, c->q[twr], c->mu[twr]);
+            cx[nid * n + k + qlp_n] = barrett128(a1, c->q[twr], c->mu[twr]);
+        }
+    }
+}
+
+void orc_moddown_from_ntt(const orc_tool *t, u64 *ct, u64 *cx, int scheme) {
+    /* DRNSTool::moddown_from_NTT rns_bconv.cu:776-828 */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp;
+    u64 *delta = (u64 *)malloc(sizeof(u64) * ql * n);
+    if (scheme == ORC_CKKS) orc_nwt_backward_map(c, cx + ql * n, t->qlp_idx + ql, t->size_p);
+    else orc_nwt_backward_map(c, cx, t->qlp_idx, qlp);
+    if (t->alpha == 1) {
+        /* moddown_bconv_single_p_kernel :691-707 */
+        u64 ip = t->qlp[ql];
+        for (size_t j = 0; j < ql; j++)
+            for (size_t k = 0; k < n; k++) {
+                u64 v = cx[ql * n + k];
+                delta[j * n + k] = ip > c->q[j] ? barrett64(v, c->q[j], c->mu[j][1]) : v;
+            }
+    } else {
+        u64 *tmp = (u64 *)malloc(sizeof(u64) * t->size_p * n);
+        bconv_mult(&t->p_to_ql, cx + ql * n, tmp, n);
+        bconv_matmul(&t->p_to_ql, tmp, delta, n, ql, 0);
+        free(tmp);
+    }
+    if (scheme == ORC_CKKS) orc_nwt_forward(c, delta, ql, 0); /* fused in ntt_moddown.cu:106-261 */
+    /* (cx - delta) * P^-1 mod q : sub_negate_const_mult uintmodmath.cuh:233-241 / moddown_kernel :680-689 */
+    for (size_t j = 0; j < ql; j++)
+        for (size_t k = 0; k < n; k++) {
+            u64 d = submod(cx[j * n + k], delta[j * n + k], c->q[j]);
+            ct[j * n + k] = shoup(d, t->pinv[j], t->pinv_s[j], c->q[j]);
+        }
+    free(delta);
+}
+
+void orc_keyswitch_inplace(const orc_tool *t, u64 *ct, const u64 *c2, const u64 *const *evks, int scheme) {
+    /* keyswitch_inplace eval_key_switch.cu:95-182 (mul_tech != hps_overq_leveled) */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp;
+    u64 *mu = (u64 *)malloc(sizeof(u64) * t->beta * qlp * n);
+    u64 *cx = (u64 *)malloc(sizeof(u64) * 2 * qlp * n);
+    orc_modup(t, mu, c2, scheme);
+    orc_key_switch_inner_prod(t, cx, mu, evks);
+    for (int i = 0; i < 2; i++) {
+        u64 *cxi = cx + (size_t)i * qlp * n;
+        orc_moddown_from_ntt(t, cxi, cxi, scheme);
+        orc_add_rns_poly(c, ct + (size_t)i * ql * n, cxi, ct + (size_t)i * ql * n, ql, 0); /* add_to_ct_kernel :763-769 */
+    }
+    free(mu);
+    free(cx);
+}
+
+void orc_rescale_ntt(const orc_tool *t, u64 *src, size_t cipher_size, u64 *dst) {
+    /* divide_and_round_q_last_ntt rns.cu:1160-1184 (floors; the "+half" of :1118 is not implemented) */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, nl = ql - 1;
+    for (size_t p = 0; p < cipher_size; p++) {
+        u64 *in = src + p * ql * n, *out = dst + p * nl * n;
+        inv1(c, in + nl * n, nl);
+        for (size_t j = 0; j < nl; j++)
+            for (size_t k = 0; k < n; k++) out[j * n + k] = barrett64(in[nl * n + k], c->q[j], c->mu[j][1]);
+        orc_nwt_forward(c, out, nl, 0);
+        for (size_t j = 0; j < nl; j++)
+            for (size_t k = 0; k < n; k++) {
+                u64 d = submod(in[j * n + k], out[j * n + k], c->q[j]);
+                out[j * n + k] = shoup(d, t->inv_q_last[j], t->inv_q_last_s[j], c->q[j]);
+            }
+    }
+}
+
+void orc_divide_and_round_q_last(const orc_tool *t, const u64 *src, size_t cipher_size, u64 *dst) {
+    /* rns.cu:1082-1126 */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, nl = ql - 1;
+    for (size_t p = 0; p < cipher_size; p++)
+        for (size_t j = 0; j < nl; j++)
+            for (size_t k = 0; k < n; k++) {
+                u64 last = barrett64(src[p * ql * n + nl * n + k], c->q[j], c->mu[j][1]);
+                u64 d = submod(src[p * ql * n + j * n + k], last, c->q[j]);
+                dst[p * nl * n + j * n + k] = shoup(d, t->inv_q_last[j], t->inv_q_last_s[j], c->q[j]);
+            }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Galois (include/galois.cuh:98-130, src/galois.cu:11-39)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_galois_ntt_table(int log_n, uint32_t elt, uint32_t *table) {
+    uint32_t n = 1u << log_n;
+    for (uint32_t i = n; i < 2 * n; i++) {
+        uint32_t rev = brev(i, log_n + 1);
+        u64 raw = ((u64)elt * rev) >> 1;
+        raw &= (u64)(n - 1);
+        table[i - n] = brev((uint32_t)raw, log_n);
+    }
+}
+void orc_apply_galois_ntt(const u64 *src, u64 *dst, const uint32_t *table, size_t n, size_t limbs) {
+    for (size_t l = 0; l < limbs; l++)
+        for (size_t k = 0; k < n; k++) dst[l * n + k] = src[l * n + table[k]];
+}
+void orc_apply_galois_coeff(const orc_ctx *c, const u64 *src, u64 *dst, uint32_t elt, size_t limbs, size_t start) {
+    const size_t n = c->n;
+    for (size_t l = 0; l < limbs; l++) {
+        u64 q = c->q[start + l];
+        u64 raw = 0;
+        for (size_t k = 0; k < n; k++) {
+            u64 v = src[l * n + k];
+            if (raw >= n) v = negmod(v, q);
+            dst[l * n + (raw % n)] = v;
+            raw = (raw + elt) & (2 * n - 1);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * evaluation-key generation (src/secretkey.cu:232-341, polymath.cu:318-338)
+ * evk_i = ( -(a_i*s + e_i) + P*new_key on limbs [i*alpha,(i+1)*alpha) , a_i ), all NTT form, over QP
+ * ---------------------------------------------------------------------------------------------- */
+void orc_gen_kswitch_key(const orc_ctx *c, const u64 *sk, const u64 *new_key, const u64 *a, const u64 *e, u64 *evk) {
+    const size_t n = c->n, qp = c->size_qp, alpha = c->size_p, dnum = c->size_q / alpha;
+    for (size_t d = 0; d < dnum; d++) {
+        u64 *b_out = evk + d * 2 * qp * n, *a_out = b_out + qp * n;
+        for (size_t j = 0; j < qp; j++) {
+            u64 q = c->q[j];
+            u64 pmod = 0;
+            int in_digit = (j >= d * alpha && j < (d + 1) * alpha);
+            if (in_digit) {
+                pmod = 1;
+                for (size_t k = 0; k < alpha; k++) pmod = orc_mulmod(pmod, c->q[c->size_q + k] % q, q);
+            }
+            for (size_t k = 0; k < n; k++) {
+                size_t id = d * qp * n + j * n + k;
+                u64 as = orc_mulmod(a[id], sk[j * n + k], q);
+                u64 b = negmod(addmod(as, e[id], q), q);
+                if (in_digit) b = addmod(b, orc_mulmod(new_key[j * n + k], pmod, q), q);
+                b_out[j * n + k] = b;
+                a_out[j * n + k] = a[id];
+            }
+        }
+    }
+}

@@ -1,0 +1,119 @@
+/*
+ * oracle.h -- CPU restatement of the PhantomFHE RNS polynomial-arithmetic hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and there
+ * only as the checker.  The product (phantom-fhe_amd/) has its own, independent host precompute
+ * and its own HIP kernels and never links or imports this code.
+ *
+ * PARITY STATUS: "parity unpinned against an executed reference".  The reference's host code
+ * cannot be compiled in this image without writing stand-in CUDA headers
+ * (include/host/defines.h:34 includes <cuda_runtime_api.h>), the reference's tests contain no
+ * golden vectors (test/ntt_test.cu:71-122 is a round trip on constants), and upstream SEAL is
+ * absent.  The oracle is pinned instead by (i) the literal constants the reference embeds
+ * (src/host/globals.cu:71 default primes), (ii) the values SURVEY.md 8(c) records from the
+ * survey's run of the reference host code, (iii) the mathematical definition of each operation
+ * (direct O(N^2) evaluation, CRT recomposition with Python big integers), since every stored
+ * output of the path is a canonical residue in [0,q) and therefore unique.
+ *
+ * Every function cites the reference file:line whose semantics it restates.
+ */
+#ifndef PHANTOM_ORACLE_H
+#define PHANTOM_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- number theory / host precompute (src/host/numth.cu, modulus.cu, ntt.cu) ---- */
+int orc_is_prime(uint64_t v);
+/* get_primes: src/host/numth.cu:207-233. Returns 0 on success. */
+int orc_get_primes(uint64_t ntt_size, int bit_size, size_t count, uint64_t *out);
+/* CoeffModulus::Create: src/host/modulus.cu:82-111 (same-size primes handed out from the back). */
+int orc_coeff_modulus_create(uint64_t n, const int *bit_sizes, size_t count, uint64_t *out);
+/* Modulus::set_value const_ratio = floor(2^128/q): src/host/modulus.cu:15-48 */
+void orc_const_ratio(uint64_t q, uint64_t ratio[2]);
+/* try_minimal_primitive_root: src/host/numth.cu:309-331 */
+int orc_minimal_primitive_root(uint64_t degree, uint64_t q, uint64_t *root);
+uint64_t orc_compute_shoup(uint64_t w, uint64_t q); /* include/host/uintarithsmallmod.h:119 */
+uint64_t orc_invmod(uint64_t a, uint64_t q);
+uint64_t orc_mulmod(uint64_t a, uint64_t b, uint64_t q);
+uint64_t orc_powmod(uint64_t a, uint64_t e, uint64_t q);
+/* NTT::NTT tables: src/host/ntt.cu:11-56 (itw[1] is pre-multiplied by n^-1, :53-55). */
+int orc_ntt_tables(int log_n, uint64_t q, uint64_t *tw, uint64_t *tw_shoup, uint64_t *itw,
+                   uint64_t *itw_shoup, uint64_t *n_inv, uint64_t *n_inv_shoup);
+
+/* ---- transforms (src/ntt/fntt_2d.cu:9-198,620-653; src/ntt/intt_2d.cu:9-207,724-757) ---- */
+void orc_ntt_forward(uint64_t *x, int log_n, uint64_t q, const uint64_t *tw, const uint64_t *tw_shoup);
+void orc_ntt_inverse(uint64_t *x, int log_n, uint64_t q, const uint64_t *itw, const uint64_t *itw_shoup,
+                     uint64_t n_inv, uint64_t n_inv_shoup);
+
+/* ---- RNS context: all tables for a QP chain (include/ntt.cuh:34-129 DNTTTable) ---- */
+typedef struct orc_ctx orc_ctx;
+orc_ctx *orc_ctx_create(int log_n, const uint64_t *primes_qp, size_t size_qp, size_t size_p);
+void orc_ctx_destroy(orc_ctx *c);
+size_t orc_ctx_n(const orc_ctx *c);
+const uint64_t *orc_ctx_twiddle(const orc_ctx *c, size_t prime_idx, int which); /* 0 tw,1 tw_shoup,2 itw,3 itw_shoup */
+uint64_t orc_ctx_n_inv(const orc_ctx *c, size_t prime_idx);
+
+/* limb-batched transforms; prime index of data limb i is start_idx+i (nwt_2d_radix8_forward_inplace
+ * fntt_2d.cu:620-653 / backward intt_2d.cu:724-757) */
+void orc_nwt_forward(const orc_ctx *c, uint64_t *data, size_t limbs, size_t start_idx);
+void orc_nwt_backward(const orc_ctx *c, uint64_t *data, size_t limbs, size_t start_idx);
+/* explicit limb -> prime map (covers the *_include_special_mod remap, fntt_2d.cu:434-437) */
+void orc_nwt_forward_map(const orc_ctx *c, uint64_t *data, const uint32_t *prime_idx, size_t limbs);
+void orc_nwt_backward_map(const orc_ctx *c, uint64_t *data, const uint32_t *prime_idx, size_t limbs);
+
+/* ---- dyadic kernels (src/polymath.cu) ; limb i uses prime start_idx+i ---- */
+void orc_add_rns_poly(const orc_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t limbs, size_t start_idx);      /* :41-56 */
+void orc_sub_rns_poly(const orc_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t limbs, size_t start_idx);      /* :110-124 */
+void orc_negate_rns_poly(const orc_ctx *c, const uint64_t *a, uint64_t *r, size_t limbs, size_t start_idx);                      /* :17-32 */
+void orc_multiply_rns_poly(const orc_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t limbs, size_t start_idx); /* :156-172 */
+void orc_multiply_and_add_rns_poly(const orc_ctx *c, const uint64_t *a, const uint64_t *b, const uint64_t *d, uint64_t *r, size_t limbs, size_t start_idx); /* :215-232 */
+void orc_multiply_scalar_rns_poly(const orc_ctx *c, const uint64_t *a, const uint64_t *scalar, uint64_t *r, size_t limbs, size_t start_idx); /* :197-213 */
+/* tensor_prod_2x2_rns_poly :463-496 ; op = [2][limbs][N], res = [3][limbs][N] */
+void orc_tensor_prod_2x2(const orc_ctx *c, const uint64_t *op1, const uint64_t *op2, uint64_t *res, size_t limbs);
+void orc_tensor_square_2x2(const orc_ctx *c, const uint64_t *op, uint64_t *res, size_t limbs); /* :498-529 */
+
+/* ---- generic fast base conversion (src/rns_bconv.cu:22-60,109-229; src/host/rns.cu:282-337,438-497) ----
+ * ibase/obase are lists of primes; src [ibase][N] -> dst [obase][N]  (DBaseConverter::bConv_BEHZ) */
+void orc_bconv(const uint64_t *ibase, size_t isz, const uint64_t *obase, size_t osz, const uint64_t *src,
+               uint64_t *dst, size_t n);
+
+/* ---- DRNSTool at level size_ql (src/rns.cu:11-200) ---- */
+typedef struct orc_tool orc_tool;
+orc_tool *orc_tool_create(const orc_ctx *c, size_t size_ql);
+void orc_tool_destroy(orc_tool *t);
+size_t orc_tool_beta(const orc_tool *t);
+/* scheme: 1 = bfv, 2 = ckks (include/host/encryptionparams.h:19-27 uses bfv=1,ckks=2,bgv=3) */
+enum { ORC_BFV = 1, ORC_CKKS = 2, ORC_BGV = 3 };
+/* DRNSTool::modup rns_bconv.cu:530-627: cks [size_ql][N] -> dst [beta][size_ql+alpha][N] */
+void orc_modup(const orc_tool *t, uint64_t *dst, const uint64_t *cks, int scheme);
+/* key_switch_inner_prod eval_key_switch.cu:14-92: evk[i] = [2][size_QP][N]; cx = [2][size_ql+alpha][N] */
+void orc_key_switch_inner_prod(const orc_tool *t, uint64_t *cx, const uint64_t *t_mod_up, const uint64_t *const *evks);
+/* DRNSTool::moddown_from_NTT rns_bconv.cu:776-828: cx [size_ql+alpha][N] (clobbered) -> ct [size_ql][N] */
+void orc_moddown_from_ntt(const orc_tool *t, uint64_t *ct, uint64_t *cx, int scheme);
+/* keyswitch_inplace eval_key_switch.cu:95-182: ct=[2][size_ql][N] += KS(c2) */
+void orc_keyswitch_inplace(const orc_tool *t, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks, int scheme);
+/* divide_and_round_q_last_ntt rns.cu:1128-1184: src [cipher][size_ql][N] (clobbered) -> dst [cipher][size_ql-1][N] */
+void orc_rescale_ntt(const orc_tool *t, uint64_t *src, size_t cipher_size, uint64_t *dst);
+/* divide_and_round_q_last rns.cu:1082-1126 (BFV coefficient-domain mod switch) */
+void orc_divide_and_round_q_last(const orc_tool *t, const uint64_t *src, size_t cipher_size, uint64_t *dst);
+
+/* ---- Galois (include/galois.cuh:98-130, src/galois.cu:11-39) ---- */
+void orc_galois_ntt_table(int log_n, uint32_t galois_elt, uint32_t *table);
+void orc_apply_galois_ntt(const uint64_t *src, uint64_t *dst, const uint32_t *table, size_t n, size_t limbs);
+void orc_apply_galois_coeff(const orc_ctx *c, const uint64_t *src, uint64_t *dst, uint32_t galois_elt, size_t limbs, size_t start_idx);
+
+/* ---- evaluation-key generation for functional tests (src/secretkey.cu:232-341, polymath.cu:318-338) ----
+ * sk_ntt [size_QP][N] (NTT form), new_key_ntt [size_Q][N] (NTT form, e.g. s^2 or galois(s)),
+ * a_ntt/e_ntt [dnum][size_QP][N] caller-provided randomness (NTT form); evk [dnum][2][size_QP][N]. */
+void orc_gen_kswitch_key(const orc_ctx *c, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,
+                         const uint64_t *a_ntt, const uint64_t *e_ntt, uint64_t *evk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

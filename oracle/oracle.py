@@ -1,0 +1,337 @@
+"""ctypes binding of oracle/liboracle.so (numpy uint64 arrays in/out).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/oracle.h.  Each wrapper mirrors one C entry point; the
+C code cites the reference file:line it restates.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BFV, CKKS, BGV = 1, 2, 3
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+
+def build(native=False, out=None):
+    """Compile the oracle with gcc.  native=True adds -march=native (used for the CPU baseline)."""
+    out = out or os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+    src = os.path.join(_HERE, "oracle.c")
+    if os.path.exists(out) and os.path.getmtime(out) >= max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "oracle.h"))):
+        return out
+    cmd = ["gcc", "-O3", "-fPIC", "-std=c11", "-fopenmp", "-shared", "-o", out, src]
+    if native:
+        cmd.insert(2, "-march=native")
+    subprocess.check_call(cmd)
+    return out
+
+
+def lib(path=None):
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or build()
+    L = C.CDLL(p)
+    L.orc_is_prime.restype = C.c_int
+    L.orc_is_prime.argtypes = [C.c_uint64]
+    L.orc_get_primes.argtypes = [C.c_uint64, C.c_int, C.c_size_t, u64p]
+    L.orc_coeff_modulus_create.argtypes = [C.c_uint64, C.POINTER(C.c_int), C.c_size_t, u64p]
+    L.orc_const_ratio.argtypes = [C.c_uint64, u64p]
+    L.orc_minimal_primitive_root.argtypes = [C.c_uint64, C.c_uint64, u64p]
+    for f in ("orc_compute_shoup", "orc_invmod", "orc_mulmod"):
+        getattr(L, f).restype = C.c_uint64
+    L.orc_compute_shoup.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_invmod.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_mulmod.argtypes = [C.c_uint64] * 3
+    L.orc_powmod.restype = C.c_uint64
+    L.orc_powmod.argtypes = [C.c_uint64] * 3
+    L.orc_ntt_tables.argtypes = [C.c_int, C.c_uint64, u64p, u64p, u64p, u64p, u64p, u64p]
+    L.orc_ntt_forward.argtypes = [u64p, C.c_int, C.c_uint64, u64p, u64p]
+    L.orc_ntt_inverse.argtypes = [u64p, C.c_int, C.c_uint64, u64p, u64p, C.c_uint64, C.c_uint64]
+    L.orc_ctx_create.restype = C.c_void_p
+    L.orc_ctx_create.argtypes = [C.c_int, u64p, C.c_size_t, C.c_size_t]
+    L.orc_ctx_destroy.argtypes = [C.c_void_p]
+    L.orc_ctx_twiddle.restype = u64p
+    L.orc_ctx_twiddle.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.orc_ctx_n_inv.restype = C.c_uint64
+    L.orc_ctx_n_inv.argtypes = [C.c_void_p, C.c_size_t]
+    L.orc_nwt_forward.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_size_t]
+    L.orc_nwt_backward.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_size_t]
+    L.orc_nwt_forward_map.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t]
+    L.orc_nwt_backward_map.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t]
+    for f in ("orc_add_rns_poly", "orc_sub_rns_poly", "orc_multiply_rns_poly", "orc_multiply_scalar_rns_poly"):
+        getattr(L, f).argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_size_t]
+    L.orc_negate_rns_poly.argtypes = [C.c_void_p, u64p, u64p, C.c_size_t, C.c_size_t]
+    L.orc_multiply_and_add_rns_poly.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p, C.c_size_t, C.c_size_t]
+    L.orc_tensor_prod_2x2.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_size_t]
+    L.orc_tensor_square_2x2.argtypes = [C.c_void_p, u64p, u64p, C.c_size_t]
+    L.orc_bconv.argtypes = [u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, C.c_size_t]
+    L.orc_tool_create.restype = C.c_void_p
+    L.orc_tool_create.argtypes = [C.c_void_p, C.c_size_t]
+    L.orc_tool_destroy.argtypes = [C.c_void_p]
+    L.orc_tool_beta.restype = C.c_size_t
+    L.orc_tool_beta.argtypes = [C.c_void_p]
+    L.orc_modup.argtypes = [C.c_void_p, u64p, u64p, C.c_int]
+    L.orc_key_switch_inner_prod.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p)]
+    L.orc_moddown_from_ntt.argtypes = [C.c_void_p, u64p, u64p, C.c_int]
+    L.orc_keyswitch_inplace.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p), C.c_int]
+    L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+    L.orc_divide_and_round_q_last.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+    L.orc_galois_ntt_table.argtypes = [C.c_int, C.c_uint32, u32p]
+    L.orc_apply_galois_ntt.argtypes = [u64p, u64p, u32p, C.c_size_t, C.c_size_t]
+    L.orc_apply_galois_coeff.argtypes = [C.c_void_p, u64p, u64p, C.c_uint32, C.c_size_t, C.c_size_t]
+    L.orc_gen_kswitch_key.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p, u64p]
+    if path is None:
+        _LIB = L
+    return L
+
+
+def _p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _p32(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def is_prime(v):
+    return bool(lib().orc_is_prime(int(v)))
+
+
+def get_primes(n, bit_size, count):
+    out = np.zeros(count, dtype=np.uint64)
+    if lib().orc_get_primes(n, bit_size, count, _p(out)):
+        raise ValueError("failed to find enough qualifying primes")
+    return out
+
+
+def coeff_modulus_create(n, bit_sizes):
+    bits = (C.c_int * len(bit_sizes))(*bit_sizes)
+    out = np.zeros(len(bit_sizes), dtype=np.uint64)
+    if lib().orc_coeff_modulus_create(n, bits, len(bit_sizes), _p(out)):
+        raise ValueError("failed to find enough qualifying primes")
+    return out
+
+
+def const_ratio(q):
+    r = np.zeros(2, dtype=np.uint64)
+    lib().orc_const_ratio(int(q), _p(r))
+    return int(r[0]), int(r[1])
+
+
+def minimal_primitive_root(degree, q):
+    r = C.c_uint64(0)
+    if lib().orc_minimal_primitive_root(int(degree), int(q), C.byref(r)):
+        raise ValueError("no primitive root")
+    return r.value
+
+
+def compute_shoup(w, q):
+    return lib().orc_compute_shoup(int(w), int(q))
+
+
+def ntt_tables(log_n, q):
+    n = 1 << log_n
+    tw, tws, itw, itws = (np.zeros(n, dtype=np.uint64) for _ in range(4))
+    ni, nis = C.c_uint64(0), C.c_uint64(0)
+    if lib().orc_ntt_tables(log_n, int(q), _p(tw), _p(tws), _p(itw), _p(itws), C.byref(ni), C.byref(nis)):
+        raise ValueError("invalid modulus")
+    return tw, tws, itw, itws, ni.value, nis.value
+
+
+class Ctx:
+    """Tables for a QP chain (mirrors the DNTTTable a PhantomContext uploads, context.cu:170-183)."""
+
+    def __init__(self, log_n, primes_qp, size_p, libpath=None):
+        self.L = lib(libpath)
+        self.log_n = log_n
+        self.n = 1 << log_n
+        self.primes = np.ascontiguousarray(primes_qp, dtype=np.uint64)
+        self.size_qp = len(self.primes)
+        self.size_p = size_p
+        self.size_q = self.size_qp - size_p
+        self.h = self.L.orc_ctx_create(log_n, _p(self.primes), self.size_qp, size_p)
+        if not self.h:
+            raise ValueError("orc_ctx_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_ctx_destroy(self.h)
+            self.h = None
+
+    def twiddle(self, prime_idx, which):
+        ptr = self.L.orc_ctx_twiddle(self.h, prime_idx, which)
+        return np.ctypeslib.as_array(ptr, shape=(self.n,)).copy()
+
+    def n_inv(self, prime_idx):
+        return self.L.orc_ctx_n_inv(self.h, prime_idx)
+
+    # transforms (in place on a copy, returns the copy)
+    def nwt_forward(self, data, limbs, start_idx=0):
+        d = np.array(data, dtype=np.uint64, copy=True).reshape(-1)
+        self.L.orc_nwt_forward(self.h, _p(d), limbs, start_idx)
+        return d.reshape(np.shape(data))
+
+    def nwt_backward(self, data, limbs, start_idx=0):
+        d = np.array(data, dtype=np.uint64, copy=True).reshape(-1)
+        self.L.orc_nwt_backward(self.h, _p(d), limbs, start_idx)
+        return d.reshape(np.shape(data))
+
+    def nwt_forward_map(self, data, prime_idx):
+        d = np.array(data, dtype=np.uint64, copy=True).reshape(-1)
+        m = np.ascontiguousarray(prime_idx, dtype=np.uint32)
+        self.L.orc_nwt_forward_map(self.h, _p(d), _p32(m), len(m))
+        return d.reshape(np.shape(data))
+
+    def nwt_backward_map(self, data, prime_idx):
+        d = np.array(data, dtype=np.uint64, copy=True).reshape(-1)
+        m = np.ascontiguousarray(prime_idx, dtype=np.uint32)
+        self.L.orc_nwt_backward_map(self.h, _p(d), _p32(m), len(m))
+        return d.reshape(np.shape(data))
+
+    def _bin(self, fn, a, b, limbs, start_idx):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        r = np.zeros(limbs * self.n, dtype=np.uint64)
+        fn(self.h, _p(a.reshape(-1)), _p(b.reshape(-1)), _p(r), limbs, start_idx)
+        return r.reshape(limbs, self.n)
+
+    def add(self, a, b, limbs, start_idx=0):
+        return self._bin(self.L.orc_add_rns_poly, a, b, limbs, start_idx)
+
+    def sub(self, a, b, limbs, start_idx=0):
+        return self._bin(self.L.orc_sub_rns_poly, a, b, limbs, start_idx)
+
+    def multiply(self, a, b, limbs, start_idx=0):
+        return self._bin(self.L.orc_multiply_rns_poly, a, b, limbs, start_idx)
+
+    def multiply_scalar(self, a, scalar, limbs, start_idx=0):
+        return self._bin(self.L.orc_multiply_scalar_rns_poly, a, scalar, limbs, start_idx)
+
+    def negate(self, a, limbs, start_idx=0):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        r = np.zeros(limbs * self.n, dtype=np.uint64)
+        self.L.orc_negate_rns_poly(self.h, _p(a.reshape(-1)), _p(r), limbs, start_idx)
+        return r.reshape(limbs, self.n)
+
+    def multiply_and_add(self, a, b, d, limbs, start_idx=0):
+        a, b, d = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1) for x in (a, b, d))
+        r = np.zeros(limbs * self.n, dtype=np.uint64)
+        self.L.orc_multiply_and_add_rns_poly(self.h, _p(a), _p(b), _p(d), _p(r), limbs, start_idx)
+        return r.reshape(limbs, self.n)
+
+    def tensor_prod_2x2(self, op1, op2, limbs):
+        op1, op2 = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1) for x in (op1, op2))
+        r = np.zeros(3 * limbs * self.n, dtype=np.uint64)
+        self.L.orc_tensor_prod_2x2(self.h, _p(op1), _p(op2), _p(r), limbs)
+        return r.reshape(3, limbs, self.n)
+
+    def tensor_square_2x2(self, op, limbs):
+        op = np.ascontiguousarray(op, dtype=np.uint64).reshape(-1)
+        r = np.zeros(3 * limbs * self.n, dtype=np.uint64)
+        self.L.orc_tensor_square_2x2(self.h, _p(op), _p(r), limbs)
+        return r.reshape(3, limbs, self.n)
+
+    def apply_galois_coeff(self, src, galois_elt, limbs, start_idx=0):
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        r = np.zeros(limbs * self.n, dtype=np.uint64)
+        self.L.orc_apply_galois_coeff(self.h, _p(src), _p(r), galois_elt, limbs, start_idx)
+        return r.reshape(limbs, self.n)
+
+    def gen_kswitch_key(self, sk_ntt, new_key_ntt, a_ntt, e_ntt):
+        dnum = self.size_q // self.size_p
+        sk, nk, a, e = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1) for x in (sk_ntt, new_key_ntt, a_ntt, e_ntt))
+        evk = np.zeros(dnum * 2 * self.size_qp * self.n, dtype=np.uint64)
+        self.L.orc_gen_kswitch_key(self.h, _p(sk), _p(nk), _p(a), _p(e), _p(evk))
+        return evk.reshape(dnum, 2, self.size_qp, self.n)
+
+
+def bconv(ibase, obase, src, n):
+    ibase = np.ascontiguousarray(ibase, dtype=np.uint64)
+    obase = np.ascontiguousarray(obase, dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+    dst = np.zeros(len(obase) * n, dtype=np.uint64)
+    lib().orc_bconv(_p(ibase), len(ibase), _p(obase), len(obase), _p(src), _p(dst), n)
+    return dst.reshape(len(obase), n)
+
+
+class Tool:
+    """DRNSTool of one data level (src/rns.cu:11-200): size_ql current data limbs."""
+
+    def __init__(self, ctx, size_ql):
+        self.ctx = ctx
+        self.L = ctx.L
+        self.size_ql = size_ql
+        self.size_qlp = size_ql + ctx.size_p
+        self.n = ctx.n
+        self.h = self.L.orc_tool_create(ctx.h, size_ql)
+        self.beta = self.L.orc_tool_beta(self.h) if ctx.size_p else 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_tool_destroy(self.h)
+            self.h = None
+
+    def _evk_ptrs(self, evks):
+        keep = [np.ascontiguousarray(e, dtype=np.uint64).reshape(-1) for e in evks]
+        arr = (u64p * len(keep))(*[_p(k) for k in keep])
+        return arr, keep
+
+    def modup(self, cks, scheme):
+        cks = np.ascontiguousarray(cks, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(self.beta * self.size_qlp * self.n, dtype=np.uint64)
+        self.L.orc_modup(self.h, _p(dst), _p(cks), scheme)
+        return dst.reshape(self.beta, self.size_qlp, self.n)
+
+    def key_switch_inner_prod(self, t_mod_up, evks):
+        t = np.ascontiguousarray(t_mod_up, dtype=np.uint64).reshape(-1)
+        cx = np.zeros(2 * self.size_qlp * self.n, dtype=np.uint64)
+        arr, keep = self._evk_ptrs(evks)
+        self.L.orc_key_switch_inner_prod(self.h, _p(cx), _p(t), arr)
+        return cx.reshape(2, self.size_qlp, self.n)
+
+    def moddown_from_ntt(self, cx, scheme):
+        cx = np.array(cx, dtype=np.uint64, copy=True).reshape(-1)
+        ct = np.zeros(self.size_ql * self.n, dtype=np.uint64)
+        self.L.orc_moddown_from_ntt(self.h, _p(ct), _p(cx), scheme)
+        return ct.reshape(self.size_ql, self.n)
+
+    def keyswitch_inplace(self, ct, c2, evks, scheme):
+        ct = np.array(ct, dtype=np.uint64, copy=True).reshape(-1)
+        c2 = np.ascontiguousarray(c2, dtype=np.uint64).reshape(-1)
+        arr, keep = self._evk_ptrs(evks)
+        self.L.orc_keyswitch_inplace(self.h, _p(ct), _p(c2), arr, scheme)
+        return ct.reshape(2, self.size_ql, self.n)
+
+    def rescale_ntt(self, src, cipher_size):
+        src = np.array(src, dtype=np.uint64, copy=True).reshape(-1)
+        dst = np.zeros(cipher_size * (self.size_ql - 1) * self.n, dtype=np.uint64)
+        self.L.orc_rescale_ntt(self.h, _p(src), cipher_size, _p(dst))
+        return dst.reshape(cipher_size, self.size_ql - 1, self.n)
+
+    def divide_and_round_q_last(self, src, cipher_size):
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(cipher_size * (self.size_ql - 1) * self.n, dtype=np.uint64)
+        self.L.orc_divide_and_round_q_last(self.h, _p(src), cipher_size, _p(dst))
+        return dst.reshape(cipher_size, self.size_ql - 1, self.n)
+
+
+def galois_ntt_table(log_n, galois_elt):
+    t = np.zeros(1 << log_n, dtype=np.uint32)
+    lib().orc_galois_ntt_table(log_n, galois_elt, _p32(t))
+    return t
+
+
+def apply_galois_ntt(src, table, n, limbs):
+    src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+    dst = np.zeros(limbs * n, dtype=np.uint64)
+    lib().orc_apply_galois_ntt(_p(src), _p(dst), _p32(np.ascontiguousarray(table, dtype=np.uint32)), n, limbs)
+    return dst.reshape(limbs, n)

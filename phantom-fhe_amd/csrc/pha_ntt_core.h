@@ -1,0 +1,253 @@
+// pha_ntt_core.h -- workgroup-tile NTT passes for gfx950.
+//
+// What it computes (reference semantics): the in-place negacyclic NTT of
+// src/ntt/fntt_2d.cu:9-198,620-653 (forward: natural in -> bit-reversed out, canonical [0,q)) and
+// src/ntt/intt_2d.cu:9-311,724-794 (inverse: bit-reversed in -> natural out, times N^-1), i.e. the
+// SEAL-order Cooley-Tukey / Gentleman-Sande stage loops with twiddle tw[m + i] for group i of the
+// stage with m groups (src/ntt/ntt_1d.cu:50, include/butterfly.cuh:39-96).
+//
+// How (MI355X-first, not the reference's 2-phase radix-8 split):
+//   * N = T1 * T2.  Two passes, each one workgroup (256 threads = 4 wavefronts) per 4096-element
+//     tile held in 32 KiB of LDS, 16 coefficients per thread in registers:
+//       strided pass  : T1-point transforms along stride T2 (first log2 T1 forward stages); a tile
+//                       is T1 rows x V=4096/T1 adjacent columns, so every global access is a run
+//                       of V*8 >= 128 contiguous bytes and every twiddle is shared by all columns.
+//       contiguous pass: T2-point transforms on V=4096/T2 whole rows (a contiguous 32 KiB chunk).
+//   * Inside a pass the log2 T stages are grouped into 2-3 register rounds of radix 16/8
+//     (4/3 stages each); rounds exchange data through padded LDS, one barrier per exchange.
+//   * The limb (RNS prime) index is uniform per workgroup (blockIdx.y), so modulus, 2q and the
+//     table base live in SGPRs and no per-thread divide/modulo by N is needed.
+//   * Twiddles are stored interleaved (w, w') so one 16-byte load feeds one butterfly.
+//
+// Everything here is plain templated C++ that also compiles for the host so tests/emu can replay
+// the exact thread program (indexing, LDS layout, twiddle addressing) on the CPU against the oracle.
+#pragma once
+#include "pha_arith.h"
+
+namespace pha {
+
+constexpr int kThreads = 256;      // 4 wavefronts of 64
+constexpr int kElemsPerThread = 16;
+constexpr int kTileElems = kThreads * kElemsPerThread;  // 4096 coefficients = 32 KiB
+
+// Epilogues of the last round of a transform (what is stored to global memory).
+enum Epilogue {
+    EPI_NONE = 0,         // intermediate pass: store lazy values
+    EPI_FWD_CANON = 1,    // forward: csub 2q, csub q            (fntt_2d.cu:187-193)
+    EPI_FWD_MODDOWN = 2,  // forward: out = (cx - NTT(delta)) * PInv  (ntt_moddown.cu:203-208)
+    EPI_INV_CANON = 3,    // inverse: csub q                     (intt_2d.cu:201-205)
+    EPI_INV_SCALE = 4,    // inverse: full Shoup multiply by per-limb scale (intt_2d.cu:305-309)
+};
+
+// Round schedule of one pass: LOGT stages split into NR rounds of R0,R1,R2 stages (forward order).
+template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0>
+struct PassCfg {
+    static constexpr int LOGT = LOGT_;
+    static constexpr int T = 1 << LOGT_;
+    static constexpr int LOGV = 12 - LOGT_;  // tile = 4096 elements
+    static constexpr int V = 1 << LOGV;
+    static constexpr bool STRIDED = STRIDED_;
+    static constexpr int NR = R2_ ? 3 : 2;
+    static_assert(R0_ + R1_ + R2_ == LOGT_, "round schedule must cover all stages");
+    static_assert(LOGT_ >= 4 && LOGT_ <= 12, "tile transform length out of range");
+    static constexpr int r(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : R2_; }
+    static constexpr int s0(int i) { return i == 0 ? 0 : i == 1 ? R0_ : R0_ + R1_; }
+    // LDS layouts (u64 units).  contiguous pass: [v][e] with 2 words of padding per 16 so that a
+    // thread's 16-coefficient run starts on a distinct 16-byte bank slot (ds_read_b128, 16-lane
+    // groups).  strided pass: [e][v] with one 128-byte skew per 16 rows (ds_read_b64).
+    static constexpr int PITCH = T + ((T >> 4) << 1);
+    static constexpr int LDS_WORDS = STRIDED_ ? (T * V + (T >> 4) * 16) : (V * PITCH);
+    static constexpr int lds_index(int e, int v) {
+        return STRIDED_ ? (e * V + v + ((e >> 4) << 4)) : (v * PITCH + e + ((e >> 4) << 1));
+    }
+};
+
+// Per-workgroup arguments (all uniform across the workgroup -> SGPRs).
+struct PassArgs {
+    const u64 *in;     // limb base to read (first round only)
+    u64 *out;          // limb base to write (last round only)
+    const u64x2 *tw;   // this prime's twiddle row: forward table or inverse table
+    u64 q;             // modulus
+    u32 tile;          // tile index inside the limb
+    u32 rho0;          // contiguous pass: T1 (root index of row r is T1 + r); strided pass: unused
+    u32 stride;        // strided pass: distance in elements between consecutive rows (= T2)
+    // inverse last stage: N^-1 and itw[1]*N^-1 (intt_2d.cu:195-198 / host/ntt.cu:53-55)
+    u64x2 ninv, w1ninv;
+    // epilogue operands
+    u64x2 scale;       // EPI_INV_SCALE: per-limb scale ; EPI_FWD_MODDOWN: PInv mod q
+    const u64 *aux;    // EPI_FWD_MODDOWN: cx limb base
+};
+
+template <class C>
+PHA_HD size_t global_index(const PassArgs &a, int e, int v) {
+    if (C::STRIDED) return (size_t)e * a.stride + (size_t)a.tile * C::V + v;
+    return ((size_t)a.tile * C::V + v) * C::T + e;
+}
+
+// Decode radix-group g of round RI into (vector lane v, high part hi, low part lo):
+// element e(k) = hi * (D << r) + k * D + lo with D = T >> (s0 + r).
+template <class C, int RI>
+PHA_HD void decode_group(int g, int &v, int &hi, int &lo) {
+    constexpr int r = C::r(RI), s0 = C::s0(RI), LOGD = C::LOGT - s0 - r;
+    if (C::STRIDED) {
+        v = g & (C::V - 1);
+        int rest = g >> C::LOGV;
+        lo = rest & ((1 << LOGD) - 1);
+        hi = rest >> LOGD;
+    } else {
+        lo = g & ((1 << LOGD) - 1);
+        int rest = g >> LOGD;
+        hi = rest & ((1 << s0) - 1);
+        v = rest >> s0;
+    }
+}
+
+// r forward stages on 2^r registers; stage j uses tw[(base0 << j) + (k >> (r - j))].
+template <int R>
+PHA_HD void ct_round(u64 *v, const u64x2 *tw, u32 base0, u64 q, u64 q2) {
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int dist = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+            if (k & dist) continue;
+            const int kk = k >> (R - j);
+            ct_bfly(v[k], v[k + dist], tw[(base0 << j) + kk], q, q2);
+        }
+    }
+}
+
+// r inverse stages (reverse order).  FOLD: the j == 0 stage is the transform's last stage (m = 1)
+// and carries N^-1: X' = (X+Y)*ninv, Y' = (X-Y)*(itw[1]*ninv), both lazy [0,2q).
+template <int R, bool FOLD>
+PHA_HD void gs_round(u64 *v, const u64x2 *tw, u32 base0, u64 q, u64 q2, u64x2 ninv, u64x2 w1ninv) {
+#pragma unroll
+    for (int j = R - 1; j >= 0; j--) {
+        const int dist = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+            if (k & dist) continue;
+            const int kk = k >> (R - j);
+            if (FOLD && j == 0) {
+                u64 s = v[k] + v[k + dist];
+                u64 d = v[k] + q2 - v[k + dist];
+                v[k] = shoup_lazy(s, ninv, q);
+                v[k + dist] = shoup_lazy(d, w1ninv, q);
+            } else {
+                gs_bfly(v[k], v[k + dist], tw[(base0 << j) + kk], q, q2);
+            }
+        }
+    }
+}
+
+template <int EPI>
+PHA_HD u64 apply_epilogue(u64 x, const PassArgs &a, size_t gi) {
+    const u64 q = a.q;
+    if (EPI == EPI_FWD_CANON) return csub(csub(x, q << 1), q);
+    if (EPI == EPI_FWD_MODDOWN) {
+        u64 t = csub(csub(x, q << 1), q);
+        return shoup(sub_mod(a.aux[gi], t, q), a.scale, q);  // sub_negate_const_mult uintmodmath.cuh:233-241
+    }
+    if (EPI == EPI_INV_CANON) return csub(x, q);
+    if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);
+    return x;
+}
+
+// Load one round's registers (from global on the first round, else from LDS) and run its stages.
+template <class C, int RI, bool FWD, bool FROM_GLOBAL, bool FOLD>
+PHA_HD void round_in(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
+    constexpr int r = C::r(RI), K = 1 << r, G = kElemsPerThread >> r, s0 = C::s0(RI);
+    constexpr int LOGD = C::LOGT - s0 - r;
+    const u64 q = a.q, q2 = a.q << 1;
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        int v, hi, lo;
+        decode_group<C, RI>(tid + kThreads * gi, v, hi, lo);
+        u64 *rg = reg + gi * K;
+        const int e0 = (hi << (LOGD + r)) + lo;
+        if (FROM_GLOBAL) {
+            if (!C::STRIDED && LOGD == 0) {  // K contiguous coefficients: 16-byte loads
+                const u64x2 *p = reinterpret_cast<const u64x2 *>(a.in + global_index<C>(a, e0, v));
+#pragma unroll
+                for (int k = 0; k < K; k += 2) {
+                    u64x2 t = p[k >> 1];
+                    rg[k] = t.x;
+                    rg[k + 1] = t.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; k++) rg[k] = a.in[global_index<C>(a, e0 + (k << LOGD), v)];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) rg[k] = lds[C::lds_index(e0 + (k << LOGD), v)];
+        }
+        const u32 rho = C::STRIDED ? 1u : (a.rho0 + a.tile * C::V + (u32)v);
+        const u32 base0 = (rho << s0) + (u32)hi;
+        if (FWD) ct_round<r>(rg, a.tw, base0, q, q2);
+        else gs_round<r, FOLD>(rg, a.tw, base0, q, q2, a.ninv, a.w1ninv);
+    }
+}
+
+// Store one round's registers (to LDS, or to global with the epilogue on the last round).
+template <class C, int RI, bool TO_GLOBAL, int EPI>
+PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
+    constexpr int r = C::r(RI), K = 1 << r, G = kElemsPerThread >> r, s0 = C::s0(RI);
+    constexpr int LOGD = C::LOGT - s0 - r;
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        int v, hi, lo;
+        decode_group<C, RI>(tid + kThreads * gi, v, hi, lo);
+        const u64 *rg = reg + gi * K;
+        const int e0 = (hi << (LOGD + r)) + lo;
+        if (TO_GLOBAL) {
+            if (!C::STRIDED && LOGD == 0) {
+                const size_t g0 = global_index<C>(a, e0, v);
+                u64x2 *p = reinterpret_cast<u64x2 *>(a.out + g0);
+#pragma unroll
+                for (int k = 0; k < K; k += 2) {
+                    u64x2 t;
+                    t.x = apply_epilogue<EPI>(rg[k], a, g0 + k);
+                    t.y = apply_epilogue<EPI>(rg[k + 1], a, g0 + k + 1);
+                    p[k >> 1] = t;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const size_t gidx = global_index<C>(a, e0 + (k << LOGD), v);
+                    a.out[gidx] = apply_epilogue<EPI>(rg[k], a, gidx);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) lds[C::lds_index(e0 + (k << LOGD), v)] = rg[k];
+        }
+    }
+}
+
+// A pass as a list of barrier-separated segments, one per round (a round reads and writes the same
+// LDS slots, so only the hand-over between rounds needs a barrier).  FWD runs rounds 0..NR-1,
+// inverse NR-1..0.  FOLD (inverse only): this pass holds the transform's last stage (round 0).
+template <class C, bool FWD, int EPI, bool FOLD>
+struct PassProgram {
+    static constexpr int NSEG = C::NR;
+
+    template <int SEG>
+    PHA_HD static void run(const PassArgs &a, u64 *lds, int tid, u64 *reg) {
+        constexpr int RI = FWD ? SEG : C::NR - 1 - SEG;
+        constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
+        round_in<C, RI, FWD, first, FOLD && RI == 0>(a, lds, tid, reg);
+        round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
+    }
+};
+
+// Split N = T1 * T2 per log2 N, with the round schedules of each pass.
+template <int LOGN> struct NttPlan;
+template <> struct NttPlan<12> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<6, false, 3, 3>; };
+template <> struct NttPlan<13> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<7, false, 4, 3>; };
+template <> struct NttPlan<14> { using P1 = PassCfg<7, true, 4, 3>;  using P2 = PassCfg<7, false, 4, 3>; };
+template <> struct NttPlan<15> { using P1 = PassCfg<7, true, 4, 3>;  using P2 = PassCfg<8, false, 4, 4>; };
+template <> struct NttPlan<16> { using P1 = PassCfg<8, true, 4, 4>;  using P2 = PassCfg<8, false, 4, 4>; };
+template <> struct NttPlan<17> { using P1 = PassCfg<8, true, 4, 4>;  using P2 = PassCfg<9, false, 3, 3, 3>; };
+
+}  // namespace pha
