@@ -1,0 +1,154 @@
+/*
+ * phantom_amd.h -- C ABI of the MI355X-native RNS polynomial-arithmetic core (libphantom_amd.so).
+ *
+ * The reference (encryptorion-lab/phantom-fhe) has no FFI layer: its boundary for this path is the
+ * C++ launchers in include/ntt.cuh:157-226, the DRNSTool / DBaseConverter methods
+ * (include/rns.cuh:156-205, include/rns_bconv.cuh:62-68) and phantom::key_switch_inner_prod /
+ * keyswitch_inplace (include/evaluate.cuh:18-32).  Each entry point below replaces exactly one of
+ * those and keeps its argument meaning; the only changes are (i) `const DNTTTable&` / `DRNSTool&`
+ * become an opaque context handle plus the level (number of live data limbs), (ii) `cudaStream_t`
+ * becomes `void*` (a hipStream_t; NULL = the legacy default stream), (iii) C++ exceptions become
+ * an int status (0 = PHA_OK) with pha_last_error() carrying the what() text.
+ *
+ * All `uint64_t*` data arguments are DEVICE pointers owned by the caller, limb-major contiguous
+ * `data[limb * N + coeff]`, values canonical in [0, q_limb).  No entry point
+ * allocates caller-visible memory; scratch comes from a per-context, per-stream arena.
+ * Nothing here touches torch types.
+ */
+#ifndef PHANTOM_AMD_H
+#define PHANTOM_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pha_context *pha_context_t;
+
+enum { PHA_OK = 0, PHA_ERR_INVALID_ARGUMENT = -1, PHA_ERR_LOGIC = -2, PHA_ERR_RUNTIME = -3 };
+/* scheme_type values of include/host/encryptionparams.h:19-27 */
+enum { PHA_SCHEME_BFV = 1, PHA_SCHEME_CKKS = 2, PHA_SCHEME_BGV = 3 };
+
+/* what() of the last failing call on this thread (std::invalid_argument / logic_error /
+ * "HIP Runtime Error" -- mirrors include/cuda_wrapper.cuh:19-43). */
+const char *pha_last_error(void);
+
+/* ---- host precompute (replaces src/host/modulus.cu:82-111 CoeffModulus::Create and the
+ *      hard-coded default table src/host/globals.cu:30-120) ---- */
+int pha_coeff_modulus_create(uint64_t poly_modulus_degree, const int *bit_sizes, size_t count, uint64_t *out);
+
+/* ---- context: replaces PhantomContext's hot-path state (src/context.cu:121-232): one DNTTTable for
+ *      all QP primes (include/ntt.cuh:34-129) plus a DRNSTool per level (src/rns.cu:11-200), built
+ *      lazily and cached.  primes_qp = [Q primes..., P primes...]; size_p = special_modulus_size. ---- */
+int pha_context_create(pha_context_t *out, uint32_t log_n, const uint64_t *primes_qp, uint32_t size_qp,
+                       uint32_t size_p, int device_id);
+void pha_context_destroy(pha_context_t ctx);
+uint32_t pha_context_log_n(pha_context_t ctx);
+uint32_t pha_context_size_qp(pha_context_t ctx);
+uint32_t pha_context_size_p(pha_context_t ctx);
+/* host copies of per-prime constants, for callers that mirror DNTTTable getters */
+int pha_context_prime_info(pha_context_t ctx, uint32_t prime_idx, uint64_t *value, uint64_t const_ratio[2],
+                           uint64_t *root, uint64_t *n_inv);
+/* download one twiddle row (host buffers of N words): which = 0 twiddle, 1 twiddle_shoup,
+ * 2 itwiddle, 3 itwiddle_shoup -- same content as DNTTTable::twiddle()/itwiddle() rows
+ * (itwiddle[1] carries N^-1 exactly like src/host/ntt.cu:53-55). */
+int pha_context_download_twiddle(pha_context_t ctx, uint32_t prime_idx, int which, uint64_t *host_out);
+/* level tool queries (DRNSTool): beta = number of key-switch digits at this level */
+int pha_tool_beta(pha_context_t ctx, uint32_t size_ql, uint32_t *beta);
+
+/* ---- NTT launchers (include/ntt.cuh:178-226).  Processed limbs are
+ *      [start_modulus_idx, start_modulus_idx + coeff_modulus_size) of the buffer. ---- */
+int pha_nwt_2d_radix8_forward_inplace(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                      size_t start_modulus_idx, void *stream);
+int pha_nwt_2d_radix8_forward_inplace_include_special_mod(pha_context_t ctx, uint64_t *inout,
+                                                          size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                          size_t size_QP, size_t size_P, void *stream);
+int pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(
+    pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, size_t start_modulus_idx, size_t size_QP,
+    size_t size_P, size_t excluded_range_start, size_t excluded_range_end, void *stream);
+int pha_nwt_2d_radix8_forward_inplace_fuse_moddown(pha_context_t ctx, uint64_t *ct, const uint64_t *cx,
+                                                   const uint64_t *bigPInv_mod_q,
+                                                   const uint64_t *bigPInv_mod_q_shoup, uint64_t *delta,
+                                                   size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                   void *stream);
+int pha_nwt_2d_radix8_backward_inplace(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                       size_t start_modulus_idx, void *stream);
+int pha_nwt_2d_radix8_backward(pha_context_t ctx, uint64_t *out, const uint64_t *in, size_t coeff_modulus_size,
+                               size_t start_modulus_idx, void *stream);
+int pha_nwt_2d_radix8_backward_scale(pha_context_t ctx, uint64_t *out, const uint64_t *in,
+                                     size_t coeff_modulus_size, size_t start_modulus_idx, const uint64_t *scale,
+                                     const uint64_t *scale_shoup, void *stream);
+int pha_nwt_2d_radix8_backward_inplace_scale(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                             size_t start_modulus_idx, const uint64_t *scale,
+                                             const uint64_t *scale_shoup, void *stream);
+int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context_t ctx, uint64_t *inout,
+                                                           size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                           size_t size_QP, size_t size_P, void *stream);
+
+/* ---- dyadic kernels (include/polymath.cuh:6-307, launched <<<N*L/128,128>>> by evaluate.cu).
+ *      The reference passes `const DModulus *modulus` (a row of the QP table); here that is
+ *      (ctx, mod_start_idx).  Buffers hold coeff_mod_size limbs. ---- */
+int pha_add_rns_poly(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *result,
+                     size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+int pha_sub_rns_poly(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *result,
+                     size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+int pha_negate_rns_poly(pha_context_t ctx, const uint64_t *op, uint64_t *result, size_t coeff_mod_size,
+                        size_t mod_start_idx, void *stream);
+int pha_multiply_rns_poly(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *result,
+                          size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+int pha_multiply_and_add_rns_poly(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2,
+                                  const uint64_t *op3, uint64_t *result, size_t coeff_mod_size,
+                                  size_t mod_start_idx, void *stream);
+/* Shoup overload polymath.cuh:97-103: scalar / scalar_shoup are device arrays, one entry per limb */
+int pha_multiply_scalar_rns_poly(pha_context_t ctx, const uint64_t *op, const uint64_t *scalar,
+                                 const uint64_t *scalar_shoup, uint64_t *result, size_t coeff_mod_size,
+                                 size_t mod_start_idx, void *stream);
+/* tensor_prod_2x2_rns_poly / tensor_square_2x2_rns_poly: operands [2][L][N], result [3][L][N];
+ * result may alias operand1 (evaluate.cu:377-383 calls it in place). */
+int pha_tensor_prod_2x2_rns_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2,
+                                 uint64_t *result, size_t coeff_mod_size, void *stream);
+int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *operand, uint64_t *result,
+                                   size_t coeff_mod_size, void *stream);
+/* add_to_ct_kernel (src/rns_bconv.cu:763-769) */
+int pha_add_to_ct(pha_context_t ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, void *stream);
+
+/* ---- RNS tool at level size_Ql (DRNSTool of context_data(chain) with size_Ql data limbs) ---- */
+/* DBaseConverter::bConv_BEHZ for base_P_to_Ql_conv (rns_bconv.cu:212-229): src [P][N] -> dst [Ql][N] */
+int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
+/* DRNSTool::modup (rns_bconv.cu:530-627): cks [Ql][N] -> dst [beta][Ql+P][N] */
+int pha_modup(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *cks, int scheme, void *stream);
+/* phantom::key_switch_inner_prod (eval_key_switch.cu:71-92): rlk = DEVICE array of beta device
+ * pointers, each key [2][size_QP][N]; p_cx [2][Ql+P][N] */
+int pha_key_switch_inner_prod(pha_context_t ctx, size_t size_Ql, uint64_t *p_cx, const uint64_t *p_t_mod_up,
+                              const uint64_t *const *rlk, void *stream);
+/* DRNSTool::moddown_from_NTT (rns_bconv.cu:776-828): cx_i [Ql+P][N] (P limbs are clobbered,
+ * exactly as in the reference) -> ct_i [Ql][N]; ct_i may alias cx_i */
+int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint64_t *cx_i, int scheme,
+                         void *stream);
+/* phantom::keyswitch_inplace (eval_key_switch.cu:95-182) on raw buffers: ct [2][Ql][N] += KS(c2) */
+int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
+                          const uint64_t *const *rlk, int scheme, void *stream);
+/* DRNSTool::divide_and_round_q_last_ntt (rns.cu:1160-1184): src [cipher][Ql][N] (last limb is
+ * clobbered, as in the reference) -> dst [cipher][Ql-1][N] */
+int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,
+                                    uint64_t *dst, void *stream);
+/* DRNSTool::divide_and_round_q_last (rns.cu:1113-1126), BFV coefficient-domain mod switch */
+int pha_divide_and_round_q_last(pha_context_t ctx, size_t size_Ql, const uint64_t *src, size_t cipher_size,
+                                uint64_t *dst, void *stream);
+
+/* ---- Galois (include/galois.cuh:98-130, src/galois.cu:11-39,67-102) ---- */
+int pha_apply_galois_ntt(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt,
+                         size_t coeff_mod_size, void *stream);
+int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt,
+                     size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+
+/* ---- measurement hook used by bench.py: time `iters` back-to-back launches of the forward NTT
+ *      with hipEvents on `stream`; returns average milliseconds per launch in *ms_out. ---- */
+int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, int iters,
+                         void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

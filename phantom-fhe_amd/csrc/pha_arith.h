@@ -18,7 +18,7 @@
 
 namespace pha {
 
-typedef unsigned long long u64;
+typedef uint64_t u64;
 typedef unsigned int u32;
 
 // (value, Shoup companion floor(value * 2^64 / q)) -- one 16-byte load fetches both.

@@ -1,0 +1,424 @@
+// pha_context.hip -- host precompute + device tables behind pha_context_t.
+//
+// Replaces, for the hot path only: PhantomContext's table upload (src/context.cu:170-183,
+// include/ntt.cuh:34-129), the SEAL-derived host tables (src/host/ntt.cu:11-56, src/host/rns.cu:282-337,
+// 438-497) and the hybrid key-switch part of the DRNSTool constructor (src/rns.cu:66-200).
+// Written independently of oracle/ (different inverse / primality / root-search code paths) so the
+// two can check each other.  Each prime's tables are computed once and shared by every level
+// (the reference recomputes them per ContextData).
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+#include "../../include/phantom_amd.h"
+#include "pha_internal.h"
+
+namespace pha {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void set_last_error(const char *what) { g_last_error = what ? what : ""; }
+int translate_exception() {
+    try {
+        throw;
+    } catch (const std::invalid_argument &e) {
+        set_last_error(e.what());
+        return PHA_ERR_INVALID_ARGUMENT;
+    } catch (const std::logic_error &e) {
+        set_last_error(e.what());
+        return PHA_ERR_LOGIC;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return PHA_ERR_RUNTIME;
+    } catch (...) {
+        set_last_error("unknown error");
+        return PHA_ERR_RUNTIME;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host number theory
+// ------------------------------------------------------------------------------------------------
+typedef unsigned __int128 u128;
+
+u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+u64 h_powmod(u64 a, u64 e, u64 q) {
+    u64 r = 1 % q;
+    a %= q;
+    for (; e; e >>= 1) {
+        if (e & 1) r = h_mulmod(r, a, q);
+        a = h_mulmod(a, a, q);
+    }
+    return r;
+}
+// extended Euclid (the reference's try_invert_uint_mod is xgcd as well, src/host/numth.cu)
+u64 h_invmod(u64 a, u64 q) {
+    __int128 t = 0, nt = 1, r = q, nr = a % q;
+    while (nr) {
+        __int128 k = r / nr;
+        __int128 tmp = t - k * nt; t = nt; nt = tmp;
+        tmp = r - k * nr; r = nr; nr = tmp;
+    }
+    if (r != 1) throw std::logic_error("value is not invertible modulo q");
+    if (t < 0) t += q;
+    return (u64)t;
+}
+u64 h_shoup(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+DModulus h_modulus(u64 q) {
+    u128 r = (~(u128)0) / q;  // floor(2^128/q) for q not a power of two
+    return DModulus{q, (u64)r, (u64)(r >> 64)};
+}
+uint32_t h_brev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+bool h_is_prime(u64 n) {
+    // deterministic Miller-Rabin, 7-base set valid for all n < 2^64
+    if (n < 2) return false;
+    static const u64 small[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (u64 p : small) {
+        if (n == p) return true;
+        if (n % p == 0) return false;
+    }
+    u64 d = n - 1;
+    int s = 0;
+    while (!(d & 1)) { d >>= 1; s++; }
+    static const u64 bases[] = {2, 325, 9375, 28178, 450775, 9780504, 1795265022};
+    for (u64 a : bases) {
+        u64 x = h_powmod(a % n, d, n);
+        if (x == 0 || x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int i = 1; i < s; i++) {
+            x = h_mulmod(x, x, n);
+            if (x == n - 1) { comp = false; break; }
+        }
+        if (comp) return false;
+    }
+    return true;
+}
+// minimal primitive degree-th root (degree = 2N a power of two): src/host/numth.cu:309-331.
+u64 h_minimal_primitive_root(u64 degree, u64 q) {
+    if ((q - 1) % degree) throw std::invalid_argument("invalid modulus in try_minimal_primitive_root");
+    const u64 quo = (q - 1) / degree;
+    u64 root = 0;
+    for (u64 g = 3; g < 4096 && !root; g += 2) {  // any generator-ish start; the minimum is start-independent
+        u64 r = h_powmod(g, quo, q);
+        if (h_powmod(r, degree >> 1, q) == q - 1) root = r;
+    }
+    if (!root) throw std::invalid_argument("invalid modulus in try_minimal_primitive_root");
+    const u64 sq = h_mulmod(root, root, q);
+    u64 cur = root, best = root;
+    for (u64 i = 0; i < degree / 2; i++) {  // the degree/2 odd powers are all the primitive roots
+        if (cur < best) best = cur;
+        cur = h_mulmod(cur, sq, q);
+    }
+    return best;
+}
+
+static void get_primes(u64 ntt_size, int bit_size, size_t count, std::vector<u64> &out) {
+    // src/host/numth.cu:207-233
+    if (bit_size < 2 || bit_size > 61) throw std::invalid_argument("bit_sizes is invalid");
+    const u64 factor = 2 * ntt_size;
+    u64 value = (u64)1 << bit_size;
+    if (value < factor) throw std::logic_error("failed to find enough qualifying primes");
+    value = value - factor + 1;
+    const u64 lower = (u64)1 << (bit_size - 1);
+    while (count > 0 && value > lower) {
+        if (h_is_prime(value)) { out.push_back(value); count--; }
+        value -= factor;
+    }
+    if (count > 0) throw std::logic_error("failed to find enough qualifying primes");
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, std::vector<u64x2> &itw,
+                               std::vector<u64x2> &ninv, std::vector<u64x2> &w1ninv) {
+    const u64 q = c.primes[i];
+    const size_t n = c.n;
+    const u64 psi = h_minimal_primitive_root(2 * n, q);
+    const u64 ipsi = h_invmod(psi, q);
+    c.roots[i] = psi;
+    u64x2 *t = tw.data() + (size_t)i * n, *it = itw.data() + (size_t)i * n;
+    u64 pw = 1, ipw = 1;
+    for (size_t e = 0; e < n; e++) {  // slot brev(e) holds psi^e (src/host/ntt.cu:27-33)
+        const uint32_t k = h_brev((uint32_t)e, (int)c.log_n);
+        t[k] = u64x2{pw, h_shoup(pw, q)};
+        it[k] = u64x2{ipw, h_shoup(ipw, q)};
+        pw = h_mulmod(pw, psi, q);
+        ipw = h_mulmod(ipw, ipsi, q);
+    }
+    const u64 ni = h_invmod((u64)(n % q), q);
+    c.n_inv[i] = ni;
+    ninv[i] = u64x2{ni, h_shoup(ni, q)};
+    const u64 w1 = h_mulmod(it[1].x, ni, q);  // what the reference stores in itwiddle[1] (ntt.cu:53-55)
+    w1ninv[i] = u64x2{w1, h_shoup(w1, q)};
+}
+
+static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uint32_t size_qp, uint32_t size_p,
+                         int device) {
+    if (log_n < 12 || log_n > 17) throw std::invalid_argument("poly_modulus_degree is invalid (2^12..2^17 supported)");
+    if (size_qp < 1 || size_qp > 64 || size_p >= size_qp) throw std::invalid_argument("RNSBase is invalid");
+    c.device = device;
+    PHA_HIP(hipSetDevice(device));
+    c.log_n = log_n;
+    c.n = (size_t)1 << log_n;
+    c.size_qp = size_qp;
+    c.size_p = size_p;
+    c.size_q = size_qp - size_p;
+    c.primes.assign(primes, primes + size_qp);
+    c.roots.resize(size_qp);
+    c.n_inv.resize(size_qp);
+    c.mods.resize(size_qp);
+    for (uint32_t i = 0; i < size_qp; i++) {
+        const u64 q = c.primes[i];
+        if (q >> 61) throw std::invalid_argument("modulus exceeds 61 bits");
+        if (!h_is_prime(q) || (q - 1) % (2 * c.n)) throw std::invalid_argument("modulus is not an NTT prime");
+        for (uint32_t j = 0; j < i; j++)
+            if (c.primes[j] == q) throw std::invalid_argument("coeff_modulus is not coprime");
+        c.mods[i] = h_modulus(q);
+    }
+    std::vector<u64x2> tw((size_t)size_qp * c.n), itw((size_t)size_qp * c.n), ninv(size_qp), w1ninv(size_qp);
+    {
+        const unsigned nthreads = std::max(1u, std::min(std::thread::hardware_concurrency(), size_qp));
+        std::vector<std::thread> pool;
+        std::vector<std::string> errs(nthreads);
+        for (unsigned t = 0; t < nthreads; t++)
+            pool.emplace_back([&, t] {
+                try {
+                    for (uint32_t i = t; i < size_qp; i += nthreads) build_prime_tables(c, i, tw, itw, ninv, w1ninv);
+                } catch (const std::exception &e) { errs[t] = e.what(); }
+            });
+        for (auto &th : pool) th.join();
+        for (auto &e : errs)
+            if (!e.empty()) throw std::invalid_argument(e);
+    }
+    c.d_mod.upload(c.mods);
+    c.d_tw.upload(tw);
+    c.d_itw.upload(itw);
+    c.d_ninv.upload(ninv);
+    c.d_w1ninv.upload(w1ninv);
+}
+
+// q-hat_i^-1 mod q_i and q-hat_i mod p_j for an (ibase -> obase) converter: src/host/rns.cu:282-337,438-457
+static void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op) {
+    b.isz = (uint32_t)ip.size();
+    b.osz = (uint32_t)op.size();
+    b.iprime = ip;
+    b.oprime = op;
+    std::vector<u64x2> hat_inv(b.isz);
+    for (uint32_t i = 0; i < b.isz; i++) {
+        const u64 qi = c.primes[ip[i]];
+        u64 h = 1;
+        for (uint32_t k = 0; k < b.isz; k++)
+            if (k != i) h = h_mulmod(h, c.primes[ip[k]] % qi, qi);
+        const u64 inv = h_invmod(h, qi);
+        hat_inv[i] = u64x2{inv, h_shoup(inv, qi)};
+    }
+    std::vector<u64> mat((size_t)b.osz * b.isz);
+    for (uint32_t j = 0; j < b.osz; j++) {
+        const u64 pj = c.primes[op[j]];
+        for (uint32_t i = 0; i < b.isz; i++) {
+            u64 h = 1;
+            for (uint32_t k = 0; k < b.isz; k++)
+                if (k != i) h = h_mulmod(h, c.primes[ip[k]] % pj, pj);
+            mat[(size_t)j * b.isz + i] = h;
+        }
+    }
+    b.hat_inv.upload(hat_inv);
+    b.mat.upload(mat);
+    b.d_iprime.upload(ip);
+    b.d_oprime.upload(op);
+}
+
+Tool &Context::tool(uint32_t size_ql) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tools.find(size_ql);
+    if (it != tools.end()) return *it->second;
+    if (size_ql < 1 || size_ql > size_q) throw std::invalid_argument("RNSBase is invalid");
+    PHA_HIP(hipSetDevice(device));
+    auto t = std::make_unique<Tool>();
+    t->size_ql = size_ql;
+    t->alpha = size_p;
+    t->size_qlp = size_ql + size_p;
+    for (uint32_t i = 0; i < size_ql; i++) t->qlp_prime.push_back(i);
+    for (uint32_t i = 0; i < size_p; i++) t->qlp_prime.push_back(size_q + i);
+    t->d_qlp_prime.upload(t->qlp_prime);
+    // rescale: q_last^-1 mod q_i (rns.cu:66-80)
+    if (size_ql > 1) {
+        std::vector<u64> v(size_ql - 1), vs(size_ql - 1);
+        std::vector<u64x2> v2(size_ql - 1);
+        for (uint32_t i = 0; i + 1 < size_ql; i++) {
+            v[i] = h_invmod(primes[size_ql - 1] % primes[i], primes[i]);
+            vs[i] = h_shoup(v[i], primes[i]);
+            v2[i] = u64x2{v[i], vs[i]};
+        }
+        t->inv_q_last.upload(v);
+        t->inv_q_last_shoup.upload(vs);
+        t->inv_q_last2.upload(v2);
+    }
+    if (size_p) {
+        // P^-1 mod q_i (rns.cu:110-123)
+        std::vector<u64> v(size_ql), vs(size_ql);
+        std::vector<u64x2> v2(size_ql);
+        for (uint32_t i = 0; i < size_ql; i++) {
+            u64 p = 1;
+            for (uint32_t k = 0; k < size_p; k++) p = h_mulmod(p, primes[size_q + k] % primes[i], primes[i]);
+            v[i] = h_invmod(p, primes[i]);
+            vs[i] = h_shoup(v[i], primes[i]);
+            v2[i] = u64x2{v[i], vs[i]};
+        }
+        t->pinv.upload(v);
+        t->pinv_shoup.upload(vs);
+        t->pinv2.upload(v2);
+        // digits (rns.cu:152-190)
+        t->beta = (size_ql + t->alpha - 1) / t->alpha;
+        t->digit.resize(t->beta);
+        std::vector<u64> phi(size_ql), phis(size_ql);
+        for (uint32_t b = 0; b < t->beta; b++) {
+            const uint32_t s = t->alpha * b;
+            const uint32_t len = (b == t->beta - 1) ? size_ql - t->alpha * (t->beta - 1) : t->alpha;
+            std::vector<uint32_t> ip, op;
+            for (uint32_t j = 0; j < t->size_qlp; j++) {
+                if (j >= s && j < s + len) ip.push_back(t->qlp_prime[j]);
+                else op.push_back(t->qlp_prime[j]);
+            }
+            build_bconv(*this, t->digit[b], ip, op);
+            std::vector<u64x2> hi(len);
+            PHA_HIP(hipMemcpy(hi.data(), t->digit[b].hat_inv.p, len * sizeof(u64x2), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < len; i++) { phi[s + i] = hi[i].x; phis[s + i] = hi[i].y; }
+        }
+        t->part_hat_inv.upload(phi);
+        t->part_hat_inv_shoup.upload(phis);
+        // P -> Ql (rns.cu:196-198)
+        std::vector<uint32_t> ip, op;
+        for (uint32_t i = 0; i < size_p; i++) ip.push_back(size_q + i);
+        for (uint32_t i = 0; i < size_ql; i++) op.push_back(i);
+        build_bconv(*this, t->p_to_ql, ip, op);
+    }
+    Tool &ref = *t;
+    tools[size_ql] = std::move(t);
+    return ref;
+}
+
+u64 *Context::scratch(void *stream, size_t words) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto &a = arenas[stream];
+    if (!a) a = std::make_unique<Arena>();
+    if (a->buf.count < words) {
+        // growing invalidates earlier pointers: make sure nothing in flight still uses the old block
+        PHA_HIP(hipStreamSynchronize(as_stream(stream)));
+        a->buf.alloc(words);
+    }
+    return a->buf.p;
+}
+
+const uint32_t *Context::galois_table(uint32_t elt) {
+    // NTT-domain permutation table, include/galois.cuh:98-113
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = galois_tables.find(elt);
+    if (it != galois_tables.end()) return it->second.p;
+    if (!(elt & 1) || elt >= 2 * n) throw std::invalid_argument("Galois element is not valid");
+    std::vector<uint32_t> tab(n);
+    for (uint32_t i = (uint32_t)n; i < 2 * n; i++) {
+        const uint32_t rev = h_brev(i, (int)log_n + 1);
+        u64 raw = ((u64)elt * rev) >> 1;
+        raw &= (u64)(n - 1);
+        tab[i - n] = h_brev((uint32_t)raw, (int)log_n);
+    }
+    DevBuf<uint32_t> d;
+    d.upload(tab);
+    const uint32_t *p = d.p;
+    galois_tables[elt] = std::move(d);
+    return p;
+}
+
+}  // namespace pha
+
+using namespace pha;
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *pha_last_error(void) { return g_last_error.c_str(); }
+
+int pha_coeff_modulus_create(uint64_t n, const int *bit_sizes, size_t count, uint64_t *out) {
+    PHA_API_BEGIN
+    if (n < 2 || n > 131072 || (n & (n - 1))) throw std::invalid_argument("poly_modulus_degree is invalid");
+    if (count > 64) throw std::invalid_argument("bit_sizes is invalid");
+    // src/host/modulus.cu:98-109: per size, find `need` primes descending, hand out from the back
+    std::map<int, std::vector<u64>> table;
+    std::map<int, size_t> need;
+    for (size_t i = 0; i < count; i++) need[bit_sizes[i]]++;
+    for (auto &kv : need) get_primes(n, kv.first, kv.second, table[kv.first]);
+    for (size_t i = 0; i < count; i++) {
+        auto &v = table[bit_sizes[i]];
+        out[i] = v.back();
+        v.pop_back();
+    }
+    PHA_API_END
+}
+
+int pha_context_create(pha_context_t *out, uint32_t log_n, const uint64_t *primes_qp, uint32_t size_qp,
+                       uint32_t size_p, int device_id) {
+    PHA_API_BEGIN
+    if (!out || !primes_qp) throw std::invalid_argument("null argument");
+    auto h = std::make_unique<pha_context>();
+    context_init(h->c, log_n, primes_qp, size_qp, size_p, device_id);
+    *out = h.release();
+    PHA_API_END
+}
+
+void pha_context_destroy(pha_context_t ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->c.device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+uint32_t pha_context_log_n(pha_context_t ctx) { return ctx->c.log_n; }
+uint32_t pha_context_size_qp(pha_context_t ctx) { return ctx->c.size_qp; }
+uint32_t pha_context_size_p(pha_context_t ctx) { return ctx->c.size_p; }
+
+int pha_context_prime_info(pha_context_t ctx, uint32_t i, uint64_t *value, uint64_t ratio[2], uint64_t *root,
+                           uint64_t *n_inv) {
+    PHA_API_BEGIN
+    Context &c = ctx->c;
+    if (i >= c.size_qp) throw std::invalid_argument("prime index out of range");
+    if (value) *value = c.primes[i];
+    if (ratio) { ratio[0] = c.mods[i].ratio0; ratio[1] = c.mods[i].ratio1; }
+    if (root) *root = c.roots[i];
+    if (n_inv) *n_inv = c.n_inv[i];
+    PHA_API_END
+}
+
+int pha_context_download_twiddle(pha_context_t ctx, uint32_t i, int which, uint64_t *host_out) {
+    PHA_API_BEGIN
+    Context &c = ctx->c;
+    if (i >= c.size_qp || which < 0 || which > 3) throw std::invalid_argument("bad twiddle selector");
+    PHA_HIP(hipSetDevice(c.device));
+    std::vector<u64x2> row(c.n);
+    const u64x2 *src = (which < 2 ? c.d_tw.p : c.d_itw.p) + (size_t)i * c.n;
+    PHA_HIP(hipMemcpy(row.data(), src, c.n * sizeof(u64x2), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < c.n; k++) host_out[k] = (which & 1) ? row[k].y : row[k].x;
+    if (which >= 2) {  // present the reference's folded slot 1 (src/host/ntt.cu:53-55)
+        const u64 q = c.primes[i];
+        const u64 w1 = h_mulmod(row[1].x, c.n_inv[i], q);
+        host_out[1] = (which == 2) ? w1 : h_shoup(w1, q);
+    }
+    PHA_API_END
+}
+
+int pha_tool_beta(pha_context_t ctx, uint32_t size_ql, uint32_t *beta) {
+    PHA_API_BEGIN
+    *beta = ctx->c.tool(size_ql).beta;
+    PHA_API_END
+}
+
+}  // extern "C"

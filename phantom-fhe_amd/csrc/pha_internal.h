@@ -1,0 +1,168 @@
+// pha_internal.h -- host-side state behind the C ABI (include/phantom_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pha_arith.h"
+
+namespace pha {
+
+// ---- errors: the C ABI turns these into status codes (phantom_amd.h) -------------------------
+void set_last_error(const char *what);
+int translate_exception();  // call inside catch(...)
+
+#define PHA_HIP(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            throw std::runtime_error(std::string("HIP Runtime Error: ") + hipGetErrorString(e__) + \
+                                     " at " #expr);                                      \
+    } while (0)
+
+#define PHA_API_BEGIN try {
+#define PHA_API_END                  \
+    return 0;                        \
+    }                                \
+    catch (...) {                    \
+        return pha::translate_exception(); \
+    }
+
+// ---- device buffer (RAII) --------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { alloc(n); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), count(o.count) { o.p = nullptr; o.count = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; count = o.count; o.p = nullptr; o.count = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n) {
+        release();
+        if (n) PHA_HIP(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+        count = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    void upload(const std::vector<T> &h) {
+        if (h.size() != count) alloc(h.size());
+        if (count) PHA_HIP(hipMemcpy(p, h.data(), count * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+// ---- fast base converter constants (DBaseConverter, include/rns_bconv.cuh:3-87) --------------
+struct BConv {
+    uint32_t isz = 0, osz = 0;
+    std::vector<uint32_t> iprime, oprime;  // indices into the QP table
+    DevBuf<u64x2> hat_inv;                 // [isz]  qhat_i^-1 mod q_i (+Shoup)
+    DevBuf<u64> mat;                       // [osz][isz]  qhat_i mod p_j
+    DevBuf<uint32_t> d_iprime, d_oprime;
+};
+
+// ---- DRNSTool of one level (src/rns.cu:11-200), hot-path constants only ----------------------
+struct Tool {
+    uint32_t size_ql = 0, size_qlp = 0, alpha = 0, beta = 0;
+    std::vector<uint32_t> qlp_prime;  // limb of [Ql || P] -> index in the QP table
+    DevBuf<uint32_t> d_qlp_prime;
+    DevBuf<u64> part_hat_inv, part_hat_inv_shoup;  // partQlHatInv_mod_Ql_concat (rns.cu:152-182)
+    std::vector<BConv> digit;                      // part Ql -> complement of QlP, per digit
+    BConv p_to_ql;                                 // base_P_to_Ql_conv (rns.cu:196-198)
+    DevBuf<u64> pinv, pinv_shoup;                  // bigPInv_mod_q (rns.cu:110-123)
+    DevBuf<u64> inv_q_last, inv_q_last_shoup;      // rns.cu:66-80
+    DevBuf<u64x2> inv_q_last2;                     // same, interleaved
+    DevBuf<u64x2> pinv2;
+};
+
+// ---- scratch arena: one per (context, stream), grown on demand, never freed until destroy ----
+struct Arena {
+    DevBuf<u64> buf;
+    u64 *get(size_t words) {
+        if (buf.count < words) buf.alloc(words);
+        return buf.p;
+    }
+};
+
+struct Context {
+    int device = 0;
+    uint32_t log_n = 0, size_qp = 0, size_p = 0, size_q = 0;
+    size_t n = 0;
+    std::vector<u64> primes, roots, n_inv;
+    std::vector<DModulus> mods;
+    // device tables
+    DevBuf<DModulus> d_mod;   // [size_qp]
+    DevBuf<u64x2> d_tw;       // [size_qp][n] forward (psi^brev(k), Shoup)
+    DevBuf<u64x2> d_itw;      // [size_qp][n] inverse (psi^-brev(k), Shoup), slot 1 NOT folded
+    DevBuf<u64x2> d_ninv;     // [size_qp] (N^-1, Shoup)
+    DevBuf<u64x2> d_w1ninv;   // [size_qp] (itw[1] * N^-1, Shoup)
+    // host copies kept for pha_context_download_twiddle and tool construction
+    std::mutex mu;
+    std::map<uint32_t, std::unique_ptr<Tool>> tools;
+    std::map<void *, std::unique_ptr<Arena>> arenas;
+    std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
+
+    Tool &tool(uint32_t size_ql);
+    u64 *scratch(void *stream, size_t words);
+    const uint32_t *galois_table(uint32_t elt);
+};
+
+// host number theory (independent of oracle/)
+u64 h_mulmod(u64 a, u64 b, u64 q);
+u64 h_powmod(u64 a, u64 e, u64 q);
+u64 h_invmod(u64 a, u64 q);
+u64 h_shoup(u64 w, u64 q);
+bool h_is_prime(u64 n);
+u64 h_minimal_primitive_root(u64 degree, u64 q);
+DModulus h_modulus(u64 q);
+uint32_t h_brev(uint32_t x, int bits);
+
+// ---- launch descriptors shared by the .hip files ---------------------------------------------
+struct LimbSel {
+    uint32_t start;       // first processed limb (absolute index in the buffer)
+    uint32_t count;       // number of processed limbs
+    uint32_t remap_from;  // limbs >= remap_from use table row limb + remap_add (special primes)
+    uint32_t remap_add;
+    uint32_t excl_start, excl_end;  // limbs in [excl_start, excl_end) are skipped
+};
+inline LimbSel plain_sel(size_t start, size_t count) {
+    return LimbSel{(uint32_t)start, (uint32_t)count, 0xffffffffu, 0, 0, 0};
+}
+// twr_idx2 of src/ntt/fntt_2d.cu:434-437
+inline LimbSel special_sel(size_t start, size_t count, size_t size_QP, size_t size_P) {
+    LimbSel s = plain_sel(start, count);
+    s.remap_from = (uint32_t)(start + count - size_P);
+    s.remap_add = (uint32_t)(size_QP - (start + count));
+    return s;
+}
+
+// NTT drivers (pha_ntt.hip): pass 1 reads `in` and writes `mid`, pass 2 reads `mid` and writes `out`
+struct NttExtra {
+    const u64 *scale = nullptr, *scale_shoup = nullptr;  // indexed by absolute limb
+    const u64 *aux = nullptr;                            // fuse_moddown: cx base
+};
+void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
+                 hipStream_t s);
+void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
+                 hipStream_t s);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline void check_launch() { PHA_HIP(hipGetLastError()); }
+
+}  // namespace pha
+
+struct pha_context {
+    pha::Context c;
+};

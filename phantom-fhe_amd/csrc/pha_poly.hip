@@ -1,0 +1,196 @@
+// pha_poly.hip -- residue-wise (dyadic) kernels over [limb][coeff] buffers.
+//
+// Reference: src/polymath.cu (one coefficient per thread, `twr = tid / N`, DModulus re-read per
+// thread).  Here the limb is blockIdx.y, so the modulus and its Barrett ratio sit in SGPRs, and
+// every thread moves two adjacent coefficients with 16-byte accesses (pure HBM streaming).
+#include "../../include/phantom_amd.h"
+#include "pha_internal.h"
+
+namespace pha {
+
+constexpr int kEwThreads = 256;
+constexpr int kEwPerThread = 2;
+
+struct EwArgs {
+    const u64 *a, *b, *d;
+    u64 *r;
+    const u64 *s0, *s1;  // per-limb scalars (Shoup pair)
+    const DModulus *mod;
+    uint32_t n, limbs, mod_start;
+};
+
+enum EwOp { EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_MULADD, EW_MULSCALAR, EW_TENSOR, EW_SQUARE };
+
+__device__ __forceinline__ u64x2 ld2(const u64 *p) { return *reinterpret_cast<const u64x2 *>(p); }
+__device__ __forceinline__ void st2(u64 *p, u64x2 v) { *reinterpret_cast<u64x2 *>(p) = v; }
+
+template <int OP>
+__global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
+    const uint32_t limb = blockIdx.y;
+    const DModulus m = k.mod[k.mod_start + limb];
+    const u64 q = m.value;
+    const size_t idx = (size_t)limb * k.n + ((size_t)blockIdx.x * kEwThreads + threadIdx.x) * kEwPerThread;
+    const size_t rc = (size_t)k.limbs * k.n;  // stride between the polynomials of a ciphertext
+
+    if (OP == EW_ADD) {  // add_rns_poly polymath.cu:41-56
+        u64x2 x = ld2(k.a + idx), y = ld2(k.b + idx);
+        st2(k.r + idx, u64x2{add_mod(x.x, y.x, q), add_mod(x.y, y.y, q)});
+    } else if (OP == EW_SUB) {  // sub_rns_poly :109-124
+        u64x2 x = ld2(k.a + idx), y = ld2(k.b + idx);
+        st2(k.r + idx, u64x2{sub_mod(x.x, y.x, q), sub_mod(x.y, y.y, q)});
+    } else if (OP == EW_NEG) {  // negate_rns_poly :17-32
+        u64x2 x = ld2(k.a + idx);
+        st2(k.r + idx, u64x2{neg_mod(x.x, q), neg_mod(x.y, q)});
+    } else if (OP == EW_MUL) {  // multiply_rns_poly :156-172
+        u64x2 x = ld2(k.a + idx), y = ld2(k.b + idx);
+        st2(k.r + idx, u64x2{mul_mod(x.x, y.x, m), mul_mod(x.y, y.y, m)});
+    } else if (OP == EW_MULADD) {  // multiply_and_add_rns_poly :225-244 (128-bit sum, one Barrett)
+        u64x2 x = ld2(k.a + idx), y = ld2(k.b + idx), z = ld2(k.d + idx);
+        u64 lo, hi, lo2, hi2;
+        mul128(x.x, y.x, lo, hi);
+        lo += z.x; hi += (lo < z.x);
+        mul128(x.y, y.y, lo2, hi2);
+        lo2 += z.y; hi2 += (lo2 < z.y);
+        st2(k.r + idx, u64x2{barrett128(lo, hi, m), barrett128(lo2, hi2, m)});
+    } else if (OP == EW_MULSCALAR) {  // multiply_scalar_rns_poly (Shoup) :198-213
+        const u64x2 w{k.s0[limb], k.s1[limb]};
+        u64x2 x = ld2(k.a + idx);
+        st2(k.r + idx, u64x2{shoup(x.x, w, q), shoup(x.y, w, q)});
+    } else if (OP == EW_TENSOR) {  // tensor_prod_2x2_rns_poly :463-496
+        u64x2 c00 = ld2(k.a + idx), c01 = ld2(k.a + idx + rc), c10 = ld2(k.b + idx), c11 = ld2(k.b + idx + rc);
+        u64x2 d0, d1, d2;
+        d0.x = mul_mod(c00.x, c10.x, m); d0.y = mul_mod(c00.y, c10.y, m);
+        d2.x = mul_mod(c01.x, c11.x, m); d2.y = mul_mod(c01.y, c11.y, m);
+        // (c0 + c1) is not reduced before the multiply (q < 2^61), exactly like :487
+        d1.x = mul_mod(c00.x + c01.x, c10.x + c11.x, m);
+        d1.y = mul_mod(c00.y + c01.y, c10.y + c11.y, m);
+        d1.x = csub(csub(d1.x + 2 * q - d0.x - d2.x, q), q);
+        d1.y = csub(csub(d1.y + 2 * q - d0.y - d2.y, q), q);
+        st2(k.r + idx, d0);
+        st2(k.r + idx + rc, d1);
+        st2(k.r + idx + 2 * rc, d2);
+    } else if (OP == EW_SQUARE) {  // tensor_square_2x2_rns_poly :500-529
+        u64x2 c0 = ld2(k.a + idx), c1 = ld2(k.a + idx + rc);
+        u64x2 d0, d1, d2;
+        d0.x = mul_mod(c0.x, c0.x, m); d0.y = mul_mod(c0.y, c0.y, m);
+        u64 lo, hi;
+        mul128(c0.x, c1.x, lo, hi);
+        d1.x = barrett128(lo << 1, (hi << 1) | (lo >> 63), m);
+        mul128(c0.y, c1.y, lo, hi);
+        d1.y = barrett128(lo << 1, (hi << 1) | (lo >> 63), m);
+        d2.x = mul_mod(c1.x, c1.x, m); d2.y = mul_mod(c1.y, c1.y, m);
+        st2(k.r + idx, d0);
+        st2(k.r + idx + rc, d1);
+        st2(k.r + idx + 2 * rc, d2);
+    }
+}
+
+template <int OP>
+static void launch_ew(Context &c, EwArgs k, size_t limbs, size_t mod_start, hipStream_t s) {
+    if (limbs == 0) return;
+    if (mod_start + limbs > c.size_qp) throw std::invalid_argument("modulus index out of range");
+    k.mod = c.d_mod.p;
+    k.n = (uint32_t)c.n;
+    k.limbs = (uint32_t)limbs;
+    k.mod_start = (uint32_t)mod_start;
+    dim3 grid((unsigned)(c.n / (kEwThreads * kEwPerThread)), (unsigned)limbs);
+    hipLaunchKernelGGL((ew_kernel<OP>), grid, dim3(kEwThreads), 0, s, k);
+    check_launch();
+}
+
+// used by pha_rns.hip
+void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s) {
+    EwArgs k{};
+    k.a = a; k.b = b; k.r = r;
+    launch_ew<EW_ADD>(c, k, limbs, mod_start, s);
+}
+
+}  // namespace pha
+
+using namespace pha;
+
+static void need(const void *p) {
+    if (!p) throw std::invalid_argument("null device pointer");
+}
+
+extern "C" {
+
+int pha_add_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t cms,
+                     size_t mod_start, void *stream) {
+    PHA_API_BEGIN
+    need(a); need(b); need(r);
+    launch_add(ctx->c, a, b, r, cms, mod_start, as_stream(stream));
+    PHA_API_END
+}
+int pha_sub_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t cms,
+                     size_t mod_start, void *stream) {
+    PHA_API_BEGIN
+    need(a); need(b); need(r);
+    EwArgs k{};
+    k.a = a; k.b = b; k.r = r;
+    launch_ew<EW_SUB>(ctx->c, k, cms, mod_start, as_stream(stream));
+    PHA_API_END
+}
+int pha_negate_rns_poly(pha_context_t ctx, const uint64_t *a, uint64_t *r, size_t cms, size_t mod_start,
+                        void *stream) {
+    PHA_API_BEGIN
+    need(a); need(r);
+    EwArgs k{};
+    k.a = a; k.r = r;
+    launch_ew<EW_NEG>(ctx->c, k, cms, mod_start, as_stream(stream));
+    PHA_API_END
+}
+int pha_multiply_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t cms,
+                          size_t mod_start, void *stream) {
+    PHA_API_BEGIN
+    need(a); need(b); need(r);
+    EwArgs k{};
+    k.a = a; k.b = b; k.r = r;
+    launch_ew<EW_MUL>(ctx->c, k, cms, mod_start, as_stream(stream));
+    PHA_API_END
+}
+int pha_multiply_and_add_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, const uint64_t *d,
+                                  uint64_t *r, size_t cms, size_t mod_start, void *stream) {
+    PHA_API_BEGIN
+    need(a); need(b); need(d); need(r);
+    EwArgs k{};
+    k.a = a; k.b = b; k.d = d; k.r = r;
+    launch_ew<EW_MULADD>(ctx->c, k, cms, mod_start, as_stream(stream));
+    PHA_API_END
+}
+int pha_multiply_scalar_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *scalar,
+                                 const uint64_t *scalar_shoup, uint64_t *r, size_t cms, size_t mod_start,
+                                 void *stream) {
+    PHA_API_BEGIN
+    need(a); need(scalar); need(scalar_shoup); need(r);
+    EwArgs k{};
+    k.a = a; k.s0 = scalar; k.s1 = scalar_shoup; k.r = r;
+    launch_ew<EW_MULSCALAR>(ctx->c, k, cms, mod_start, as_stream(stream));
+    PHA_API_END
+}
+int pha_tensor_prod_2x2_rns_poly(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *res,
+                                 size_t cms, void *stream) {
+    PHA_API_BEGIN
+    need(op1); need(op2); need(res);
+    EwArgs k{};
+    k.a = op1; k.b = op2; k.r = res;
+    launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream));
+    PHA_API_END
+}
+int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *op, uint64_t *res, size_t cms,
+                                   void *stream) {
+    PHA_API_BEGIN
+    need(op); need(res);
+    EwArgs k{};
+    k.a = op; k.r = res;
+    launch_ew<EW_SQUARE>(ctx->c, k, cms, 0, as_stream(stream));
+    PHA_API_END
+}
+int pha_add_to_ct(pha_context_t ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, void *stream) {
+    PHA_API_BEGIN
+    need(ct); need(cx);
+    launch_add(ctx->c, ct, cx, ct, size_Ql, 0, as_stream(stream));  // add_to_ct_kernel rns_bconv.cu:763-769
+    PHA_API_END
+}
+
+}  // extern "C"

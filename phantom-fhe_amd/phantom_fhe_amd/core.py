@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference's hot-path objects over the C ABI.
+
+Names follow the reference (PhantomContext / DNTTTable launchers in include/ntt.cuh:157-226,
+DRNSTool methods in include/rns.cuh:156-205, key_switch_inner_prod / keyswitch_inplace in
+include/evaluate.cuh:18-32).  torch is used only as the owner of device memory and of the HIP
+stream; every call goes straight to libphantom_amd.so with raw device pointers.
+Polynomials are torch.int64 CUDA tensors whose bit patterns are the uint64 residues, limb-major
+[limb][coeff] (a ciphertext is [poly][limb][coeff], include/ciphertext.h:15-25).
+"""
+import ctypes as C
+from enum import IntEnum
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+class scheme_type(IntEnum):  # include/host/encryptionparams.h:19-27
+    none = 0
+    bfv = 1
+    ckks = 2
+    bgv = 3
+
+
+def to_device(arr, device="cuda:0"):
+    """numpy uint64 array -> int64 device tensor with the same bits."""
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t):
+    """int64 device tensor -> numpy uint64 array with the same bits."""
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.int64):
+        raise ValueError("expected a contiguous torch.int64 CUDA tensor")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def coeff_modulus_create(poly_modulus_degree, bit_sizes):
+    """CoeffModulus::Create (src/host/modulus.cu:82-111)."""
+    L = _lib.load()
+    bits = (C.c_int * len(bit_sizes))(*bit_sizes)
+    out = np.zeros(len(bit_sizes), dtype=np.uint64)
+    _lib.check(L.pha_coeff_modulus_create(poly_modulus_degree, bits, len(bit_sizes),
+                                          out.ctypes.data_as(_lib.u64p)))
+    return out
+
+
+class PhantomContext:
+    """Hot-path state of PhantomContext (src/context.cu:121-232): NTT tables for all QP primes on
+    one device plus a lazily built DRNSTool per level."""
+
+    def __init__(self, log_n, coeff_modulus, special_modulus_size, device=0):
+        self._L = _lib.load()
+        self.log_n = int(log_n)
+        self.n = 1 << self.log_n
+        self.coeff_modulus = np.ascontiguousarray(coeff_modulus, dtype=np.uint64)
+        self.size_QP = len(self.coeff_modulus)
+        self.size_P = int(special_modulus_size)
+        self.size_Q = self.size_QP - self.size_P
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        if not torch.cuda.is_available():
+            raise RuntimeError("phantom_fhe_amd needs a HIP device; there is no CPU path")
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.pha_context_create(C.byref(h), self.log_n,
+                                                  self.coeff_modulus.ctypes.data_as(_lib.u64p),
+                                                  self.size_QP, self.size_P, self.device.index or 0))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.pha_context_destroy(h)
+            self._h = None
+
+    # -- table queries ------------------------------------------------------------------------
+    def prime_info(self, idx):
+        v, root, ninv = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ratio = (C.c_uint64 * 2)()
+        _lib.check(self._L.pha_context_prime_info(self._h, idx, C.byref(v), ratio, C.byref(root), C.byref(ninv)))
+        return {"value": v.value, "const_ratio": (ratio[0], ratio[1]), "root": root.value, "n_inv": ninv.value}
+
+    def twiddle_row(self, idx, which):
+        out = np.zeros(self.n, dtype=np.uint64)
+        _lib.check(self._L.pha_context_download_twiddle(self._h, idx, which, out.ctypes.data_as(_lib.u64p)))
+        return out
+
+    def beta(self, size_Ql):
+        b = C.c_uint32()
+        _lib.check(self._L.pha_tool_beta(self._h, size_Ql, C.byref(b)))
+        return b.value
+
+    # -- NTT launchers (include/ntt.cuh:178-226) ------------------------------------------------
+    def nwt_2d_radix8_forward_inplace(self, inout, coeff_modulus_size, start_modulus_idx=0):
+        _lib.check(self._L.pha_nwt_2d_radix8_forward_inplace(self._h, _ptr(inout), coeff_modulus_size,
+                                                             start_modulus_idx, _stream()))
+
+    def nwt_2d_radix8_forward_inplace_include_special_mod(self, inout, cms, start, size_QP, size_P):
+        _lib.check(self._L.pha_nwt_2d_radix8_forward_inplace_include_special_mod(
+            self._h, _ptr(inout), cms, start, size_QP, size_P, _stream()))
+
+    def nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(self, inout, cms, start, size_QP,
+                                                                       size_P, ex_start, ex_end):
+        _lib.check(self._L.pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(
+            self._h, _ptr(inout), cms, start, size_QP, size_P, ex_start, ex_end, _stream()))
+
+    def nwt_2d_radix8_forward_inplace_fuse_moddown(self, ct, cx, bigPInv_mod_q, bigPInv_mod_q_shoup, delta,
+                                                   cms, start=0):
+        _lib.check(self._L.pha_nwt_2d_radix8_forward_inplace_fuse_moddown(
+            self._h, _ptr(ct), _ptr(cx), _ptr(bigPInv_mod_q), _ptr(bigPInv_mod_q_shoup), _ptr(delta), cms,
+            start, _stream()))
+
+    def nwt_2d_radix8_backward_inplace(self, inout, coeff_modulus_size, start_modulus_idx=0):
+        _lib.check(self._L.pha_nwt_2d_radix8_backward_inplace(self._h, _ptr(inout), coeff_modulus_size,
+                                                              start_modulus_idx, _stream()))
+
+    def nwt_2d_radix8_backward(self, out, inp, coeff_modulus_size, start_modulus_idx=0):
+        _lib.check(self._L.pha_nwt_2d_radix8_backward(self._h, _ptr(out), _ptr(inp), coeff_modulus_size,
+                                                      start_modulus_idx, _stream()))
+
+    def nwt_2d_radix8_backward_scale(self, out, inp, cms, start, scale, scale_shoup):
+        _lib.check(self._L.pha_nwt_2d_radix8_backward_scale(self._h, _ptr(out), _ptr(inp), cms, start,
+                                                            _ptr(scale), _ptr(scale_shoup), _stream()))
+
+    def nwt_2d_radix8_backward_inplace_include_special_mod(self, inout, cms, start, size_QP, size_P):
+        _lib.check(self._L.pha_nwt_2d_radix8_backward_inplace_include_special_mod(
+            self._h, _ptr(inout), cms, start, size_QP, size_P, _stream()))
+
+    # -- dyadic kernels (include/polymath.cuh) ------------------------------------------------
+    def add_rns_poly(self, a, b, r, cms, mod_start=0):
+        _lib.check(self._L.pha_add_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(r), cms, mod_start, _stream()))
+
+    def sub_rns_poly(self, a, b, r, cms, mod_start=0):
+        _lib.check(self._L.pha_sub_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(r), cms, mod_start, _stream()))
+
+    def negate_rns_poly(self, a, r, cms, mod_start=0):
+        _lib.check(self._L.pha_negate_rns_poly(self._h, _ptr(a), _ptr(r), cms, mod_start, _stream()))
+
+    def multiply_rns_poly(self, a, b, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(r), cms, mod_start, _stream()))
+
+    def multiply_and_add_rns_poly(self, a, b, d, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_and_add_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(d), _ptr(r), cms,
+                                                         mod_start, _stream()))
+
+    def multiply_scalar_rns_poly(self, a, scalar, scalar_shoup, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_scalar_rns_poly(self._h, _ptr(a), _ptr(scalar), _ptr(scalar_shoup),
+                                                        _ptr(r), cms, mod_start, _stream()))
+
+    def tensor_prod_2x2_rns_poly(self, op1, op2, result, cms):
+        _lib.check(self._L.pha_tensor_prod_2x2_rns_poly(self._h, _ptr(op1), _ptr(op2), _ptr(result), cms, _stream()))
+
+    def tensor_square_2x2_rns_poly(self, op, result, cms):
+        _lib.check(self._L.pha_tensor_square_2x2_rns_poly(self._h, _ptr(op), _ptr(result), cms, _stream()))
+
+    def add_to_ct(self, ct, cx, size_Ql):
+        _lib.check(self._L.pha_add_to_ct(self._h, _ptr(ct), _ptr(cx), size_Ql, _stream()))
+
+    # -- DRNSTool at level size_Ql (include/rns.cuh:156-205) --------------------------------------
+    def bconv_P_to_Ql(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_bconv_P_to_Ql(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
+
+    def modup(self, size_Ql, dst, cks, scheme):
+        _lib.check(self._L.pha_modup(self._h, size_Ql, _ptr(dst), _ptr(cks), int(scheme), _stream()))
+
+    def key_switch_inner_prod(self, size_Ql, p_cx, p_t_mod_up, rlk_ptrs):
+        """rlk_ptrs: int64 CUDA tensor holding beta device pointers (PhantomRelinKey::public_keys_ptr())."""
+        _lib.check(self._L.pha_key_switch_inner_prod(self._h, size_Ql, _ptr(p_cx), _ptr(p_t_mod_up),
+                                                     _ptr(rlk_ptrs), _stream()))
+
+    def moddown_from_NTT(self, size_Ql, ct_i, cx_i, scheme):
+        _lib.check(self._L.pha_moddown_from_NTT(self._h, size_Ql, _ptr(ct_i), _ptr(cx_i), int(scheme), _stream()))
+
+    def keyswitch_inplace(self, size_Ql, ct, c2, rlk_ptrs, scheme):
+        _lib.check(self._L.pha_keyswitch_inplace(self._h, size_Ql, _ptr(ct), _ptr(c2), _ptr(rlk_ptrs),
+                                                 int(scheme), _stream()))
+
+    def divide_and_round_q_last_ntt(self, size_Ql, src, cipher_size, dst):
+        _lib.check(self._L.pha_divide_and_round_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
+                                                           _stream()))
+
+    def divide_and_round_q_last(self, size_Ql, src, cipher_size, dst):
+        _lib.check(self._L.pha_divide_and_round_q_last(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
+                                                       _stream()))
+
+    # -- Galois (src/galois.cu:67-102) --------------------------------------------------------
+    def apply_galois_ntt(self, src, dst, galois_elt, cms):
+        _lib.check(self._L.pha_apply_galois_ntt(self._h, _ptr(src), _ptr(dst), galois_elt, cms, _stream()))
+
+    def apply_galois(self, src, dst, galois_elt, cms, mod_start=0):
+        _lib.check(self._L.pha_apply_galois(self._h, _ptr(src), _ptr(dst), galois_elt, cms, mod_start, _stream()))
+
+    # -- measurement ------------------------------------------------------------------------------
+    def time_forward_ntt(self, inout, cms, iters):
+        ms = C.c_float()
+        _lib.check(self._L.pha_time_forward_ntt(self._h, _ptr(inout), cms, iters, _stream(), C.byref(ms)))
+        return ms.value
+
+
+class PhantomRelinKey:
+    """Device layout of PhantomRelinKey (include/secretkey.h:102-165): dnum public keys, each
+    [2][size_QP][N], plus a device array of their pointers."""
+
+    def __init__(self, keys):
+        self.public_keys = [k.contiguous() for k in keys]
+        self.public_keys_ptr = torch.tensor([k.data_ptr() for k in self.public_keys], dtype=torch.int64,
+                                            device=self.public_keys[0].device)
+
+    @classmethod
+    def from_numpy(cls, evk, device="cuda:0"):
+        return cls([to_device(evk[i], device) for i in range(evk.shape[0])])

@@ -1,0 +1,98 @@
+"""ctypes binding of libphantom_amd.so (the C ABI declared in include/phantom_amd.h).
+
+The HIP library is the product; there is NO CPU fallback.  Importing this module without the
+built library raises immediately (run `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C phantom-fhe_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphantom_amd.so")
+
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+sz = C.c_size_t
+
+# name -> argtypes (restype is int status unless listed in _SPECIAL)
+_SIGS = {
+    "pha_coeff_modulus_create": [C.c_uint64, C.POINTER(C.c_int), sz, u64p],
+    "pha_context_create": [C.POINTER(vp), C.c_uint32, u64p, C.c_uint32, C.c_uint32, C.c_int],
+    "pha_context_prime_info": [vp, C.c_uint32, u64p, u64p, u64p, u64p],
+    "pha_context_download_twiddle": [vp, C.c_uint32, C.c_int, u64p],
+    "pha_tool_beta": [vp, C.c_uint32, C.POINTER(C.c_uint32)],
+    "pha_nwt_2d_radix8_forward_inplace": [vp, vp, sz, sz, vp],
+    "pha_nwt_2d_radix8_forward_inplace_include_special_mod": [vp, vp, sz, sz, sz, sz, vp],
+    "pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range": [vp, vp, sz, sz, sz, sz, sz, sz, vp],
+    "pha_nwt_2d_radix8_forward_inplace_fuse_moddown": [vp, vp, vp, vp, vp, vp, sz, sz, vp],
+    "pha_nwt_2d_radix8_backward_inplace": [vp, vp, sz, sz, vp],
+    "pha_nwt_2d_radix8_backward": [vp, vp, vp, sz, sz, vp],
+    "pha_nwt_2d_radix8_backward_scale": [vp, vp, vp, sz, sz, vp, vp, vp],
+    "pha_nwt_2d_radix8_backward_inplace_scale": [vp, vp, sz, sz, vp, vp, vp],
+    "pha_nwt_2d_radix8_backward_inplace_include_special_mod": [vp, vp, sz, sz, sz, sz, vp],
+    "pha_add_rns_poly": [vp, vp, vp, vp, sz, sz, vp],
+    "pha_sub_rns_poly": [vp, vp, vp, vp, sz, sz, vp],
+    "pha_negate_rns_poly": [vp, vp, vp, sz, sz, vp],
+    "pha_multiply_rns_poly": [vp, vp, vp, vp, sz, sz, vp],
+    "pha_multiply_and_add_rns_poly": [vp, vp, vp, vp, vp, sz, sz, vp],
+    "pha_multiply_scalar_rns_poly": [vp, vp, vp, vp, vp, sz, sz, vp],
+    "pha_tensor_prod_2x2_rns_poly": [vp, vp, vp, vp, sz, vp],
+    "pha_tensor_square_2x2_rns_poly": [vp, vp, vp, sz, vp],
+    "pha_add_to_ct": [vp, vp, vp, sz, vp],
+    "pha_bconv_P_to_Ql": [vp, sz, vp, vp, vp],
+    "pha_modup": [vp, sz, vp, vp, C.c_int, vp],
+    "pha_key_switch_inner_prod": [vp, sz, vp, vp, vp, vp],
+    "pha_moddown_from_NTT": [vp, sz, vp, vp, C.c_int, vp],
+    "pha_keyswitch_inplace": [vp, sz, vp, vp, vp, C.c_int, vp],
+    "pha_divide_and_round_q_last_ntt": [vp, sz, vp, sz, vp, vp],
+    "pha_divide_and_round_q_last": [vp, sz, vp, sz, vp, vp],
+    "pha_apply_galois_ntt": [vp, vp, vp, C.c_uint32, sz, vp],
+    "pha_apply_galois": [vp, vp, vp, C.c_uint32, sz, sz, vp],
+    "pha_time_forward_ntt": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)],
+}
+_SPECIAL = {
+    "pha_last_error": (C.c_char_p, []),
+    "pha_context_destroy": (None, [vp]),
+    "pha_context_log_n": (C.c_uint32, [vp]),
+    "pha_context_size_qp": (C.c_uint32, [vp]),
+    "pha_context_size_p": (C.c_uint32, [vp]),
+}
+
+EXPORTED = sorted(list(_SIGS) + list(_SPECIAL))
+
+_lib = None
+
+
+class PhantomError(RuntimeError):
+    pass
+
+
+_EXC = {-1: ValueError, -2: ArithmeticError, -3: PhantomError}  # invalid_argument, logic_error, runtime_error
+
+
+def load():
+    """dlopen the HIP library and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(make -C phantom-fhe_amd/csrc).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    for name, (res, args) in _SPECIAL.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = res
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        msg = load().pha_last_error().decode("utf-8", "replace")
+        raise _EXC.get(status, PhantomError)(msg)

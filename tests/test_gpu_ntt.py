@@ -1,0 +1,156 @@
+"""GPU parity: HIP NTT launchers (through the C ABI) vs the CPU oracle, bit-exact.
+
+Reference analogue: test/ntt_test.cu:71-122 (round trip) -- here the forward values themselves are
+pinned against the oracle, plus the variants used by key switching (include/ntt.cuh:178-226)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import oracle_ctx, primes_of, rng_for, uniform_poly
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(name, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    return P.PhantomContext(log_n, list(primes), size_p, device=gpu)
+
+
+@pytest.mark.parametrize("name", ["c1_bfv4096", "hyb13_a3", "c2_ntt14", "c4_bfv15", "c3_ckks16"])
+def test_forward_inverse_inplace(name, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    oc = oracle_ctx(name)
+    ctx = _ctx(name, gpu)
+    L = len(primes)
+    x = uniform_poly(rng_for(1), primes, n)
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace(d, L, 0)
+    got = P.to_host(d)
+    ref = oc.nwt_forward(x, L, 0)
+    assert np.array_equal(got, ref)
+    ctx.nwt_2d_radix8_backward_inplace(d, L, 0)
+    assert np.array_equal(P.to_host(d), x)          # round trip (ntt_test.cu:100-110)
+    # inverse values too (input need not be a forward image)
+    d2 = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_backward_inplace(d2, L, 0)
+    assert np.array_equal(P.to_host(d2), oc.nwt_backward(x, L, 0))
+
+
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
+def test_all_degrees(log_n, gpu):
+    import phantom_fhe_amd as P
+    n = 1 << log_n
+    primes = [int(p) for p in O.coeff_modulus_create(n, [60, 50, 40])]
+    oc = O.Ctx(log_n, primes, 0)
+    ctx = P.PhantomContext(log_n, primes, 0, device=gpu)
+    x = uniform_poly(rng_for(100 + log_n), primes, n)
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace(d, 3, 0)
+    assert np.array_equal(P.to_host(d), oc.nwt_forward(x, 3, 0))
+    ctx.nwt_2d_radix8_backward_inplace(d, 3, 0)
+    assert np.array_equal(P.to_host(d), x)
+    # tables equal the oracle's (DNTTTable content, include/ntt.cuh:34-129), incl. folded itwiddle[1]
+    for which in range(4):
+        assert np.array_equal(ctx.twiddle_row(1, which), oc.twiddle(1, which))
+    info = ctx.prime_info(0)
+    assert info["value"] == primes[0] and info["const_ratio"] == O.const_ratio(primes[0])
+    assert info["root"] == O.minimal_primitive_root(2 * n, primes[0]) and info["n_inv"] == oc.n_inv(0)
+
+
+def test_start_index_and_partial(gpu):
+    """start_modulus_idx / coeff_modulus_size select limbs [start, start+size) (fntt_2d.cu:40-41)."""
+    import phantom_fhe_amd as P
+    name = "hyb13_a3"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    x = uniform_poly(rng_for(2), primes, n)
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace(d, 3, 2)
+    ref = x.copy()
+    ref[2:5] = oc.nwt_forward(x[2:5], 3, 2)
+    assert np.array_equal(P.to_host(d), ref)
+    ctx.nwt_2d_radix8_backward_inplace(d, 1, 4)     # rescale uses size 1 at the last limb (rns.cu:1171)
+    ref[4:5] = oc.nwt_backward(ref[4:5], 1, 4)
+    assert np.array_equal(P.to_host(d), ref)
+
+
+def test_special_mod_and_exclude_range(gpu):
+    """[Ql || P] buffers: P limbs use the last rows of the table (fntt_2d.cu:434-437); the digit's own
+    range is skipped (ntt_modup.cu:422)."""
+    import phantom_fhe_amd as P
+    name = "hyb13_a3"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_qp, size_q = len(primes), len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    ql = 5
+    qlp_idx = list(range(ql)) + [size_q + i for i in range(size_p)]
+    x = uniform_poly(rng_for(3), [primes[i] for i in qlp_idx], n)
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_include_special_mod(d, ql + size_p, 0, size_qp, size_p)
+    ref = oc.nwt_forward_map(x, qlp_idx)
+    assert np.array_equal(P.to_host(d), ref)
+    ctx.nwt_2d_radix8_backward_inplace_include_special_mod(d, size_p, ql, size_qp, size_p)   # moddown's call
+    ref2 = ref.copy()
+    ref2[ql:] = oc.nwt_backward_map(ref[ql:], qlp_idx[ql:])
+    assert np.array_equal(P.to_host(d), ref2)
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(d, ql + size_p, 0, size_qp, size_p, 3, 5)
+    ref3 = oc.nwt_forward_map(x, qlp_idx)
+    ref3[3:5] = x[3:5]
+    assert np.array_equal(P.to_host(d), ref3)
+
+
+def test_backward_out_of_place_and_scale(gpu):
+    import phantom_fhe_amd as P
+    name = "hyb12_a2"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L = 6
+    x = uniform_poly(rng_for(4), primes[:L], n)
+    d_in = P.to_device(x, gpu)
+    d_out = P.to_device(np.zeros_like(x), gpu)
+    ctx.nwt_2d_radix8_backward(d_out, d_in, L, 0)
+    ref = oc.nwt_backward(x, L, 0)
+    assert np.array_equal(P.to_host(d_out), ref)
+    assert np.array_equal(P.to_host(d_in), x)       # source untouched
+    scale = np.array([rng_for(5).integers(1, int(q)) for q in primes[:L]], dtype=np.uint64)
+    shoup = np.array([O.compute_shoup(int(s), int(q)) for s, q in zip(scale, primes[:L])], dtype=np.uint64)
+    ctx.nwt_2d_radix8_backward_scale(d_out, d_in, L, 0, P.to_device(scale, gpu), P.to_device(shoup, gpu))
+    assert np.array_equal(P.to_host(d_out), oc.multiply_scalar(ref, scale, L, 0))
+
+
+def test_forward_fuse_moddown(gpu):
+    """ct = (cx - NTT(delta)) * PInv (ntt_moddown.cu:203-208), also with ct aliasing cx."""
+    import phantom_fhe_amd as P
+    name = "hyb12_a2"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L = 5
+    r = rng_for(6)
+    cx = uniform_poly(r, primes[:L], n)
+    delta = uniform_poly(r, primes[:L], n)
+    c = np.array([r.integers(1, int(q)) for q in primes[:L]], dtype=np.uint64)
+    cs = np.array([O.compute_shoup(int(s), int(q)) for s, q in zip(c, primes[:L])], dtype=np.uint64)
+    ref = oc.multiply_scalar(oc.sub(cx, oc.nwt_forward(delta, L, 0), L, 0), c, L, 0)
+    d_cx, d_delta = P.to_device(cx, gpu), P.to_device(delta, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_fuse_moddown(d_cx, d_cx, P.to_device(c, gpu), P.to_device(cs, gpu), d_delta, L, 0)
+    assert np.array_equal(P.to_host(d_cx), ref)
+
+
+def test_invalid_arguments(gpu):
+    import phantom_fhe_amd as P
+    ctx = _ctx("c1_bfv4096", gpu)
+    d = P.to_device(np.zeros((3, 4096), dtype=np.uint64), gpu)
+    with pytest.raises(ValueError):
+        ctx.nwt_2d_radix8_forward_inplace(d, 4, 0)   # beyond the table
+    with pytest.raises(ValueError):
+        P.PhantomContext(12, [97, 193], 0, device=gpu)  # not NTT primes for N=4096
+    with pytest.raises(ValueError):
+        P.PhantomContext(9, [0xffffee001], 0, device=gpu)

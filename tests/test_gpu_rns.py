@@ -1,0 +1,188 @@
+"""GPU parity: dyadic kernels, fast base conversion, mod-up, key-switch inner product, mod-down,
+keyswitch_inplace, CKKS rescale and Galois permutations vs the CPU oracle, bit-exact, at the
+BASELINE.json configurations (full size for C3/C4)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import oracle_ctx, primes_of, rng_for, uniform_poly
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(name, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    return P.PhantomContext(log_n, list(primes), size_p, device=gpu)
+
+
+@pytest.mark.parametrize("name", ["c1_bfv4096", "c3_ckks16"])
+def test_dyadic(name, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    L = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(10)
+    a, b, d = (uniform_poly(r, primes[:L], n) for _ in range(3))
+    da, db, dd = (P.to_device(v, gpu) for v in (a, b, d))
+    out = P.to_device(np.zeros_like(a), gpu)
+    ctx.add_rns_poly(da, db, out, L); assert np.array_equal(P.to_host(out), oc.add(a, b, L))
+    ctx.sub_rns_poly(da, db, out, L); assert np.array_equal(P.to_host(out), oc.sub(a, b, L))
+    ctx.negate_rns_poly(da, out, L); assert np.array_equal(P.to_host(out), oc.negate(a, L))
+    ctx.multiply_rns_poly(da, db, out, L); assert np.array_equal(P.to_host(out), oc.multiply(a, b, L))
+    ctx.multiply_and_add_rns_poly(da, db, dd, out, L)
+    assert np.array_equal(P.to_host(out), oc.multiply_and_add(a, b, d, L))
+    sc = np.array([r.integers(0, int(q)) for q in primes[:L]], dtype=np.uint64)
+    scs = np.array([O.compute_shoup(int(s), int(q)) for s, q in zip(sc, primes[:L])], dtype=np.uint64)
+    ctx.multiply_scalar_rns_poly(da, P.to_device(sc, gpu), P.to_device(scs, gpu), out, L)
+    assert np.array_equal(P.to_host(out), oc.multiply_scalar(a, sc, L))
+    # edge values: 0 and q-1 everywhere
+    z = np.zeros_like(a)
+    m1 = np.stack([np.full(n, int(q) - 1, dtype=np.uint64) for q in primes[:L]])
+    ctx.negate_rns_poly(P.to_device(z, gpu), out, L); assert np.array_equal(P.to_host(out), z)
+    dm = P.to_device(m1, gpu)
+    ctx.add_rns_poly(dm, dm, out, L); assert np.array_equal(P.to_host(out), oc.add(m1, m1, L))
+    ctx.multiply_rns_poly(dm, dm, out, L); assert np.array_equal(P.to_host(out), oc.multiply(m1, m1, L))
+    # tensor product, in place on operand1 as evaluate.cu:377-383 calls it
+    ct1 = np.stack([a, b]); ct2 = np.stack([d, a])
+    buf = P.to_device(np.concatenate([ct1, np.zeros((1, L, n), dtype=np.uint64)]), gpu)
+    ctx.tensor_prod_2x2_rns_poly(buf, P.to_device(ct2, gpu), buf, L)
+    assert np.array_equal(P.to_host(buf), oc.tensor_prod_2x2(ct1, ct2, L))
+    buf = P.to_device(np.concatenate([ct1, np.zeros((1, L, n), dtype=np.uint64)]), gpu)
+    ctx.tensor_square_2x2_rns_poly(buf, buf, L)
+    assert np.array_equal(P.to_host(buf), oc.tensor_square_2x2(ct1, L))
+    mm = np.stack([m1, m1])
+    buf = P.to_device(np.concatenate([mm, np.zeros((1, L, n), dtype=np.uint64)]), gpu)
+    ctx.tensor_prod_2x2_rns_poly(buf, P.to_device(mm, gpu), buf, L)   # unreduced (c0+c1) at its maximum
+    assert np.array_equal(P.to_host(buf), oc.tensor_prod_2x2(mm, mm, L))
+
+
+def _keys(oc, rng, primes, n, size_q, size_p):
+    """Uniform synthetic evaluation keys [dnum][2][QP][N] (arithmetic is data-independent)."""
+    dnum = size_q // size_p
+    return np.stack([np.stack([uniform_poly(rng, primes, n), uniform_poly(rng, primes, n)]) for _ in range(dnum)])
+
+
+# (config, scheme, levels to test as number of live data limbs)
+KS_CASES = [
+    ("hyb12_a2", O.CKKS, [6, 5, 1]),
+    ("hyb12_a2", O.BFV, [6]),
+    ("hyb13_a3", O.CKKS, [9, 7, 4]),     # 7 and 4: short last digit (rns.cu:152-157)
+    ("c1_bfv4096", O.BFV, [2]),          # alpha = 1 fast paths
+    ("c1_bfv4096", O.CKKS, [2, 1]),
+    ("c4_bfv15", O.BFV, [30]),
+    ("c3_ckks16", O.CKKS, [45, 31]),
+]
+
+
+@pytest.mark.parametrize("name,scheme,levels", KS_CASES)
+def test_keyswitch_stages(name, scheme, levels, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_qp, size_q = len(primes), len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(20)
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    for ql in levels:
+        tool = O.Tool(oc, ql)
+        qlp = ql + size_p
+        beta = tool.beta
+        assert ctx.beta(ql) == beta
+        c2 = uniform_poly(r, primes[:ql], n)
+        # mod-up (rns_bconv.cu:530-627)
+        d_mu = P.to_device(np.zeros((beta, qlp, n), dtype=np.uint64), gpu)
+        ctx.modup(ql, d_mu, P.to_device(c2, gpu), scheme)
+        ref_mu = tool.modup(c2, scheme)
+        assert np.array_equal(P.to_host(d_mu), ref_mu), f"modup ql={ql}"
+        # inner product (eval_key_switch.cu:14-92)
+        d_cx = P.to_device(np.zeros((2, qlp, n), dtype=np.uint64), gpu)
+        ctx.key_switch_inner_prod(ql, d_cx, d_mu, rlk.public_keys_ptr)
+        ref_cx = tool.key_switch_inner_prod(ref_mu, [evk[i] for i in range(beta)])
+        assert np.array_equal(P.to_host(d_cx), ref_cx), f"inner product ql={ql}"
+        # mod-down (rns_bconv.cu:776-828), in place like keyswitch_inplace does
+        for i in range(2):
+            ctx.moddown_from_NTT(ql, d_cx[i], d_cx[i], scheme)
+            ref = tool.moddown_from_ntt(ref_cx[i], scheme)
+            assert np.array_equal(P.to_host(d_cx[i])[:ql], ref), f"moddown ql={ql} poly={i}"
+        # whole key switch on raw buffers (eval_key_switch.cu:95-182)
+        ct = np.stack([uniform_poly(r, primes[:ql], n), uniform_poly(r, primes[:ql], n)])
+        d_ct = P.to_device(ct, gpu)
+        ctx.keyswitch_inplace(ql, d_ct, P.to_device(c2, gpu), rlk.public_keys_ptr, scheme)
+        assert np.array_equal(P.to_host(d_ct), tool.keyswitch_inplace(ct, c2, [evk[i] for i in range(beta)], scheme))
+
+
+@pytest.mark.parametrize("name,ql", [("hyb12_a2", 6), ("c3_ckks16", 45)])
+def test_bconv_P_to_Ql(name, ql, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    ctx = _ctx(name, gpu)
+    src = uniform_poly(rng_for(30), primes[size_q:], n)
+    dst = P.to_device(np.zeros((ql, n), dtype=np.uint64), gpu)
+    ctx.bconv_P_to_Ql(ql, dst, P.to_device(src, gpu))
+    assert np.array_equal(P.to_host(dst), O.bconv(primes[size_q:], primes[:ql], src, n))
+
+
+@pytest.mark.parametrize("name,ql", [("hyb12_a2", 6), ("hyb12_a2", 2), ("c3_ckks16", 45)])
+def test_rescale(name, ql, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(40)
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    dst = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+    ctx.divide_and_round_q_last_ntt(ql, P.to_device(ct, gpu), 2, dst)
+    assert np.array_equal(P.to_host(dst), tool.rescale_ntt(ct, 2))
+    ctx.divide_and_round_q_last(ql, P.to_device(ct, gpu), 2, dst)      # BFV coefficient-domain switch
+    assert np.array_equal(P.to_host(dst), tool.divide_and_round_q_last(ct, 2))
+
+
+def test_galois(gpu):
+    import phantom_fhe_amd as P
+    name = "hyb12_a2"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L = 6
+    x = uniform_poly(rng_for(50), primes[:L], n)
+    dx = P.to_device(x, gpu)
+    out = P.to_device(np.zeros_like(x), gpu)
+    for elt in (3, 5, 25, 2 * n - 1, 1):
+        ctx.apply_galois_ntt(dx, out, elt, L)
+        assert np.array_equal(P.to_host(out), O.apply_galois_ntt(x, O.galois_ntt_table(log_n, elt), n, L))
+        ctx.apply_galois(dx, out, elt, L)
+        assert np.array_equal(P.to_host(out), oc.apply_galois_coeff(x, elt, L))
+    with pytest.raises(ValueError):
+        ctx.apply_galois_ntt(dx, out, 4, L)
+
+
+def test_hommul_relin_rescale_c3(gpu):
+    """CKKS HomMul + relinearize + rescale at N=2^16, 45 limbs, stage by stage."""
+    import phantom_fhe_amd as P
+    name = "c3_ckks16"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    ql = size_q
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(60)
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    ct1 = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    ct2 = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    buf = P.to_device(np.concatenate([ct1, np.zeros((1, ql, n), dtype=np.uint64)]), gpu)
+    ctx.tensor_prod_2x2_rns_poly(buf, P.to_device(ct2, gpu), buf, ql)                  # multiply_inplace
+    ref3 = oc.tensor_prod_2x2(ct1, ct2, ql)
+    ctx.keyswitch_inplace(ql, buf, buf[2], rlk.public_keys_ptr, O.CKKS)              # relinearize_inplace
+    ref2 = tool.keyswitch_inplace(ref3[:2], ref3[2], [evk[i] for i in range(tool.beta)], O.CKKS)
+    assert np.array_equal(P.to_host(buf)[:2], ref2)
+    dst = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+    ctx.divide_and_round_q_last_ntt(ql, buf[:2].contiguous(), 2, dst)                 # rescale_to_next
+    assert np.array_equal(P.to_host(dst), tool.rescale_ntt(ref2, 2))

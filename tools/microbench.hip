@@ -1,0 +1,118 @@
+// microbench.hip -- gfx950 instruction-rate and bandwidth probes that size the NTT design
+// (is the 64-bit modular butterfly ALU-bound before it is HBM-bound?).
+// Build: hipcc --offload-arch=gfx950 -O3 -o microbench tools/microbench.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+typedef uint64_t u64;
+typedef uint32_t u32;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); return 1; } } while (0)
+
+enum { OP_FMA32, OP_ADD32, OP_MULLO, OP_MULHI, OP_MAD64, OP_ADD64, OP_FMA64, OP_MUL64LO, OP_MUL64HI, OP_SHOUP, OP_BFLY };
+static const char *names[] = {"v_fma_f32", "v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "add64(v_lshl_add_u64)",
+                              "v_fma_f64", "mul64 lo (a*b)", "mul64 hi (__umul64hi)", "shoup_lazy", "ct butterfly"};
+constexpr int CH = 8;      // independent chains per thread
+constexpr int INNER = 64;  // ops per chain per outer iteration
+
+template <int OP>
+__global__ __launch_bounds__(256) void rate_kernel(u64 *out, u64 seed, int iters) {
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 a[CH], b[CH];
+    float fa[CH]; double da[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) { a[c] = seed * (tid + 1) + c * 0x9e3779b97f4a7c15ull; b[c] = a[c] ^ (seed >> 3); fa[c] = (float)(a[c] & 1023); da[c] = (double)(a[c] & 1023); }
+    const u64 q = (seed | 1) & ((1ull << 60) - 1), q2 = q * 2;
+    const u64 w = seed * 3 + 1, ws = seed * 7 + 5;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < INNER; j++) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                if (OP == OP_FMA32) fa[c] = __builtin_fmaf(fa[c], 1.0001f, 0.5f);
+                else if (OP == OP_ADD32) { u32 x = (u32)a[c]; x = x + (u32)b[c]; a[c] = x; }
+                else if (OP == OP_MULLO) { u32 x = (u32)a[c]; x = x * (u32)b[c] + 1; a[c] = x; }
+                else if (OP == OP_MULHI) { u32 x = (u32)a[c]; x = __umulhi(x, (u32)b[c]) | 0x10001u; a[c] = x; }
+                else if (OP == OP_MAD64) { a[c] = (u64)(u32)a[c] * (u64)(u32)b[c] + a[c]; }
+                else if (OP == OP_ADD64) { a[c] = a[c] + b[c]; }
+                else if (OP == OP_FMA64) da[c] = __builtin_fma(da[c], 1.0000001, 0.5);
+                else if (OP == OP_MUL64LO) a[c] = a[c] * b[c] + 1;
+                else if (OP == OP_MUL64HI) a[c] = __umul64hi(a[c], b[c]) | 0x100000001ull;
+                else if (OP == OP_SHOUP) a[c] = a[c] * w - __umul64hi(a[c], ws) * q;
+                else if (OP == OP_BFLY) {
+                    u64 X = a[c], Y = b[c];
+                    u64 x = X >= q2 ? X - q2 : X;
+                    u64 t = Y * w - __umul64hi(Y, ws) * q;
+                    a[c] = x + t; b[c] = x + q2 - t;
+                }
+            }
+        }
+    }
+    u64 acc = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++) acc += a[c] + b[c] + (u64)fa[c] + (u64)da[c];
+    out[tid] = acc;
+}
+
+template <int OP>
+static int run_rate(u64 *out, int blocks, double clk_ghz) {
+    const int iters = 64;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(256), 0, 0, out, 0x123456789abcdefull, 2);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(256), 0, 0, out, 0x123456789abcdefull, iters);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double ops = (double)blocks * 256 * iters * INNER * CH;            // lane-ops
+    const double wave_ops_per_simd = ops / 64.0 / (256.0 * 4);                // wave-instructions per SIMD
+    const double ns_per = ms * 1e6 / wave_ops_per_simd;
+    printf("%-26s %8.3f ms  %8.2f Tlane-op/s  %6.2f ns/wave-op/SIMD = %6.2f cyc @%.2fGHz\n", names[OP], ms, ops / ms / 1e9,
+           ns_per, ns_per * clk_ghz, clk_ghz);
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void rw_kernel(uint4 *__restrict__ buf, size_t n16) {  // in-place read+write
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 v = buf[i]; v.x += 1; buf[i] = v;
+    }
+}
+
+int main() {
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    const double clk = p.clockRate / 1e6;
+    printf("device %s  CUs %d  clock %.2f GHz  L2 %d KiB\n", p.name, p.multiProcessorCount, clk, p.l2CacheSize / 1024);
+    const int blocks = p.multiProcessorCount * 8;  // 8 blocks x 4 waves = 32 waves/CU = 8/SIMD
+    u64 *out; CK(hipMalloc(&out, (size_t)blocks * 256 * 8));
+    run_rate<OP_FMA32>(out, blocks, clk); run_rate<OP_ADD32>(out, blocks, clk); run_rate<OP_MULLO>(out, blocks, clk);
+    run_rate<OP_MULHI>(out, blocks, clk); run_rate<OP_MAD64>(out, blocks, clk); run_rate<OP_ADD64>(out, blocks, clk);
+    run_rate<OP_FMA64>(out, blocks, clk); run_rate<OP_MUL64LO>(out, blocks, clk); run_rate<OP_MUL64HI>(out, blocks, clk);
+    run_rate<OP_SHOUP>(out, blocks, clk); run_rate<OP_BFLY>(out, blocks, clk);
+
+    const size_t sizes_mib[] = {8, 23, 45, 90, 180, 512, 2048};
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (size_t mib : sizes_mib) {
+        const size_t bytes = mib << 20, n16 = bytes / 16;
+        uint4 *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+        CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+        const int grid = p.multiProcessorCount * 16, reps = 20;
+        hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, 0, a, b, n16); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, 0, a, b, n16);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double copy_tbs = 2.0 * bytes * reps / ms / 1e9;
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(rw_kernel, dim3(grid), dim3(256), 0, 0, a, n16);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double rw_tbs = 2.0 * bytes * reps / ms / 1e9;
+        printf("buffer %5zu MiB: copy a->b %6.2f TB/s (r+w, %.1f us/launch)   in-place rw %6.2f TB/s (%.1f us/launch)\n", mib, copy_tbs,
+               2.0 * bytes / copy_tbs / 1e6, rw_tbs, ms * 1000 / reps);
+        CK(hipFree(a)); CK(hipFree(b));
+    }
+    return 0;
+}
