@@ -1,0 +1,206 @@
+"""Pins the CPU oracle (oracle/) -- runs without a GPU.
+
+The reference ships no golden vectors (test/ntt_test.cu is a round trip on constants; examples compare
+decryptions with eps = 1e-3), and it cannot be compiled here (include/host/defines.h:34 needs CUDA
+headers), so the oracle is "parity unpinned against an executed reference".  It is pinned by:
+  * the values SURVEY.md 8(c) records from the survey's run of the reference host code,
+  * the literal default primes the reference embeds (src/host/globals.cu:71),
+  * the mathematical definition of every operation (all stored outputs are canonical residues).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import C1_PRIMES, brev, crt_compose, oracle_ctx, primes_of, rng_for, uniform_poly
+
+
+def test_reference_kats_from_survey():
+    # CoeffModulus::Create(2^14, {60, 40x6, 60})[0], its const_ratio, its minimal root
+    p = O.coeff_modulus_create(1 << 14, [60] + [40] * 6 + [60])
+    assert int(p[0]) == 1152921504606683137
+    assert O.const_ratio(int(p[0])) == (0x27fff00, 0x10)
+    assert O.minimal_primitive_root(1 << 15, int(p[0])) == 212089012217363
+    # same-size primes are handed out from the back of the descending list (modulus.cu:105-109)
+    found = O.get_primes(1 << 14, 60, 2)
+    assert int(p[0]) == int(found[1]) and int(p[-1]) == int(found[0]) and int(found[0]) > int(found[1])
+
+
+def test_reference_default_primes_are_ntt_primes():
+    for q in C1_PRIMES:  # src/host/globals.cu:71
+        assert O.is_prime(q) and (q - 1) % (2 * 4096) == 0
+
+
+@pytest.mark.parametrize("bits", [30, 50, 60])
+def test_prime_search_definition(bits):
+    n = 4096
+    ps = [int(x) for x in O.get_primes(n, bits, 4)]
+    assert ps == sorted(ps, reverse=True)
+    v, want = (1 << bits) - 2 * n + 1, []
+    while len(want) < 4:          # numth.cu:207-233: descend from 2^bits - 2N + 1 in steps of 2N
+        if pow(2, v - 1, v) == 1 and all(v % s for s in (3, 5, 7, 11, 13)) and O.is_prime(v):
+            want.append(v)
+        v -= 2 * n
+    assert ps == want
+
+
+def test_minimal_root_is_minimal():
+    n, q = 64, int(O.get_primes(64, 20, 1)[0])
+    r = O.minimal_primitive_root(2 * n, q)
+    roots = [x for x in range(1, q) if pow(x, n, q) == q - 1]
+    assert r == min(roots)
+
+
+def test_tables_follow_ntt_cu():
+    log_n, n = 6, 64
+    q = int(O.get_primes(n, 30, 1)[0])
+    tw, tws, itw, itws, ni, nis = O.ntt_tables(log_n, q)
+    psi = O.minimal_primitive_root(2 * n, q)
+    ipsi = pow(psi, -1, q)
+    assert ni == pow(n, -1, q) and nis == (ni << 64) // q
+    for k in range(n):
+        assert int(tw[k]) == pow(psi, brev(k, log_n), q) and int(tws[k]) == (int(tw[k]) << 64) // q
+        want = pow(ipsi, brev(k, log_n), q)
+        if k == 1:
+            want = want * ni % q                  # src/host/ntt.cu:53-55
+        assert int(itw[k]) == want and int(itws[k]) == (want << 64) // q
+
+
+@pytest.mark.parametrize("log_n,bits", [(4, 20), (6, 30), (8, 50), (8, 60)])
+def test_forward_is_evaluation_at_odd_powers(log_n, bits):
+    n = 1 << log_n
+    q = int(O.get_primes(n, bits, 1)[0])
+    psi = O.minimal_primitive_root(2 * n, q)
+    c = O.Ctx(log_n, [q], 0)
+    x = rng_for(log_n).integers(0, q, n, dtype=np.uint64)
+    y = c.nwt_forward(x.reshape(1, n), 1)[0]
+    for k in range(n):   # out[k] = x(psi^(2*brev(k)+1)), SURVEY.md a3
+        assert int(y[k]) == sum(int(x[j]) * pow(psi, (2 * brev(k, log_n) + 1) * j, q) for j in range(n)) % q
+    assert np.array_equal(c.nwt_backward(y.reshape(1, n), 1)[0], x)
+
+
+def test_negacyclic_convolution_and_edges():
+    log_n, n = 8, 256
+    q = int(O.get_primes(n, 50, 1)[0])
+    c = O.Ctx(log_n, [q], 0)
+    r = rng_for(77)
+    a, b = r.integers(0, q, n, dtype=np.uint64), r.integers(0, q, n, dtype=np.uint64)
+    fa, fb = c.nwt_forward(a.reshape(1, n), 1), c.nwt_forward(b.reshape(1, n), 1)
+    prod = c.nwt_backward(c.multiply(fa, fb, 1), 1)[0]
+    want = [0] * n
+    for i in range(n):
+        for j in range(n):
+            k, s = (i + j) % n, (-1 if i + j >= n else 1)
+            want[k] = (want[k] + s * int(a[i]) * int(b[j])) % q
+    assert [int(v) for v in prod] == want
+    for v in (0, q - 1):   # constant / extreme inputs round-trip (ntt_test.cu uses all-ones / all-twos)
+        x = np.full((1, n), v, dtype=np.uint64)
+        assert np.array_equal(c.nwt_backward(c.nwt_forward(x, 1), 1), x)
+
+
+def test_dyadic_against_python_ints():
+    log_n, primes, size_p = primes_of("hyb12_a2")
+    oc = oracle_ctx("hyb12_a2")
+    n, L = 1 << log_n, 3
+    r = rng_for(5)
+    a, b, d = (uniform_poly(r, primes[:L], n) for _ in range(3))
+    a[:, 0] = 0
+    b[:, 1] = [q - 1 for q in primes[:L]]
+    a[:, 1] = [q - 1 for q in primes[:L]]
+    for l, q in enumerate(primes[:L]):
+        ai, bi, di = ([int(v) for v in arr[l][:64]] for arr in (a, b, d))
+        assert [int(v) for v in oc.add(a, b, L)[l][:64]] == [(x + y) % q for x, y in zip(ai, bi)]
+        assert [int(v) for v in oc.sub(a, b, L)[l][:64]] == [(x - y) % q for x, y in zip(ai, bi)]
+        assert [int(v) for v in oc.negate(a, L)[l][:64]] == [(-x) % q for x in ai]
+        assert [int(v) for v in oc.multiply(a, b, L)[l][:64]] == [x * y % q for x, y in zip(ai, bi)]
+        assert [int(v) for v in oc.multiply_and_add(a, b, d, L)[l][:64]] == [(x * y + z) % q for x, y, z in zip(ai, bi, di)]
+    t = oc.tensor_prod_2x2(np.stack([a, b]), np.stack([d, a]), L)
+    for l, q in enumerate(primes[:L]):
+        for k in range(16):
+            c0, c1, e0, e1 = int(a[l, k]), int(b[l, k]), int(d[l, k]), int(a[l, k])
+            assert [int(t[p, l, k]) for p in range(3)] == [c0 * e0 % q, (c0 * e1 + c1 * e0) % q, c1 * e1 % q]
+    s = oc.tensor_square_2x2(np.stack([a, b]), L)
+    assert np.array_equal(s, oc.tensor_prod_2x2(np.stack([a, b]), np.stack([a, b]), L))
+
+
+def test_fast_base_conversion_is_crt_plus_small_multiple_of_q():
+    """bConv_BEHZ (rns_bconv.cu:212-229) is the uncorrected conversion: out_j = (x + u*Q) mod p_j, 0<=u<#ibase."""
+    log_n, primes, size_p = primes_of("hyb12_a2")
+    n = 1 << log_n
+    ib, ob = list(primes[6:8]) + [primes[0]], list(primes[1:5])
+    src = uniform_poly(rng_for(9), ib, n)
+    out = O.bconv(ib, ob, src, n)
+    for k in range(0, n, 257):
+        x, Q = crt_compose([src[i, k] for i in range(len(ib))], ib)
+        us = {next(u for u in range(len(ib) + 1) if (x + u * Q) % int(p) == int(out[j, k])) for j, p in enumerate(ob)}
+        assert len(us) == 1     # one common overflow count u for all output primes
+
+
+def _small_keys(oc, primes, n, size_q, size_p, r, new_key_ntt, sk_ntt):
+    dnum = size_q // size_p
+    a = np.stack([uniform_poly(r, primes, n) for _ in range(dnum)])
+    e_small = r.integers(-3, 4, (dnum, n))
+    e = np.stack([np.stack([np.array([int(v) % int(q) for v in e_small[d]], dtype=np.uint64) for q in primes]) for d in range(dnum)])
+    e_ntt = np.stack([oc.nwt_forward(e[d], len(primes), 0) for d in range(dnum)])
+    return oc.gen_kswitch_key(sk_ntt, new_key_ntt, a, e_ntt)
+
+
+@pytest.mark.parametrize("name,ql", [("hyb12_a2", 6), ("hyb12_a2", 3), ("c1_bfv4096", 2)])
+def test_relinearize_decrypts_correctly(name, ql):
+    """Functional pin of mod-up / inner product / mod-down and of the evk layout (secretkey.cu:297-341):
+    with genuine keys, c0' + c1' s = c0 + c1 s + c2 s^2 + small, checked with big integers (CKKS form)."""
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc = oracle_ctx(name)
+    r = rng_for(31)
+    s_small = r.integers(-1, 2, n)
+    sk = np.stack([np.array([int(v) % int(q) for v in s_small], dtype=np.uint64) for q in primes])
+    sk_ntt = oc.nwt_forward(sk, len(primes), 0)
+    s2_ntt = oc.multiply(sk_ntt[:size_q], sk_ntt[:size_q], size_q)
+    evk = _small_keys(oc, primes, n, size_q, size_p, r, s2_ntt, sk_ntt)
+    tool = O.Tool(oc, ql)
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(3)])    # (c0, c1, c2) in NTT form
+    out = tool.keyswitch_inplace(ct[:2], ct[2], [evk[i] for i in range(tool.beta)], O.CKKS)
+    s1, s2 = sk_ntt[:ql], s2_ntt[:ql]
+    before = oc.add(oc.add(ct[0], oc.multiply(ct[1], s1, ql), ql), oc.multiply(ct[2], s2, ql), ql)
+    after = oc.add(out[0], oc.multiply(out[1], s1, ql), ql)
+    diff = oc.nwt_backward(oc.sub(after, before, ql), ql)
+    Q = 1
+    for q in primes[:ql]:
+        Q *= int(q)
+    worst = 0
+    for k in range(0, n, 97):
+        v, _ = crt_compose([diff[l, k] for l in range(ql)], primes[:ql])
+        v = v - Q if v > Q // 2 else v
+        worst = max(worst, abs(v))
+    assert worst < n * 64 * (size_q // size_p + ql)   # key-switch noise, nowhere near Q
+    assert worst.bit_length() < Q.bit_length() - 20
+
+
+def test_rescale_is_floor_division_by_q_last():
+    """divide_and_round_q_last_ntt floors (rns.cu:1118 comment notwithstanding): dst = (c - [c]_qlast)/qlast."""
+    name, ql = "hyb12_a2", 4
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc = oracle_ctx(name)
+    tool = O.Tool(oc, ql)
+    c = uniform_poly(rng_for(41), primes[:ql], n)            # coefficient form
+    c_ntt = oc.nwt_forward(c, ql, 0)
+    out = oc.nwt_backward(tool.rescale_ntt(c_ntt.reshape(1, ql, n), 1)[0], ql - 1)
+    assert np.array_equal(out, tool.divide_and_round_q_last(c.reshape(1, ql, n), 1)[0])
+    for k in range(0, n, 131):
+        v, _ = crt_compose([c[l, k] for l in range(ql)], primes[:ql])
+        want = (v - int(c[ql - 1, k])) // int(primes[ql - 1])
+        assert [int(out[l, k]) for l in range(ql - 1)] == [want % int(q) for q in primes[:ql - 1]]
+
+
+def test_galois_ntt_permutation_matches_coefficient_automorphism():
+    name = "hyb12_a2"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc = oracle_ctx(name)
+    x = uniform_poly(rng_for(51), primes[:2], n)
+    for elt in (3, 5, 2 * n - 1):
+        via_coeff = oc.nwt_forward(oc.apply_galois_coeff(x, elt, 2), 2, 0)
+        via_ntt = O.apply_galois_ntt(oc.nwt_forward(x, 2, 0), O.galois_ntt_table(log_n, elt), n, 2)
+        assert np.array_equal(via_coeff, via_ntt)
