@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native RNS core (BASELINE.json metric).
+
+A "step" is one forward negacyclic NTT over one ciphertext polynomial of the CKKS set
+N = 2^16, 45 RNS limbs (examples/3_ckks.cu:729-739) -- exactly the reference call
+nwt_2d_radix8_forward_inplace(data, tables, 45, 0) (src/ntt/fntt_2d.cu:620-653) -- on synthetic
+uniform residues already resident in HBM.  `value` is limb-transforms per second over all ranks.
+The same line also carries HomMul+relinearize+rescale/s for the same parameter set,
+the roofline object for the forward NTT, and the CPU baseline (the oracle, timed on host cores).
+
+Multi-GPU: independent ciphertexts shard across ranks (weak scaling, no data-path collective); the
+evaluation key is generated on rank 0 and broadcast once over RCCL (setup, not timed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "phantom-fhe_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+LOG_N = 16
+BITS = [60] + [50] * 44 + [60] * 15   # 45 data primes + 15 special primes
+SIZE_P = 15
+PEAK_HBM = 8.0e12                     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+
+
+def uniform_residues(primes, n, device, gen):
+    """[len(primes)][n] int64 tensor, limb i uniform in [0, primes[i]) (bits = uint64 residues)."""
+    out = torch.empty((len(primes), n), dtype=torch.int64, device=device)
+    for i, q in enumerate(primes):
+        out[i] = torch.randint(0, int(q), (n,), dtype=torch.int64, device=device, generator=gen)
+    return out
+
+
+def cpu_baseline(primes, n, seconds=12.0):
+    """Time the oracle's forward NTT (scalar C port of the reference semantics) on one host core."""
+    from oracle import oracle as O
+    path = O.build(native=True)
+    oc = O.Ctx(LOG_N, [int(p) for p in primes[:45]], 0, libpath=path)
+    rng = np.random.default_rng(1)
+    x = np.stack([rng.integers(0, int(q), n, dtype=np.uint64) for q in primes[:45]]).reshape(-1)
+    import ctypes as C
+    ptr = x.ctypes.data_as(C.POINTER(C.c_uint64))
+    oc.L.orc_nwt_forward(oc.h, ptr, 45, 0)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        oc.L.orc_nwt_forward(oc.h, ptr, 45, 0)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": 45 * reps / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} forward NTTs of 45 limbs at N=2^16 ({dt:.1f} s, oracle/oracle.c -O3 -march=native, 1 thread)",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://")   # "nccl" is RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import phantom_fhe_amd as P
+    n = 1 << LOG_N
+    primes = [int(p) for p in P.coeff_modulus_create(n, BITS)]
+    size_q = len(primes) - SIZE_P
+    ctx = P.PhantomContext(LOG_N, primes, SIZE_P, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0000 + 3 + rank)
+
+    # ---- evaluation key: generated on rank 0, broadcast once over RCCL/xGMI --------
+    dnum = size_q // SIZE_P
+    evk = [torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum)]
+    if rank == 0:
+        for k in evk:
+            k[0] = uniform_residues(primes, n, dev, gen)
+            k[1] = uniform_residues(primes, n, dev, gen)
+    if world > 1:
+        for k in evk:
+            dist.broadcast(k, src=0)
+    rlk = P.PhantomRelinKey(evk)
+
+    # ---- forward NTT: the timed headline ---------------------------------------------------------------
+    poly = uniform_residues(primes[:size_q], n, dev, gen)
+    for _ in range(args.warmup):
+        ctx.nwt_2d_radix8_forward_inplace(poly, size_q, 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()                       # same stream the launches go to (torch's current stream)
+    for _ in range(args.steps):
+        ctx.nwt_2d_radix8_forward_inplace(poly, size_q, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps      # average duration of one forward NTT (2 kernels)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ntt_per_s = world * args.steps * size_q / elapsed
+
+    # ---- HomMul + relinearize + rescale (secondary figure, same parameter set) -------------------------
+    ct1 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
+    ct2 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
+    buf = torch.zeros((3, size_q, n), dtype=torch.int64, device=dev)
+    out = torch.zeros((2, size_q - 1, n), dtype=torch.int64, device=dev)
+
+    def hommul():
+        buf[:2].copy_(ct1)
+        ctx.tensor_prod_2x2_rns_poly(buf, ct2, buf, size_q)                              # multiply_inplace
+        ctx.keyswitch_inplace(size_q, buf, buf[2], rlk.public_keys_ptr, P.scheme_type.ckks)  # relinearize
+        ctx.divide_and_round_q_last_ntt(size_q, buf, 2, out)                             # rescale_to_next
+
+    hm_steps = max(5, args.steps // 10)
+    for _ in range(3):
+        hommul()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(hm_steps):
+        hommul()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    hm_elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([hm_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hm_elapsed = float(t.item())
+
+    if rank == 0:
+        alg_bytes = 16.0 * n * size_q                  # 8 B read + 8 B write per coefficient
+        achieved = alg_bytes / (kernel_ms * 1e-3)
+        line = {
+            "metric": "forward NTT limb-transforms/s at N=2^16, 45 RNS moduli",
+            "value": ntt_per_s, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "CKKS N=2^16, 45 data limbs (+15 special), forward NTT of one ciphertext "
+                                   "polynomial per step (configs[2] parameter set)",
+                       "N": n, "limbs": size_q, "special_limbs": SIZE_P, "parallelism": f"ciphertext-batch x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                         "frac": achieved / PEAK_HBM, "traffic": None,
+                         "kernel": "ntt_pass_kernel pair (strided pass + contiguous pass)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms},
+            "hommul_relin_rescale": {"value": world * hm_steps / hm_elapsed, "unit": "ops/s",
+                                     "ms_per_op": 1e3 * hm_elapsed / hm_steps, "steps": hm_steps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(primes, n)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
