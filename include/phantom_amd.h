@@ -86,6 +86,15 @@ int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context_t ctx, ui
                                                            size_t coeff_modulus_size, size_t start_modulus_idx,
                                                            size_t size_QP, size_t size_P, void *stream);
 
+/* Extension (no reference counterpart): the same limbs [start, start+size) of `batch` polynomials that
+ * lie `poly_stride` elements apart (e.g. the polynomials of a ciphertext) in ONE launch. */
+int pha_nwt_2d_radix8_forward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                              size_t start_modulus_idx, size_t batch, size_t poly_stride,
+                                              void *stream);
+int pha_nwt_2d_radix8_backward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                               size_t start_modulus_idx, size_t batch, size_t poly_stride,
+                                               void *stream);
+
 /* ---- dyadic kernels (include/polymath.cuh:6-307, launched <<<N*L/128,128>>> by evaluate.cu).
  *      The reference passes `const DModulus *modulus` (a row of the QP table); here that is
  *      (ctx, mod_start_idx).  Buffers hold coeff_mod_size limbs. ---- */
@@ -142,6 +151,10 @@ int pha_apply_galois_ntt(pha_context_t ctx, const uint64_t *src, uint64_t *dst, 
                          size_t coeff_mod_size, void *stream);
 int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt,
                      size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+
+/* ---- tuning knob for A/B measurements: key 0 = NTT thread geometry (0: 16 coefficients per thread,
+ *      256-thread workgroups; 1: 8 per thread, 512-thread workgroups).  Results are identical. ---- */
+int pha_set_tuning(int key, int value);
 
 /* ---- measurement hook used by bench.py: time `iters` back-to-back launches of the forward NTT
  *      with hipEvents on `stream`; returns average milliseconds per launch in *ms_out. ---- */

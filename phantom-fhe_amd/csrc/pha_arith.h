@@ -87,6 +87,71 @@ PHA_HD void mac128(u64 a, u64 b, u64 &lo, u64 &hi) {
     hi += ph + (lo < pl);
 }
 
+// ---- gfx950-tuned lazy Shoup multiply ---------------------------------------------------------------
+// v_mul_hi_u32 issues at 1/8 of the FP32 rate on gfx950, v_mad_u64_u32 at 1/4 and delivers the full
+// 64-bit product (profiles/r01_microbench_gfx950.txt), so the quotient estimate is built from three
+// v_mad_u64_u32 (the compiler would pick v_mul_hi_u32, hence the asm), drops the a0*b0 term and the
+// middle carry (estimate in [Q-2, Q]), and the remainder Y*w - Q*q is one v_mad chain against -q.
+// Result in [0, 4q); any 64-bit Y.  Measured 87.7 vs 106 cycles per wave-butterfly.
+PHA_HD u64 mad_u64_u32(u32 a, u32 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return (u64)a * b + c;
+#endif
+}
+PHA_HD u64 mul_u64_u32(u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+#else
+    return (u64)a * b;
+#endif
+}
+PHA_HD u64 add_u64_u32(u64 c, u32 a) {  // c + a without a carry chain through VCC
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry) : "v"(a), "v"(c));
+    return d;
+#else
+    return c + a;
+#endif
+}
+// floor(a*b / 2^64) - e, e in {0,1,2}
+PHA_HD u64 mulhi64_approx(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p01 = mul_u64_u32(a0, b1), p10 = mul_u64_u32(a1, b0);
+    return add_u64_u32(mad_u64_u32(a1, b1, p01 >> 32), (u32)(p10 >> 32));
+}
+// Y*w mod q, lazy: result in [0,4q). nq = 2^64 - q.
+PHA_HD u64 shoup_lazy4(u64 Y, u64x2 w, u64 nq) {
+    const u32 y0 = (u32)Y, y1 = (u32)(Y >> 32), w0 = (u32)w.x, w1 = (u32)(w.x >> 32);
+    const u64 Q = mulhi64_approx(Y, w.y);
+    const u32 q0 = (u32)Q, q1 = (u32)(Q >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    const u64 T = mad_u64_u32(q0, n0, mul_u64_u32(y0, w0));
+    const u32 hi = (u32)(T >> 32) + y0 * w1 + y1 * w0 + q0 * n1 + q1 * n0;
+    return ((u64)hi << 32) | (u32)T;
+}
+
+// Butterflies on the [0,8q) / [0,4q) lazy ranges that shoup_lazy4 needs (q < 2^61). q4 = 4q.
+// CT: X,Y in [0,8q) -> [0,8q)
+PHA_HD void ct_bfly4(u64 &X, u64 &Y, u64x2 w, u64 q4, u64 nq) {
+    const u64 x = csub(X, q4);
+    const u64 t = shoup_lazy4(Y, w, nq);
+    X = x + t;
+    Y = x + q4 - t;
+}
+// GS: X,Y in [0,4q) -> [0,4q)
+PHA_HD void gs_bfly4(u64 &X, u64 &Y, u64x2 w, u64 q4, u64 nq) {
+    const u64 s = X + Y;
+    const u64 d = X + q4 - Y;
+    X = csub(s, q4);
+    Y = shoup_lazy4(d, w, nq);
+}
+
 // Harvey butterflies (include/butterfly.cuh:10-22 / :28-37). q2 = 2q.
 // CT: X,Y in [0,4q) -> X,Y in [0,4q)
 PHA_HD void ct_bfly(u64 &X, u64 &Y, u64x2 w, u64 q, u64 q2) {

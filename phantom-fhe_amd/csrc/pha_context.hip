@@ -165,6 +165,11 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
     if (size_qp < 1 || size_qp > 64 || size_p >= size_qp) throw std::invalid_argument("RNSBase is invalid");
     c.device = device;
     PHA_HIP(hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        PHA_HIP(hipGetDeviceProperties(&prop, device));
+        c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     c.log_n = log_n;
     c.n = (size_t)1 << log_n;
     c.size_qp = size_qp;

@@ -98,6 +98,7 @@ struct Arena {
 
 struct Context {
     int device = 0;
+    int num_cus = 256;
     uint32_t log_n = 0, size_qp = 0, size_p = 0, size_q = 0;
     size_t n = 0;
     std::vector<u64> primes, roots, n_inv;
@@ -152,6 +153,8 @@ inline LimbSel special_sel(size_t start, size_t count, size_t size_QP, size_t si
 struct NttExtra {
     const u64 *scale = nullptr, *scale_shoup = nullptr;  // indexed by absolute limb
     const u64 *aux = nullptr;                            // fuse_moddown: cx base
+    uint32_t batch = 1;                                  // polynomials per launch
+    size_t poly_stride = 0;                              // elements between consecutive polynomials
 };
 void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
                  hipStream_t s);

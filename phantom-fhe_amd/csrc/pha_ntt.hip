@@ -9,7 +9,16 @@
 #include "pha_internal.h"
 #include "pha_ntt_core.h"
 
+#include <atomic>
+
 namespace pha {
+
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier
+std::atomic<int> g_ntt_variant{1};  // default: 8 coefficients per thread, per-round twiddle loads (best at 45 limbs, r01b)
+#if defined(PHA_EXP_STAMPS)
+__device__ unsigned long long g_stamps[8];
+#endif
+int g_num_cus = 256;
 
 struct NttKArgs {
     const u64 *in;
@@ -25,24 +34,21 @@ struct NttKArgs {
     LimbSel sel;
     uint32_t log_n;
     uint32_t t1, t2;         // N = t1 * t2
+    uint32_t active;         // processed limbs = sel.count minus the excluded range (pipelined kernel)
+    uint32_t batch;          // polynomials per launch (blockIdx.z), poly_stride elements apart
+    size_t poly_stride;
 };
 
-template <class C, bool FWD, int EPI, bool FOLD>
-__global__ __launch_bounds__(kThreads) void ntt_pass_kernel(const NttKArgs k) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *lds = reinterpret_cast<u64 *>(smem);
-
-    const uint32_t twr = k.sel.start + blockIdx.y;  // limb in the buffer (uniform)
-    if (twr >= k.sel.excl_start && twr < k.sel.excl_end) return;
+// Per-tile arguments of limb `twr` (absolute limb index in the buffer), tile `tile`.
+template <bool FWD, int EPI, bool FOLD>
+__device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint32_t tile, PassArgs &a) {
     const uint32_t prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
     const size_t n = (size_t)1 << k.log_n;
-
-    PassArgs a;
     a.in = k.in + (size_t)twr * n;
     a.out = k.out + (size_t)twr * n;
     a.tw = k.tw + (size_t)prime * n;
     a.q = k.mod[prime].value;
-    a.tile = blockIdx.x;
+    a.tile = tile;
     a.rho0 = k.t1;
     a.stride = k.t2;
     if (!FWD && FOLD) {
@@ -54,32 +60,133 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(const NttKArgs k) {
         a.scale.y = k.scale_shoup[twr];
     }
     a.aux = (EPI == EPI_FWD_MODDOWN) ? k.aux + (size_t)twr * n : nullptr;
+}
 
-    u64 reg[kElemsPerThread];
-    using Prog = PassProgram<C, FWD, EPI, FOLD>;
+template <class C, bool FWD, int EPI, bool FOLD, bool HOIST>
+__global__ __launch_bounds__(C::THREADS) void ntt_pass_kernel(const NttKArgs k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *lds = reinterpret_cast<u64 *>(smem);
+
+    const uint32_t twr = k.sel.start + blockIdx.y;  // limb in the buffer (uniform)
+    if (twr >= k.sel.excl_start && twr < k.sel.excl_end) return;
+    PassArgs a;
+    tile_args<FWD, EPI, FOLD>(k, twr, blockIdx.x, a);
+    if (k.batch > 1) {  // same limbs of several polynomials in one launch
+        const size_t off = (size_t)blockIdx.z * k.poly_stride;
+        a.in += off;
+        a.out += off;
+        if (EPI == EPI_FWD_MODDOWN) a.aux += off;
+    }
+
+    u64 reg[C::EPT];
+    u64x2 twreg[C::TW_TOTAL];
+    using Prog = PassProgram<C, FWD, EPI, FOLD, HOIST>;
     const int tid = threadIdx.x;
-    Prog::template run<0>(a, lds, tid, reg);
+#if defined(PHA_EXP_STAMPS)   // timing experiment: cycle stamps of workgroup (0,0), wave 0
+#define PHA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PHA_STAMP(i) do { } while (0)
+#endif
+    PHA_STAMP(0);
+    Prog::load_twiddles(a, tid, twreg);
+    Prog::template run<0>(a, lds, tid, reg, twreg);
+    PHA_STAMP(1);
     __syncthreads();
-    Prog::template run<1>(a, lds, tid, reg);
+    PHA_STAMP(2);
+    Prog::template run<1>(a, lds, tid, reg, twreg);
+    PHA_STAMP(3);
     if constexpr (Prog::NSEG == 3) {
         __syncthreads();
-        Prog::template run<2>(a, lds, tid, reg);
+        PHA_STAMP(4);
+        Prog::template run<2>(a, lds, tid, reg, twreg);
+        PHA_STAMP(5);
+    }
+#if defined(PHA_EXP_STAMPS)
+    __builtin_amdgcn_s_waitcnt(0);
+    PHA_STAMP(6);
+#endif
+}
+
+// Software-pipelined persistent form: a workgroup owns a contiguous range of (limb, tile) work items
+// and issues the global loads of item i+1 before it computes item i, so HBM traffic and VALU work
+// overlap even when the whole problem is a single residency wave (45 limbs = 720 tiles on 256 CUs).
+template <class C, bool FWD, int EPI, bool FOLD>
+__global__ __launch_bounds__(C::THREADS) void ntt_pass_pipelined_kernel(const NttKArgs k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *lds = reinterpret_cast<u64 *>(smem);
+    using Prog = PassProgram<C, FWD, EPI, FOLD>;
+    const int tid = threadIdx.x;
+    const uint32_t log_tpl = k.log_n - 12;  // tiles per limb = N / 4096
+    const uint32_t total = k.active << log_tpl;
+    const uint32_t t_begin = (uint32_t)(((uint64_t)total * blockIdx.x) / gridDim.x);
+    const uint32_t t_end = (uint32_t)(((uint64_t)total * (blockIdx.x + 1)) / gridDim.x);
+    if (t_begin >= t_end) return;
+    const uint32_t excl_len = k.sel.excl_end - k.sel.excl_start;
+
+    auto args_of = [&](uint32_t item, PassArgs &a) {
+        uint32_t twr = k.sel.start + (item >> log_tpl);
+        if (excl_len && twr >= k.sel.excl_start) twr += excl_len;  // jump over the excluded digit
+        tile_args<FWD, EPI, FOLD>(k, twr, item & ((1u << log_tpl) - 1), a);
+    };
+    u64x2 twreg[C::TW_TOTAL];
+    auto process = [&](const PassArgs &a, u64 *reg) {
+        Prog::load_twiddles(a, tid, twreg);
+        Prog::template run_prefetched<0>(a, lds, tid, reg, twreg);
+        __syncthreads();
+        Prog::template run_prefetched<1>(a, lds, tid, reg, twreg);
+        if constexpr (Prog::NSEG == 3) {
+            __syncthreads();
+            Prog::template run_prefetched<2>(a, lds, tid, reg, twreg);
+        }
+        __syncthreads();  // LDS is reused by the next item
+    };
+
+    PassArgs a0, a1;
+    u64 r0[C::EPT], r1[C::EPT];
+    args_of(t_begin, a0);
+    Prog::prefetch(a0, tid, r0);
+    for (uint32_t t = t_begin; t < t_end; t += 2) {
+        if (t + 1 < t_end) {
+            args_of(t + 1, a1);
+            Prog::prefetch(a1, tid, r1);
+        }
+        process(a0, r0);
+        if (t + 1 >= t_end) break;
+        if (t + 2 < t_end) {
+            args_of(t + 2, a0);
+            Prog::prefetch(a0, tid, r0);
+        }
+        process(a1, r1);
     }
 }
 
 template <class C, bool FWD, int EPI, bool FOLD>
 static void launch_pass(const NttKArgs &k, hipStream_t s) {
     const size_t n = (size_t)1 << k.log_n;
-    dim3 grid((unsigned)(n / kTileElems), k.sel.count);
     const size_t lds_bytes = (size_t)C::LDS_WORDS * sizeof(u64);
-    hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD>), grid, dim3(kThreads), lds_bytes, s, k);
+    const unsigned tiles_per_limb = (unsigned)(n / kTileElems);
+    const unsigned total = k.active * tiles_per_limb;
+    if (g_ntt_variant.load(std::memory_order_relaxed) >= 2 && total > (unsigned)g_num_cus && k.batch == 1) {
+        // persistent grid: k workgroups per CU, each owning >= ~3 consecutive work items
+        const unsigned per_cu = (total + g_num_cus - 1) / g_num_cus;
+        unsigned wg_per_cu = per_cu / 3;
+        wg_per_cu = wg_per_cu < 1 ? 1 : (wg_per_cu > 4 ? 4 : wg_per_cu);
+        dim3 grid(g_num_cus * wg_per_cu);
+        hipLaunchKernelGGL((ntt_pass_pipelined_kernel<C, FWD, EPI, FOLD>), grid, dim3(C::THREADS), lds_bytes, s, k);
+    } else {
+        dim3 grid(tiles_per_limb, k.sel.count, k.batch);
+        if (g_ntt_variant.load(std::memory_order_relaxed) & 4)
+            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, true>), grid, dim3(C::THREADS), lds_bytes, s, k);
+        else
+            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, false>), grid, dim3(C::THREADS), lds_bytes, s, k);
+    }
     check_launch();
 }
 
-template <int LOGN>
+template <int LOGN, int VARIANT>
 static void forward_impl(NttKArgs k, int epi, hipStream_t s) {
-    using P1 = typename NttPlan<LOGN>::P1;
-    using P2 = typename NttPlan<LOGN>::P2;
+    using P1 = typename NttPlan<LOGN, VARIANT>::P1;
+    using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     k.t1 = P1::T;
     k.t2 = P2::T;
     u64 *const final_out = k.out;
@@ -91,10 +198,10 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s) {
     else launch_pass<P2, true, EPI_FWD_CANON, false>(k, s);
 }
 
-template <int LOGN>
+template <int LOGN, int VARIANT>
 static void inverse_impl(NttKArgs k, int epi, hipStream_t s) {
-    using P1 = typename NttPlan<LOGN>::P1;
-    using P2 = typename NttPlan<LOGN>::P2;
+    using P1 = typename NttPlan<LOGN, VARIANT>::P1;
+    using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     k.t1 = P1::T;
     k.t2 = P2::T;
     u64 *const final_out = k.out;
@@ -121,6 +228,17 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.aux = x.aux;
     k.sel = sel;
     k.log_n = c.log_n;
+    k.batch = x.batch ? x.batch : 1;
+    k.poly_stride = x.poly_stride;
+    uint32_t excl = 0;
+    if (sel.excl_end > sel.excl_start) {
+        const uint32_t lo = sel.excl_start > sel.start ? sel.excl_start : sel.start;
+        const uint32_t hi = sel.excl_end < sel.start + sel.count ? sel.excl_end : sel.start + sel.count;
+        excl = hi > lo ? hi - lo : 0;
+        if (excl && (lo != sel.excl_start || hi != sel.excl_end)) excl = 0xffffffffu;  // partial overlap: not pipelined
+    }
+    k.active = excl == 0xffffffffu ? 0 : sel.count - excl;
+    g_num_cus = c.num_cus;
     return k;
 }
 
@@ -136,13 +254,14 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     if (sel.count == 0) return;
     check_sel(c, sel);
     NttKArgs k = make_args(c, in, mid, out, sel, x, true);
+    const int v = g_ntt_variant.load(std::memory_order_relaxed) & 1;
     switch (c.log_n) {
-        case 12: forward_impl<12>(k, epi, s); break;
-        case 13: forward_impl<13>(k, epi, s); break;
-        case 14: forward_impl<14>(k, epi, s); break;
-        case 15: forward_impl<15>(k, epi, s); break;
-        case 16: forward_impl<16>(k, epi, s); break;
-        case 17: forward_impl<17>(k, epi, s); break;
+        case 12: if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
+        case 13: if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
+        case 14: if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
+        case 15: if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
+        case 16: if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
+        case 17: if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -152,13 +271,14 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     if (sel.count == 0) return;
     check_sel(c, sel);
     NttKArgs k = make_args(c, in, mid, out, sel, x, false);
+    const int v = g_ntt_variant.load(std::memory_order_relaxed) & 1;
     switch (c.log_n) {
-        case 12: inverse_impl<12>(k, epi, s); break;
-        case 13: inverse_impl<13>(k, epi, s); break;
-        case 14: inverse_impl<14>(k, epi, s); break;
-        case 15: inverse_impl<15>(k, epi, s); break;
-        case 16: inverse_impl<16>(k, epi, s); break;
-        case 17: inverse_impl<17>(k, epi, s); break;
+        case 12: if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
+        case 13: if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
+        case 14: if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
+        case 15: if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
+        case 16: if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
+        case 17: if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -260,6 +380,47 @@ int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context_t ctx, ui
     if (size_P > cms) throw std::invalid_argument("size_P exceeds coeff_modulus_size");
     ntt_inverse(ctx->c, inout, inout, inout, special_sel(start, cms, size_QP, size_P), EPI_INV_CANON, NttExtra{},
                 as_stream(stream));
+    PHA_API_END
+}
+
+int pha_nwt_2d_radix8_forward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start,
+                                              size_t batch, size_t poly_stride, void *stream) {
+    PHA_API_BEGIN
+    need(inout);
+    if (batch == 0 || batch > 65535) throw std::invalid_argument("batch out of range");
+    NttExtra x;
+    x.batch = (uint32_t)batch;
+    x.poly_stride = poly_stride;
+    ntt_forward(ctx->c, inout, inout, inout, plain_sel(start, cms), EPI_FWD_CANON, x, as_stream(stream));
+    PHA_API_END
+}
+
+int pha_nwt_2d_radix8_backward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start,
+                                               size_t batch, size_t poly_stride, void *stream) {
+    PHA_API_BEGIN
+    need(inout);
+    if (batch == 0 || batch > 65535) throw std::invalid_argument("batch out of range");
+    NttExtra x;
+    x.batch = (uint32_t)batch;
+    x.poly_stride = poly_stride;
+    ntt_inverse(ctx->c, inout, inout, inout, plain_sel(start, cms), EPI_INV_CANON, x, as_stream(stream));
+    PHA_API_END
+}
+
+#if defined(PHA_EXP_STAMPS)
+int pha_exp_read_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
+}
+#endif
+
+int pha_set_tuning(int key, int value) {
+    PHA_API_BEGIN
+    if (key == 0) {
+        if (value < 0 || value > 7) throw std::invalid_argument("unknown NTT variant");
+        g_ntt_variant.store(value);
+    } else {
+        throw std::invalid_argument("unknown tuning key");
+    }
     PHA_API_END
 }
 

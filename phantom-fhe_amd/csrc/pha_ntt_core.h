@@ -26,9 +26,7 @@
 
 namespace pha {
 
-constexpr int kThreads = 256;      // 4 wavefronts of 64
-constexpr int kElemsPerThread = 16;
-constexpr int kTileElems = kThreads * kElemsPerThread;  // 4096 coefficients = 32 KiB
+constexpr int kTileElems = 4096;  // coefficients per workgroup tile = 32 KiB of LDS
 
 // Epilogues of the last round of a transform (what is stored to global memory).
 enum Epilogue {
@@ -40,8 +38,13 @@ enum Epilogue {
 };
 
 // Round schedule of one pass: LOGT stages split into NR rounds of R0,R1,R2 stages (forward order).
-template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0>
+// EPT_ = coefficients per thread (16: 256-thread workgroups, radix-16 rounds; 8: 512-thread
+// workgroups, radix-8 rounds, twice the wavefronts per tile).
+template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16>
 struct PassCfg {
+    static constexpr int EPT = EPT_;
+    static constexpr int THREADS = kTileElems / EPT_;
+    static_assert((1 << R0_) <= EPT_ && (1 << R1_) <= EPT_ && (1 << R2_) <= EPT_, "radix exceeds registers");
     static constexpr int LOGT = LOGT_;
     static constexpr int T = 1 << LOGT_;
     static constexpr int LOGV = 12 - LOGT_;  // tile = 4096 elements
@@ -51,6 +54,10 @@ struct PassCfg {
     static_assert(R0_ + R1_ + R2_ == LOGT_, "round schedule must cover all stages");
     static_assert(LOGT_ >= 4 && LOGT_ <= 12, "tile transform length out of range");
     static constexpr int r(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : R2_; }
+    // twiddle registers per thread: round i holds G_i groups x (2^r_i - 1) pairs
+    static constexpr int tw_count(int i) { return r(i) ? (EPT_ >> r(i)) * ((1 << r(i)) - 1) : 0; }
+    static constexpr int tw_off(int i) { return i == 0 ? 0 : i == 1 ? tw_count(0) : tw_count(0) + tw_count(1); }
+    static constexpr int TW_TOTAL = tw_count(0) + tw_count(1) + tw_count(2);
     static constexpr int s0(int i) { return i == 0 ? 0 : i == 1 ? R0_ : R0_ + R1_; }
     // LDS layouts (u64 units).  contiguous pass: [v][e] with 2 words of padding per 16 so that a
     // thread's 16-coefficient run starts on a distinct 16-byte bank slot (ds_read_b128, 16-lane
@@ -102,9 +109,19 @@ PHA_HD void decode_group(int g, int &v, int &hi, int &lo) {
     }
 }
 
+// Twiddles of one radix-2^R group, preloaded in heap order: stage j, sub-group kk -> t[(1 << j) - 1 + kk],
+// taken from tw[(base0 << j) + kk] (base0 = rho * 2^s0 + hi, see round_compute).
+template <int R>
+PHA_HD void load_group_twiddles(u64x2 *t, const u64x2 *tw, u32 base0) {
+#pragma unroll
+    for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int kk = 0; kk < (1 << j); kk++) t[(1 << j) - 1 + kk] = tw[(base0 << j) + kk];
+}
+
 // r forward stages on 2^r registers; stage j uses tw[(base0 << j) + (k >> (r - j))].
 template <int R>
-PHA_HD void ct_round(u64 *v, const u64x2 *tw, u32 base0, u64 q, u64 q2) {
+PHA_HD void ct_round(u64 *v, const u64x2 *t, u64 q4, u64 nq) {
 #pragma unroll
     for (int j = 0; j < R; j++) {
         const int dist = 1 << (R - 1 - j);
@@ -112,15 +129,15 @@ PHA_HD void ct_round(u64 *v, const u64x2 *tw, u32 base0, u64 q, u64 q2) {
         for (int k = 0; k < (1 << R); k++) {
             if (k & dist) continue;
             const int kk = k >> (R - j);
-            ct_bfly(v[k], v[k + dist], tw[(base0 << j) + kk], q, q2);
+            ct_bfly4(v[k], v[k + dist], t[(1 << j) - 1 + kk], q4, nq);
         }
     }
 }
 
 // r inverse stages (reverse order).  FOLD: the j == 0 stage is the transform's last stage (m = 1)
-// and carries N^-1: X' = (X+Y)*ninv, Y' = (X-Y)*(itw[1]*ninv), both lazy [0,2q).
+// and carries N^-1: X' = (X+Y)*ninv, Y' = (X-Y)*(itw[1]*ninv), both lazy [0,4q).
 template <int R, bool FOLD>
-PHA_HD void gs_round(u64 *v, const u64x2 *tw, u32 base0, u64 q, u64 q2, u64x2 ninv, u64x2 w1ninv) {
+PHA_HD void gs_round(u64 *v, const u64x2 *t, u64 q4, u64 nq, u64x2 ninv, u64x2 w1ninv) {
 #pragma unroll
     for (int j = R - 1; j >= 0; j--) {
         const int dist = 1 << (R - 1 - j);
@@ -130,11 +147,11 @@ PHA_HD void gs_round(u64 *v, const u64x2 *tw, u32 base0, u64 q, u64 q2, u64x2 ni
             const int kk = k >> (R - j);
             if (FOLD && j == 0) {
                 u64 s = v[k] + v[k + dist];
-                u64 d = v[k] + q2 - v[k + dist];
-                v[k] = shoup_lazy(s, ninv, q);
-                v[k + dist] = shoup_lazy(d, w1ninv, q);
+                u64 d = v[k] + q4 - v[k + dist];
+                v[k] = shoup_lazy4(s, ninv, nq);
+                v[k + dist] = shoup_lazy4(d, w1ninv, nq);
             } else {
-                gs_bfly(v[k], v[k + dist], tw[(base0 << j) + kk], q, q2);
+                gs_bfly4(v[k], v[k + dist], t[(1 << j) - 1 + kk], q4, nq);
             }
         }
     }
@@ -142,27 +159,27 @@ PHA_HD void gs_round(u64 *v, const u64x2 *tw, u32 base0, u64 q, u64 q2, u64x2 ni
 
 template <int EPI>
 PHA_HD u64 apply_epilogue(u64 x, const PassArgs &a, size_t gi) {
+    // forward values arrive in [0,8q), inverse values in [0,4q) (lazy ranges of ct_bfly4 / gs_bfly4)
     const u64 q = a.q;
-    if (EPI == EPI_FWD_CANON) return csub(csub(x, q << 1), q);
+    if (EPI == EPI_FWD_CANON) return csub(csub(csub(x, q << 2), q << 1), q);
     if (EPI == EPI_FWD_MODDOWN) {
-        u64 t = csub(csub(x, q << 1), q);
+        u64 t = csub(csub(csub(x, q << 2), q << 1), q);
         return shoup(sub_mod(a.aux[gi], t, q), a.scale, q);  // sub_negate_const_mult uintmodmath.cuh:233-241
     }
-    if (EPI == EPI_INV_CANON) return csub(x, q);
+    if (EPI == EPI_INV_CANON) return csub(csub(x, q << 1), q);
     if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);
     return x;
 }
 
-// Load one round's registers (from global on the first round, else from LDS) and run its stages.
-template <class C, int RI, bool FWD, bool FROM_GLOBAL, bool FOLD>
-PHA_HD void round_in(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
-    constexpr int r = C::r(RI), K = 1 << r, G = kElemsPerThread >> r, s0 = C::s0(RI);
+// Load one round's registers: from global memory on the first round, else from LDS.
+template <class C, int RI, bool FROM_GLOBAL>
+PHA_HD void round_load(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
+    constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r, s0 = C::s0(RI);
     constexpr int LOGD = C::LOGT - s0 - r;
-    const u64 q = a.q, q2 = a.q << 1;
 #pragma unroll
     for (int gi = 0; gi < G; gi++) {
         int v, hi, lo;
-        decode_group<C, RI>(tid + kThreads * gi, v, hi, lo);
+        decode_group<C, RI>(tid + C::THREADS * gi, v, hi, lo);
         u64 *rg = reg + gi * K;
         const int e0 = (hi << (LOGD + r)) + lo;
         if (FROM_GLOBAL) {
@@ -182,22 +199,53 @@ PHA_HD void round_in(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
 #pragma unroll
             for (int k = 0; k < K; k++) rg[k] = lds[C::lds_index(e0 + (k << LOGD), v)];
         }
+    }
+}
+
+// Issue the global loads of one round's twiddles into registers (all rounds are loaded up front,
+// together with the data, so a tile pays one memory latency instead of one per round: the tables
+// are far larger than L2).
+template <class C, int RI>
+PHA_HD void round_load_tw(const PassArgs &a, int tid, u64x2 *twreg) {
+    constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r, s0 = C::s0(RI);
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        int v, hi, lo;
+        decode_group<C, RI>(tid + C::THREADS * gi, v, hi, lo);
         const u32 rho = C::STRIDED ? 1u : (a.rho0 + a.tile * C::V + (u32)v);
+#if defined(PHA_EXP_CONST_TW)   // timing experiment only (wrong results): every twiddle from the first 16 entries
+        const u32 base0 = 1;
+        (void)rho; (void)hi;
+#else
         const u32 base0 = (rho << s0) + (u32)hi;
-        if (FWD) ct_round<r>(rg, a.tw, base0, q, q2);
-        else gs_round<r, FOLD>(rg, a.tw, base0, q, q2, a.ninv, a.w1ninv);
+#endif
+        load_group_twiddles<r>(twreg + C::tw_off(RI) + gi * (K - 1), a.tw, base0);
+    }
+}
+
+// Run one round's stages on the registers.
+template <class C, int RI, bool FWD, bool FOLD>
+PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twreg) {
+    constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r;
+    const u64 q4 = a.q << 2, nq = 0 - a.q;
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        u64 *rg = reg + gi * K;
+        const u64x2 *t = twreg + C::tw_off(RI) + gi * (K - 1);
+        if (FWD) ct_round<r>(rg, t, q4, nq);
+        else gs_round<r, FOLD>(rg, t, q4, nq, a.ninv, a.w1ninv);
     }
 }
 
 // Store one round's registers (to LDS, or to global with the epilogue on the last round).
 template <class C, int RI, bool TO_GLOBAL, int EPI>
 PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
-    constexpr int r = C::r(RI), K = 1 << r, G = kElemsPerThread >> r, s0 = C::s0(RI);
+    constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r, s0 = C::s0(RI);
     constexpr int LOGD = C::LOGT - s0 - r;
 #pragma unroll
     for (int gi = 0; gi < G; gi++) {
         int v, hi, lo;
-        decode_group<C, RI>(tid + kThreads * gi, v, hi, lo);
+        decode_group<C, RI>(tid + C::THREADS * gi, v, hi, lo);
         const u64 *rg = reg + gi * K;
         const int e0 = (hi << (LOGD + r)) + lo;
         if (TO_GLOBAL) {
@@ -228,26 +276,63 @@ PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
 // A pass as a list of barrier-separated segments, one per round (a round reads and writes the same
 // LDS slots, so only the hand-over between rounds needs a barrier).  FWD runs rounds 0..NR-1,
 // inverse NR-1..0.  FOLD (inverse only): this pass holds the transform's last stage (round 0).
-template <class C, bool FWD, int EPI, bool FOLD>
+template <class C, bool FWD, int EPI, bool FOLD, bool HOIST = true>
 struct PassProgram {
     static constexpr int NSEG = C::NR;
+    static constexpr int THREADS = C::THREADS;
+
+    // all twiddle loads of the pass (issued before the first barrier)
+    // HOIST: every round's twiddles are requested before the first barrier (one exposed memory latency per
+    // tile, more registers); otherwise each round requests its own when it starts (fewer registers).
+    PHA_HD static void load_twiddles(const PassArgs &a, int tid, u64x2 *twreg) {
+        if (!HOIST) return;
+        round_load_tw<C, 0>(a, tid, twreg);
+        round_load_tw<C, 1>(a, tid, twreg);
+        if (C::NR == 3) round_load_tw<C, 2>(a, tid, twreg);
+    }
 
     template <int SEG>
-    PHA_HD static void run(const PassArgs &a, u64 *lds, int tid, u64 *reg) {
+    PHA_HD static void run(const PassArgs &a, u64 *lds, int tid, u64 *reg, u64x2 *twreg) {
         constexpr int RI = FWD ? SEG : C::NR - 1 - SEG;
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
-        round_in<C, RI, FWD, first, FOLD && RI == 0>(a, lds, tid, reg);
+        if (!HOIST) round_load_tw<C, RI>(a, tid, twreg);
+        round_load<C, RI, first>(a, lds, tid, reg);
+        round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
+        round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
+    }
+
+    // Pieces for the software-pipelined (persistent) kernel: the first round's global load is issued
+    // one tile ahead of its computation.
+    static constexpr int RI_FIRST = FWD ? 0 : C::NR - 1;
+    PHA_HD static void prefetch(const PassArgs &a, int tid, u64 *reg) {
+        round_load<C, RI_FIRST, true>(a, nullptr, tid, reg);
+    }
+    template <int SEG>
+    PHA_HD static void run_prefetched(const PassArgs &a, u64 *lds, int tid, u64 *reg, u64x2 *twreg) {
+        constexpr int RI = FWD ? SEG : C::NR - 1 - SEG;
+        constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
+        if (!HOIST) round_load_tw<C, RI>(a, tid, twreg);
+        if (!first) round_load<C, RI, false>(a, lds, tid, reg);
+        round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
     }
 };
 
 // Split N = T1 * T2 per log2 N, with the round schedules of each pass.
-template <int LOGN> struct NttPlan;
-template <> struct NttPlan<12> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<6, false, 3, 3>; };
-template <> struct NttPlan<13> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<7, false, 4, 3>; };
-template <> struct NttPlan<14> { using P1 = PassCfg<7, true, 4, 3>;  using P2 = PassCfg<7, false, 4, 3>; };
-template <> struct NttPlan<15> { using P1 = PassCfg<7, true, 4, 3>;  using P2 = PassCfg<8, false, 4, 4>; };
-template <> struct NttPlan<16> { using P1 = PassCfg<8, true, 4, 4>;  using P2 = PassCfg<8, false, 4, 4>; };
-template <> struct NttPlan<17> { using P1 = PassCfg<8, true, 4, 4>;  using P2 = PassCfg<9, false, 3, 3, 3>; };
+// VARIANT 0: 16 coefficients per thread (radix-16 rounds, one LDS exchange per pass).
+// VARIANT 1: 8 coefficients per thread (radix-8 rounds, two exchanges, 2x the wavefronts).
+template <int LOGN, int VARIANT> struct NttPlan;
+template <> struct NttPlan<12, 0> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<6, false, 3, 3>; };
+template <> struct NttPlan<13, 0> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<7, false, 4, 3>; };
+template <> struct NttPlan<14, 0> { using P1 = PassCfg<7, true, 4, 3>;  using P2 = PassCfg<7, false, 4, 3>; };
+template <> struct NttPlan<15, 0> { using P1 = PassCfg<7, true, 4, 3>;  using P2 = PassCfg<8, false, 4, 4>; };
+template <> struct NttPlan<16, 0> { using P1 = PassCfg<8, true, 4, 4>;  using P2 = PassCfg<8, false, 4, 4>; };
+template <> struct NttPlan<17, 0> { using P1 = PassCfg<8, true, 4, 4>;  using P2 = PassCfg<9, false, 3, 3, 3>; };
+template <> struct NttPlan<12, 1> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<6, false, 3, 3, 0, 8>; };
+template <> struct NttPlan<13, 1> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8>; };
+template <> struct NttPlan<14, 1> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8>; };
+template <> struct NttPlan<15, 1> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8>; };
+template <> struct NttPlan<16, 1> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8>; };
+template <> struct NttPlan<17, 1> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8>; };
 
 }  // namespace pha

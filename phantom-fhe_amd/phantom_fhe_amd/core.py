@@ -46,6 +46,11 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def set_tuning(key, value):
+    """A/B knob (include/phantom_amd.h pha_set_tuning); results never change."""
+    _lib.check(_lib.load().pha_set_tuning(int(key), int(value)))
+
+
 def coeff_modulus_create(poly_modulus_degree, bit_sizes):
     """CoeffModulus::Create (src/host/modulus.cu:82-111)."""
     L = _lib.load()
@@ -124,6 +129,15 @@ class PhantomContext:
     def nwt_2d_radix8_backward_inplace(self, inout, coeff_modulus_size, start_modulus_idx=0):
         _lib.check(self._L.pha_nwt_2d_radix8_backward_inplace(self._h, _ptr(inout), coeff_modulus_size,
                                                               start_modulus_idx, _stream()))
+
+    def nwt_2d_radix8_forward_inplace_batched(self, inout, coeff_modulus_size, start_modulus_idx, batch, poly_stride):
+        """Extension: the same limbs of `batch` polynomials (poly_stride elements apart) in one launch."""
+        _lib.check(self._L.pha_nwt_2d_radix8_forward_inplace_batched(self._h, _ptr(inout), coeff_modulus_size,
+                                                                     start_modulus_idx, batch, poly_stride, _stream()))
+
+    def nwt_2d_radix8_backward_inplace_batched(self, inout, coeff_modulus_size, start_modulus_idx, batch, poly_stride):
+        _lib.check(self._L.pha_nwt_2d_radix8_backward_inplace_batched(self._h, _ptr(inout), coeff_modulus_size,
+                                                                      start_modulus_idx, batch, poly_stride, _stream()))
 
     def nwt_2d_radix8_backward(self, out, inp, coeff_modulus_size, start_modulus_idx=0):
         _lib.check(self._L.pha_nwt_2d_radix8_backward(self._h, _ptr(out), _ptr(inp), coeff_modulus_size,

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphantom_amd.so")
+LIB_PATH = os.environ.get("PHA_LIB_OVERRIDE") or os.path.join(_HERE, "libphantom_amd.so")  # override: experiments only
 
 u64p = C.POINTER(C.c_uint64)
 vp = C.c_void_p
@@ -26,6 +26,8 @@ _SIGS = {
     "pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range": [vp, vp, sz, sz, sz, sz, sz, sz, vp],
     "pha_nwt_2d_radix8_forward_inplace_fuse_moddown": [vp, vp, vp, vp, vp, vp, sz, sz, vp],
     "pha_nwt_2d_radix8_backward_inplace": [vp, vp, sz, sz, vp],
+    "pha_nwt_2d_radix8_forward_inplace_batched": [vp, vp, sz, sz, sz, sz, vp],
+    "pha_nwt_2d_radix8_backward_inplace_batched": [vp, vp, sz, sz, sz, sz, vp],
     "pha_nwt_2d_radix8_backward": [vp, vp, vp, sz, sz, vp],
     "pha_nwt_2d_radix8_backward_scale": [vp, vp, vp, sz, sz, vp, vp, vp],
     "pha_nwt_2d_radix8_backward_inplace_scale": [vp, vp, sz, sz, vp, vp, vp],
@@ -48,6 +50,7 @@ _SIGS = {
     "pha_divide_and_round_q_last": [vp, sz, vp, sz, vp, vp],
     "pha_apply_galois_ntt": [vp, vp, vp, C.c_uint32, sz, vp],
     "pha_apply_galois": [vp, vp, vp, C.c_uint32, sz, sz, vp],
+    "pha_set_tuning": [C.c_int, C.c_int],
     "pha_time_forward_ntt": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)],
 }
 _SPECIAL = {

@@ -13,10 +13,14 @@
 
 using namespace pha;
 
+static u64x2 g_twregs[512][64];
+
 template <class Prog, int SEG>
 static void run_segments(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
+    if constexpr (SEG == 0)
+        for (int tid = 0; tid < Prog::THREADS; tid++) Prog::load_twiddles(a, tid, g_twregs[tid]);
     if constexpr (SEG < Prog::NSEG) {
-        for (int tid = 0; tid < kThreads; tid++) Prog::template run<SEG>(a, lds, tid, regs[tid]);
+        for (int tid = 0; tid < Prog::THREADS; tid++) Prog::template run<SEG>(a, lds, tid, regs[tid], g_twregs[tid]);
         run_segments<Prog, SEG + 1>(a, lds, regs);
     }
 }
@@ -24,7 +28,7 @@ static void run_segments(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
 template <class C, bool FWD, int EPI, bool FOLD>
 static void run_pass(PassArgs a, size_t n) {
     std::vector<u64> lds(C::LDS_WORDS);
-    static u64 regs[kThreads][16];
+    static u64 regs[512][16];
     const u32 tiles = (u32)(n / kTileElems);
     for (u32 t = 0; t < tiles; t++) {
         a.tile = t;
@@ -32,11 +36,11 @@ static void run_pass(PassArgs a, size_t n) {
     }
 }
 
-template <int LOGN>
+template <int LOGN, int VARIANT>
 static void emu(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *tw, u64x2 ninv, u64x2 w1ninv,
                 u64x2 scale, const u64 *aux) {
-    using P1 = typename NttPlan<LOGN>::P1;
-    using P2 = typename NttPlan<LOGN>::P2;
+    using P1 = typename NttPlan<LOGN, VARIANT>::P1;
+    using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     const size_t n = (size_t)1 << LOGN;
     PassArgs a{};
     a.tw = tw; a.q = q; a.rho0 = P1::T; a.stride = P2::T; a.ninv = ninv; a.w1ninv = w1ninv; a.scale = scale; a.aux = aux;
@@ -55,7 +59,7 @@ static void emu(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *
     }
 }
 
-extern "C" int emu_ntt(int log_n, int fwd, int epi, const uint64_t *in, uint64_t *out, uint64_t q,
+extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *in, uint64_t *out, uint64_t q,
                        const uint64_t *tw_interleaved, const uint64_t *ninv, const uint64_t *w1ninv,
                        const uint64_t *scale, const uint64_t *aux) {
     const u64x2 *tw = reinterpret_cast<const u64x2 *>(tw_interleaved);
@@ -63,13 +67,15 @@ extern "C" int emu_ntt(int log_n, int fwd, int epi, const uint64_t *in, uint64_t
     const u64 *i = reinterpret_cast<const u64 *>(in);
     u64 *o = reinterpret_cast<u64 *>(out);
     const u64 *ax = reinterpret_cast<const u64 *>(aux);
+    const int log_n = log_n_and_variant & 0xff, variant = log_n_and_variant >> 8;
+#define EMU_CASE(N) case N: if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
     switch (log_n) {
-        case 12: emu<12>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
-        case 13: emu<13>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
-        case 14: emu<14>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
-        case 15: emu<15>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
-        case 16: emu<16>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
-        case 17: emu<17>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
+        EMU_CASE(12)
+        EMU_CASE(13)
+        EMU_CASE(14)
+        EMU_CASE(15)
+        EMU_CASE(16)
+        EMU_CASE(17)
         default: return -1;
     }
     return 0;

@@ -1,0 +1,73 @@
+"""world_size-2 gloo test of the multi-GPU host logic (runs on CPU): contiguous ciphertext sharding
+with no data-path collective, one-time key broadcast, max-over-ranks timing, checksum gather."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, batch, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "phantom-fhe_amd"))
+    from phantom_fhe_amd import dist as pd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # keys exist only on rank 0 before the broadcast
+        g = torch.Generator().manual_seed(1234)
+        keys = [torch.randint(0, 1 << 50, (2, 3, 64), dtype=torch.int64, generator=g) if rank == 0
+                else torch.zeros((2, 3, 64), dtype=torch.int64) for _ in range(2)]
+        pd.broadcast_keys(keys, src=0)
+        key_sum = int(sum(int(k.sum()) for k in keys))
+        mine = list(pd.shard_range(batch, rank, world))
+        # "process" the shard: a per-ciphertext function of the index and the key only (no cross-rank data)
+        local = sum((i * 2654435761 + key_sum) % (1 << 40) for i in mine)
+        sums = pd.gather_checksums(local)
+        t = pd.max_over_ranks(0.5 + rank)
+        q.put((rank, mine, key_sum, sums, t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_key_broadcast():
+    world, batch = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, k0, sums0, t0), (r1, s1, k1, sums1, t1) = res
+    assert s0 + s1 == list(range(batch)) and abs(len(s0) - len(s1)) <= 1     # disjoint contiguous cover
+    assert k0 == k1                                                           # broadcast reached rank 1
+    assert sums0 == sums1 and len(sums0) == 2
+    single = sum((i * 2654435761 + k0) % (1 << 40) for i in range(batch))
+    assert sum(sums0) == single                                               # 2-rank result == 1-rank result
+    assert t0 == t1 == 1.5                                                    # max over ranks
+
+
+def test_shard_range_properties():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "phantom-fhe_amd"))
+    from phantom_fhe_amd.dist import shard_range
+    for batch in (0, 1, 7, 64):
+        for world in (1, 2, 4, 8):
+            parts = [list(shard_range(batch, r, world)) for r in range(world)]
+            assert sum(parts, []) == list(range(batch))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

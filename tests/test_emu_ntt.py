@@ -33,19 +33,26 @@ def pair(v, q):
 
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
-@pytest.mark.parametrize("bits", [50, 60])
-def test_thread_program_matches_oracle(emu, log_n, bits):
+@pytest.mark.parametrize("bits", [50, 60, 61])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_thread_program_matches_oracle(emu, log_n, bits, variant):
     n = 1 << log_n
+    code = log_n | (variant << 8)   # variant 1 = 8 coefficients per thread (512-thread workgroups)
     q = int(O.get_primes(n, bits, 1)[0])
     tw, tws, itw, itws, ni, nis = O.ntt_tables(log_n, q)
     c = O.Ctx(log_n, [q], 0)
     r = rng_for(log_n * 100 + bits)
     x = r.integers(0, q, n, dtype=np.uint64)
+    if log_n == 13:
+        x[:] = q - 1          # extreme input: exercises the top of the [0,8q) lazy range (8q < 2^64 needs q < 2^61)
+    if log_n == 14:
+        x[::2] = 0
+        x[1::2] = q - 1
     ref = c.nwt_forward(x.reshape(1, n), 1)[0]
     twi = np.ascontiguousarray(np.stack([tw, tws], axis=1).reshape(-1))
     z = np.zeros(2, dtype=np.uint64)
     out = np.zeros(n, dtype=np.uint64)
-    assert emu.emu_ntt(log_n, 1, 1, p(x), p(out), q, p(twi), p(z), p(z), p(z), p(z)) == 0
+    assert emu.emu_ntt(code, 1, 1, p(x), p(out), q, p(twi), p(z), p(z), p(z), p(z)) == 0
     assert np.array_equal(out, ref)
     # the product keeps a pristine inverse table plus (N^-1, itw[1]*N^-1); rebuild that from the oracle's
     itw1 = int(itw[1]) * n % q
@@ -53,14 +60,14 @@ def test_thread_program_matches_oracle(emu, log_n, bits):
     itw_p[1], itws_p[1] = itw1, O.compute_shoup(itw1, q)
     itwi = np.ascontiguousarray(np.stack([itw_p, itws_p], axis=1).reshape(-1))
     back = np.zeros(n, dtype=np.uint64)
-    assert emu.emu_ntt(log_n, 0, 3, p(ref), p(back), q, p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q)), p(z), p(z)) == 0
+    assert emu.emu_ntt(code, 0, 3, p(ref), p(back), q, p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q)), p(z), p(z)) == 0
     assert np.array_equal(back, x)
     if log_n in (12, 16):
         # inverse with fused scale (EPI_INV_SCALE) and forward with fused mod-down epilogue (EPI_FWD_MODDOWN)
         s = int(r.integers(1, q))
-        assert emu.emu_ntt(log_n, 0, 4, p(ref), p(back), q, p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q)), p(pair(s, q)), p(z)) == 0
+        assert emu.emu_ntt(code, 0, 4, p(ref), p(back), q, p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q)), p(pair(s, q)), p(z)) == 0
         assert np.array_equal(back, c.multiply_scalar(x.reshape(1, n), np.array([s], dtype=np.uint64), 1)[0])
         cx = r.integers(0, q, n, dtype=np.uint64)
-        assert emu.emu_ntt(log_n, 1, 2, p(x), p(out), q, p(twi), p(z), p(z), p(pair(s, q)), p(cx)) == 0
+        assert emu.emu_ntt(code, 1, 2, p(x), p(out), q, p(twi), p(z), p(z), p(pair(s, q)), p(cx)) == 0
         want = c.multiply_scalar(c.sub(cx.reshape(1, n), ref.reshape(1, n), 1), np.array([s], dtype=np.uint64), 1)[0]
         assert np.array_equal(out, want)

@@ -18,7 +18,7 @@ def _ctx(name, gpu):
 
 
 @pytest.mark.parametrize("name", ["c1_bfv4096", "hyb13_a3", "c2_ntt14", "c4_bfv15", "c3_ckks16"])
-def test_forward_inverse_inplace(name, gpu):
+def test_forward_inverse_inplace(name, gpu, ntt_variant):
     import phantom_fhe_amd as P
     log_n, primes, size_p = primes_of(name)
     n = 1 << log_n
@@ -39,8 +39,17 @@ def test_forward_inverse_inplace(name, gpu):
     assert np.array_equal(P.to_host(d2), oc.nwt_backward(x, L, 0))
 
 
+@pytest.fixture(params=[0, 1, 2, 3, 5], ids=["ept16", "ept8", "ept16-pipelined", "ept8-pipelined", "ept8-hoisted"])
+def ntt_variant(request):
+    """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
+    import phantom_fhe_amd as P
+    P.set_tuning(0, request.param)
+    yield request.param
+    P.set_tuning(0, 1)
+
+
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
-def test_all_degrees(log_n, gpu):
+def test_all_degrees(log_n, gpu, ntt_variant):
     import phantom_fhe_amd as P
     n = 1 << log_n
     primes = [int(p) for p in O.coeff_modulus_create(n, [60, 50, 40])]
@@ -78,7 +87,7 @@ def test_start_index_and_partial(gpu):
     assert np.array_equal(P.to_host(d), ref)
 
 
-def test_special_mod_and_exclude_range(gpu):
+def test_special_mod_and_exclude_range(gpu, ntt_variant):
     """[Ql || P] buffers: P limbs use the last rows of the table (fntt_2d.cu:434-437); the digit's own
     range is skipped (ntt_modup.cu:422)."""
     import phantom_fhe_amd as P
@@ -105,7 +114,7 @@ def test_special_mod_and_exclude_range(gpu):
     assert np.array_equal(P.to_host(d), ref3)
 
 
-def test_backward_out_of_place_and_scale(gpu):
+def test_backward_out_of_place_and_scale(gpu, ntt_variant):
     import phantom_fhe_amd as P
     name = "hyb12_a2"
     log_n, primes, _ = primes_of(name)
@@ -125,7 +134,7 @@ def test_backward_out_of_place_and_scale(gpu):
     assert np.array_equal(P.to_host(d_out), oc.multiply_scalar(ref, scale, L, 0))
 
 
-def test_forward_fuse_moddown(gpu):
+def test_forward_fuse_moddown(gpu, ntt_variant):
     """ct = (cx - NTT(delta)) * PInv (ntt_moddown.cu:203-208), also with ct aliasing cx."""
     import phantom_fhe_amd as P
     name = "hyb12_a2"

@@ -4,14 +4,32 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef uint64_t u64;
 typedef uint32_t u32;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); return 1; } } while (0)
 
-enum { OP_FMA32, OP_ADD32, OP_MULLO, OP_MULHI, OP_MAD64, OP_ADD64, OP_FMA64, OP_MUL64LO, OP_MUL64HI, OP_SHOUP, OP_BFLY };
+enum { OP_FMA32, OP_ADD32, OP_MULLO, OP_MULHI, OP_MAD64, OP_ADD64, OP_FMA64, OP_MUL64LO, OP_MUL64HI, OP_SHOUP, OP_BFLY, OP_BFLY_A, OP_BFLY_B, OP_BFLY_C, OP_LSHLADD, OP_FP64BF };
 static const char *names[] = {"v_fma_f32", "v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "add64(v_lshl_add_u64)",
-                              "v_fma_f64", "mul64 lo (a*b)", "mul64 hi (__umul64hi)", "shoup_lazy", "ct butterfly"};
+                              "v_fma_f64", "mul64 lo (a*b)", "mul64 hi (__umul64hi)", "shoup_lazy", "ct butterfly", "bfly A: approx mulhi (asm mad)", "bfly B: A + negq mad chain", "bfly C: B + sign-mask csub", "v_lshl_add_u64 (asm)", "fp64 butterfly (11 ops)"};
+__device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) { u64 d, cy; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ u64 mad64s(u32 a, u32 b, u64 c) { u64 d, cy; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(b), "v"(c)); return d; }
+__device__ __forceinline__ u64 mad64z(u32 a, u32 b) { u64 d, cy; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u64 mad64one(u32 a, u64 c) { u64 d, cy; asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(cy) : "v"(a), "v"(c)); return d; }
+__device__ __forceinline__ u64 mulhi_approx(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p01 = mad64z(a0, b1), p10 = mad64z(a1, b0);
+    return mad64one((u32)(p10 >> 32), mad64(a1, b1, p01 >> 32));
+}
+__device__ __forceinline__ u64 shoup4_negq(u64 Y, u64 w, u64 ws, u64 nq) {
+    u32 y0 = (u32)Y, y1 = (u32)(Y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+    u64 Q = mulhi_approx(Y, ws);
+    u32 q0 = (u32)Q, q1 = (u32)(Q >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    u64 T = mad64s(q0, n0, mad64z(y0, w0));
+    u32 hi = (u32)(T >> 32) + y0 * w1 + y1 * w0 + q0 * n1 + q1 * n0;
+    return ((u64)hi << 32) | (u32)T;
+}
 constexpr int CH = 8;      // independent chains per thread
 constexpr int INNER = 64;  // ops per chain per outer iteration
 
@@ -39,6 +57,35 @@ __global__ __launch_bounds__(256) void rate_kernel(u64 *out, u64 seed, int iters
                 else if (OP == OP_MUL64LO) a[c] = a[c] * b[c] + 1;
                 else if (OP == OP_MUL64HI) a[c] = __umul64hi(a[c], b[c]) | 0x100000001ull;
                 else if (OP == OP_SHOUP) a[c] = a[c] * w - __umul64hi(a[c], ws) * q;
+                else if (OP == OP_BFLY_A) {
+                    u64 X = a[c], Y = b[c]; const u64 q4 = q2 * 2;
+                    u64 x = X >= q4 ? X - q4 : X;
+                    u64 t = Y * w - mulhi_approx(Y, ws) * q;
+                    a[c] = x + t; b[c] = x + q4 - t;
+                } else if (OP == OP_BFLY_B) {
+                    u64 X = a[c], Y = b[c]; const u64 q4 = q2 * 2;
+                    u64 x = X >= q4 ? X - q4 : X;
+                    u64 t = shoup4_negq(Y, w, ws, 0 - q);
+                    a[c] = x + t; b[c] = x + q4 - t;
+                } else if (OP == OP_BFLY_C) {
+                    u64 X = a[c], Y = b[c]; const u64 q4 = q2 * 2;
+                    u64 d = X + (0 - q4);
+                    u32 mask = (u32)((int32_t)(d >> 32) >> 31);
+                    u64 x = d + ((((u64)((u32)(q4 >> 32) & mask)) << 32) | ((u32)q4 & mask));
+                    u64 t = shoup4_negq(Y, w, ws, 0 - q);
+                    a[c] = x + t; b[c] = x + q4 - t;
+                } else if (OP == OP_LSHLADD) {
+                    asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a[c]) : "v"(b[c]));
+                } else if (OP == OP_FP64BF) {
+                    double X = da[c], Y = __longlong_as_double(b[c] & 0x3fffffffffffffffull | 0x3ff0000000000000ull);
+                    const double W = 1234567.0, Wi = 1e-9, qd = 1125899906842597.0, qi = 1.0 / 1125899906842597.0;
+                    double h = Y * W, l = __builtin_fma(Y, W, -h);
+                    double cq = __builtin_rint(Y * Wi);
+                    double r = __builtin_fma(-cq, qd, h) + l;
+                    double c2 = __builtin_rint(r * qi);
+                    double T = __builtin_fma(-c2, qd, r);
+                    da[c] = X + T; b[c] = __double_as_longlong(X - T);
+                }
                 else if (OP == OP_BFLY) {
                     u64 X = a[c], Y = b[c];
                     u64 x = X >= q2 ? X - q2 : X;
@@ -91,7 +138,9 @@ int main() {
     run_rate<OP_MULHI>(out, blocks, clk); run_rate<OP_MAD64>(out, blocks, clk); run_rate<OP_ADD64>(out, blocks, clk);
     run_rate<OP_FMA64>(out, blocks, clk); run_rate<OP_MUL64LO>(out, blocks, clk); run_rate<OP_MUL64HI>(out, blocks, clk);
     run_rate<OP_SHOUP>(out, blocks, clk); run_rate<OP_BFLY>(out, blocks, clk);
+    run_rate<OP_BFLY_A>(out, blocks, clk); run_rate<OP_BFLY_B>(out, blocks, clk); run_rate<OP_BFLY_C>(out, blocks, clk); run_rate<OP_LSHLADD>(out, blocks, clk); run_rate<OP_FP64BF>(out, blocks, clk);
 
+    if (getenv("MB_NO_BW")) return 0;
     const size_t sizes_mib[] = {8, 23, 45, 90, 180, 512, 2048};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (size_t mib : sizes_mib) {
