@@ -153,7 +153,9 @@ int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint
                      size_t coeff_mod_size, size_t mod_start_idx, void *stream);
 
 /* ---- tuning knob for A/B measurements: key 0 = NTT thread geometry (0: 16 coefficients per thread,
- *      256-thread workgroups; 1: 8 per thread, 512-thread workgroups).  Results are identical. ---- */
+ *      256-thread workgroups; bit 0: 8 per thread, 512-thread workgroups; bit 1: persistent pipelined grid;
+ *      bit 2: all twiddle loads before the first barrier); key 1 = base-conversion MAC (1: carry-free split
+ *      accumulators, 0: 128-bit carry chain).  Results are identical for every setting. ---- */
 int pha_set_tuning(int key, int value);
 
 /* ---- measurement hook used by bench.py: time `iters` back-to-back launches of the forward NTT

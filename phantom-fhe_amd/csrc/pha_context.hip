@@ -234,8 +234,14 @@ static void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, c
             mat[(size_t)j * b.isz + i] = h;
         }
     }
+    std::vector<uint32_t> mat30(mat.size() * 2);
+    for (size_t k = 0; k < mat.size(); k++) {
+        mat30[2 * k] = (uint32_t)(mat[k] & 0x3fffffffu);
+        mat30[2 * k + 1] = (uint32_t)(mat[k] >> 30);
+    }
     b.hat_inv.upload(hat_inv);
     b.mat.upload(mat);
+    b.mat30.upload(mat30);
     b.d_iprime.upload(ip);
     b.d_oprime.upload(op);
 }
@@ -304,6 +310,21 @@ Tool &Context::tool(uint32_t size_ql) {
         for (uint32_t i = 0; i < size_p; i++) ip.push_back(size_q + i);
         for (uint32_t i = 0; i < size_ql; i++) op.push_back(i);
         build_bconv(*this, t->p_to_ql, ip, op);
+        // device descriptors for the batched launches
+        auto describe = [](const BConv &b, uint32_t pad_start, uint32_t pad_len, uint32_t src_limb, uint32_t copy_own) {
+            return BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.isz, b.osz,
+                            pad_start, pad_len, src_limb, copy_own};
+        };
+        std::vector<BConvDev> dd;
+        for (uint32_t b = 0; b < t->beta; b++) {
+            const uint32_t s = t->alpha * b;
+            dd.push_back(describe(t->digit[b], s, t->digit[b].isz, s, 1));
+        }
+        t->d_digit_convs.upload(dd);
+        t->d_p_to_ql_conv.upload({describe(t->p_to_ql, 0xffffffffu, 0, size_ql, 0)});
+        t->split_ok = true;
+        for (uint32_t i = 0; i < t->size_qlp; i++)
+            if (primes[t->qlp_prime[i]] >> 60) t->split_ok = false;
     }
     Tool &ref = *t;
     tools[size_ql] = std::move(t);

@@ -65,11 +65,27 @@ struct DevBuf {
 };
 
 // ---- fast base converter constants (DBaseConverter, include/rns_bconv.cuh:3-87) --------------
+// Device-resident description of one converter (uploaded once per Tool); a launch indexes an array
+// of these with blockIdx.z (one per mod-up digit) or uses the same one for every z (mod-down polys).
+struct BConvDev {
+    const u64x2 *hat_inv;        // [isz] qhat_i^-1 mod q_i (+Shoup), used when SCALE_IN
+    const uint32_t *iprime;      // [isz] rows of the QP table
+    const uint32_t *oprime;      // [osz]
+    const u64 *mat;              // [osz][isz] qhat_i mod p_j
+    const uint32_t *mat30;       // [osz][isz][2] the same, split into 30-bit halves (m & (2^30-1), m >> 30)
+    uint32_t isz, osz;
+    uint32_t pad_start, pad_len; // output j goes to limb j + (j >= pad_start ? pad_len : 0)
+    uint32_t src_limb;           // first input limb inside the source polynomial
+    uint32_t copy_own;           // mod-up: also copy the digit's own limbs [src_limb, src_limb+isz) verbatim
+};
+
+
 struct BConv {
     uint32_t isz = 0, osz = 0;
     std::vector<uint32_t> iprime, oprime;  // indices into the QP table
     DevBuf<u64x2> hat_inv;                 // [isz]  qhat_i^-1 mod q_i (+Shoup)
     DevBuf<u64> mat;                       // [osz][isz]  qhat_i mod p_j
+    DevBuf<uint32_t> mat30;                // [osz][isz][2] 30-bit halves of mat
     DevBuf<uint32_t> d_iprime, d_oprime;
 };
 
@@ -81,6 +97,8 @@ struct Tool {
     DevBuf<u64> part_hat_inv, part_hat_inv_shoup;  // partQlHatInv_mod_Ql_concat (rns.cu:152-182)
     std::vector<BConv> digit;                      // part Ql -> complement of QlP, per digit
     BConv p_to_ql;                                 // base_P_to_Ql_conv (rns.cu:196-198)
+    DevBuf<BConvDev> d_digit_convs, d_p_to_ql_conv; // device descriptors used by the batched launches
+    bool split_ok = false;                         // every prime <= 60 bits: carry-free split MAC is valid
     DevBuf<u64> pinv, pinv_shoup;                  // bigPInv_mod_q (rns.cu:110-123)
     DevBuf<u64> inv_q_last, inv_q_last_shoup;      // rns.cu:66-80
     DevBuf<u64x2> inv_q_last2;                     // same, interleaved
@@ -153,8 +171,11 @@ inline LimbSel special_sel(size_t start, size_t count, size_t size_QP, size_t si
 struct NttExtra {
     const u64 *scale = nullptr, *scale_shoup = nullptr;  // indexed by absolute limb
     const u64 *aux = nullptr;                            // fuse_moddown: cx base
-    uint32_t batch = 1;                                  // polynomials per launch
-    size_t poly_stride = 0;                              // elements between consecutive polynomials
+    uint32_t batch = 1;                                  // polynomials per launch (blockIdx.z)
+    size_t poly_stride = 0;                              // elements between consecutive polynomials of in / mid
+    size_t out_stride = 0, aux_stride = 0;               // same for out and aux (0 = poly_stride)
+    uint32_t excl_step = 0;                              // polynomial z skips [excl_start + z*step, min(+len, limit))
+    uint32_t excl_limit = 0xffffffffu;
 };
 void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
                  hipStream_t s);

@@ -19,6 +19,7 @@ std::atomic<int> g_ntt_variant{1};  // default: 8 coefficients per thread, per-r
 __device__ unsigned long long g_stamps[8];
 #endif
 int g_num_cus = 256;
+extern std::atomic<int> g_bconv_split;  // pha_rns.hip
 
 struct NttKArgs {
     const u64 *in;
@@ -35,8 +36,9 @@ struct NttKArgs {
     uint32_t log_n;
     uint32_t t1, t2;         // N = t1 * t2
     uint32_t active;         // processed limbs = sel.count minus the excluded range (pipelined kernel)
-    uint32_t batch;          // polynomials per launch (blockIdx.z), poly_stride elements apart
-    size_t poly_stride;
+    uint32_t batch;          // polynomials per launch (blockIdx.z)
+    size_t poly_stride, out_stride, aux_stride;
+    uint32_t excl_step, excl_limit;
 };
 
 // Per-tile arguments of limb `twr` (absolute limb index in the buffer), tile `tile`.
@@ -55,11 +57,11 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
         a.ninv = k.ninv[prime];
         a.w1ninv = k.w1ninv[prime];
     }
-    if (EPI == EPI_INV_SCALE || EPI == EPI_FWD_MODDOWN) {
+    if (EPI == EPI_INV_SCALE || EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) {
         a.scale.x = k.scale[twr];
         a.scale.y = k.scale_shoup[twr];
     }
-    a.aux = (EPI == EPI_FWD_MODDOWN) ? k.aux + (size_t)twr * n : nullptr;
+    a.aux = (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) ? k.aux + (size_t)twr * n : nullptr;
 }
 
 template <class C, bool FWD, int EPI, bool FOLD, bool HOIST>
@@ -68,14 +70,19 @@ __global__ __launch_bounds__(C::THREADS) void ntt_pass_kernel(const NttKArgs k) 
     u64 *lds = reinterpret_cast<u64 *>(smem);
 
     const uint32_t twr = k.sel.start + blockIdx.y;  // limb in the buffer (uniform)
-    if (twr >= k.sel.excl_start && twr < k.sel.excl_end) return;
+    {
+        // polynomial z skips its own digit: [excl_start + z*step, min(that + len, limit))  (ntt_modup.cu:422)
+        const uint32_t es = k.sel.excl_start + blockIdx.z * k.excl_step;
+        uint32_t ee = es + (k.sel.excl_end - k.sel.excl_start);
+        ee = ee < k.excl_limit ? ee : k.excl_limit;
+        if (twr >= es && twr < ee) return;
+    }
     PassArgs a;
     tile_args<FWD, EPI, FOLD>(k, twr, blockIdx.x, a);
     if (k.batch > 1) {  // same limbs of several polynomials in one launch
-        const size_t off = (size_t)blockIdx.z * k.poly_stride;
-        a.in += off;
-        a.out += off;
-        if (EPI == EPI_FWD_MODDOWN) a.aux += off;
+        a.in += (size_t)blockIdx.z * k.poly_stride;
+        a.out += (size_t)blockIdx.z * k.out_stride;
+        if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) a.aux += (size_t)blockIdx.z * k.aux_stride;
     }
 
     u64 reg[C::EPT];
@@ -190,11 +197,16 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s) {
     k.t1 = P1::T;
     k.t2 = P2::T;
     u64 *const final_out = k.out;
+    const size_t final_stride = k.out_stride;
     k.out = k.mid;
+    k.out_stride = k.poly_stride;
     launch_pass<P1, true, EPI_NONE, false>(k, s);
     k.in = k.mid;
     k.out = final_out;
+    k.out_stride = final_stride;
+    // pass 1 ran in -> mid with the input stride; pass 2 reads mid and writes out with the output stride
     if (epi == EPI_FWD_MODDOWN) launch_pass<P2, true, EPI_FWD_MODDOWN, false>(k, s);
+    else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<P2, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
     else launch_pass<P2, true, EPI_FWD_CANON, false>(k, s);
 }
 
@@ -205,10 +217,13 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s) {
     k.t1 = P1::T;
     k.t2 = P2::T;
     u64 *const final_out = k.out;
+    const size_t final_stride = k.out_stride;
     k.out = k.mid;
+    k.out_stride = k.poly_stride;
     launch_pass<P2, false, EPI_NONE, false>(k, s);
     k.in = k.mid;
     k.out = final_out;
+    k.out_stride = final_stride;
     if (epi == EPI_INV_SCALE) launch_pass<P1, false, EPI_INV_SCALE, true>(k, s);
     else launch_pass<P1, false, EPI_INV_CANON, true>(k, s);
 }
@@ -230,6 +245,10 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.log_n = c.log_n;
     k.batch = x.batch ? x.batch : 1;
     k.poly_stride = x.poly_stride;
+    k.out_stride = x.out_stride ? x.out_stride : x.poly_stride;
+    k.aux_stride = x.aux_stride ? x.aux_stride : x.poly_stride;
+    k.excl_step = x.excl_step;
+    k.excl_limit = x.excl_limit;
     uint32_t excl = 0;
     if (sel.excl_end > sel.excl_start) {
         const uint32_t lo = sel.excl_start > sel.start ? sel.excl_start : sel.start;
@@ -418,6 +437,8 @@ int pha_set_tuning(int key, int value) {
     if (key == 0) {
         if (value < 0 || value > 7) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
+    } else if (key == 1) {
+        g_bconv_split.store(value ? 1 : 0);
     } else {
         throw std::invalid_argument("unknown tuning key");
     }

@@ -35,6 +35,7 @@ enum Epilogue {
     EPI_FWD_MODDOWN = 2,  // forward: out = (cx - NTT(delta)) * PInv  (ntt_moddown.cu:203-208)
     EPI_INV_CANON = 3,    // inverse: csub q                     (intt_2d.cu:201-205)
     EPI_INV_SCALE = 4,    // inverse: full Shoup multiply by per-limb scale (intt_2d.cu:305-309)
+    EPI_FWD_MODDOWN_ADD = 5,  // forward: out += (cx - NTT(delta)) * PInv  (mod-down fused with add_to_ct_kernel)
 };
 
 // Round schedule of one pass: LOGT stages split into NR rounds of R0,R1,R2 stages (forward order).
@@ -165,6 +166,10 @@ PHA_HD u64 apply_epilogue(u64 x, const PassArgs &a, size_t gi) {
     if (EPI == EPI_FWD_MODDOWN) {
         u64 t = csub(csub(csub(x, q << 2), q << 1), q);
         return shoup(sub_mod(a.aux[gi], t, q), a.scale, q);  // sub_negate_const_mult uintmodmath.cuh:233-241
+    }
+    if (EPI == EPI_FWD_MODDOWN_ADD) {
+        u64 t = csub(csub(csub(x, q << 2), q << 1), q);
+        return add_mod(a.out[gi], shoup(sub_mod(a.aux[gi], t, q), a.scale, q), q);  // + add_to_ct rns_bconv.cu:763-769
     }
     if (EPI == EPI_INV_CANON) return csub(csub(x, q << 1), q);
     if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);

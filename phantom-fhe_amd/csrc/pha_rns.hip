@@ -13,92 +13,150 @@
 //   * mod-down and rescale reuse the forward NTT's fused epilogue (cx - NTT(delta)) * c.
 #include "../../include/phantom_amd.h"
 #include "pha_internal.h"
+#include <atomic>
+
 #include "pha_ntt_core.h"
 
 namespace pha {
 
 void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s);
 
+// tuning knob (pha_set_tuning key 1): carry-free split-accumulator MAC in base conversion
+std::atomic<int> g_bconv_split{1};
+
 constexpr int kBcThreads = 256;
 constexpr int kBcOutPerBlock = 8;
 
-struct BConvArgs {
-    u64 *dst;              // output buffer; output j goes to limb j + (j >= pad_start ? pad_len : 0)
-    const u64 *src;        // input limbs [isz][n]
-    const u64x2 *hat_inv;  // [isz] (only when SCALE_IN)
-    const uint32_t *iprime, *oprime;
-    const u64 *mat;        // [osz][isz]
-    const DModulus *mod;   // QP table
-    uint32_t isz, osz, n, pad_start, pad_len;
+struct BConvLaunch {
+    const BConvDev *convs;       // device array
+    uint32_t conv_step;          // converter of polynomial z = convs[z * conv_step]
+    u64 *dst;                    // polynomial z: dst + z * dst_stride
+    const u64 *src;              // polynomial z: src + z * src_stride (+ src_limb * n)
+    const u64 *own;              // copy_own source (the NTT-form input of mod-up), same for every z
+    size_t dst_stride, src_stride;
+    const DModulus *mod;
+    uint32_t n;
 };
 
-// bconv_mult (+) bconv_matmul: src/rns_bconv.cu:22-60,109-170 and the padded variant :455-485
-template <int ISZ_PAD, bool SCALE_IN>
-__global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvArgs k) {
+// bconv_mult (+) bconv_matmul (src/rns_bconv.cu:22-60,109-170; padded variant :455-485).
+// SPLIT: carry-free MAC -- inputs and matrix entries are cut into 30-bit halves, the four partial
+// products (< 2^60 each, <= 16 of them) accumulate in plain 64-bit registers with one
+// v_mad_u64_u32 each and are recombined once per output; valid for primes <= 60 bits, isz <= 16.
+template <int ISZ_PAD, bool SCALE_IN, bool SPLIT>
+__global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) {
+    const BConvDev &d = L.convs[blockIdx.z * L.conv_step];
     const uint32_t coeff = blockIdx.x * kBcThreads + threadIdx.x;
+    const uint32_t n = L.n;
+    const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)d.src_limb * n;
+    u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
+    const uint32_t isz = d.isz;
     u64 y[ISZ_PAD];
 #pragma unroll
     for (int i = 0; i < ISZ_PAD; i++) {
         y[i] = 0;
-        if (i < (int)k.isz) {
-            u64 x = k.src[(size_t)i * k.n + coeff];
-            if (SCALE_IN) x = shoup(x, k.hat_inv[i], k.mod[k.iprime[i]].value);
+        if (i < (int)isz) {
+            u64 x = src[(size_t)i * n + coeff];
+            if (SCALE_IN) x = shoup(x, d.hat_inv[i], L.mod[d.iprime[i]].value);
             y[i] = x;
         }
     }
+    if (d.copy_own && blockIdx.y == 0) {  // modup_copy_partQl_kernel rns_bconv.cu:522-528
+        for (uint32_t i = 0; i < isz; i++)
+            dst[(size_t)(d.src_limb + i) * n + coeff] = L.own[(size_t)(d.src_limb + i) * n + coeff];
+    }
     const uint32_t j0 = blockIdx.y * kBcOutPerBlock;
-    const uint32_t j1 = min(j0 + kBcOutPerBlock, k.osz);
+    const uint32_t j1 = min(j0 + kBcOutPerBlock, d.osz);
     for (uint32_t j = j0; j < j1; j++) {
-        const DModulus m = k.mod[k.oprime[j]];
-        const u64 *row = k.mat + (size_t)j * k.isz;
-        u64 lo = 0, hi = 0;
+        const DModulus m = L.mod[d.oprime[j]];
+        u64 lo, hi;
+        if (SPLIT) {
+            const uint32_t *row = d.mat30 + (size_t)j * isz * 2;
+            u64 ll = 0, lh = 0, hl = 0, hh = 0;
 #pragma unroll
-        for (int i = 0; i < ISZ_PAD; i++)
-            if (i < (int)k.isz) mac128(y[i], row[i], lo, hi);
-        const uint32_t jo = j + (j >= k.pad_start ? k.pad_len : 0);
-        k.dst[(size_t)jo * k.n + coeff] = barrett128(lo, hi, m);
+            for (int i = 0; i < ISZ_PAD; i++)
+                if (i < (int)isz) {
+                    const u32 y0 = (u32)y[i] & 0x3fffffffu, y1 = (u32)(y[i] >> 30);
+                    const u32 m0 = row[2 * i], m1 = row[2 * i + 1];
+                    ll = (u64)y0 * m0 + ll;
+                    lh = (u64)y0 * m1 + lh;
+                    hl = (u64)y1 * m0 + hl;
+                    hh = (u64)y1 * m1 + hh;
+                }
+            // value = ll + (lh + hl) * 2^30 + hh * 2^60   (mid < 2^65: keep its carry)
+            const u64 mid = lh + hl;
+            const u64 mid_c = mid < lh ? 1 : 0;
+            lo = ll;
+            hi = 0;
+            const u64 t1 = mid << 30;
+            lo += t1;
+            hi += (lo < t1) + (mid >> 34) + (mid_c << 30);
+            const u64 t2 = hh << 60;
+            lo += t2;
+            hi += (lo < t2) + (hh >> 4);
+        } else {
+            const u64 *row = d.mat + (size_t)j * isz;
+            lo = 0;
+            hi = 0;
+#pragma unroll
+            for (int i = 0; i < ISZ_PAD; i++)
+                if (i < (int)isz) mac128(y[i], row[i], lo, hi);
+        }
+        const uint32_t jo = j + (j >= d.pad_start ? d.pad_len : 0);
+        dst[(size_t)jo * n + coeff] = barrett128(lo, hi, m);
     }
 }
 
 // generic fallback for very wide input bases (isz > 16): inputs are re-read per output prime
 template <bool SCALE_IN>
-__global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvArgs k) {
+__global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunch L) {
+    const BConvDev &d = L.convs[blockIdx.z * L.conv_step];
     const uint32_t coeff = blockIdx.x * kBcThreads + threadIdx.x;
+    const uint32_t n = L.n;
+    const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)d.src_limb * n;
+    u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
+    if (d.copy_own && blockIdx.y == 0) {
+        for (uint32_t i = 0; i < d.isz; i++)
+            dst[(size_t)(d.src_limb + i) * n + coeff] = L.own[(size_t)(d.src_limb + i) * n + coeff];
+    }
     const uint32_t j0 = blockIdx.y * kBcOutPerBlock;
-    const uint32_t j1 = min(j0 + kBcOutPerBlock, k.osz);
+    const uint32_t j1 = min(j0 + kBcOutPerBlock, d.osz);
     for (uint32_t j = j0; j < j1; j++) {
-        const DModulus m = k.mod[k.oprime[j]];
-        const u64 *row = k.mat + (size_t)j * k.isz;
+        const DModulus m = L.mod[d.oprime[j]];
+        const u64 *row = d.mat + (size_t)j * d.isz;
         u64 lo = 0, hi = 0;
-        for (uint32_t i = 0; i < k.isz; i++) {
-            u64 x = k.src[(size_t)i * k.n + coeff];
-            if (SCALE_IN) x = shoup(x, k.hat_inv[i], k.mod[k.iprime[i]].value);
+        for (uint32_t i = 0; i < d.isz; i++) {
+            u64 x = src[(size_t)i * n + coeff];
+            if (SCALE_IN) x = shoup(x, d.hat_inv[i], L.mod[d.iprime[i]].value);
             mac128(x, row[i], lo, hi);
         }
-        const uint32_t jo = j + (j >= k.pad_start ? k.pad_len : 0);
-        k.dst[(size_t)jo * k.n + coeff] = barrett128(lo, hi, m);
+        const uint32_t jo = j + (j >= d.pad_start ? d.pad_len : 0);
+        dst[(size_t)jo * n + coeff] = barrett128(lo, hi, m);
     }
 }
 
-static void launch_bconv(Context &c, const BConv &b, u64 *dst, const u64 *src, bool scale_in, uint32_t pad_start,
-                         uint32_t pad_len, hipStream_t s) {
-    BConvArgs k{};
-    k.dst = dst; k.src = src; k.hat_inv = b.hat_inv.p; k.iprime = b.d_iprime.p; k.oprime = b.d_oprime.p;
-    k.mat = b.mat.p; k.mod = c.d_mod.p; k.isz = b.isz; k.osz = b.osz; k.n = (uint32_t)c.n;
-    k.pad_start = pad_start; k.pad_len = pad_len;
-    dim3 grid((unsigned)(c.n / kBcThreads), (b.osz + kBcOutPerBlock - 1) / kBcOutPerBlock);
+// convs: device array; max_isz / max_osz over the converters used; split_ok: all primes <= 60 bits
+static void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
+                         uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src,
+                         size_t src_stride, const u64 *own, bool scale_in, hipStream_t s) {
+    BConvLaunch L{};
+    L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;
+    L.dst_stride = dst_stride; L.src_stride = src_stride; L.mod = c.d_mod.p; L.n = (uint32_t)c.n;
+    dim3 grid((unsigned)(c.n / kBcThreads), (max_osz + kBcOutPerBlock - 1) / kBcOutPerBlock, batch);
     dim3 block(kBcThreads);
-#define PHA_BC(P)                                                                          \
-    do {                                                                                   \
-        if (scale_in) hipLaunchKernelGGL((bconv_kernel<P, true>), grid, block, 0, s, k);   \
-        else hipLaunchKernelGGL((bconv_kernel<P, false>), grid, block, 0, s, k);           \
+    const bool split = split_ok && g_bconv_split.load(std::memory_order_relaxed);
+#define PHA_BC(P)                                                                                        \
+    do {                                                                                                 \
+        if (scale_in && split) hipLaunchKernelGGL((bconv_kernel<P, true, true>), grid, block, 0, s, L);   \
+        else if (scale_in) hipLaunchKernelGGL((bconv_kernel<P, true, false>), grid, block, 0, s, L);      \
+        else if (split) hipLaunchKernelGGL((bconv_kernel<P, false, true>), grid, block, 0, s, L);         \
+        else hipLaunchKernelGGL((bconv_kernel<P, false, false>), grid, block, 0, s, L);                   \
     } while (0)
-    if (b.isz <= 2) PHA_BC(2);
-    else if (b.isz <= 4) PHA_BC(4);
-    else if (b.isz <= 8) PHA_BC(8);
-    else if (b.isz <= 16) PHA_BC(16);
-    else if (scale_in) hipLaunchKernelGGL((bconv_wide_kernel<true>), grid, block, 0, s, k);
-    else hipLaunchKernelGGL((bconv_wide_kernel<false>), grid, block, 0, s, k);
+    if (max_isz <= 2) PHA_BC(2);
+    else if (max_isz <= 4) PHA_BC(4);
+    else if (max_isz <= 8) PHA_BC(8);
+    else if (max_isz <= 16) PHA_BC(16);
+    else if (scale_in) hipLaunchKernelGGL((bconv_wide_kernel<true>), grid, block, 0, s, L);
+    else hipLaunchKernelGGL((bconv_wide_kernel<false>), grid, block, 0, s, L);
 #undef PHA_BC
     check_launch();
 }
@@ -187,12 +245,14 @@ struct ReduceArgs {
     const u64 *last;
     const DModulus *mod;
     uint32_t n;
+    size_t dst_stride, last_stride;  // per polynomial (blockIdx.z)
 };
 __global__ __launch_bounds__(256) void reduce_last_kernel(const ReduceArgs k) {
     const uint32_t limb = blockIdx.y;
     const DModulus m = k.mod[limb];
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
-    k.dst[(size_t)limb * k.n + coeff] = barrett64(k.last[coeff], m.value, m.ratio1);
+    const u64 v = k.last[(size_t)blockIdx.z * k.last_stride + coeff];
+    k.dst[(size_t)blockIdx.z * k.dst_stride + (size_t)limb * k.n + coeff] = barrett64(v, m.value, m.ratio1);
 }
 
 // ---- Galois (src/galois.cu:11-39) ----------------------------------------------------------------
@@ -222,7 +282,8 @@ static bool ntt_domain_scheme(int scheme) {
     throw std::invalid_argument("unsupported scheme");
 }
 
-// DRNSTool::modup rns_bconv.cu:530-627
+// DRNSTool::modup rns_bconv.cu:530-627.  All beta digits go through ONE base-conversion launch and ONE
+// forward-NTT launch pair (blockIdx.z = digit; digit z skips its own limbs, ntt_modup.cu:422).
 static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64 *t_cks, hipStream_t s) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp, alpha = t.alpha;
@@ -237,26 +298,31 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
             ntt_inverse(c, cks, t_cks, t_cks, plain_sel(0, ql), EPI_INV_SCALE, x, s);
         }
     }
-    for (uint32_t b = 0; b < t.beta; b++) {
-        const uint32_t st = alpha * b;
-        const uint32_t len = (b == t.beta - 1) ? ql - alpha * (t.beta - 1) : alpha;
-        u64 *out = dst + (size_t)b * qlp * n;
-        if (alpha == 1) {
-            SinglePArgs k{out, cks + (size_t)st * n, (ntt_dom ? t_cks : cks) + (size_t)st * n, c.d_mod.p,
-                          t.d_qlp_prime.p, st, (uint32_t)n};
+    if (alpha == 1) {
+        for (uint32_t b = 0; b < t.beta; b++) {
+            u64 *out = dst + (size_t)b * qlp * n;
+            SinglePArgs k{out, cks + (size_t)b * n, (ntt_dom ? t_cks : cks) + (size_t)b * n, c.d_mod.p,
+                          t.d_qlp_prime.p, b, (uint32_t)n};
             hipLaunchKernelGGL(single_p_kernel, dim3((unsigned)(n / 256), qlp), dim3(256), 0, s, k);
             check_launch();
-        } else {
-            // own limbs are kept verbatim (modup_copy_partQl_kernel :522-528)
-            PHA_HIP(hipMemcpyAsync(out + (size_t)st * n, cks + (size_t)st * n, (size_t)len * n * sizeof(u64),
-                                   hipMemcpyDeviceToDevice, s));
-            // BFV still needs the q-hat^-1 scaling (bconv_mult_kernel :603-607); ckks/bgv got it in the iNTT
-            launch_bconv(c, t.digit[b], out, (ntt_dom ? t_cks : cks) + (size_t)st * n, !ntt_dom, st, len, s);
         }
-        LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);
-        if (ntt_dom) { sel.excl_start = st; sel.excl_end = st + len; }  // ntt_modup.cu:422
-        ntt_forward(c, out, out, out, sel, EPI_FWD_CANON, NttExtra{}, s);
+    } else {
+        // own limbs are copied verbatim by the same kernel (modup_copy_partQl_kernel :522-528);
+        // BFV still needs the q-hat^-1 scaling (bconv_mult_kernel :603-607), ckks/bgv got it in the iNTT
+        launch_bconv(c, t.d_digit_convs.p, 1, t.beta, alpha, qlp, t.split_ok, dst, (size_t)qlp * n,
+                     ntt_dom ? t_cks : cks, 0, cks, !ntt_dom, s);
     }
+    LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);
+    NttExtra x;
+    x.batch = t.beta;
+    x.poly_stride = (size_t)qlp * n;
+    if (ntt_dom) {  // digit z skips [z*alpha, min((z+1)*alpha, ql))
+        sel.excl_start = 0;
+        sel.excl_end = alpha;
+        x.excl_step = alpha;
+        x.excl_limit = ql;
+    }
+    ntt_forward(c, dst, dst, dst, sel, EPI_FWD_CANON, x, s);
 }
 
 // phantom::key_switch_inner_prod eval_key_switch.cu:71-92
@@ -268,35 +334,52 @@ static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const 
     check_launch();
 }
 
-// DRNSTool::moddown_from_NTT rns_bconv.cu:776-828
-static void moddown_from_ntt(Context &c, Tool &t, u64 *ct_i, u64 *cx_i, int scheme, u64 *delta, hipStream_t s) {
+// DRNSTool::moddown_from_NTT rns_bconv.cu:776-828 for `polys` polynomials cx + z*cx_stride at once.
+// accumulate = false: ct_z = result (the reference call).  accumulate = true: ct_z += result, i.e. the
+// add_to_ct_kernel of keyswitch_inplace (rns_bconv.cu:763-769) fused into the NTT epilogue.
+static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64 *cx, size_t cx_stride,
+                             uint32_t polys, int scheme, bool accumulate, u64 *delta, hipStream_t s) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp;
+    NttExtra xb;
+    xb.batch = polys;
+    xb.poly_stride = cx_stride;
     if (scheme == PHA_SCHEME_CKKS)
-        ntt_inverse(c, cx_i, cx_i, cx_i, special_sel(ql, c.size_p, c.size_qp, c.size_p), EPI_INV_CANON, NttExtra{}, s);
+        ntt_inverse(c, cx, cx, cx, special_sel(ql, c.size_p, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
     else if (scheme == PHA_SCHEME_BFV)
-        ntt_inverse(c, cx_i, cx_i, cx_i, special_sel(0, qlp, c.size_qp, c.size_p), EPI_INV_CANON, NttExtra{}, s);
+        ntt_inverse(c, cx, cx, cx, special_sel(0, qlp, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
     else
         throw std::invalid_argument("unsupported scheme (bgv mod-down is not on the accelerated path yet)");
+    const size_t d_stride = (size_t)ql * n;
     if (t.alpha == 1) {
-        SinglePArgs k{delta, nullptr, cx_i + (size_t)ql * n, c.d_mod.p, t.d_qlp_prime.p, 0xffffffffu, (uint32_t)n};
-        // in_prime is the special prime: pass its limb so the kernel can compare moduli
-        k.in_limb = ql;
-        hipLaunchKernelGGL(single_p_kernel, dim3((unsigned)(n / 256), ql), dim3(256), 0, s, k);
-        check_launch();
+        for (uint32_t z = 0; z < polys; z++) {
+            SinglePArgs k{delta + z * d_stride, nullptr, cx + z * cx_stride + (size_t)ql * n, c.d_mod.p,
+                          t.d_qlp_prime.p, ql, (uint32_t)n};
+            hipLaunchKernelGGL(single_p_kernel, dim3((unsigned)(n / 256), ql), dim3(256), 0, s, k);
+            check_launch();
+        }
     } else {
-        launch_bconv(c, t.p_to_ql, delta, cx_i + (size_t)ql * n, true, 0xffffffffu, 0, s);
+        launch_bconv(c, t.d_p_to_ql_conv.p, 0, polys, t.alpha, ql, t.split_ok, delta, d_stride, cx, cx_stride,
+                     nullptr, true, s);
     }
     if (scheme == PHA_SCHEME_CKKS) {
         NttExtra x;  // NTT(delta) fused with (cx - .) * P^-1 (ntt_moddown.cu:106-261)
         x.scale = t.pinv.p;
         x.scale_shoup = t.pinv_shoup.p;
-        x.aux = cx_i;
-        ntt_forward(c, delta, delta, ct_i, plain_sel(0, ql), EPI_FWD_MODDOWN, x, s);
+        x.aux = cx;
+        x.batch = polys;
+        x.poly_stride = d_stride;
+        x.out_stride = ct_stride;
+        x.aux_stride = cx_stride;
+        ntt_forward(c, delta, delta, ct, plain_sel(0, ql), accumulate ? EPI_FWD_MODDOWN_ADD : EPI_FWD_MODDOWN, x, s);
     } else {
-        SubMulArgs k{ct_i, cx_i, delta, t.pinv2.p, c.d_mod.p, (uint32_t)n};
-        hipLaunchKernelGGL(sub_mul_kernel<false>, dim3((unsigned)(n / 256), ql), dim3(256), 0, s, k);
-        check_launch();
+        for (uint32_t z = 0; z < polys; z++) {
+            u64 *out = accumulate ? delta + z * d_stride : ct + z * ct_stride;
+            SubMulArgs k{out, cx + z * cx_stride, delta + z * d_stride, t.pinv2.p, c.d_mod.p, (uint32_t)n};
+            hipLaunchKernelGGL(sub_mul_kernel<false>, dim3((unsigned)(n / 256), ql), dim3(256), 0, s, k);
+            check_launch();
+            if (accumulate) launch_add(c, ct + z * ct_stride, out, ct + z * ct_stride, ql, 0, s);
+        }
     }
 }
 
@@ -321,7 +404,9 @@ int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const ui
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
-    launch_bconv(c, t.p_to_ql, dst, src, true, 0xffffffffu, 0, as_stream(stream));
+    // src is the bare [P][N] block: the converter's src_limb offset (Ql) must not be applied
+    launch_bconv(c, t.d_p_to_ql_conv.p, 0, 1, t.alpha, (uint32_t)size_Ql, t.split_ok, dst, 0,
+                 src - (size_t)size_Ql * c.n, 0, nullptr, true, as_stream(stream));
     PHA_API_END
 }
 
@@ -354,7 +439,7 @@ int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
     u64 *delta = c.scratch(stream, size_Ql * c.n);
-    moddown_from_ntt(c, t, ct_i, cx_i, scheme, delta, as_stream(stream));
+    moddown_from_ntt(c, t, ct_i, 0, cx_i, 0, 1, scheme, false, delta, as_stream(stream));
     PHA_API_END
 }
 
@@ -367,16 +452,13 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     Tool &t = c.tool((uint32_t)size_Ql);
     hipStream_t s = as_stream(stream);
     const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
-    // scratch: t_cks / delta [Ql][N] | t_mod_up [beta][QlP][N] | cx [2][QlP][N]  (eval_key_switch.cu:151,155)
-    u64 *base = c.scratch(stream, ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n);
-    u64 *tmp = base, *t_mod_up = base + ql_n, *cx = t_mod_up + (size_t)t.beta * qlp_n;
+    // scratch: t_cks / delta [2][Ql][N] | t_mod_up [beta][QlP][N] | cx [2][QlP][N]  (eval_key_switch.cu:151,155)
+    u64 *base = c.scratch(stream, 2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n);
+    u64 *tmp = base, *t_mod_up = base + 2 * ql_n, *cx = t_mod_up + (size_t)t.beta * qlp_n;
     modup(c, t, t_mod_up, c2, scheme, tmp, s);
     inner_prod(c, t, cx, t_mod_up, rlk, s);
-    for (int i = 0; i < 2; i++) {
-        u64 *cx_i = cx + (size_t)i * qlp_n;
-        moddown_from_ntt(c, t, cx_i, cx_i, scheme, tmp, s);
-        launch_add(c, ct + (size_t)i * ql_n, cx_i, ct + (size_t)i * ql_n, size_Ql, 0, s);  // add_to_ct_kernel
-    }
+    // both polynomials at once; ct += moddown(cx) with the add fused into the NTT epilogue
+    moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2, scheme, true, tmp, s);
     PHA_API_END
 }
 
@@ -390,21 +472,28 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
     Tool &t = c.tool((uint32_t)size_Ql);
     hipStream_t s = as_stream(stream);
     const size_t n = c.n, nl = size_Ql - 1;
-    u64 *tmp = c.scratch(stream, nl * n);
-    for (size_t p = 0; p < cipher_size; p++) {
-        u64 *ci_in = src + p * size_Ql * n, *ci_out = dst + p * nl * n;
-        // ci[last] -> coefficient form (rns.cu:1171)
-        ntt_inverse(c, ci_in, ci_in, ci_in, plain_sel(nl, 1), EPI_INV_CANON, NttExtra{}, s);
-        ReduceArgs k{tmp, ci_in + nl * n, c.d_mod.p, (uint32_t)n};
-        hipLaunchKernelGGL(reduce_last_kernel, dim3((unsigned)(n / 256), (unsigned)nl), dim3(256), 0, s, k);
-        check_launch();
-        // NTT(ci[last] mod qj) fused with (ci[j] - .) * q_last^-1 (rns.cu:1178-1182)
-        NttExtra x;
-        x.scale = t.inv_q_last.p;
-        x.scale_shoup = t.inv_q_last_shoup.p;
-        x.aux = ci_in;
-        ntt_forward(c, tmp, tmp, ci_out, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
-    }
+    if (cipher_size == 0) return 0;
+    if (cipher_size > 65535) throw std::invalid_argument("cipher_size out of range");
+    u64 *tmp = c.scratch(stream, cipher_size * nl * n);
+    // all polynomials of the ciphertext in one launch each (blockIdx.z = polynomial)
+    NttExtra xi;
+    xi.batch = (uint32_t)cipher_size;
+    xi.poly_stride = size_Ql * n;
+    ntt_inverse(c, src, src, src, plain_sel(nl, 1), EPI_INV_CANON, xi, s);  // ci[last] -> coefficients (rns.cu:1171)
+    ReduceArgs k{tmp, src + nl * n, c.d_mod.p, (uint32_t)n, nl * n, size_Ql * n};
+    hipLaunchKernelGGL(reduce_last_kernel, dim3((unsigned)(n / 256), (unsigned)nl, (unsigned)cipher_size), dim3(256), 0,
+                       s, k);
+    check_launch();
+    // NTT(ci[last] mod qj) fused with (ci[j] - .) * q_last^-1 (rns.cu:1178-1182)
+    NttExtra x;
+    x.scale = t.inv_q_last.p;
+    x.scale_shoup = t.inv_q_last_shoup.p;
+    x.aux = src;
+    x.batch = (uint32_t)cipher_size;
+    x.poly_stride = nl * n;
+    x.out_stride = nl * n;
+    x.aux_stride = size_Ql * n;
+    ntt_forward(c, tmp, tmp, dst, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
     PHA_API_END
 }
 
