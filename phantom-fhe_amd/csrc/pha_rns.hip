@@ -51,6 +51,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
     const uint32_t isz = d.isz;
     u64 y[ISZ_PAD];
+    u32 ylo[ISZ_PAD], yhi[ISZ_PAD];  // SPLIT: 30-bit halves, cut once per input
 #pragma unroll
     for (int i = 0; i < ISZ_PAD; i++) {
         y[i] = 0;
@@ -59,6 +60,8 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
             if (SCALE_IN) x = shoup(x, d.hat_inv[i], L.mod[d.iprime[i]].value);
             y[i] = x;
         }
+        ylo[i] = (u32)y[i] & 0x3fffffffu;
+        yhi[i] = (u32)(y[i] >> 30);
     }
     if (d.copy_own && blockIdx.y == 0) {  // modup_copy_partQl_kernel rns_bconv.cu:522-528
         for (uint32_t i = 0; i < isz; i++)
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
 #pragma unroll
             for (int i = 0; i < ISZ_PAD; i++)
                 if (i < (int)isz) {
-                    const u32 y0 = (u32)y[i] & 0x3fffffffu, y1 = (u32)(y[i] >> 30);
+                    const u32 y0 = ylo[i], y1 = yhi[i];
                     const u32 m0 = row[2 * i], m1 = row[2 * i + 1];
                     ll = (u64)y0 * m0 + ll;
                     lh = (u64)y0 * m1 + lh;
