@@ -1,0 +1,573 @@
+// phantom.h -- C++ host mirror of the reference's hot-path API over the C ABI (include/phantom_amd.h).
+//
+// The reference is compiled C++ (CUDA); its boundary for the accelerated path is the set of public
+// headers include/context.cuh, ciphertext.h, secretkey.h (key containers) and evaluate.cuh.  This header
+// keeps those names, members, argument meaning, pre-condition checks and exception types for everything
+// that sits on the RNS hot path, so code written against the reference's evaluate.* API compiles against
+// it for: negate / add / sub / multiply (CKKS, BGV tensor) / relinearize / multiply_and_relin /
+// rescale_to_next / mod_switch_to_next (drop) / apply_galois / rotate / keyswitch_inplace.
+// Out of scope here exactly as in SURVEY.md section 8: key generation, encryption, decryption, encoders,
+// BFV BEHZ/HPS multiply (those callers are not on the accelerated path yet and throw).
+//
+// Header-only; needs the HIP runtime for device memory (hipMallocAsync / hipFreeAsync on the
+// per-thread stream, like include/cuda_wrapper.cuh:65-189) and libphantom_amd.so for every kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <phantom_amd.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+// the reference spells the stream type cudaStream_t in every signature
+using cudaStream_t = hipStream_t;
+#ifndef cudaStreamPerThread
+#define cudaStreamPerThread hipStreamPerThread
+#endif
+
+namespace phantom {
+
+enum class scheme_type : std::uint8_t { none = 0x0, bfv = 0x1, ckks = 0x2, bgv = 0x3 };  // encryptionparams.h:19-27
+enum class mul_tech_type : std::uint8_t { none = 0x0, behz = 0x1, hps = 0x2, hps_overq = 0x3, hps_overq_leveled = 0x4 };
+
+namespace util {
+
+inline void check_hip(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("CUDA Runtime Error: ") + hipGetErrorString(e) + " (" + what + ")");
+}
+inline void check_pha(int status) {  // C-ABI status -> the reference's exception types
+    if (status == PHA_OK) return;
+    if (status == PHA_ERR_INVALID_ARGUMENT) throw std::invalid_argument(pha_last_error());
+    if (status == PHA_ERR_LOGIC) throw std::logic_error(pha_last_error());
+    throw std::runtime_error(pha_last_error());
+}
+
+// cuda_auto_ptr<T> (include/cuda_wrapper.cuh:65-189): stream-ordered RAII buffer; move steals, copy is a
+// deep device copy on the source's stream.
+template <class T>
+class cuda_auto_ptr {
+    T *ptr_ = nullptr;
+    size_t n_ = 0;
+    cudaStream_t stream_ = nullptr;
+
+public:
+    cuda_auto_ptr() = default;
+    cuda_auto_ptr(size_t n, const cudaStream_t &stream) : n_(n), stream_(stream) {
+        if (n) check_hip(hipMallocAsync(reinterpret_cast<void **>(&ptr_), n * sizeof(T), stream), "hipMallocAsync");
+    }
+    cuda_auto_ptr(const cuda_auto_ptr &o) : n_(o.n_), stream_(o.stream_) {
+        if (n_) {
+            check_hip(hipMallocAsync(reinterpret_cast<void **>(&ptr_), n_ * sizeof(T), stream_), "hipMallocAsync");
+            check_hip(hipMemcpyAsync(ptr_, o.ptr_, n_ * sizeof(T), hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync");
+        }
+    }
+    cuda_auto_ptr(cuda_auto_ptr &&o) noexcept : ptr_(o.ptr_), n_(o.n_), stream_(o.stream_) { o.ptr_ = nullptr; o.n_ = 0; }
+    cuda_auto_ptr &operator=(const cuda_auto_ptr &o) {
+        if (this != &o) { cuda_auto_ptr tmp(o); swap(tmp); }
+        return *this;
+    }
+    cuda_auto_ptr &operator=(cuda_auto_ptr &&o) noexcept {
+        if (this != &o) { reset(); ptr_ = o.ptr_; n_ = o.n_; stream_ = o.stream_; o.ptr_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~cuda_auto_ptr() { reset(); }
+    void swap(cuda_auto_ptr &o) noexcept { std::swap(ptr_, o.ptr_); std::swap(n_, o.n_); std::swap(stream_, o.stream_); }
+    void reset() {
+        if (ptr_) (void)hipFreeAsync(ptr_, stream_);
+        ptr_ = nullptr;
+        n_ = 0;
+    }
+    [[nodiscard]] T *get() const { return ptr_; }
+    [[nodiscard]] size_t get_n() const { return n_; }
+};
+template <class T>
+inline cuda_auto_ptr<T> make_cuda_auto_ptr(size_t n, const cudaStream_t &stream) { return cuda_auto_ptr<T>(n, stream); }
+
+// get_elt_from_step (include/galois.cuh:16-49): generator 5, step 0 = conjugation (2N - 1)
+[[nodiscard]] inline uint32_t get_elt_from_step(int step, size_t coeff_count) {
+    const auto n = static_cast<uint32_t>(coeff_count);
+    const uint32_t m32 = n * 2;
+    const auto m = static_cast<uint64_t>(m32);
+    if (step == 0) return static_cast<uint32_t>(m - 1);
+    const bool sign = step < 0;
+    auto pos_step = static_cast<uint32_t>(std::abs(step));
+    if (pos_step >= (n >> 1)) throw std::invalid_argument("step count too large");
+    pos_step &= m32 - 1;
+    step = sign ? static_cast<int>(n >> 1) - static_cast<int>(pos_step) : static_cast<int>(pos_step);
+    uint64_t galois_elt = 1;
+    while (step--) {
+        galois_elt *= 5;
+        galois_elt &= m - 1;
+    }
+    return static_cast<uint32_t>(galois_elt);
+}
+[[nodiscard]] inline std::vector<uint32_t> get_elts_from_steps(const std::vector<int> &steps, size_t coeff_count) {
+    std::vector<uint32_t> elts;
+    for (int s : steps) elts.push_back(get_elt_from_step(s, coeff_count));
+    return elts;
+}
+// non-adjacent form of a rotation step (src/host/numth.cu naf)
+[[nodiscard]] inline std::vector<int> naf(int value) {
+    std::vector<int> res;
+    const bool sign = value < 0;
+    value = std::abs(value);
+    for (int i = 0; value; i++) {
+        const int zi = (value & 1) ? 2 - (value & 3) : 0;
+        value = (value - zi) >> 1;
+        if (zi) res.push_back((sign ? -zi : zi) * (1 << i));
+    }
+    return res;
+}
+
+}  // namespace util
+
+namespace arith {
+
+// Modulus (include/host/modulus.h): value + Barrett const_ratio floor(2^128 / value)
+class Modulus {
+    uint64_t value_ = 0;
+    std::array<uint64_t, 3> const_ratio_{{0, 0, 0}};
+    int bit_count_ = 0;
+
+public:
+    Modulus() = default;
+    explicit Modulus(uint64_t value) : value_(value) {
+        if (value >> 61) throw std::invalid_argument("value can be at most 61-bit");
+        if (value == 1) throw std::invalid_argument("value can not be 1");
+        if (value) {
+            const unsigned __int128 r = (~static_cast<unsigned __int128>(0)) / value;
+            const_ratio_ = {static_cast<uint64_t>(r), static_cast<uint64_t>(r >> 64),
+                            static_cast<uint64_t>((~static_cast<unsigned __int128>(0)) - r * value + 1)};
+            bit_count_ = 64 - __builtin_clzll(value);
+        }
+    }
+    [[nodiscard]] uint64_t value() const { return value_; }
+    [[nodiscard]] const std::array<uint64_t, 3> &const_ratio() const { return const_ratio_; }
+    [[nodiscard]] int bit_count() const { return bit_count_; }
+    [[nodiscard]] bool is_zero() const { return value_ == 0; }
+};
+
+// CoeffModulus::Create (src/host/modulus.cu:82-111), computed by the library
+struct CoeffModulus {
+    static std::vector<Modulus> Create(size_t poly_modulus_degree, const std::vector<int> &bit_sizes) {
+        std::vector<uint64_t> v(bit_sizes.size());
+        util::check_pha(pha_coeff_modulus_create(poly_modulus_degree, bit_sizes.data(), bit_sizes.size(), v.data()));
+        std::vector<Modulus> out;
+        for (uint64_t q : v) out.emplace_back(q);
+        return out;
+    }
+};
+
+}  // namespace arith
+
+// EncryptionParameters (include/host/encryptionparams.h:29-246), the members the hot path reads
+class EncryptionParameters {
+    scheme_type scheme_;
+    mul_tech_type mul_tech_ = mul_tech_type::hps;
+    size_t poly_modulus_degree_ = 0;
+    std::vector<arith::Modulus> coeff_modulus_;
+    size_t special_modulus_size_ = 1;  // default 1 (:235)
+    arith::Modulus plain_modulus_;
+    std::vector<uint32_t> galois_elts_;
+
+public:
+    explicit EncryptionParameters(scheme_type scheme = scheme_type::none) : scheme_(scheme) {}
+    void set_poly_modulus_degree(size_t n) { poly_modulus_degree_ = n; }
+    void set_coeff_modulus(const std::vector<arith::Modulus> &m) { coeff_modulus_ = m; }
+    void set_special_modulus_size(size_t s) { special_modulus_size_ = s; }
+    void set_plain_modulus(const arith::Modulus &t) { plain_modulus_ = t; }
+    void set_mul_tech(mul_tech_type t) { mul_tech_ = t; }
+    void set_galois_elts(const std::vector<uint32_t> &e) { galois_elts_ = e; }
+    [[nodiscard]] scheme_type scheme() const { return scheme_; }
+    [[nodiscard]] mul_tech_type mul_tech() const { return mul_tech_; }
+    [[nodiscard]] size_t poly_modulus_degree() const { return poly_modulus_degree_; }
+    [[nodiscard]] const std::vector<arith::Modulus> &coeff_modulus() const { return coeff_modulus_; }
+    [[nodiscard]] size_t special_modulus_size() const { return special_modulus_size_; }
+    [[nodiscard]] const arith::Modulus &plain_modulus() const { return plain_modulus_; }
+    [[nodiscard]] const std::vector<uint32_t> &galois_elts() const { return galois_elts_; }
+};
+
+// ContextData (include/context.cuh:19-131): the parameters of one level of the modulus chain
+class ContextData {
+    EncryptionParameters parms_;
+    size_t chain_index_ = 0;
+
+public:
+    ContextData(EncryptionParameters parms, size_t chain_index) : parms_(std::move(parms)), chain_index_(chain_index) {}
+    [[nodiscard]] const EncryptionParameters &parms() const { return parms_; }
+    [[nodiscard]] size_t chain_index() const { return chain_index_; }
+};
+
+}  // namespace phantom
+
+// PhantomContext (include/context.cuh:133-273, src/context.cu:121-232): the modulus chain
+// (context_data_[0] = key level QP, [1] = Q, [1 + l] drops l primes) plus the device tables, which
+// live behind one pha_context_t (tables for every QP prime + a lazily built DRNSTool per level).
+class PhantomContext {
+    pha_context_t amd_ = nullptr;
+    std::vector<phantom::ContextData> context_data_;
+    bool using_keyswitching_ = false;
+    size_t first_parm_index_ = 0;
+    size_t poly_degree_ = 0;
+    size_t coeff_mod_size_ = 0;
+
+public:
+    explicit PhantomContext(const phantom::EncryptionParameters &params, int device = -1) {
+        using namespace phantom;
+        const auto &qp = params.coeff_modulus();
+        const size_t n = params.poly_modulus_degree();
+        if (n == 0 || (n & (n - 1))) throw std::invalid_argument("poly_modulus_degree is invalid");
+        if (qp.empty()) throw std::invalid_argument("coeff_modulus is empty");
+        const size_t size_p = params.special_modulus_size();
+        if (size_p >= qp.size() && qp.size() > 1) throw std::invalid_argument("special_modulus_size is invalid");
+        poly_degree_ = n;
+        coeff_mod_size_ = qp.size();
+        // a single-prime chain has no special prime and no key switching (src/context.cu:142-168)
+        using_keyswitching_ = qp.size() > 1 && size_p > 0;
+        const size_t sp = using_keyswitching_ ? size_p : 0;
+        context_data_.emplace_back(params, 0);
+        if (using_keyswitching_) {
+            const size_t size_q = qp.size() - sp;
+            for (size_t drop = 0; drop < size_q; drop++) {
+                EncryptionParameters p = params;
+                p.set_coeff_modulus(std::vector<arith::Modulus>(qp.begin(), qp.begin() + (size_q - drop)));
+                context_data_.emplace_back(p, 1 + drop);
+            }
+            first_parm_index_ = 1;
+        }
+        if (device < 0) util::check_hip(hipGetDevice(&device), "hipGetDevice");
+        std::vector<uint64_t> primes;
+        for (const auto &m : qp) primes.push_back(m.value());
+        int log_n = 0;
+        while ((size_t(1) << log_n) < n) log_n++;
+        util::check_pha(pha_context_create(&amd_, log_n, primes.data(), primes.size(), sp, device));
+    }
+    PhantomContext(const PhantomContext &) = delete;
+    PhantomContext &operator=(const PhantomContext &) = delete;
+    ~PhantomContext() { pha_context_destroy(amd_); }
+
+    [[nodiscard]] pha_context_t amd() const { return amd_; }
+    [[nodiscard]] const phantom::ContextData &get_context_data(size_t index) const {
+        if (index >= context_data_.size()) throw std::invalid_argument("index is out of range");
+        return context_data_[index];
+    }
+    [[nodiscard]] size_t total_parm_size() const { return context_data_.size(); }
+    [[nodiscard]] bool using_keyswitching() const { return using_keyswitching_; }
+    [[nodiscard]] size_t get_first_index() const { return first_parm_index_; }
+    [[nodiscard]] size_t get_next_index(size_t index) const {
+        if (index + 1 >= context_data_.size()) throw std::invalid_argument("no next parameters");
+        return index + 1;
+    }
+    [[nodiscard]] size_t poly_degree() const { return poly_degree_; }
+    [[nodiscard]] size_t coeff_mod_size() const { return coeff_mod_size_; }
+};
+
+// PhantomCiphertext (include/ciphertext.h:7-171): metadata + one device buffer [poly][limb][coeff]
+class PhantomCiphertext {
+    size_t chain_index_ = 0, size_ = 0, poly_modulus_degree_ = 0, coeff_modulus_size_ = 0;
+    double scale_ = 1.0;
+    uint64_t correction_factor_ = 1;
+    size_t noiseScaleDeg_ = 1;
+    bool is_ntt_form_ = true, is_asymmetric_ = false;
+    phantom::util::cuda_auto_ptr<uint64_t> data_;
+
+public:
+    void resize(const PhantomContext &context, size_t chain_index, size_t size, const cudaStream_t &stream) {
+        const auto &parms = context.get_context_data(chain_index).parms();
+        resize(size, parms.coeff_modulus().size(), parms.poly_modulus_degree(), stream);
+        chain_index_ = chain_index;
+    }
+    // when the size changes the previous data is copied (ciphertext.h:44-72)
+    void resize(size_t size, size_t coeff_modulus_size, size_t poly_modulus_degree, const cudaStream_t &stream) {
+        const size_t old_size = size_ * coeff_modulus_size_ * poly_modulus_degree_;
+        const size_t new_size = size * coeff_modulus_size * poly_modulus_degree;
+        if (new_size == 0) {
+            data_.reset();
+            return;
+        }
+        if (new_size != old_size) {
+            auto prev(std::move(data_));
+            data_ = phantom::util::make_cuda_auto_ptr<uint64_t>(new_size, stream);
+            const size_t copy = std::min(old_size, new_size);
+            if (copy)
+                phantom::util::check_hip(hipMemcpyAsync(data_.get(), prev.get(), copy * sizeof(uint64_t),
+                                                        hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
+        }
+        size_ = size;
+        coeff_modulus_size_ = coeff_modulus_size;
+        poly_modulus_degree_ = poly_modulus_degree;
+    }
+    void set_scale(double scale) { scale_ = scale; }
+    void set_chain_index(size_t i) { chain_index_ = i; }
+    void set_ntt_form(bool f) { is_ntt_form_ = f; }
+    void set_correction_factor(uint64_t c) { correction_factor_ = c; }
+    void SetNoiseScaleDeg(size_t d) { noiseScaleDeg_ = d; }
+    [[nodiscard]] size_t GetNoiseScaleDeg() const { return noiseScaleDeg_; }
+    [[nodiscard]] bool is_asymmetric() const { return is_asymmetric_; }
+    [[nodiscard]] bool is_ntt_form() const { return is_ntt_form_; }
+    [[nodiscard]] size_t chain_index() const { return chain_index_; }
+    [[nodiscard]] size_t size() const { return size_; }
+    [[nodiscard]] size_t poly_modulus_degree() const { return poly_modulus_degree_; }
+    [[nodiscard]] size_t coeff_modulus_size() const { return coeff_modulus_size_; }
+    [[nodiscard]] double scale() const { return scale_; }
+    [[nodiscard]] uint64_t correction_factor() const { return correction_factor_; }
+    [[nodiscard]] uint64_t *data() const { return data_.get(); }
+
+    // test / interop helpers (the reference fills ciphertexts by encryption, which is out of scope)
+    void load_from_host(const PhantomContext &context, size_t chain_index, size_t size, const uint64_t *host,
+                        const cudaStream_t &stream = cudaStreamPerThread) {
+        resize(context, chain_index, size, stream);
+        phantom::util::check_hip(hipMemcpyAsync(data_.get(), host, size_ * coeff_modulus_size_ * poly_modulus_degree_ * 8,
+                                                hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+    }
+    void store_to_host(uint64_t *host, const cudaStream_t &stream = cudaStreamPerThread) const {
+        phantom::util::check_hip(hipMemcpyAsync(host, data_.get(), size_ * coeff_modulus_size_ * poly_modulus_degree_ * 8,
+                                                hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+        phantom::util::check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    }
+};
+
+// PhantomRelinKey (include/secretkey.h:102-165): dnum public keys [2][#QP][N] + device pointer table
+class PhantomRelinKey {
+    std::vector<phantom::util::cuda_auto_ptr<uint64_t>> public_keys_;
+    phantom::util::cuda_auto_ptr<uint64_t *> public_keys_ptr_;
+    bool gen_flag_ = false;
+
+public:
+    PhantomRelinKey() = default;
+    // keys come from outside (key generation is out of scope): evk = [dnum][2][#QP][N] on the host
+    void load_from_host(const PhantomContext &context, const uint64_t *evk, size_t dnum,
+                        const cudaStream_t &stream = cudaStreamPerThread) {
+        const size_t words = 2 * context.coeff_mod_size() * context.poly_degree();
+        public_keys_.clear();
+        std::vector<uint64_t *> ptrs;
+        for (size_t d = 0; d < dnum; d++) {
+            public_keys_.emplace_back(words, stream);
+            phantom::util::check_hip(hipMemcpyAsync(public_keys_.back().get(), evk + d * words, words * 8,
+                                                    hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            ptrs.push_back(public_keys_.back().get());
+        }
+        public_keys_ptr_ = phantom::util::make_cuda_auto_ptr<uint64_t *>(dnum, stream);
+        phantom::util::check_hip(hipMemcpyAsync(public_keys_ptr_.get(), ptrs.data(), dnum * sizeof(uint64_t *),
+                                                hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+        phantom::util::check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        gen_flag_ = true;
+    }
+    [[nodiscard]] uint64_t **public_keys_ptr() const { return public_keys_ptr_.get(); }
+    [[nodiscard]] size_t dnum() const { return public_keys_.size(); }
+    [[nodiscard]] bool generated() const { return gen_flag_; }
+};
+
+// PhantomGaloisKey (include/secretkey.h:170-220): one relin key per Galois element
+class PhantomGaloisKey {
+    std::vector<uint32_t> galois_elts_;
+    std::vector<PhantomRelinKey> relin_keys_;
+
+public:
+    void add(uint32_t galois_elt, PhantomRelinKey &&key) {
+        galois_elts_.push_back(galois_elt);
+        relin_keys_.push_back(std::move(key));
+    }
+    [[nodiscard]] const std::vector<uint32_t> &galois_elts() const { return galois_elts_; }
+    [[nodiscard]] const PhantomRelinKey &get_relin_keys(size_t index) const { return relin_keys_.at(index); }
+};
+
+namespace phantom {
+
+namespace detail {
+inline size_t level_size_Ql(const PhantomContext &context, const PhantomCiphertext &ct) {
+    // keyswitch_inplace src/eval_key_switch.cu:112-127: bfv -> level 1; ckks/bgv -> chain_index
+    const auto scheme = context.get_context_data(0).parms().scheme();
+    const size_t idx = scheme == scheme_type::bfv ? 1 : ct.chain_index();
+    return context.get_context_data(idx).parms().coeff_modulus().size();
+}
+inline void same_shape(const PhantomCiphertext &a, const PhantomCiphertext &b) {
+    if (a.chain_index() != b.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+    if (a.is_ntt_form() != b.is_ntt_form()) throw std::invalid_argument("NTT form mismatch");
+    if (a.scale() != b.scale()) throw std::invalid_argument("scale mismatch");
+    if (a.size() != b.size()) throw std::invalid_argument("poly number mismatch");
+}
+}  // namespace detail
+
+// phantom::keyswitch_inplace (include/evaluate.cuh:29-32, src/eval_key_switch.cu:95-182)
+inline void keyswitch_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, uint64_t *c2,
+                              const PhantomRelinKey &relin_keys, bool /*is_relin*/, const cudaStream_t &stream) {
+    const auto &key_parms = context.get_context_data(0).parms();
+    if (key_parms.mul_tech() == mul_tech_type::hps_overq_leveled && key_parms.scheme() == scheme_type::bfv)
+        throw std::invalid_argument("hps_overq_leveled key switching is not on the accelerated path");
+    util::check_pha(pha_keyswitch_inplace(context.amd(), detail::level_size_Ql(context, encrypted), encrypted.data(), c2,
+                                          relin_keys.public_keys_ptr(), static_cast<int>(key_parms.scheme()), stream));
+}
+
+// negate / add / sub (src/evaluate.cu:80-343): residue-wise over size * coeff_modulus_size limbs
+inline void negate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted) {
+    const auto &s = cudaStreamPerThread;
+    const size_t L = encrypted.coeff_modulus_size(), n = encrypted.poly_modulus_degree();
+    for (size_t i = 0; i < encrypted.size(); i++)
+        util::check_pha(pha_negate_rns_poly(context.amd(), encrypted.data() + i * L * n, encrypted.data() + i * L * n, L, 0, s));
+}
+inline void add_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2) {
+    detail::same_shape(encrypted1, encrypted2);
+    const auto &s = cudaStreamPerThread;
+    const size_t L = encrypted1.coeff_modulus_size(), n = encrypted1.poly_modulus_degree();
+    for (size_t i = 0; i < encrypted1.size(); i++)
+        util::check_pha(pha_add_rns_poly(context.amd(), encrypted1.data() + i * L * n, encrypted2.data() + i * L * n,
+                                         encrypted1.data() + i * L * n, L, 0, s));
+}
+inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                        bool negate = false) {
+    detail::same_shape(encrypted1, encrypted2);
+    const auto &s = cudaStreamPerThread;
+    const size_t L = encrypted1.coeff_modulus_size(), n = encrypted1.poly_modulus_degree();
+    for (size_t i = 0; i < encrypted1.size(); i++) {
+        uint64_t *a = encrypted1.data() + i * L * n;
+        const uint64_t *b = encrypted2.data() + i * L * n;
+        if (negate) util::check_pha(pha_sub_rns_poly(context.amd(), b, a, a, L, 0, s));
+        else util::check_pha(pha_sub_rns_poly(context.amd(), a, b, a, L, 0, s));
+    }
+}
+
+// multiply_inplace (src/evaluate.cu:1030-1079 -> bgv_ckks_multiply :345-397)
+inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2) {
+    const auto &parms = context.get_context_data(encrypted1.chain_index()).parms();
+    if (parms.scheme() == scheme_type::bfv)
+        throw std::invalid_argument("BFV multiply (BEHZ/HPS) is not on the accelerated path");
+    if (!(encrypted1.is_ntt_form() && encrypted2.is_ntt_form()))
+        throw std::invalid_argument("encrypted1 and encrypted2 must be in NTT form");
+    if (encrypted1.chain_index() != encrypted2.chain_index())
+        throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+    if (encrypted1.size() != 2 || encrypted2.size() != 2)
+        throw std::invalid_argument("only 2x2 tensor products are on the accelerated path");
+    const auto &s = cudaStreamPerThread;
+    const size_t L = parms.coeff_modulus().size();
+    const bool square = &encrypted1 == &encrypted2;
+    encrypted1.resize(context, encrypted1.chain_index(), 3, s);
+    if (square) util::check_pha(pha_tensor_square_2x2_rns_poly(context.amd(), encrypted1.data(), encrypted1.data(), L, s));
+    else util::check_pha(pha_tensor_prod_2x2_rns_poly(context.amd(), encrypted1.data(), encrypted2.data(), encrypted1.data(), L, s));
+    if (parms.scheme() == scheme_type::ckks) encrypted1.set_scale(encrypted1.scale() * encrypted2.scale());
+}
+
+// relinearize_inplace (src/evaluate.cu:1342-1374)
+inline void relinearize_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomRelinKey &relin_keys) {
+    const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
+    const size_t decomp_modulus_size = parms.coeff_modulus().size();
+    const size_t n = parms.poly_modulus_degree();
+    const auto scheme = parms.scheme();
+    if (encrypted.size() != 3) throw std::invalid_argument("destination_size must be 3");
+    if (scheme == scheme_type::bfv && encrypted.is_ntt_form()) throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+    if (scheme == scheme_type::ckks && !encrypted.is_ntt_form()) throw std::invalid_argument("CKKS encrypted must be in NTT form");
+    if (scheme == scheme_type::bgv && !encrypted.is_ntt_form()) throw std::invalid_argument("BGV encrypted must be in NTT form");
+    uint64_t *c2 = encrypted.data() + 2 * decomp_modulus_size * n;
+    const auto &s = cudaStreamPerThread;
+    keyswitch_inplace(context, encrypted, c2, relin_keys, true, s);
+    encrypted.resize(2, decomp_modulus_size, n, s);
+}
+inline void multiply_and_relin_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1,
+                                       const PhantomCiphertext &encrypted2, const PhantomRelinKey &relin_keys) {
+    multiply_inplace(context, encrypted1, encrypted2);
+    relinearize_inplace(context, encrypted1, relin_keys);
+}
+
+// rescale_to_next (src/evaluate.cu:1545-1565 -> mod_switch_scale_to_next :1376-1427)
+[[nodiscard]] inline PhantomCiphertext rescale_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted) {
+    const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
+    if (parms.scheme() != scheme_type::ckks) throw std::invalid_argument("unsupported operation for scheme type");
+    if (!encrypted.is_ntt_form()) throw std::invalid_argument("CKKS encrypted must be in NTT form");
+    const auto &s = cudaStreamPerThread;
+    const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree(), size = encrypted.size();
+    const size_t next = context.get_next_index(encrypted.chain_index());
+    auto copy = util::make_cuda_auto_ptr<uint64_t>(size * L * n, s);  // the reference rescales a copy (:1392-1395)
+    util::check_hip(hipMemcpyAsync(copy.get(), encrypted.data(), size * L * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    PhantomCiphertext destination;
+    destination.resize(context, next, size, s);
+    util::check_pha(pha_divide_and_round_q_last_ntt(context.amd(), L, copy.get(), size, destination.data(), s));
+    destination.set_ntt_form(encrypted.is_ntt_form());
+    destination.set_scale(encrypted.scale() / static_cast<double>(parms.coeff_modulus().back().value()));
+    return destination;
+}
+inline void rescale_to_next_inplace(const PhantomContext &context, PhantomCiphertext &encrypted) {
+    encrypted = rescale_to_next(context, encrypted);
+}
+
+// mod_switch_to_next for CKKS = drop the last limb (src/evaluate.cu:1429-1470 mod_switch_drop_to_next)
+[[nodiscard]] inline PhantomCiphertext mod_switch_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted) {
+    const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
+    if (parms.scheme() != scheme_type::ckks)
+        throw std::invalid_argument("BFV/BGV modulus switching is not on the accelerated path");
+    const auto &s = cudaStreamPerThread;
+    const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree(), size = encrypted.size();
+    const size_t next = context.get_next_index(encrypted.chain_index());
+    PhantomCiphertext destination;
+    destination.resize(context, next, size, s);
+    for (size_t i = 0; i < size; i++)
+        util::check_hip(hipMemcpyAsync(destination.data() + i * (L - 1) * n, encrypted.data() + i * L * n, (L - 1) * n * 8,
+                                       hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    destination.set_ntt_form(encrypted.is_ntt_form());
+    destination.set_scale(encrypted.scale());
+    return destination;
+}
+inline void mod_switch_to_next_inplace(const PhantomContext &context, PhantomCiphertext &encrypted) {
+    encrypted = mod_switch_to_next(context, encrypted);
+}
+
+// apply_galois_inplace (src/evaluate.cu:1567-1630)
+inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, size_t galois_elt,
+                                 const PhantomGaloisKey &galois_keys) {
+    const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
+    const size_t N = parms.poly_modulus_degree(), L = parms.coeff_modulus().size();
+    if (encrypted.size() > 2) throw std::invalid_argument("encrypted size must be 2");
+    const auto &elts = galois_keys.galois_elts();
+    const auto it = std::find(elts.begin(), elts.end(), static_cast<uint32_t>(galois_elt));
+    if (it == elts.end()) throw std::invalid_argument("Galois elt not present");
+    const size_t idx = static_cast<size_t>(it - elts.begin());
+    const auto &s = cudaStreamPerThread;
+    auto temp = util::make_cuda_auto_ptr<uint64_t>(L * N, s);
+    uint64_t *c0 = encrypted.data(), *c1 = encrypted.data() + L * N;
+    // execution order matters: the permutation is not in place (:1597-1622)
+    if (parms.scheme() == scheme_type::bfv) {
+        util::check_pha(pha_apply_galois(context.amd(), c0, temp.get(), static_cast<uint32_t>(galois_elt), L, 0, s));
+        util::check_hip(hipMemcpyAsync(c0, temp.get(), L * N * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        util::check_pha(pha_apply_galois(context.amd(), c1, temp.get(), static_cast<uint32_t>(galois_elt), L, 0, s));
+    } else if (parms.scheme() == scheme_type::ckks || parms.scheme() == scheme_type::bgv) {
+        util::check_pha(pha_apply_galois_ntt(context.amd(), c0, temp.get(), static_cast<uint32_t>(galois_elt), L, s));
+        util::check_hip(hipMemcpyAsync(c0, temp.get(), L * N * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        util::check_pha(pha_apply_galois_ntt(context.amd(), c1, temp.get(), static_cast<uint32_t>(galois_elt), L, s));
+    } else {
+        throw std::logic_error("scheme not implemented");
+    }
+    util::check_hip(hipMemsetAsync(c1, 0, L * N * 8, s), "hipMemsetAsync");
+    keyswitch_inplace(context, encrypted, temp.get(), galois_keys.get_relin_keys(idx), false, s);
+}
+
+// rotate_inplace (src/evaluate.cu:1632-1668): direct key if present, else NAF decomposition of the step
+inline void rotate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, int step,
+                           const PhantomGaloisKey &galois_key) {
+    const size_t coeff_count = context.get_context_data(encrypted.chain_index()).parms().poly_modulus_degree();
+    const auto &elts = galois_key.galois_elts();
+    const uint32_t elt = util::get_elt_from_step(step, coeff_count);
+    if (std::find(elts.begin(), elts.end(), elt) != elts.end()) {
+        apply_galois_inplace(context, encrypted, elt, galois_key);
+        return;
+    }
+    const std::vector<int> naf_step = util::naf(step);
+    if (naf_step.size() == 1) throw std::invalid_argument("Galois key not present");
+    for (int t : naf_step)
+        if (static_cast<size_t>(std::abs(t)) != (coeff_count >> 1)) rotate_inplace(context, encrypted, t, galois_key);
+}
+
+// out-of-place forms (include/evaluate.cuh): copy, then the in-place op
+inline PhantomCiphertext negate(const PhantomContext &c, const PhantomCiphertext &e) { PhantomCiphertext d = e; negate_inplace(c, d); return d; }
+inline PhantomCiphertext add(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b) { PhantomCiphertext d = a; add_inplace(c, d, b); return d; }
+inline PhantomCiphertext sub(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b, bool negate = false) { PhantomCiphertext d = a; sub_inplace(c, d, b, negate); return d; }
+inline PhantomCiphertext multiply(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b) { PhantomCiphertext d = a; multiply_inplace(c, d, b); return d; }
+inline PhantomCiphertext relinearize(const PhantomContext &c, const PhantomCiphertext &e, const PhantomRelinKey &k) { PhantomCiphertext d = e; relinearize_inplace(c, d, k); return d; }
+inline PhantomCiphertext multiply_and_relin(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b, const PhantomRelinKey &k) { PhantomCiphertext d = a; multiply_and_relin_inplace(c, d, b, k); return d; }
+inline PhantomCiphertext apply_galois(const PhantomContext &c, const PhantomCiphertext &e, size_t elt, const PhantomGaloisKey &k) { PhantomCiphertext d = e; apply_galois_inplace(c, d, elt, k); return d; }
+inline PhantomCiphertext rotate(const PhantomContext &c, const PhantomCiphertext &e, int step, const PhantomGaloisKey &k) { PhantomCiphertext d = e; rotate_inplace(c, d, step, k); return d; }
+
+}  // namespace phantom

@@ -1,0 +1,174 @@
+// test_host_api.cpp -- exercises the C++ host mirror (phantom-fhe_amd/host/phantom.h) the way the
+// reference's examples drive evaluate.* (examples/3_ckks.cu:447-520: multiply, relinearize, rescale,
+// rotate), on synthetic ciphertexts/keys, and compares every result bit for bit with the CPU oracle.
+// Needs a GPU; built and run by tests/test_gpu_host_api.py.
+#include <phantom.h>
+
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+extern "C" {
+#include "../../oracle/oracle.h"
+}
+
+using namespace phantom;
+using namespace phantom::arith;
+
+static std::vector<uint64_t> uniform(std::mt19937_64 &g, const std::vector<uint64_t> &primes, size_t n) {
+    std::vector<uint64_t> v(primes.size() * n);
+    for (size_t i = 0; i < primes.size(); i++)
+        for (size_t k = 0; k < n; k++) v[i * n + k] = g() % primes[i];
+    return v;
+}
+#define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+template <class F>
+static bool throws_invalid(F f) {
+    try { f(); } catch (const std::invalid_argument &) { return true; } catch (...) { return false; }
+    return false;
+}
+
+int main() {
+    const size_t n = 4096, alpha = 2;
+    const int log_n = 12;
+    EncryptionParameters parms(scheme_type::ckks);
+    parms.set_poly_modulus_degree(n);
+    parms.set_special_modulus_size(alpha);
+    parms.set_coeff_modulus(CoeffModulus::Create(n, {60, 40, 40, 40, 40, 40, 60, 60}));
+    PhantomContext context(parms);
+    const size_t size_qp = 8, size_q = 6, dnum = size_q / alpha;
+    REQUIRE(context.using_keyswitching() && context.get_first_index() == 1 && context.total_parm_size() == 1 + size_q);
+    REQUIRE(context.get_context_data(3).parms().coeff_modulus().size() == 4);
+    std::vector<uint64_t> qp;
+    for (auto &m : parms.coeff_modulus()) qp.push_back(m.value());
+    const std::vector<uint64_t> q(qp.begin(), qp.begin() + size_q);
+
+    orc_ctx *oc = orc_ctx_create(log_n, qp.data(), size_qp, alpha);
+    orc_tool *tool = orc_tool_create(oc, size_q);
+    std::mt19937_64 g(0x5EED0000 + 7);
+
+    // synthetic keys: relin key + one Galois key (step 1)
+    auto make_key = [&](std::vector<std::vector<uint64_t>> &host, PhantomRelinKey &key) {
+        std::vector<uint64_t> flat;
+        for (size_t d = 0; d < dnum; d++) {
+            std::vector<uint64_t> k;
+            for (int h = 0; h < 2; h++) { auto part = uniform(g, qp, n); k.insert(k.end(), part.begin(), part.end()); }
+            flat.insert(flat.end(), k.begin(), k.end());
+            host.push_back(std::move(k));
+        }
+        key.load_from_host(context, flat.data(), dnum);
+    };
+    std::vector<std::vector<uint64_t>> rlk_host, glk_host;
+    PhantomRelinKey rlk, glk1;
+    make_key(rlk_host, rlk);
+    make_key(glk_host, glk1);
+    const uint32_t elt1 = util::get_elt_from_step(1, n);
+    REQUIRE(elt1 == 5 && util::get_elt_from_step(0, n) == 2 * n - 1 && util::get_elt_from_step(-1, n) != 5);
+    PhantomGaloisKey glk;
+    glk.add(elt1, std::move(glk1));
+    std::vector<const uint64_t *> rlk_ptrs, glk_ptrs;
+    for (auto &k : rlk_host) rlk_ptrs.push_back(k.data());
+    for (auto &k : glk_host) glk_ptrs.push_back(k.data());
+
+    // ciphertexts at the top data level (chain index 1), NTT form
+    std::vector<uint64_t> h1, h2;
+    for (int p = 0; p < 2; p++) { auto a = uniform(g, q, n); h1.insert(h1.end(), a.begin(), a.end()); }
+    for (int p = 0; p < 2; p++) { auto a = uniform(g, q, n); h2.insert(h2.end(), a.begin(), a.end()); }
+    PhantomCiphertext ct1, ct2;
+    ct1.load_from_host(context, 1, 2, h1.data());
+    ct2.load_from_host(context, 1, 2, h2.data());
+    ct1.set_scale(std::pow(2.0, 40));
+    ct2.set_scale(std::pow(2.0, 40));
+    const size_t ln = size_q * n;
+
+    // add / sub / negate
+    {
+        auto sum = add(context, ct1, ct2), diff = sub(context, ct1, ct2), neg = negate(context, ct1);
+        std::vector<uint64_t> got(2 * ln), ref(2 * ln);
+        sum.store_to_host(got.data());
+        for (int p = 0; p < 2; p++) orc_add_rns_poly(oc, h1.data() + p * ln, h2.data() + p * ln, ref.data() + p * ln, size_q, 0);
+        REQUIRE(got == ref);
+        diff.store_to_host(got.data());
+        for (int p = 0; p < 2; p++) orc_sub_rns_poly(oc, h1.data() + p * ln, h2.data() + p * ln, ref.data() + p * ln, size_q, 0);
+        REQUIRE(got == ref);
+        neg.store_to_host(got.data());
+        for (int p = 0; p < 2; p++) orc_negate_rns_poly(oc, h1.data() + p * ln, ref.data() + p * ln, size_q, 0);
+        REQUIRE(got == ref);
+    }
+
+    // multiply -> relinearize -> rescale (examples/3_ckks.cu:496-498)
+    std::vector<uint64_t> ref3(3 * ln);
+    orc_tensor_prod_2x2(oc, h1.data(), h2.data(), ref3.data(), size_q);
+    PhantomCiphertext prod = multiply(context, ct1, ct2);
+    REQUIRE(prod.size() == 3 && prod.scale() == std::pow(2.0, 80));
+    {
+        std::vector<uint64_t> got(3 * ln);
+        prod.store_to_host(got.data());
+        REQUIRE(got == ref3);
+    }
+    relinearize_inplace(context, prod, rlk);
+    REQUIRE(prod.size() == 2);
+    std::vector<uint64_t> ref2(ref3.begin(), ref3.begin() + 2 * ln);
+    orc_keyswitch_inplace(tool, ref2.data(), ref3.data() + 2 * ln, rlk_ptrs.data(), ORC_CKKS);
+    {
+        std::vector<uint64_t> got(2 * ln);
+        prod.store_to_host(got.data());
+        REQUIRE(got == ref2);
+    }
+    PhantomCiphertext sq = ct1;   // square path + multiply_and_relin
+    multiply_and_relin_inplace(context, sq, sq, rlk);
+    {
+        std::vector<uint64_t> r3(3 * ln), got(2 * ln);
+        orc_tensor_square_2x2(oc, h1.data(), r3.data(), size_q);
+        std::vector<uint64_t> r2(r3.begin(), r3.begin() + 2 * ln);
+        orc_keyswitch_inplace(tool, r2.data(), r3.data() + 2 * ln, rlk_ptrs.data(), ORC_CKKS);
+        sq.store_to_host(got.data());
+        REQUIRE(got == r2);
+    }
+    PhantomCiphertext rescaled = rescale_to_next(context, prod);
+    REQUIRE(rescaled.chain_index() == 2 && rescaled.coeff_modulus_size() == size_q - 1);
+    REQUIRE(rescaled.scale() == std::pow(2.0, 80) / static_cast<double>(q.back()));
+    {
+        std::vector<uint64_t> src = ref2, ref((size_q - 1) * n * 2), got((size_q - 1) * n * 2);
+        orc_rescale_ntt(tool, src.data(), 2, ref.data());
+        rescaled.store_to_host(got.data());
+        REQUIRE(got == ref);
+        std::vector<uint64_t> still(2 * ln);
+        prod.store_to_host(still.data());
+        REQUIRE(still == ref2);  // rescale_to_next leaves its input untouched (it works on a copy)
+    }
+
+    // rotate by one slot with a synthetic Galois key (apply_galois_inplace evaluate.cu:1567-1630)
+    {
+        PhantomCiphertext rot = rotate(context, ct1, 1, glk);
+        std::vector<uint32_t> table(n);
+        orc_galois_ntt_table(log_n, elt1, table.data());
+        std::vector<uint64_t> ref(2 * ln, 0), c1g(ln), got(2 * ln);
+        orc_apply_galois_ntt(h1.data(), ref.data(), table.data(), n, size_q);          // c0 <- galois(c0)
+        orc_apply_galois_ntt(h1.data() + ln, c1g.data(), table.data(), n, size_q);     // temp <- galois(c1); c1 <- 0
+        orc_keyswitch_inplace(tool, ref.data(), c1g.data(), glk_ptrs.data(), ORC_CKKS);
+        rot.store_to_host(got.data());
+        REQUIRE(got == ref);
+        REQUIRE(throws_invalid([&] { rotate_inplace(context, rot, 2, glk); }));   // power of two without a key
+        REQUIRE(throws_invalid([&] { apply_galois_inplace(context, rot, 25, glk); }));
+    }
+
+    // pre-condition checks of the reference
+    REQUIRE(throws_invalid([&] { relinearize_inplace(context, ct1, rlk); }));            // size must be 3
+    {
+        PhantomCiphertext c = ct1;
+        c.set_ntt_form(false);
+        REQUIRE(throws_invalid([&] { multiply_inplace(context, c, ct2); }));              // must be in NTT form
+        PhantomCiphertext low = mod_switch_to_next(context, ct1);
+        REQUIRE(low.chain_index() == 2 && low.coeff_modulus_size() == size_q - 1);
+        REQUIRE(throws_invalid([&] { multiply_inplace(context, low, ct2); }));            // chain index mismatch
+        PhantomCiphertext last = ct1;
+        while (last.coeff_modulus_size() > 1) mod_switch_to_next_inplace(context, last);
+        REQUIRE(throws_invalid([&] { rescale_to_next_inplace(context, last); }));         // no next parameters
+    }
+    phantom::util::check_hip(hipDeviceSynchronize(), "sync");
+    orc_tool_destroy(tool);
+    orc_ctx_destroy(oc);
+    std::printf("HOST_API_OK\n");
+    return 0;
+}
