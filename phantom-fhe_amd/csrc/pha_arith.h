@@ -152,6 +152,52 @@ PHA_HD void gs_bfly4(u64 &X, u64 &Y, u64x2 w, u64 q4, u64 nq) {
     Y = shoup_lazy4(d, w, nq);
 }
 
+// ---- FP64 residue arithmetic for primes q < 2^50 ------------------------------------------------------
+// On gfx950 v_fma_f64 / v_mul_f64 / v_add_f64 issue at the same rate as v_mad_u64_u32, and a modular
+// multiply needs 9 of them with no carry chains or zero-extensions (52.8 vs 87.7 cycles per
+// wave-butterfly, profiles/r01_microbench_gfx950.txt).  Residues are held as doubles with integer values,
+// |x| < 2^52.6, so sums/differences are exact; products are exact through the fma error term:
+//   h = Y*W (rounded), l = fma(Y, W, -h) = Y*W - h exactly, c = rint(Y * (W/q)) is the quotient to
+//   within 2, r = fma(-c, q, h) + l = Y*W - c*q exactly (an integer below 2^52), and one more
+//   rint/fma step centres it: result == Y*W (mod q), |result| <= q/2 + 1.
+// Every stored output is converted back to the canonical integer residue, so results are bit-identical
+// to the integer path.
+PHA_HD double as_f64(u64 x) { return __builtin_bit_cast(double, x); }
+PHA_HD u64 as_u64(double x) { return __builtin_bit_cast(u64, x); }
+struct FpMod {
+    double q, qinv;  // q and fl(1/q)
+};
+// x - rint(x/q)*q : |result| <= q/2 + 1 for |x| < 2^52.6
+PHA_HD double fp_reduce(double x, FpMod m) { return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x); }
+// Y*W mod q, centred. W in [0,q), Wi = fl(W/q), |Y| < 2^52.6
+PHA_HD double fp_mulmod(double Y, double W, double Wi, FpMod m) {
+    const double h = Y * W;
+    const double l = __builtin_fma(Y, W, -h);
+    const double c = __builtin_rint(Y * Wi);
+    const double r = __builtin_fma(-c, m.q, h) + l;
+    return fp_reduce(r, m);
+}
+// CT butterfly: (X, Y) -> (X + Y*W, X - Y*W); magnitudes grow by at most q/2 + 1 per stage
+PHA_HD void fp_ct_bfly(double &X, double &Y, double W, double Wi, FpMod m) {
+    const double t = fp_mulmod(Y, W, Wi, m);
+    const double x = X;
+    X = x + t;
+    Y = x - t;
+}
+// GS butterfly: (X, Y) -> ((X + Y) mod q, (X - Y)*W mod q), both centred (inputs |.| <= 2q)
+PHA_HD void fp_gs_bfly(double &X, double &Y, double W, double Wi, FpMod m) {
+    const double s = X + Y, d = X - Y;
+    X = fp_reduce(s, m);
+    Y = fp_mulmod(d, W, Wi, m);
+}
+// canonical integer residue [0,q) (q < 2^50) <-> double, via the 2^52 mantissa trick
+PHA_HD double fp_from_canon(u64 x) { return as_f64(x | 0x4330000000000000ull) - 4503599627370496.0; }
+PHA_HD u64 fp_to_canon(double x, FpMod m) {
+    double r = fp_reduce(x, m);              // [-q/2-1, q/2+1]
+    r = r < 0.0 ? r + m.q : r;               // [0, q)
+    return as_u64(r + 4503599627370496.0) & 0x000fffffffffffffull;
+}
+
 // Harvey butterflies (include/butterfly.cuh:10-22 / :28-37). q2 = 2q.
 // CT: X,Y in [0,4q) -> X,Y in [0,4q)
 PHA_HD void ct_bfly(u64 &X, u64 &Y, u64x2 w, u64 q, u64 q2) {

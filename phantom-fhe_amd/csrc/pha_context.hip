@@ -136,8 +136,17 @@ static void get_primes(u64 ntt_size, int bit_size, size_t count, std::vector<u64
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+struct FpTables {
+    std::vector<u64x2> tw, itw, ninv, w1ninv;
+    std::vector<FpInfo> info;
+};
+static u64x2 fp_pair(u64 w, u64 q) {  // (W, fl(W/q)) as bit patterns
+    const double wd = (double)w, wi = (double)w / (double)q;
+    return u64x2{as_u64(wd), as_u64(wi)};
+}
+
 static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, std::vector<u64x2> &itw,
-                               std::vector<u64x2> &ninv, std::vector<u64x2> &w1ninv) {
+                               std::vector<u64x2> &ninv, std::vector<u64x2> &w1ninv, FpTables &fp) {
     const u64 q = c.primes[i];
     const size_t n = c.n;
     const u64 psi = h_minimal_primitive_root(2 * n, q);
@@ -157,6 +166,18 @@ static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, s
     ninv[i] = u64x2{ni, h_shoup(ni, q)};
     const u64 w1 = h_mulmod(it[1].x, ni, q);  // what the reference stores in itwiddle[1] (ntt.cu:53-55)
     w1ninv[i] = u64x2{w1, h_shoup(w1, q)};
+    // FP64 tables (q < 2^50 only; see pha_arith.h)
+    const bool ok = (q >> 50) == 0;
+    fp.info[i] = FpInfo{(double)q, 1.0 / (double)q, ok ? 1u : 0u, 0u};
+    if (ok) {
+        u64x2 *tf = fp.tw.data() + (size_t)i * n, *itf = fp.itw.data() + (size_t)i * n;
+        for (size_t k = 0; k < n; k++) {
+            tf[k] = fp_pair(t[k].x, q);
+            itf[k] = fp_pair(it[k].x, q);
+        }
+        fp.ninv[i] = fp_pair(ni, q);
+        fp.w1ninv[i] = fp_pair(w1, q);
+    }
 }
 
 static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uint32_t size_qp, uint32_t size_p,
@@ -188,6 +209,12 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
         c.mods[i] = h_modulus(q);
     }
     std::vector<u64x2> tw((size_t)size_qp * c.n), itw((size_t)size_qp * c.n), ninv(size_qp), w1ninv(size_qp);
+    FpTables fp;
+    fp.tw.assign((size_t)size_qp * c.n, u64x2{0, 0});
+    fp.itw.assign((size_t)size_qp * c.n, u64x2{0, 0});
+    fp.ninv.assign(size_qp, u64x2{0, 0});
+    fp.w1ninv.assign(size_qp, u64x2{0, 0});
+    fp.info.resize(size_qp);
     {
         const unsigned nthreads = std::max(1u, std::min(std::thread::hardware_concurrency(), size_qp));
         std::vector<std::thread> pool;
@@ -195,7 +222,7 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
         for (unsigned t = 0; t < nthreads; t++)
             pool.emplace_back([&, t] {
                 try {
-                    for (uint32_t i = t; i < size_qp; i += nthreads) build_prime_tables(c, i, tw, itw, ninv, w1ninv);
+                    for (uint32_t i = t; i < size_qp; i += nthreads) build_prime_tables(c, i, tw, itw, ninv, w1ninv, fp);
                 } catch (const std::exception &e) { errs[t] = e.what(); }
             });
         for (auto &th : pool) th.join();
@@ -207,6 +234,11 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
     c.d_itw.upload(itw);
     c.d_ninv.upload(ninv);
     c.d_w1ninv.upload(w1ninv);
+    c.d_twf.upload(fp.tw);
+    c.d_itwf.upload(fp.itw);
+    c.d_ninvf.upload(fp.ninv);
+    c.d_w1ninvf.upload(fp.w1ninv);
+    c.d_fpinfo.upload(fp.info);
 }
 
 // q-hat_i^-1 mod q_i and q-hat_i mod p_j for an (ibase -> obase) converter: src/host/rns.cu:282-337,438-457

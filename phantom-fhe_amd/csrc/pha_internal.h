@@ -64,6 +64,12 @@ struct DevBuf {
     }
 };
 
+// per-prime constants of the FP64 NTT path
+struct FpInfo {
+    double q, qinv;
+    uint32_t ok, pad;
+};
+
 // ---- fast base converter constants (DBaseConverter, include/rns_bconv.cuh:3-87) --------------
 // Device-resident description of one converter (uploaded once per Tool); a launch indexes an array
 // of these with blockIdx.z (one per mod-up digit) or uses the same one for every z (mod-down polys).
@@ -127,6 +133,10 @@ struct Context {
     DevBuf<u64x2> d_itw;      // [size_qp][n] inverse (psi^-brev(k), Shoup), slot 1 NOT folded
     DevBuf<u64x2> d_ninv;     // [size_qp] (N^-1, Shoup)
     DevBuf<u64x2> d_w1ninv;   // [size_qp] (itw[1] * N^-1, Shoup)
+    // FP64 path for primes below 2^50: the same tables as (W, W/q) doubles (bit patterns), rows of the
+    // other primes are zero; d_fpinfo[prime] = (q, 1/q, usable flag)
+    DevBuf<u64x2> d_twf, d_itwf, d_ninvf, d_w1ninvf;
+    DevBuf<FpInfo> d_fpinfo;
     // host copies kept for pha_context_download_twiddle and tool construction
     std::mutex mu;
     std::map<uint32_t, std::unique_ptr<Tool>> tools;

@@ -13,7 +13,7 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier, bit 3 = integer butterflies for every prime (FP64 path off)
 std::atomic<int> g_ntt_variant{1};  // default: 8 coefficients per thread, per-round twiddle loads (best at 45 limbs, r01b)
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
@@ -29,6 +29,9 @@ struct NttKArgs {
     const DModulus *mod;     // [prime]
     const u64x2 *ninv;       // [prime]
     const u64x2 *w1ninv;     // [prime]
+    const u64x2 *twf;        // FP64 path: table base [prime][n] of (W, W/q) doubles (forward or inverse)
+    const u64x2 *ninvf, *w1ninvf;
+    const FpInfo *fpinfo;    // [prime]; null = FP64 path off
     const u64 *scale;        // [limb] or null
     const u64 *scale_shoup;  // [limb] or null
     const u64 *aux;          // fuse_moddown: cx base
@@ -56,6 +59,19 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
     if (!FWD && FOLD) {
         a.ninv = k.ninv[prime];
         a.w1ninv = k.w1ninv[prime];
+    }
+    a.fp = false;
+    if (k.fpinfo) {  // primes below 2^50 take the FP64 butterflies (uniform per workgroup)
+        const FpInfo fi = k.fpinfo[prime];
+        if (fi.ok) {
+            a.fp = true;
+            a.fpm = FpMod{fi.q, fi.qinv};
+            a.tw = k.twf + (size_t)prime * n;
+            if (!FWD && FOLD) {
+                a.ninv = k.ninvf[prime];
+                a.w1ninv = k.w1ninvf[prime];
+            }
+        }
     }
     if (EPI == EPI_INV_SCALE || EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) {
         a.scale.x = k.scale[twr];
@@ -173,7 +189,7 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     const size_t lds_bytes = (size_t)C::LDS_WORDS * sizeof(u64);
     const unsigned tiles_per_limb = (unsigned)(n / kTileElems);
     const unsigned total = k.active * tiles_per_limb;
-    if (g_ntt_variant.load(std::memory_order_relaxed) >= 2 && total > (unsigned)g_num_cus && k.batch == 1) {
+    if ((g_ntt_variant.load(std::memory_order_relaxed) & 2) && total > (unsigned)g_num_cus && k.batch == 1) {
         // persistent grid: k workgroups per CU, each owning >= ~3 consecutive work items
         const unsigned per_cu = (total + g_num_cus - 1) / g_num_cus;
         unsigned wg_per_cu = per_cu / 3;
@@ -238,6 +254,11 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.mod = c.d_mod.p;
     k.ninv = c.d_ninv.p;
     k.w1ninv = c.d_w1ninv.p;
+    const bool use_fp = !(g_ntt_variant.load(std::memory_order_relaxed) & 8);
+    k.twf = fwd ? c.d_twf.p : c.d_itwf.p;
+    k.ninvf = c.d_ninvf.p;
+    k.w1ninvf = c.d_w1ninvf.p;
+    k.fpinfo = use_fp ? c.d_fpinfo.p : nullptr;
     k.scale = x.scale;
     k.scale_shoup = x.scale_shoup;
     k.aux = x.aux;
@@ -435,7 +456,7 @@ int pha_exp_read_stamps(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 7) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 15) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

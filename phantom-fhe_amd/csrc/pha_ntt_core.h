@@ -84,6 +84,10 @@ struct PassArgs {
     // epilogue operands
     u64x2 scale;       // EPI_INV_SCALE: per-limb scale ; EPI_FWD_MODDOWN: PInv mod q
     const u64 *aux;    // EPI_FWD_MODDOWN: cx limb base
+    // FP64 path (q < 2^50): tw / ninv / w1ninv then hold (W, W/q) doubles; registers, LDS and the
+    // inter-pass buffer carry doubles; global inputs and outputs stay canonical integers
+    bool fp;
+    FpMod fpm;
 };
 
 template <class C>
@@ -131,6 +135,46 @@ PHA_HD void ct_round(u64 *v, const u64x2 *t, u64 q4, u64 nq) {
             if (k & dist) continue;
             const int kk = k >> (R - j);
             ct_bfly4(v[k], v[k + dist], t[(1 << j) - 1 + kk], q4, nq);
+        }
+    }
+}
+
+// FP64 forms of the two rounds (same twiddle order; t[i].x = W, t[i].y = W/q as doubles)
+template <int R>
+PHA_HD void fp_ct_round(u64 *v, const u64x2 *t, FpMod m) {
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int dist = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+            if (k & dist) continue;
+            const u64x2 w = t[(1 << j) - 1 + (k >> (R - j))];
+            double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
+            fp_ct_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+            v[k] = as_u64(X);
+            v[k + dist] = as_u64(Y);
+        }
+    }
+}
+template <int R, bool FOLD>
+PHA_HD void fp_gs_round(u64 *v, const u64x2 *t, FpMod m, u64x2 ninv, u64x2 w1ninv) {
+#pragma unroll
+    for (int j = R - 1; j >= 0; j--) {
+        const int dist = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+            if (k & dist) continue;
+            double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
+            if (FOLD && j == 0) {
+                const double s = X + Y, d = X - Y;
+                X = fp_mulmod(s, as_f64(ninv.x), as_f64(ninv.y), m);
+                Y = fp_mulmod(d, as_f64(w1ninv.x), as_f64(w1ninv.y), m);
+            } else {
+                const u64x2 w = t[(1 << j) - 1 + (k >> (R - j))];
+                fp_gs_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+            }
+            v[k] = as_u64(X);
+            v[k + dist] = as_u64(Y);
         }
     }
 }
@@ -233,6 +277,16 @@ template <class C, int RI, bool FWD, bool FOLD>
 PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twreg) {
     constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r;
     const u64 q4 = a.q << 2, nq = 0 - a.q;
+    if (a.fp) {  // uniform per workgroup
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) {
+            u64 *rg = reg + gi * K;
+            const u64x2 *t = twreg + C::tw_off(RI) + gi * (K - 1);
+            if (FWD) fp_ct_round<r>(rg, t, a.fpm);
+            else fp_gs_round<r, FOLD>(rg, t, a.fpm, a.ninv, a.w1ninv);
+        }
+        return;
+    }
 #pragma unroll
     for (int gi = 0; gi < G; gi++) {
         u64 *rg = reg + gi * K;
@@ -285,6 +339,23 @@ template <class C, bool FWD, int EPI, bool FOLD, bool HOIST = true>
 struct PassProgram {
     static constexpr int NSEG = C::NR;
     static constexpr int THREADS = C::THREADS;
+    // the transform's first pass is the strided one going forward and the contiguous one going backward
+    static constexpr bool FIRST_PASS = FWD ? C::STRIDED : !C::STRIDED;
+
+    // FP64 path: what just came from global memory becomes a small double.  First pass: canonical
+    // integers -> doubles; second pass: the lazy doubles of the first pass are centred again.
+    PHA_HD static void fp_after_global_load(const PassArgs &a, u64 *reg) {
+        if (!a.fp) return;
+#pragma unroll
+        for (int i = 0; i < C::EPT; i++)
+            reg[i] = as_u64(FIRST_PASS ? fp_from_canon(reg[i]) : fp_reduce(as_f64(reg[i]), a.fpm));
+    }
+    // FP64 path, last pass: doubles -> canonical integers (the integer epilogue then sees [0,q))
+    PHA_HD static void fp_before_global_store(const PassArgs &a, u64 *reg) {
+        if (!a.fp || FIRST_PASS) return;
+#pragma unroll
+        for (int i = 0; i < C::EPT; i++) reg[i] = fp_to_canon(as_f64(reg[i]), a.fpm);
+    }
 
     // all twiddle loads of the pass (issued before the first barrier)
     // HOIST: every round's twiddles are requested before the first barrier (one exposed memory latency per
@@ -302,7 +373,9 @@ struct PassProgram {
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
         if (!HOIST) round_load_tw<C, RI>(a, tid, twreg);
         round_load<C, RI, first>(a, lds, tid, reg);
+        if (first) fp_after_global_load(a, reg);
         round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
+        if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
     }
 
@@ -318,7 +391,9 @@ struct PassProgram {
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
         if (!HOIST) round_load_tw<C, RI>(a, tid, twreg);
         if (!first) round_load<C, RI, false>(a, lds, tid, reg);
+        if (first) fp_after_global_load(a, reg);
         round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
+        if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
     }
 };

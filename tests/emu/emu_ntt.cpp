@@ -38,12 +38,13 @@ static void run_pass(PassArgs a, size_t n) {
 
 template <int LOGN, int VARIANT>
 static void emu(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *tw, u64x2 ninv, u64x2 w1ninv,
-                u64x2 scale, const u64 *aux) {
+                u64x2 scale, const u64 *aux, bool fp) {
     using P1 = typename NttPlan<LOGN, VARIANT>::P1;
     using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     const size_t n = (size_t)1 << LOGN;
     PassArgs a{};
     a.tw = tw; a.q = q; a.rho0 = P1::T; a.stride = P2::T; a.ninv = ninv; a.w1ninv = w1ninv; a.scale = scale; a.aux = aux;
+    a.fp = fp; a.fpm = FpMod{(double)q, 1.0 / (double)q};
     if (fwd) {
         a.in = in; a.out = out;
         run_pass<P1, true, EPI_NONE, false>(a, n);
@@ -59,6 +60,7 @@ static void emu(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *
     }
 }
 
+// bit 16 of log_n_and_variant: FP64 path (tw / ninv / w1ninv then carry (W, W/q) double bit patterns)
 extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *in, uint64_t *out, uint64_t q,
                        const uint64_t *tw_interleaved, const uint64_t *ninv, const uint64_t *w1ninv,
                        const uint64_t *scale, const uint64_t *aux) {
@@ -67,8 +69,9 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
     const u64 *i = reinterpret_cast<const u64 *>(in);
     u64 *o = reinterpret_cast<u64 *>(out);
     const u64 *ax = reinterpret_cast<const u64 *>(aux);
-    const int log_n = log_n_and_variant & 0xff, variant = log_n_and_variant >> 8;
-#define EMU_CASE(N) case N: if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax); break;
+    const int log_n = log_n_and_variant & 0xff, variant = (log_n_and_variant >> 8) & 0xff;
+    const bool fp = (log_n_and_variant >> 16) & 1;
+#define EMU_CASE(N) case N: if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;
     switch (log_n) {
         EMU_CASE(12)
         EMU_CASE(13)

@@ -33,7 +33,7 @@ def pair(v, q):
 
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
-@pytest.mark.parametrize("bits", [50, 60, 61])
+@pytest.mark.parametrize("bits", [40, 50, 60, 61])
 @pytest.mark.parametrize("variant", [0, 1])
 def test_thread_program_matches_oracle(emu, log_n, bits, variant):
     n = 1 << log_n
@@ -62,6 +62,24 @@ def test_thread_program_matches_oracle(emu, log_n, bits, variant):
     back = np.zeros(n, dtype=np.uint64)
     assert emu.emu_ntt(code, 0, 3, p(ref), p(back), q, p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q)), p(z), p(z)) == 0
     assert np.array_equal(back, x)
+    if bits <= 50:
+        # FP64 path (primes below 2^50): tables of (W, W/q) doubles; results must stay bit-identical
+        def fpairs(w):
+            wd = w.astype(np.float64)
+            return np.ascontiguousarray(np.stack([wd.view(np.uint64), (wd / float(q)).view(np.uint64)], axis=1).reshape(-1))
+        def fpair1(v):
+            d = np.array([float(v), float(v) / float(q)], dtype=np.float64)
+            return d.view(np.uint64).copy()
+        fcode = code | (1 << 16)
+        out_f = np.zeros(n, dtype=np.uint64)
+        assert emu.emu_ntt(fcode, 1, 1, p(x), p(out_f), q, p(fpairs(tw)), p(z), p(z), p(z), p(z)) == 0
+        assert np.array_equal(out_f, ref)
+        back_f = np.zeros(n, dtype=np.uint64)
+        assert emu.emu_ntt(fcode, 0, 3, p(ref), p(back_f), q, p(fpairs(itw_p)), p(fpair1(ni)), p(fpair1(int(itw[1]))), p(z), p(z)) == 0
+        assert np.array_equal(back_f, x)
+        s2 = int(r.integers(1, q))
+        assert emu.emu_ntt(fcode, 0, 4, p(ref), p(back_f), q, p(fpairs(itw_p)), p(fpair1(ni)), p(fpair1(int(itw[1]))), p(pair(s2, q)), p(z)) == 0
+        assert np.array_equal(back_f, c.multiply_scalar(x.reshape(1, n), np.array([s2], dtype=np.uint64), 1)[0])
     if log_n in (12, 16):
         # inverse with fused scale (EPI_INV_SCALE) and forward with fused mod-down epilogue (EPI_FWD_MODDOWN)
         s = int(r.integers(1, q))
