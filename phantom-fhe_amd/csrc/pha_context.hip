@@ -266,11 +266,14 @@ static void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, c
             mat[(size_t)j * b.isz + i] = h;
         }
     }
-    std::vector<uint32_t> mat30(mat.size() * 2);
-    for (size_t k = 0; k < mat.size(); k++) {
-        mat30[2 * k] = (uint32_t)(mat[k] & 0x3fffffffu);
-        mat30[2 * k + 1] = (uint32_t)(mat[k] >> 30);
-    }
+    std::vector<uint32_t> mat30((size_t)b.osz * kBcRowPad * 2, 0u);
+    if (b.isz <= (uint32_t)kBcRowPad)
+        for (uint32_t j = 0; j < b.osz; j++)
+            for (uint32_t i = 0; i < b.isz; i++) {
+                const u64 m = mat[(size_t)j * b.isz + i];
+                mat30[((size_t)j * kBcRowPad + i) * 2] = (uint32_t)(m & 0x3fffffffu);
+                mat30[((size_t)j * kBcRowPad + i) * 2 + 1] = (uint32_t)(m >> 30);
+            }
     b.hat_inv.upload(hat_inv);
     b.mat.upload(mat);
     b.mat30.upload(mat30);

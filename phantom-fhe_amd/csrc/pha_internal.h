@@ -64,6 +64,8 @@ struct DevBuf {
     }
 };
 
+constexpr int kBcRowPad = 16;  // row pitch (entries) of the split base-conversion matrix
+
 // per-prime constants of the FP64 NTT path
 struct FpInfo {
     double q, qinv;
@@ -78,7 +80,7 @@ struct BConvDev {
     const uint32_t *iprime;      // [isz] rows of the QP table
     const uint32_t *oprime;      // [osz]
     const u64 *mat;              // [osz][isz] qhat_i mod p_j
-    const uint32_t *mat30;       // [osz][isz][2] the same, split into 30-bit halves (m & (2^30-1), m >> 30)
+    const uint32_t *mat30;       // [osz][kBcRowPad][2] the same, split into 30-bit halves, rows zero-padded
     uint32_t isz, osz;
     uint32_t pad_start, pad_len; // output j goes to limb j + (j >= pad_start ? pad_len : 0)
     uint32_t src_limb;           // first input limb inside the source polynomial
@@ -91,7 +93,7 @@ struct BConv {
     std::vector<uint32_t> iprime, oprime;  // indices into the QP table
     DevBuf<u64x2> hat_inv;                 // [isz]  qhat_i^-1 mod q_i (+Shoup)
     DevBuf<u64> mat;                       // [osz][isz]  qhat_i mod p_j
-    DevBuf<uint32_t> mat30;                // [osz][isz][2] 30-bit halves of mat
+    DevBuf<uint32_t> mat30;                // [osz][kBcRowPad][2] 30-bit halves of mat, zero-padded rows
     DevBuf<uint32_t> d_iprime, d_oprime;
 };
 

@@ -202,6 +202,21 @@ PHA_HD void gs_round(u64 *v, const u64x2 *t, u64 q4, u64 nq, u64x2 ninv, u64x2 w
     }
 }
 
+// value-only form: aux / accumulate operands are passed in (so the caller can fetch them with 16-byte loads)
+template <int EPI>
+PHA_HD u64 apply_epilogue_v(u64 x, const PassArgs &a, u64 aux, u64 acc) {
+    const u64 q = a.q;
+    if (EPI == EPI_FWD_CANON) return csub(csub(csub(x, q << 2), q << 1), q);
+    if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) {
+        const u64 t = csub(csub(csub(x, q << 2), q << 1), q);
+        const u64 r = shoup(sub_mod(aux, t, q), a.scale, q);
+        return EPI == EPI_FWD_MODDOWN_ADD ? add_mod(acc, r, q) : r;
+    }
+    if (EPI == EPI_INV_CANON) return csub(csub(x, q << 1), q);
+    if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);
+    return x;
+}
+
 template <int EPI>
 PHA_HD u64 apply_epilogue(u64 x, const PassArgs &a, size_t gi) {
     // forward values arrive in [0,8q), inverse values in [0,4q) (lazy ranges of ct_bfly4 / gs_bfly4)
@@ -313,9 +328,13 @@ PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
                 u64x2 *p = reinterpret_cast<u64x2 *>(a.out + g0);
 #pragma unroll
                 for (int k = 0; k < K; k += 2) {
+                    u64x2 aux{0, 0}, acc{0, 0};
+                    if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD)
+                        aux = reinterpret_cast<const u64x2 *>(a.aux + g0)[k >> 1];
+                    if (EPI == EPI_FWD_MODDOWN_ADD) acc = p[k >> 1];
                     u64x2 t;
-                    t.x = apply_epilogue<EPI>(rg[k], a, g0 + k);
-                    t.y = apply_epilogue<EPI>(rg[k + 1], a, g0 + k + 1);
+                    t.x = apply_epilogue_v<EPI>(rg[k], a, aux.x, acc.x);
+                    t.y = apply_epilogue_v<EPI>(rg[k + 1], a, aux.y, acc.y);
                     p[k >> 1] = t;
                 }
             } else {

@@ -73,18 +73,18 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         const DModulus m = L.mod[d.oprime[j]];
         u64 lo, hi;
         if (SPLIT) {
-            const uint32_t *row = d.mat30 + (size_t)j * isz * 2;
+            // rows are zero-padded to kBcRowPad entries, and y[i] = 0 beyond isz: no per-term branch
+            const uint32_t *row = d.mat30 + (size_t)j * kBcRowPad * 2;
             u64 ll = 0, lh = 0, hl = 0, hh = 0;
 #pragma unroll
-            for (int i = 0; i < ISZ_PAD; i++)
-                if (i < (int)isz) {
-                    const u32 y0 = ylo[i], y1 = yhi[i];
-                    const u32 m0 = row[2 * i], m1 = row[2 * i + 1];
-                    ll = (u64)y0 * m0 + ll;
-                    lh = (u64)y0 * m1 + lh;
-                    hl = (u64)y1 * m0 + hl;
-                    hh = (u64)y1 * m1 + hh;
-                }
+            for (int i = 0; i < ISZ_PAD; i++) {
+                const u32 y0 = ylo[i], y1 = yhi[i];
+                const u32 m0 = row[2 * i], m1 = row[2 * i + 1];
+                ll = (u64)y0 * m0 + ll;
+                lh = (u64)y0 * m1 + lh;
+                hl = (u64)y1 * m0 + hl;
+                hh = (u64)y1 * m1 + hh;
+            }
             // value = ll + (lh + hl) * 2^30 + hh * 2^60   (mid < 2^65: keep its carry)
             const u64 mid = lh + hl;
             const u64 mid_c = mid < lh ? 1 : 0;
