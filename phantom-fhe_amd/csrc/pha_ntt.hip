@@ -13,8 +13,8 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier, bit 3 = integer butterflies for every prime (FP64 path off)
-std::atomic<int> g_ntt_variant{1};  // default: 8 coefficients per thread, per-round twiddle loads (best at 45 limbs, r01b)
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier, bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles
+std::atomic<int> g_ntt_variant{1 | 32};  // default: 8 coefficients per thread, per-round twiddle loads (best at 45 limbs, r01b)
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
 #endif
@@ -294,14 +294,18 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     if (sel.count == 0) return;
     check_sel(c, sel);
     NttKArgs k = make_args(c, in, mid, out, sel, x, true);
-    const int v = g_ntt_variant.load(std::memory_order_relaxed) & 1;
+    const int vv = g_ntt_variant.load(std::memory_order_relaxed);
+    // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
+    // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
+    const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
+    const int v = ((vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024)) ? 2 : (vv & 1);
     switch (c.log_n) {
-        case 12: if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
-        case 13: if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
-        case 14: if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
-        case 15: if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
-        case 16: if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
-        case 17: if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
+        case 12: if (v == 2) forward_impl<12, 2>(k, epi, s); else if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
+        case 13: if (v == 2) forward_impl<13, 2>(k, epi, s); else if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
+        case 14: if (v == 2) forward_impl<14, 2>(k, epi, s); else if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
+        case 15: if (v == 2) forward_impl<15, 2>(k, epi, s); else if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
+        case 16: if (v == 2) forward_impl<16, 2>(k, epi, s); else if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
+        case 17: if (v == 2) forward_impl<17, 2>(k, epi, s); else if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -311,14 +315,18 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     if (sel.count == 0) return;
     check_sel(c, sel);
     NttKArgs k = make_args(c, in, mid, out, sel, x, false);
-    const int v = g_ntt_variant.load(std::memory_order_relaxed) & 1;
+    const int vv = g_ntt_variant.load(std::memory_order_relaxed);
+    // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
+    // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
+    const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
+    const int v = ((vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024)) ? 2 : (vv & 1);
     switch (c.log_n) {
-        case 12: if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
-        case 13: if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
-        case 14: if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
-        case 15: if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
-        case 16: if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
-        case 17: if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
+        case 12: if (v == 2) inverse_impl<12, 2>(k, epi, s); else if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
+        case 13: if (v == 2) inverse_impl<13, 2>(k, epi, s); else if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
+        case 14: if (v == 2) inverse_impl<14, 2>(k, epi, s); else if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
+        case 15: if (v == 2) inverse_impl<15, 2>(k, epi, s); else if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
+        case 16: if (v == 2) inverse_impl<16, 2>(k, epi, s); else if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
+        case 17: if (v == 2) inverse_impl<17, 2>(k, epi, s); else if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -456,7 +464,7 @@ int pha_exp_read_stamps(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 15) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 63) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

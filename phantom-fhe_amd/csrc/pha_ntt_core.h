@@ -41,9 +41,16 @@ enum Epilogue {
 // Round schedule of one pass: LOGT stages split into NR rounds of R0,R1,R2 stages (forward order).
 // EPT_ = coefficients per thread (16: 256-thread workgroups, radix-16 rounds; 8: 512-thread
 // workgroups, radix-8 rounds, twice the wavefronts per tile).
-template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16>
+// OT_ (contiguous pass only): the twiddles of the pass's LAST round (the 2-3 finest stages, which hold
+// 75-88 % of the table bytes) are not streamed from their own table rows but formed on the fly from
+//     tw[(T1 + r) * 2^s + i] = tw[(T1 + r) * 2^s] * tw[i]   (mod q)
+// i.e. one per-row factor and one entry of the first T2/2 table slots shared by every row; the
+// butterfly multiplies by the two factors in turn.  Costs one extra modular multiply per butterfly in
+// that round, removes most of the twiddle traffic of the memory-bound contiguous pass.
+template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16, bool OT_ = false>
 struct PassCfg {
     static constexpr int EPT = EPT_;
+    static constexpr bool OT = OT_ && !STRIDED_;
     static constexpr int THREADS = kTileElems / EPT_;
     static_assert((1 << R0_) <= EPT_ && (1 << R1_) <= EPT_ && (1 << R2_) <= EPT_, "radix exceeds registers");
     static constexpr int LOGT = LOGT_;
@@ -56,7 +63,11 @@ struct PassCfg {
     static_assert(LOGT_ >= 4 && LOGT_ <= 12, "tile transform length out of range");
     static constexpr int r(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : R2_; }
     // twiddle registers per thread: round i holds G_i groups x (2^r_i - 1) pairs
-    static constexpr int tw_count(int i) { return r(i) ? (EPT_ >> r(i)) * ((1 << r(i)) - 1) : 0; }
+    static constexpr bool ot_round(int i) { return OT && i == NR - 1; }
+    // on-the-fly round: (2^r - 1) shared factors + r per-row factors for each of the G groups
+    static constexpr int tw_count(int i) {
+        return !r(i) ? 0 : ot_round(i) ? ((1 << r(i)) - 1) + (EPT_ >> r(i)) * r(i) : (EPT_ >> r(i)) * ((1 << r(i)) - 1);
+    }
     static constexpr int tw_off(int i) { return i == 0 ? 0 : i == 1 ? tw_count(0) : tw_count(0) + tw_count(1); }
     static constexpr int TW_TOTAL = tw_count(0) + tw_count(1) + tw_count(2);
     static constexpr int s0(int i) { return i == 0 ? 0 : i == 1 ? R0_ : R0_ + R1_; }
@@ -135,6 +146,59 @@ PHA_HD void ct_round(u64 *v, const u64x2 *t, u64 q4, u64 nq) {
             if (k & dist) continue;
             const int kk = k >> (R - j);
             ct_bfly4(v[k], v[k + dist], t[(1 << j) - 1 + kk], q4, nq);
+        }
+    }
+}
+
+// On-the-fly forms: tc = shared factors in heap order (stage j, sub-group kk -> tc[(1<<j)-1+kk]),
+// tr[j] = the row factor of stage j.  Y is multiplied by tr[j], then by tc[...].
+template <int R, bool FWD>
+PHA_HD void ot_round_int(u64 *v, const u64x2 *tc, const u64x2 *tr, u64 q4, u64 nq) {
+#pragma unroll
+    for (int jj = 0; jj < R; jj++) {
+        const int j = FWD ? jj : R - 1 - jj;
+        const int dist = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+            if (k & dist) continue;
+            const u64x2 wc = tc[(1 << j) - 1 + (k >> (R - j))], wr = tr[j];
+            u64 &X = v[k], &Y = v[k + dist];
+            if (FWD) {
+                const u64 x = csub(X, q4);
+                const u64 t = shoup_lazy4(shoup_lazy4(Y, wr, nq), wc, nq);
+                X = x + t;
+                Y = x + q4 - t;
+            } else {
+                const u64 s = X + Y, d = X + q4 - Y;
+                X = csub(s, q4);
+                Y = shoup_lazy4(shoup_lazy4(d, wr, nq), wc, nq);
+            }
+        }
+    }
+}
+template <int R, bool FWD>
+PHA_HD void ot_round_fp(u64 *v, const u64x2 *tc, const u64x2 *tr, FpMod m) {
+#pragma unroll
+    for (int jj = 0; jj < R; jj++) {
+        const int j = FWD ? jj : R - 1 - jj;
+        const int dist = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+            if (k & dist) continue;
+            const u64x2 wc = tc[(1 << j) - 1 + (k >> (R - j))], wr = tr[j];
+            double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
+            if (FWD) {
+                const double t = fp_mulmod(fp_mulmod(Y, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
+                const double x = X;
+                X = x + t;
+                Y = x - t;
+            } else {
+                const double s = X + Y, d = X - Y;
+                X = fp_reduce(s, m);
+                Y = fp_mulmod(fp_mulmod(d, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
+            }
+            v[k] = as_u64(X);
+            v[k + dist] = as_u64(Y);
         }
     }
 }
@@ -272,6 +336,23 @@ PHA_HD void round_load(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
 template <class C, int RI>
 PHA_HD void round_load_tw(const PassArgs &a, int tid, u64x2 *twreg) {
     constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r, s0 = C::s0(RI);
+    if (C::ot_round(RI)) {
+        // shared factors tw[(hi << j) + kk] (hi is the same for every group of a thread: THREADS is a
+        // multiple of 2^s0), then per group the row factors tw[rho << (s0 + j)]
+        static_assert(!C::ot_round(RI) || (C::THREADS % (1 << s0)) == 0, "groups of a thread must share hi");
+        u64x2 *base = twreg + C::tw_off(RI);
+        int v, hi, lo;
+        decode_group<C, RI>(tid, v, hi, lo);
+        load_group_twiddles<r>(base, a.tw, (u32)hi);
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) {
+            decode_group<C, RI>(tid + C::THREADS * gi, v, hi, lo);
+            const u32 rho = a.rho0 + a.tile * C::V + (u32)v;
+#pragma unroll
+            for (int j = 0; j < r; j++) base[(K - 1) + gi * r + j] = a.tw[rho << (s0 + j)];
+        }
+        return;
+    }
 #pragma unroll
     for (int gi = 0; gi < G; gi++) {
         int v, hi, lo;
@@ -292,6 +373,17 @@ template <class C, int RI, bool FWD, bool FOLD>
 PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twreg) {
     constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r;
     const u64 q4 = a.q << 2, nq = 0 - a.q;
+    if (C::ot_round(RI)) {
+        const u64x2 *tc = twreg + C::tw_off(RI);
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) {
+            u64 *rg = reg + gi * K;
+            const u64x2 *tr = tc + (K - 1) + gi * r;
+            if (a.fp) ot_round_fp<r, FWD>(rg, tc, tr, a.fpm);
+            else ot_round_int<r, FWD>(rg, tc, tr, q4, nq);
+        }
+        return;
+    }
     if (a.fp) {  // uniform per workgroup
 #pragma unroll
         for (int gi = 0; gi < G; gi++) {
@@ -420,6 +512,7 @@ struct PassProgram {
 // Split N = T1 * T2 per log2 N, with the round schedules of each pass.
 // VARIANT 0: 16 coefficients per thread (radix-16 rounds, one LDS exchange per pass).
 // VARIANT 1: 8 coefficients per thread (radix-8 rounds, two exchanges, 2x the wavefronts).
+// VARIANT 2: variant 1 with on-the-fly twiddles in the contiguous pass (see PassCfg::OT).
 template <int LOGN, int VARIANT> struct NttPlan;
 template <> struct NttPlan<12, 0> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<6, false, 3, 3>; };
 template <> struct NttPlan<13, 0> { using P1 = PassCfg<6, true, 3, 3>;  using P2 = PassCfg<7, false, 4, 3>; };
@@ -433,5 +526,12 @@ template <> struct NttPlan<14, 1> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  us
 template <> struct NttPlan<15, 1> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8>; };
 template <> struct NttPlan<16, 1> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8>; };
 template <> struct NttPlan<17, 1> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8>; };
+// VARIANT 2: variant 1 + on-the-fly twiddles in the last round of the contiguous pass
+template <> struct NttPlan<12, 2> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<6, false, 3, 3, 0, 8, true>; };
+template <> struct NttPlan<13, 2> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8, true>; };
+template <> struct NttPlan<14, 2> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8, true>; };
+template <> struct NttPlan<15, 2> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true>; };
+template <> struct NttPlan<16, 2> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true>; };
+template <> struct NttPlan<17, 2> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, true>; };
 
 }  // namespace pha

@@ -50,6 +50,19 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)d.src_limb * n;
     u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
     const uint32_t isz = d.isz;
+    const uint32_t j0 = blockIdx.y * kBcOutPerBlock;
+    const uint32_t j1 = min(j0 + kBcOutPerBlock, d.osz);
+    // SPLIT: this block's kBcOutPerBlock matrix rows (8 x 16 x 2 dwords = one dword per thread) go through
+    // LDS once; the MAC loop then reads them as broadcast ds_read_b64 instead of stalling on scalar loads
+    __shared__ uint2 s_rows[kBcOutPerBlock * kBcRowPad];
+    if (SPLIT) {
+        static_assert(kBcOutPerBlock * kBcRowPad * 2 == kBcThreads, "one dword per thread");
+        const size_t base = (size_t)j0 * kBcRowPad * 2 + threadIdx.x;
+        const uint32_t limit = d.osz * kBcRowPad * 2;
+        reinterpret_cast<uint32_t *>(s_rows)[threadIdx.x] = base < limit ? d.mat30[base] : 0u;
+        __syncthreads();
+    }
+    if (j0 >= d.osz) return;  // (after the barrier) nothing to produce for this group
     u64 y[ISZ_PAD];
     u32 ylo[ISZ_PAD], yhi[ISZ_PAD];  // SPLIT: 30-bit halves, cut once per input
 #pragma unroll
@@ -67,19 +80,18 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         for (uint32_t i = 0; i < isz; i++)
             dst[(size_t)(d.src_limb + i) * n + coeff] = L.own[(size_t)(d.src_limb + i) * n + coeff];
     }
-    const uint32_t j0 = blockIdx.y * kBcOutPerBlock;
-    const uint32_t j1 = min(j0 + kBcOutPerBlock, d.osz);
     for (uint32_t j = j0; j < j1; j++) {
         const DModulus m = L.mod[d.oprime[j]];
         u64 lo, hi;
         if (SPLIT) {
             // rows are zero-padded to kBcRowPad entries, and y[i] = 0 beyond isz: no per-term branch
-            const uint32_t *row = d.mat30 + (size_t)j * kBcRowPad * 2;
+            const uint2 *row = s_rows + (j - j0) * kBcRowPad;
             u64 ll = 0, lh = 0, hl = 0, hh = 0;
 #pragma unroll
             for (int i = 0; i < ISZ_PAD; i++) {
                 const u32 y0 = ylo[i], y1 = yhi[i];
-                const u32 m0 = row[2 * i], m1 = row[2 * i + 1];
+                const uint2 mm = row[i];
+                const u32 m0 = mm.x, m1 = mm.y;
                 ll = (u64)y0 * m0 + ll;
                 lh = (u64)y0 * m1 + lh;
                 hl = (u64)y1 * m0 + hl;
@@ -312,7 +324,9 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
     } else {
         // own limbs are copied verbatim by the same kernel (modup_copy_partQl_kernel :522-528);
         // BFV still needs the q-hat^-1 scaling (bconv_mult_kernel :603-607), ckks/bgv got it in the iNTT
-        launch_bconv(c, t.d_digit_convs.p, 1, t.beta, alpha, qlp, t.split_ok, dst, (size_t)qlp * n,
+        uint32_t max_osz = 0;
+        for (const BConv &b : t.digit) max_osz = b.osz > max_osz ? b.osz : max_osz;
+        launch_bconv(c, t.d_digit_convs.p, 1, t.beta, alpha, max_osz, t.split_ok, dst, (size_t)qlp * n,
                      ntt_dom ? t_cks : cks, 0, cks, !ntt_dom, s);
     }
     LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);

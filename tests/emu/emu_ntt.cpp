@@ -71,7 +71,7 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
     const u64 *ax = reinterpret_cast<const u64 *>(aux);
     const int log_n = log_n_and_variant & 0xff, variant = (log_n_and_variant >> 8) & 0xff;
     const bool fp = (log_n_and_variant >> 16) & 1;
-#define EMU_CASE(N) case N: if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;
+#define EMU_CASE(N) case N: if (variant == 2) emu<N, 2>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;
     switch (log_n) {
         EMU_CASE(12)
         EMU_CASE(13)

@@ -9,7 +9,7 @@ log_n, primes, size_p = primes_of("c3_ckks16")
 n = 1 << log_n
 ctx = P.PhantomContext(log_n, list(primes), size_p, device=0)
 x = P.to_device(np.stack([uniform_poly(rng_for(1), primes[:45], n) for _ in range(4)]), "cuda:0")
-for variant in (1, 9):
+for variant in (1, 17):
     P.set_tuning(0, variant)
     for limbs, batch in [(1, 1), (4, 1), (16, 1), (45, 1), (45, 2), (45, 4)]:
         for _ in range(12):
