@@ -13,10 +13,11 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier, bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier, bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = twiddle loads one round ahead
 std::atomic<int> g_ntt_variant{1 | 32};  // default: 8 coefficients per thread, per-round twiddle loads (best at 45 limbs, r01b)
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_wg_times[2048];
 #endif
 int g_num_cus = 256;
 extern std::atomic<int> g_bconv_split;  // pha_rns.hip
@@ -80,7 +81,7 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
     a.aux = (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) ? k.aux + (size_t)twr * n : nullptr;
 }
 
-template <class C, bool FWD, int EPI, bool FOLD, bool HOIST>
+template <class C, bool FWD, int EPI, bool FOLD, int HOIST>
 __global__ __launch_bounds__(C::THREADS) void ntt_pass_kernel(const NttKArgs k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *lds = reinterpret_cast<u64 *>(smem);
@@ -110,6 +111,9 @@ __global__ __launch_bounds__(C::THREADS) void ntt_pass_kernel(const NttKArgs k) 
 #else
 #define PHA_STAMP(i) do { } while (0)
 #endif
+#if defined(PHA_EXP_STAMPS)
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     PHA_STAMP(0);
     Prog::load_twiddles(a, tid, twreg);
     Prog::template run<0>(a, lds, tid, reg, twreg);
@@ -127,6 +131,10 @@ __global__ __launch_bounds__(C::THREADS) void ntt_pass_kernel(const NttKArgs k) 
 #if defined(PHA_EXP_STAMPS)
     __builtin_amdgcn_s_waitcnt(0);
     PHA_STAMP(6);
+    if (tid == 0) {  // wall-clock (100 MHz) start/end of every workgroup of the last launch
+        const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+        if (id < 1024) { g_wg_times[2 * id] = wg_t0; g_wg_times[2 * id + 1] = wall_clock64(); }
+    }
 #endif
 }
 
@@ -198,10 +206,13 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
         hipLaunchKernelGGL((ntt_pass_pipelined_kernel<C, FWD, EPI, FOLD>), grid, dim3(C::THREADS), lds_bytes, s, k);
     } else {
         dim3 grid(tiles_per_limb, k.sel.count, k.batch);
-        if (g_ntt_variant.load(std::memory_order_relaxed) & 4)
-            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, true>), grid, dim3(C::THREADS), lds_bytes, s, k);
+        const int hv = g_ntt_variant.load(std::memory_order_relaxed);
+        if (hv & 4)
+            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 1>), grid, dim3(C::THREADS), lds_bytes, s, k);
+        else if (hv & 64)
+            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 2>), grid, dim3(C::THREADS), lds_bytes, s, k);
         else
-            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, false>), grid, dim3(C::THREADS), lds_bytes, s, k);
+            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, k);
     }
     check_launch();
 }
@@ -459,12 +470,15 @@ int pha_nwt_2d_radix8_backward_inplace_batched(pha_context_t ctx, uint64_t *inou
 int pha_exp_read_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
 }
+int pha_exp_read_wg_times(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), sizeof(unsigned long long) * 2048);
+}
 #endif
 
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 63) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 127) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

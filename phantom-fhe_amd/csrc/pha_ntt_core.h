@@ -270,33 +270,24 @@ PHA_HD void gs_round(u64 *v, const u64x2 *t, u64 q4, u64 nq, u64x2 ninv, u64x2 w
 template <int EPI>
 PHA_HD u64 apply_epilogue_v(u64 x, const PassArgs &a, u64 aux, u64 acc) {
     const u64 q = a.q;
-    if (EPI == EPI_FWD_CANON) return csub(csub(csub(x, q << 2), q << 1), q);
+    // the FP64 path hands over canonical residues already (fp_to_canon); a.fp is uniform per workgroup
+    if (EPI == EPI_FWD_CANON) return a.fp ? x : csub(csub(csub(x, q << 2), q << 1), q);
     if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) {
-        const u64 t = csub(csub(csub(x, q << 2), q << 1), q);
+        const u64 t = a.fp ? x : csub(csub(csub(x, q << 2), q << 1), q);
         const u64 r = shoup(sub_mod(aux, t, q), a.scale, q);
         return EPI == EPI_FWD_MODDOWN_ADD ? add_mod(acc, r, q) : r;
     }
-    if (EPI == EPI_INV_CANON) return csub(csub(x, q << 1), q);
+    if (EPI == EPI_INV_CANON) return a.fp ? x : csub(csub(x, q << 1), q);
     if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);
     return x;
 }
 
 template <int EPI>
 PHA_HD u64 apply_epilogue(u64 x, const PassArgs &a, size_t gi) {
-    // forward values arrive in [0,8q), inverse values in [0,4q) (lazy ranges of ct_bfly4 / gs_bfly4)
-    const u64 q = a.q;
-    if (EPI == EPI_FWD_CANON) return csub(csub(csub(x, q << 2), q << 1), q);
-    if (EPI == EPI_FWD_MODDOWN) {
-        u64 t = csub(csub(csub(x, q << 2), q << 1), q);
-        return shoup(sub_mod(a.aux[gi], t, q), a.scale, q);  // sub_negate_const_mult uintmodmath.cuh:233-241
-    }
-    if (EPI == EPI_FWD_MODDOWN_ADD) {
-        u64 t = csub(csub(csub(x, q << 2), q << 1), q);
-        return add_mod(a.out[gi], shoup(sub_mod(a.aux[gi], t, q), a.scale, q), q);  // + add_to_ct rns_bconv.cu:763-769
-    }
-    if (EPI == EPI_INV_CANON) return csub(csub(x, q << 1), q);
-    if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);
-    return x;
+    u64 aux = 0, acc = 0;
+    if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) aux = a.aux[gi];
+    if (EPI == EPI_FWD_MODDOWN_ADD) acc = a.out[gi];
+    return apply_epilogue_v<EPI>(x, a, aux, acc);
 }
 
 // Load one round's registers: from global memory on the first round, else from LDS.
@@ -446,7 +437,10 @@ PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
 // A pass as a list of barrier-separated segments, one per round (a round reads and writes the same
 // LDS slots, so only the hand-over between rounds needs a barrier).  FWD runs rounds 0..NR-1,
 // inverse NR-1..0.  FOLD (inverse only): this pass holds the transform's last stage (round 0).
-template <class C, bool FWD, int EPI, bool FOLD, bool HOIST = true>
+// HOIST: 0 = every round requests its own twiddles when it starts; 1 = all rounds up front (one exposed
+// memory latency per tile, most registers); 2 = one round ahead (round k+1's twiddles are requested when
+// round k starts, so their latency hides behind round k's butterflies and the barrier).
+template <class C, bool FWD, int EPI, bool FOLD, int HOIST = 1>
 struct PassProgram {
     static constexpr int NSEG = C::NR;
     static constexpr int THREADS = C::THREADS;
@@ -471,18 +465,27 @@ struct PassProgram {
     // all twiddle loads of the pass (issued before the first barrier)
     // HOIST: every round's twiddles are requested before the first barrier (one exposed memory latency per
     // tile, more registers); otherwise each round requests its own when it starts (fewer registers).
+    static constexpr int round_of(int seg) { return FWD ? seg : C::NR - 1 - seg; }
     PHA_HD static void load_twiddles(const PassArgs &a, int tid, u64x2 *twreg) {
-        if (!HOIST) return;
-        round_load_tw<C, 0>(a, tid, twreg);
-        round_load_tw<C, 1>(a, tid, twreg);
-        if (C::NR == 3) round_load_tw<C, 2>(a, tid, twreg);
+        if (HOIST == 1) {
+            round_load_tw<C, 0>(a, tid, twreg);
+            round_load_tw<C, 1>(a, tid, twreg);
+            if (C::NR == 3) round_load_tw<C, 2>(a, tid, twreg);
+        } else if (HOIST == 2) {
+            round_load_tw<C, round_of(0)>(a, tid, twreg);
+        }
+    }
+    template <int SEG>
+    PHA_HD static void segment_twiddles(const PassArgs &a, int tid, u64x2 *twreg) {
+        if (HOIST == 0) round_load_tw<C, round_of(SEG)>(a, tid, twreg);
+        if (HOIST == 2 && SEG + 1 < C::NR) round_load_tw<C, round_of(SEG + 1 < C::NR ? SEG + 1 : SEG)>(a, tid, twreg);
     }
 
     template <int SEG>
     PHA_HD static void run(const PassArgs &a, u64 *lds, int tid, u64 *reg, u64x2 *twreg) {
         constexpr int RI = FWD ? SEG : C::NR - 1 - SEG;
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
-        if (!HOIST) round_load_tw<C, RI>(a, tid, twreg);
+        segment_twiddles<SEG>(a, tid, twreg);
         round_load<C, RI, first>(a, lds, tid, reg);
         if (first) fp_after_global_load(a, reg);
         round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
@@ -500,7 +503,7 @@ struct PassProgram {
     PHA_HD static void run_prefetched(const PassArgs &a, u64 *lds, int tid, u64 *reg, u64x2 *twreg) {
         constexpr int RI = FWD ? SEG : C::NR - 1 - SEG;
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
-        if (!HOIST) round_load_tw<C, RI>(a, tid, twreg);
+        segment_twiddles<SEG>(a, tid, twreg);
         if (!first) round_load<C, RI, false>(a, lds, tid, reg);
         if (first) fp_after_global_load(a, reg);
         round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);

@@ -32,7 +32,7 @@ static void run_pass(PassArgs a, size_t n) {
     const u32 tiles = (u32)(n / kTileElems);
     for (u32 t = 0; t < tiles; t++) {
         a.tile = t;
-        run_segments<PassProgram<C, FWD, EPI, FOLD>, 0>(a, lds.data(), regs);
+        run_segments<PassProgram<C, FWD, EPI, FOLD, 2>, 0>(a, lds.data(), regs);
     }
 }
 
