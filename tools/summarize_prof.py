@@ -12,7 +12,7 @@ def stats(d, out):
             o.write(f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(f)})\n")
             o.write("calls,total_ns,avg_ns,min_ns,max_ns,pct,name\n")
             for r in rows:
-                o.write(f"{r.get('Calls')},{r.get('TotalDurationNs')},{r.get('AverageNs')},{r.get('MinNs')},{r.get('MaxNs')},{r.get('Percentage')},{short(r.get('Name',''))}\n")
+                o.write(f"{r.get('Calls')},{r.get('TotalDurationNs')},{r.get('AverageNs')},{r.get('MinNs')},{r.get('MaxNs')},{r.get('Percentage')},\"{short(r.get('Name',''))}\"\n")
         return True
     return False
 
@@ -25,14 +25,14 @@ def pmc(d, out):
     for f in files:
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                k = (short(r["Kernel_Name"]), r["Counter_Name"])
+                k = (short(r["Kernel_Name"]) + " grid=" + str(int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))), r["Counter_Name"])
                 agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
-                meta[short(r["Kernel_Name"])] = (r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("LDS_Block_Size"), r.get("VGPR_Count"), r.get("SGPR_Count"))
+                meta[k[0]] = (r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("LDS_Block_Size"), r.get("VGPR_Count"), r.get("SGPR_Count"))
     with open(out, "w") as o:
         o.write("# rocprofv3 --pmc per-kernel mean per dispatch\nkernel,grid,wg,lds,vgpr,sgpr,counter,mean,dispatches\n")
         for (k, c), (s, n) in sorted(agg.items()):
             m = meta[k]
-            o.write(f"{k},{m[0]},{m[1]},{m[2]},{m[3]},{m[4]},{c},{s/n:.1f},{n}\n")
+            o.write(f"\"{k}\",{m[0]},{m[1]},{m[2]},{m[3]},{m[4]},{c},{s/n:.1f},{n}\n")
     return True
 
 if __name__ == "__main__":
