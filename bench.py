@@ -78,12 +78,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (1-GPU boxes): PHA_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, to exercise the
+    # multi-rank code path where RCCL cannot be used (it refuses two ranks on one device)
+    share = os.environ.get("PHA_BENCH_SHARE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://")   # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://")   # "nccl" is RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import phantom_fhe_amd as P
     n = 1 << LOG_N
@@ -101,7 +105,13 @@ def main():
             k[0] = uniform_residues(primes, n, dev, gen)
             k[1] = uniform_residues(primes, n, dev, gen)
     from phantom_fhe_amd import dist as pdist
-    pdist.broadcast_keys(evk, src=0)      # one-time RCCL broadcast; no collective on the data path
+    if share and world > 1:               # gloo moves host tensors
+        host = [k.cpu() for k in evk]
+        pdist.broadcast_keys(host, src=0)
+        for k, h in zip(evk, host):
+            k.copy_(h)
+    else:
+        pdist.broadcast_keys(evk, src=0)  # one-time RCCL broadcast; no collective on the data path
     rlk = P.PhantomRelinKey(evk)
 
     # ---- forward NTT: the timed headline ---------------------------------------------------------------
@@ -144,10 +154,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps      # average duration of one forward NTT (2 kernels)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pdist.max_over_ranks(elapsed, device=None if share else dev)
     ntt_per_s = world * args.steps * size_q / elapsed
 
     # ---- HomMul + relinearize + rescale (secondary figure, same parameter set) -------------------------
@@ -175,10 +182,7 @@ def main():
     if world > 1:
         dist.barrier()
     hm_elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([hm_elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        hm_elapsed = float(t.item())
+    hm_elapsed = pdist.max_over_ranks(hm_elapsed, device=None if share else dev)
 
     if rank == 0:
         alg_bytes = 16.0 * n * size_q                  # 8 B read + 8 B write per coefficient
