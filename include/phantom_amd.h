@@ -138,6 +138,12 @@ int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint
 /* phantom::keyswitch_inplace (eval_key_switch.cu:95-182) on raw buffers: ct [2][Ql][N] += KS(c2) */
 int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
                           const uint64_t *const *rlk, int scheme, void *stream);
+/* phantom::hoisting_inplace (include/evaluate.cuh:233-241, src/evaluate.cu:1670-1866) on raw buffers:
+ * ct [2][Ql][N] <- sum over the n_elts Galois elements of rotate(ct).  galois_elts is a HOST array;
+ * glk is a HOST array of n_elts DEVICE pointer tables (PhantomRelinKey::public_keys_ptr() of each
+ * element's key).  One mod-up, one fused gather + inner-product kernel, one pair of mod-downs. */
+int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
+                 const uint64_t *const *const *glk, int scheme, void *stream);
 /* DRNSTool::divide_and_round_q_last_ntt (rns.cu:1160-1184): src [cipher][Ql][N] (last limb is
  * clobbered, as in the reference) -> dst [cipher][Ql-1][N] */
 int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,

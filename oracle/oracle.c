@@ -711,6 +711,44 @@ void orc_apply_galois_coeff(const orc_ctx *c, const u64 *src, u64 *dst, uint32_t
     }
 }
 
+void orc_hoisting(const orc_tool *t, u64 *ct, const uint32_t *elts, size_t n_elts, const u64 *const *const *glk,
+                  int scheme) {
+    /* hoisting_inplace src/evaluate.cu:1670-1866 (mul_tech != hps_overq_leveled): ct <- sum over the
+     * Galois elements of rotate(ct): one mod-up of c1, per element a permutation of c0 and of every
+     * mod-up digit + an inner product with that element's key, one pair of mod-downs at the end. */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp, beta = t->beta;
+    u64 *c0 = (u64 *)malloc(sizeof(u64) * ql * n), *c1 = (u64 *)malloc(sizeof(u64) * ql * n);
+    u64 *acc_c0 = (u64 *)calloc(ql * n, sizeof(u64)), *tmp_c0 = (u64 *)malloc(sizeof(u64) * ql * n);
+    u64 *mu = (u64 *)malloc(sizeof(u64) * beta * qlp * n), *pmu = (u64 *)malloc(sizeof(u64) * beta * qlp * n);
+    u64 *acc_cx = (u64 *)calloc(2 * qlp * n, sizeof(u64)), *tmp_cx = (u64 *)malloc(sizeof(u64) * 2 * qlp * n);
+    uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    memcpy(c0, ct, sizeof(u64) * ql * n);
+    memcpy(c1, ct + ql * n, sizeof(u64) * ql * n);
+    orc_modup(t, mu, c1, scheme);
+    for (size_t e = 0; e < n_elts; e++) {
+        orc_galois_ntt_table(c->log_n, elts[e], table);
+        if (scheme == ORC_BFV) orc_apply_galois_coeff(c, c0, tmp_c0, elts[e], ql, 0);
+        else orc_apply_galois_ntt(c0, tmp_c0, table, n, ql);
+        orc_add_rns_poly(c, acc_c0, tmp_c0, acc_c0, ql, 0);
+        for (size_t b = 0; b < beta; b++) orc_apply_galois_ntt(mu + b * qlp * n, pmu + b * qlp * n, table, n, qlp);
+        orc_key_switch_inner_prod(t, tmp_cx, pmu, glk[e]);
+        for (int p = 0; p < 2; p++)
+            for (size_t j = 0; j < qlp; j++) {
+                const u64 q = c->q[t->qlp_idx[j]];
+                for (size_t k = 0; k < n; k++) {
+                    const size_t id = (size_t)p * qlp * n + j * n + k;
+                    acc_cx[id] = addmod(acc_cx[id], tmp_cx[id], q);
+                }
+            }
+    }
+    orc_moddown_from_ntt(t, acc_cx, acc_cx, scheme);
+    orc_moddown_from_ntt(t, acc_cx + qlp * n, acc_cx + qlp * n, scheme);
+    orc_add_rns_poly(c, acc_c0, acc_cx, ct, ql, 0);
+    memcpy(ct + ql * n, acc_cx + qlp * n, sizeof(u64) * ql * n);
+    free(c0); free(c1); free(acc_c0); free(tmp_c0); free(mu); free(pmu); free(acc_cx); free(tmp_cx); free(table);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * evaluation-key generation (src/secretkey.cu:232-341, polymath.cu:318-338)
  * evk_i = ( -(a_i*s + e_i) + P*new_key on limbs [i*alpha,(i+1)*alpha) , a_i ), all NTT form, over QP

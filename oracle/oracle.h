@@ -97,6 +97,9 @@ void orc_key_switch_inner_prod(const orc_tool *t, uint64_t *cx, const uint64_t *
 void orc_moddown_from_ntt(const orc_tool *t, uint64_t *ct, uint64_t *cx, int scheme);
 /* keyswitch_inplace eval_key_switch.cu:95-182: ct=[2][size_ql][N] += KS(c2) */
 void orc_keyswitch_inplace(const orc_tool *t, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks, int scheme);
+/* hoisting_inplace evaluate.cu:1670-1866: ct=[2][size_ql][N] <- sum_e rotate_e(ct); glk[e][digit] = key [2][size_QP][N] */
+void orc_hoisting(const orc_tool *t, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
+                  const uint64_t *const *const *glk, int scheme);
 /* divide_and_round_q_last_ntt rns.cu:1128-1184: src [cipher][size_ql][N] (clobbered) -> dst [cipher][size_ql-1][N] */
 void orc_rescale_ntt(const orc_tool *t, uint64_t *src, size_t cipher_size, uint64_t *dst);
 /* divide_and_round_q_last rns.cu:1082-1126 (BFV coefficient-domain mod switch) */

@@ -81,6 +81,7 @@ def lib(path=None):
     L.orc_key_switch_inner_prod.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p)]
     L.orc_moddown_from_ntt.argtypes = [C.c_void_p, u64p, u64p, C.c_int]
     L.orc_keyswitch_inplace.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p), C.c_int]
+    L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_divide_and_round_q_last.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_galois_ntt_table.argtypes = [C.c_int, C.c_uint32, u32p]
@@ -309,6 +310,19 @@ class Tool:
         c2 = np.ascontiguousarray(c2, dtype=np.uint64).reshape(-1)
         arr, keep = self._evk_ptrs(evks)
         self.L.orc_keyswitch_inplace(self.h, _p(ct), _p(c2), arr, scheme)
+        return ct.reshape(2, self.size_ql, self.n)
+
+    def hoisting(self, ct, galois_elts, glk, scheme):
+        """glk[e] = list of beta keys ([2][QP][N]) of Galois element e; returns sum_e rotate_e(ct)."""
+        ct = np.array(ct, dtype=np.uint64, copy=True).reshape(-1)
+        elts = np.ascontiguousarray(galois_elts, dtype=np.uint32)
+        keep, tabs = [], []
+        for keys in glk:
+            arr, k = self._evk_ptrs(keys)
+            keep.append(k)
+            tabs.append(arr)
+        outer = (C.POINTER(u64p) * len(tabs))(*[C.cast(a, C.POINTER(u64p)) for a in tabs])
+        self.L.orc_hoisting(self.h, _p(ct), _p32(elts), len(elts), outer, scheme)
         return ct.reshape(2, self.size_ql, self.n)
 
     def rescale_ntt(self, src, cipher_size):

@@ -13,6 +13,7 @@
 //   * mod-down and rescale reuse the forward NTT's fused epilogue (cx - NTT(delta)) * c.
 #include "../../include/phantom_amd.h"
 #include "pha_internal.h"
+#include <algorithm>
 #include <atomic>
 
 #include "pha_ntt_core.h"
@@ -232,6 +233,64 @@ __global__ __launch_bounds__(256) void inner_prod_kernel(const InnerArgs k) {
     u64x2 r1{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
     *reinterpret_cast<u64x2 *>(k.cx + c2_id) = r0;
     *reinterpret_cast<u64x2 *>(k.cx + c2_id + k.qlp_n) = r1;
+}
+
+// ---- hoisted rotations (src/evaluate.cu:1670-1866): for every output coefficient, sum over the Galois
+//      elements e and digits b of  modup_b[perm_e[k]] * key_{e,b}[k].  The reference materialises the
+//      permuted digits and adds per-element inner products; here the permutation is a gather inside ONE
+//      inner-product kernel and the accumulation over elements stays in the 128-bit registers
+//      (n_elts * beta * 2^120 < 2^128 needs n_elts * beta < 256; larger sets are split by the driver). ----
+struct HoistArgs {
+    u64 *cx;                          // [2][QlP][N]
+    const u64 *t_mod_up;              // [beta][QlP][N]
+    const u64 *const *const *keys;    // device array [n_elts] of device arrays [beta] of keys [2][QP][N]
+    const uint32_t *const *tables;    // device array [n_elts] of NTT-domain permutation tables
+    const DModulus *mod;
+    const uint32_t *qlp_prime;
+    uint32_t n, beta, n_elts, accumulate;  // accumulate: add to what cx already holds (split calls)
+    size_t qlp_n, qp_n;
+};
+__global__ __launch_bounds__(256) void hoist_inner_prod_kernel(const HoistArgs k) {
+    const uint32_t nid = blockIdx.y;
+    const uint32_t twr = k.qlp_prime[nid];
+    const DModulus m = k.mod[twr];
+    const size_t coeff = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t out_id = (size_t)nid * k.n + coeff;
+    const size_t evk_id = (size_t)twr * k.n + coeff;
+    u64 a0l = 0, a0h = 0, a1l = 0, a1h = 0, b0l = 0, b0h = 0, b1l = 0, b1h = 0;
+    if (k.accumulate) {
+        const u64x2 p0 = *reinterpret_cast<const u64x2 *>(k.cx + out_id);
+        const u64x2 p1 = *reinterpret_cast<const u64x2 *>(k.cx + out_id + k.qlp_n);
+        a0l = p0.x; a1l = p0.y; b0l = p1.x; b1l = p1.y;
+    }
+    for (uint32_t e = 0; e < k.n_elts; e++) {
+        const uint2 idx = *reinterpret_cast<const uint2 *>(k.tables[e] + coeff);
+        const u64 *const *keys = k.keys[e];
+        for (uint32_t i = 0; i < k.beta; i++) {
+            const u64 *digit = k.t_mod_up + (size_t)i * k.qlp_n + (size_t)nid * k.n;
+            const u64 v0 = digit[idx.x], v1 = digit[idx.y];
+            const u64 *key = keys[i];
+            const u64x2 kb = *reinterpret_cast<const u64x2 *>(key + evk_id);
+            const u64x2 ka = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+            mac128(v0, kb.x, a0l, a0h);
+            mac128(v1, kb.y, a1l, a1h);
+            mac128(v0, ka.x, b0l, b0h);
+            mac128(v1, ka.y, b1l, b1h);
+        }
+    }
+    *reinterpret_cast<u64x2 *>(k.cx + out_id) = u64x2{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
+    *reinterpret_cast<u64x2 *>(k.cx + out_id + k.qlp_n) = u64x2{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
+}
+
+// dst[limb][k] = sum_e src[limb][perm_e[k]] mod q  (c0 part of hoisting for ckks / bgv)
+__global__ __launch_bounds__(256) void hoist_c0_kernel(u64 *dst, const u64 *src, const uint32_t *const *tables,
+                                                       uint32_t n_elts, const DModulus *mod, uint32_t n) {
+    const uint32_t limb = blockIdx.y;
+    const u64 q = mod[limb].value;
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    u64 acc = 0;
+    for (uint32_t e = 0; e < n_elts; e++) acc = add_mod(acc, src[(size_t)limb * n + tables[e][coeff]], q);
+    dst[(size_t)limb * n + coeff] = acc;
 }
 
 // ---- (cx - delta) * c element-wise: moddown_kernel rns_bconv.cu:680-689 and
@@ -476,6 +535,66 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     inner_prod(c, t, cx, t_mod_up, rlk, s);
     // both polynomials at once; ct += moddown(cx) with the add fused into the NTT epilogue
     moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2, scheme, true, tmp, s);
+    PHA_API_END
+}
+
+int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
+                 const uint64_t *const *const *glk, int scheme, void *stream) {
+    PHA_API_BEGIN
+    need(ct); need(galois_elts); need(glk);
+    if (n_elts == 0) throw std::invalid_argument("steps must not be empty");
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    Tool &t = c.tool((uint32_t)size_Ql);
+    hipStream_t s = as_stream(stream);
+    const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
+    const bool ntt_dom = ntt_domain_scheme(scheme);
+    // per-element device tables: permutation tables and key pointer tables
+    std::vector<const uint32_t *> h_tabs(n_elts);
+    for (size_t e = 0; e < n_elts; e++) {
+        if (!glk[e]) throw std::logic_error("Galois key not present in hoisting");
+        h_tabs[e] = c.galois_table(galois_elts[e]);
+    }
+    // scratch: c0 copy [Ql][N] | tmp / delta [2][Ql][N] | mod-up [beta][QlP][N] | acc_cx [2][QlP][N] | pointer tables
+    const size_t ptr_words = 2 * n_elts;
+    u64 *base = c.scratch(stream, 3 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n + ptr_words);
+    u64 *c0 = base, *tmp = c0 + ql_n, *t_mod_up = tmp + 2 * ql_n, *acc_cx = t_mod_up + (size_t)t.beta * qlp_n;
+    u64 *d_ptrs = acc_cx + 2 * qlp_n;
+    PHA_HIP(hipMemcpyAsync(d_ptrs, h_tabs.data(), n_elts * sizeof(void *), hipMemcpyHostToDevice, s));
+    PHA_HIP(hipMemcpyAsync(d_ptrs + n_elts, glk, n_elts * sizeof(void *), hipMemcpyHostToDevice, s));
+    const uint32_t *const *d_tabs = reinterpret_cast<const uint32_t *const *>(d_ptrs);
+    const u64 *const *const *d_keys = reinterpret_cast<const u64 *const *const *>(d_ptrs + n_elts);
+
+    PHA_HIP(hipMemcpyAsync(c0, ct, ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    // one mod-up of c1 shared by every rotation (evaluate.cu:1758-1760)
+    modup(c, t, t_mod_up, ct + ql_n, scheme, tmp, s);
+    // all rotations' inner products in one kernel (128-bit headroom: at most 255 terms per call)
+    const size_t per_call = std::max<size_t>(1, 255 / t.beta);
+    for (size_t e0 = 0; e0 < n_elts; e0 += per_call) {
+        HoistArgs k{};
+        k.cx = acc_cx; k.t_mod_up = t_mod_up; k.keys = d_keys + e0; k.tables = d_tabs + e0; k.mod = c.d_mod.p;
+        k.qlp_prime = t.d_qlp_prime.p; k.n = (uint32_t)n; k.beta = t.beta;
+        k.n_elts = (uint32_t)std::min(per_call, n_elts - e0); k.accumulate = e0 ? 1 : 0;
+        k.qlp_n = qlp_n; k.qp_n = (size_t)c.size_qp * n;
+        hipLaunchKernelGGL(hoist_inner_prod_kernel, dim3((unsigned)(n / 512), t.size_qlp), dim3(256), 0, s, k);
+        check_launch();
+    }
+    // ct0 <- sum_e galois_e(c0) ; ct1 <- 0 ; then both += moddown(acc_cx) (fused into the NTT epilogue)
+    if (ntt_dom) {
+        hipLaunchKernelGGL(hoist_c0_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql), dim3(256), 0, s, ct, c0,
+                           d_tabs, (uint32_t)n_elts, c.d_mod.p, (uint32_t)n);
+        check_launch();
+    } else {
+        PHA_HIP(hipMemsetAsync(ct, 0, ql_n * sizeof(u64), s));
+        for (size_t e = 0; e < n_elts; e++) {  // coefficient-domain automorphism (src/galois.cu:20-39)
+            hipLaunchKernelGGL(galois_coeff_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql), dim3(256), 0, s,
+                               tmp, c0, c.d_mod.p, 0u, galois_elts[e], (uint32_t)n);
+            check_launch();
+            launch_add(c, ct, tmp, ct, size_Ql, 0, s);
+        }
+    }
+    PHA_HIP(hipMemsetAsync(ct + ql_n, 0, ql_n * sizeof(u64), s));
+    moddown_from_ntt(c, t, ct, ql_n, acc_cx, qlp_n, 2, scheme, true, tmp, s);
     PHA_API_END
 }
 

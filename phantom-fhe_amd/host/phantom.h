@@ -5,7 +5,7 @@
 // keeps those names, members, argument meaning, pre-condition checks and exception types for everything
 // that sits on the RNS hot path, so code written against the reference's evaluate.* API compiles against
 // it for: negate / add / sub / multiply (CKKS, BGV tensor) / relinearize / multiply_and_relin /
-// rescale_to_next / mod_switch_to_next (drop) / apply_galois / rotate / keyswitch_inplace.
+// rescale_to_next / mod_switch_to_next (drop) / apply_galois / rotate / hoisting / keyswitch_inplace.
 // Out of scope here exactly as in SURVEY.md section 8: key generation, encryption, decryption, encoders,
 // BFV BEHZ/HPS multiply (those callers are not on the accelerated path yet and throw).
 //
@@ -559,6 +559,24 @@ inline void rotate_inplace(const PhantomContext &context, PhantomCiphertext &enc
     for (int t : naf_step)
         if (static_cast<size_t>(std::abs(t)) != (coeff_count >> 1)) rotate_inplace(context, encrypted, t, galois_key);
 }
+
+// hoisting_inplace (src/evaluate.cu:1670-1866): ct <- sum over `steps` of rotate(ct, step) with ONE shared mod-up
+inline void hoisting_inplace(const PhantomContext &context, PhantomCiphertext &ct, const PhantomGaloisKey &glk,
+                             const std::vector<int> &steps) {
+    if (ct.size() > 2) throw std::invalid_argument("ciphertext size must be 2");
+    const auto &key_parms = context.get_context_data(0).parms();
+    const std::vector<uint32_t> elts = util::get_elts_from_steps(steps, key_parms.poly_modulus_degree());
+    const auto &have = glk.galois_elts();
+    std::vector<const uint64_t *const *> tables;
+    for (uint32_t e : elts) {
+        const auto it = std::find(have.begin(), have.end(), e);
+        if (it == have.end()) throw std::logic_error("Galois key not present in hoisting");
+        tables.push_back(glk.get_relin_keys(static_cast<size_t>(it - have.begin())).public_keys_ptr());
+    }
+    util::check_pha(pha_hoisting(context.amd(), detail::level_size_Ql(context, ct), ct.data(), elts.data(), elts.size(),
+                                 tables.data(), static_cast<int>(key_parms.scheme()), cudaStreamPerThread));
+}
+inline PhantomCiphertext hoisting(const PhantomContext &c, const PhantomCiphertext &e, const PhantomGaloisKey &k, const std::vector<int> &steps) { PhantomCiphertext d = e; hoisting_inplace(c, d, k, steps); return d; }
 
 // out-of-place forms (include/evaluate.cuh): copy, then the in-place op
 inline PhantomCiphertext negate(const PhantomContext &c, const PhantomCiphertext &e) { PhantomCiphertext d = e; negate_inplace(c, d); return d; }

@@ -200,6 +200,13 @@ class PhantomContext:
         _lib.check(self._L.pha_keyswitch_inplace(self._h, size_Ql, _ptr(ct), _ptr(c2), _ptr(rlk_ptrs),
                                                  int(scheme), _stream()))
 
+    def hoisting(self, size_Ql, ct, galois_elts, galois_keys, scheme):
+        """hoisting_inplace (src/evaluate.cu:1670-1866): ct <- sum_e rotate_e(ct); galois_keys[e] is the
+        PhantomRelinKey of Galois element galois_elts[e]."""
+        elts = (C.c_uint32 * len(galois_elts))(*[int(e) for e in galois_elts])
+        tabs = (C.c_void_p * len(galois_keys))(*[k.public_keys_ptr.data_ptr() for k in galois_keys])
+        _lib.check(self._L.pha_hoisting(self._h, size_Ql, _ptr(ct), elts, len(galois_elts), tabs, int(scheme), _stream()))
+
     def divide_and_round_q_last_ntt(self, size_Ql, src, cipher_size, dst):
         _lib.check(self._L.pha_divide_and_round_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
                                                            _stream()))

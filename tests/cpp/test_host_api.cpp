@@ -153,6 +153,35 @@ int main() {
         REQUIRE(throws_invalid([&] { apply_galois_inplace(context, rot, 25, glk); }));
     }
 
+    // hoisted rotations: sum of rotate(ct, 1) and rotate(ct, 2) with one mod-up (evaluate.cu:1670-1866)
+    {
+        std::vector<std::vector<uint64_t>> glk2_host;
+        PhantomRelinKey glk2;
+        make_key(glk2_host, glk2);
+        const uint32_t elt2 = util::get_elt_from_step(2, n);
+        PhantomGaloisKey both;
+        PhantomRelinKey glk1_again;
+        {
+            std::vector<uint64_t> flat;
+            for (auto &k : glk_host) flat.insert(flat.end(), k.begin(), k.end());
+            glk1_again.load_from_host(context, flat.data(), dnum);
+        }
+        both.add(elt1, std::move(glk1_again));
+        both.add(elt2, std::move(glk2));
+        PhantomCiphertext h = hoisting(context, ct1, both, {1, 2});
+        std::vector<const uint64_t *> g2_ptrs;
+        for (auto &k : glk2_host) g2_ptrs.push_back(k.data());
+        const uint64_t *const *tabs[2] = {glk_ptrs.data(), g2_ptrs.data()};
+        const uint32_t elts[2] = {elt1, elt2};
+        std::vector<uint64_t> ref = h1, got(2 * ln);
+        orc_hoisting(tool, ref.data(), elts, 2, tabs, ORC_CKKS);
+        h.store_to_host(got.data());
+        REQUIRE(got == ref);
+        bool threw = false;
+        try { hoisting_inplace(context, h, both, {3}); } catch (const std::logic_error &) { threw = true; }
+        REQUIRE(threw);  // "Galois key not present in hoisting" is a logic_error in the reference
+    }
+
     // pre-condition checks of the reference
     REQUIRE(throws_invalid([&] { relinearize_inplace(context, ct1, rlk); }));            // size must be 3
     {

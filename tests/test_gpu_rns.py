@@ -162,6 +162,27 @@ def test_galois(gpu):
         ctx.apply_galois_ntt(dx, out, 4, L)
 
 
+@pytest.mark.parametrize("name,scheme,ql,elts", [("hyb12_a2", O.CKKS, 6, [5, 25, 125]), ("hyb12_a2", O.CKKS, 3, [5]),
+                                                 ("hyb12_a2", O.BFV, 6, [5, 8191]), ("c1_bfv4096", O.CKKS, 2, [5, 25]),
+                                                 ("c3_ckks16", O.CKKS, 45, [5, 25, 125, 625])])
+def test_hoisting(name, scheme, ql, elts, gpu):
+    """hoisting_inplace (src/evaluate.cu:1670-1866): ct <- sum_e rotate_e(ct) with one shared mod-up."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(70)
+    glk = [_keys(oc, r, primes, n, size_q, size_p) for _ in elts]
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    d_ct = P.to_device(ct, gpu)
+    keys = [P.PhantomRelinKey.from_numpy(k, gpu) for k in glk]
+    ctx.hoisting(ql, d_ct, elts, keys, scheme)
+    ref = tool.hoisting(ct, elts, [[k[i] for i in range(tool.beta)] for k in glk], scheme)
+    assert np.array_equal(P.to_host(d_ct), ref)
+
+
 def test_hommul_relin_rescale_c3(gpu):
     """CKKS HomMul + relinearize + rescale at N=2^16, 45 limbs, stage by stage."""
     import phantom_fhe_amd as P
