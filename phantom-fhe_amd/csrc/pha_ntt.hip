@@ -13,7 +13,7 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 1 = pipelined persistent grid, bit 2 = hoist all twiddle loads before the first barrier, bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = twiddle loads one round ahead
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles
 std::atomic<int> g_ntt_variant{1 | 32};  // default: 8 coefficients per thread, per-round twiddle loads (best at 45 limbs, r01b)
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
@@ -138,82 +138,17 @@ __global__ __launch_bounds__(C::THREADS) void ntt_pass_kernel(const NttKArgs k) 
 #endif
 }
 
-// Software-pipelined persistent form: a workgroup owns a contiguous range of (limb, tile) work items
-// and issues the global loads of item i+1 before it computes item i, so HBM traffic and VALU work
-// overlap even when the whole problem is a single residency wave (45 limbs = 720 tiles on 256 CUs).
-template <class C, bool FWD, int EPI, bool FOLD>
-__global__ __launch_bounds__(C::THREADS) void ntt_pass_pipelined_kernel(const NttKArgs k) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *lds = reinterpret_cast<u64 *>(smem);
-    using Prog = PassProgram<C, FWD, EPI, FOLD>;
-    const int tid = threadIdx.x;
-    const uint32_t log_tpl = k.log_n - 12;  // tiles per limb = N / 4096
-    const uint32_t total = k.active << log_tpl;
-    const uint32_t t_begin = (uint32_t)(((uint64_t)total * blockIdx.x) / gridDim.x);
-    const uint32_t t_end = (uint32_t)(((uint64_t)total * (blockIdx.x + 1)) / gridDim.x);
-    if (t_begin >= t_end) return;
-    const uint32_t excl_len = k.sel.excl_end - k.sel.excl_start;
-
-    auto args_of = [&](uint32_t item, PassArgs &a) {
-        uint32_t twr = k.sel.start + (item >> log_tpl);
-        if (excl_len && twr >= k.sel.excl_start) twr += excl_len;  // jump over the excluded digit
-        tile_args<FWD, EPI, FOLD>(k, twr, item & ((1u << log_tpl) - 1), a);
-    };
-    u64x2 twreg[C::TW_TOTAL];
-    auto process = [&](const PassArgs &a, u64 *reg) {
-        Prog::load_twiddles(a, tid, twreg);
-        Prog::template run_prefetched<0>(a, lds, tid, reg, twreg);
-        __syncthreads();
-        Prog::template run_prefetched<1>(a, lds, tid, reg, twreg);
-        if constexpr (Prog::NSEG == 3) {
-            __syncthreads();
-            Prog::template run_prefetched<2>(a, lds, tid, reg, twreg);
-        }
-        __syncthreads();  // LDS is reused by the next item
-    };
-
-    PassArgs a0, a1;
-    u64 r0[C::EPT], r1[C::EPT];
-    args_of(t_begin, a0);
-    Prog::prefetch(a0, tid, r0);
-    for (uint32_t t = t_begin; t < t_end; t += 2) {
-        if (t + 1 < t_end) {
-            args_of(t + 1, a1);
-            Prog::prefetch(a1, tid, r1);
-        }
-        process(a0, r0);
-        if (t + 1 >= t_end) break;
-        if (t + 2 < t_end) {
-            args_of(t + 2, a0);
-            Prog::prefetch(a0, tid, r0);
-        }
-        process(a1, r1);
-    }
-}
-
 template <class C, bool FWD, int EPI, bool FOLD>
 static void launch_pass(const NttKArgs &k, hipStream_t s) {
     const size_t n = (size_t)1 << k.log_n;
     const size_t lds_bytes = (size_t)C::LDS_WORDS * sizeof(u64);
     const unsigned tiles_per_limb = (unsigned)(n / kTileElems);
     const unsigned total = k.active * tiles_per_limb;
-    if ((g_ntt_variant.load(std::memory_order_relaxed) & 2) && total > (unsigned)g_num_cus && k.batch == 1) {
-        // persistent grid: k workgroups per CU, each owning >= ~3 consecutive work items
-        const unsigned per_cu = (total + g_num_cus - 1) / g_num_cus;
-        unsigned wg_per_cu = per_cu / 3;
-        wg_per_cu = wg_per_cu < 1 ? 1 : (wg_per_cu > 4 ? 4 : wg_per_cu);
-        dim3 grid(g_num_cus * wg_per_cu);
-        hipLaunchKernelGGL((ntt_pass_pipelined_kernel<C, FWD, EPI, FOLD>), grid, dim3(C::THREADS), lds_bytes, s, k);
-    } else {
-        dim3 grid(tiles_per_limb, k.sel.count, k.batch);
-        const int hv = g_ntt_variant.load(std::memory_order_relaxed);
-        if (hv & 4)
-            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 1>), grid, dim3(C::THREADS), lds_bytes, s, k);
-        else if (hv & 64)
-            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 2>), grid, dim3(C::THREADS), lds_bytes, s, k);
-        else
-            hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, k);
-    }
+    // (a persistent software-pipelined form and twiddle-prefetch policies were measured and dropped:
+    //  DESIGN.md section 7)
+    dim3 grid(tiles_per_limb, k.sel.count, k.batch);
+    (void)total;
+    hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, k);
     check_launch();
 }
 
@@ -478,7 +413,7 @@ int pha_exp_read_wg_times(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 127) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 63 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

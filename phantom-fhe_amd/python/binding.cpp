@@ -1,0 +1,98 @@
+// binding.cpp -- pybind11 module `pyPhantom` over the C++ host mirror (host/phantom.h).
+//
+// Mirrors the names of the reference's python/src/binding.cu:8-166 for everything that is on the
+// accelerated path: enums scheme_type / mul_tech_type, classes modulus, params, context, ciphertext,
+// relin_key, galois_key, and the functions create_coeff_modulus, get_elt_from_step(s), negate, add, sub,
+// multiply, multiply_and_relin, relinearize, rescale_to_next, mod_switch_to_next, apply_galois, rotate,
+// hoisting.  Like the reference, every function returns by value.  Key generation, encryption,
+// decryption and the encoders are out of scope, so ciphertexts and keys enter as
+// numpy uint64 arrays (`ciphertext.load`, `relin_key.load`) and leave with `ciphertext.to_numpy()`.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <phantom.h>
+
+namespace py = pybind11;
+using namespace phantom;
+using namespace phantom::arith;
+using u64_array = py::array_t<uint64_t, py::array::c_style | py::array::forcecast>;
+
+PYBIND11_MODULE(pyPhantom, m) {
+    m.doc() = "MI355X-native PhantomFHE hot path (libphantom_amd.so) -- reference-compatible surface";
+
+    py::enum_<scheme_type>(m, "scheme_type")
+        .value("none", scheme_type::none).value("bfv", scheme_type::bfv)
+        .value("ckks", scheme_type::ckks).value("bgv", scheme_type::bgv);
+    py::enum_<mul_tech_type>(m, "mul_tech_type")
+        .value("none", mul_tech_type::none).value("behz", mul_tech_type::behz).value("hps", mul_tech_type::hps)
+        .value("hps_overq", mul_tech_type::hps_overq).value("hps_overq_leveled", mul_tech_type::hps_overq_leveled);
+
+    py::class_<Modulus>(m, "modulus").def(py::init<uint64_t>()).def("value", &Modulus::value).def("bit_count", &Modulus::bit_count);
+    m.def("create_coeff_modulus", &CoeffModulus::Create);
+    m.def("get_elt_from_step", &util::get_elt_from_step);
+    m.def("get_elts_from_steps", &util::get_elts_from_steps);
+
+    py::class_<EncryptionParameters>(m, "params")
+        .def(py::init<scheme_type>())
+        .def("set_mul_tech", &EncryptionParameters::set_mul_tech)
+        .def("set_poly_modulus_degree", &EncryptionParameters::set_poly_modulus_degree)
+        .def("set_special_modulus_size", &EncryptionParameters::set_special_modulus_size)
+        .def("set_galois_elts", &EncryptionParameters::set_galois_elts)
+        .def("set_coeff_modulus", &EncryptionParameters::set_coeff_modulus)
+        .def("set_plain_modulus", &EncryptionParameters::set_plain_modulus);
+
+    py::class_<PhantomContext>(m, "context")
+        .def(py::init<const EncryptionParameters &>())
+        .def("total_parm_size", &PhantomContext::total_parm_size)
+        .def("get_first_index", &PhantomContext::get_first_index)
+        .def("coeff_modulus_size", [](const PhantomContext &c, size_t chain_index) {
+            return c.get_context_data(chain_index).parms().coeff_modulus().size();
+        });
+
+    py::class_<PhantomCiphertext>(m, "ciphertext")
+        .def(py::init<>())
+        .def("set_scale", &PhantomCiphertext::set_scale)
+        .def("scale", &PhantomCiphertext::scale)
+        .def("size", &PhantomCiphertext::size)
+        .def("chain_index", &PhantomCiphertext::chain_index)
+        .def("coeff_modulus_size", &PhantomCiphertext::coeff_modulus_size)
+        .def("set_ntt_form", &PhantomCiphertext::set_ntt_form)
+        .def("is_ntt_form", &PhantomCiphertext::is_ntt_form)
+        .def("load", [](PhantomCiphertext &ct, const PhantomContext &c, size_t chain_index, u64_array data) {
+            if (data.ndim() != 3) throw std::invalid_argument("expected [poly][limb][coeff]");
+            ct.load_from_host(c, chain_index, static_cast<size_t>(data.shape(0)), data.data());
+            (void)hipStreamSynchronize(cudaStreamPerThread);
+        })
+        .def("to_numpy", [](const PhantomCiphertext &ct) {
+            u64_array out({ct.size(), ct.coeff_modulus_size(), ct.poly_modulus_degree()});
+            ct.store_to_host(out.mutable_data());
+            return out;
+        });
+
+    py::class_<PhantomRelinKey>(m, "relin_key")
+        .def(py::init<>())
+        .def("load", [](PhantomRelinKey &k, const PhantomContext &c, u64_array evk) {
+            if (evk.ndim() != 4) throw std::invalid_argument("expected [dnum][2][QP][N]");
+            k.load_from_host(c, evk.data(), static_cast<size_t>(evk.shape(0)));
+        });
+    py::class_<PhantomGaloisKey>(m, "galois_key")
+        .def(py::init<>())
+        .def("load", [](PhantomGaloisKey &g, const PhantomContext &c, uint32_t galois_elt, u64_array evk) {
+            PhantomRelinKey k;
+            k.load_from_host(c, evk.data(), static_cast<size_t>(evk.shape(0)));
+            g.add(galois_elt, std::move(k));
+        });
+
+    m.def("negate", &negate);
+    m.def("add", &add);
+    m.def("sub", &sub, py::arg(), py::arg(), py::arg(), py::arg("negate") = false);
+    m.def("multiply", &multiply);
+    m.def("multiply_and_relin", &multiply_and_relin);
+    m.def("relinearize", &relinearize);
+    m.def("rescale_to_next", &rescale_to_next);
+    m.def("mod_switch_to_next", &mod_switch_to_next);
+    m.def("apply_galois", &apply_galois);
+    m.def("rotate", &rotate);
+    m.def("hoisting", &hoisting);
+}

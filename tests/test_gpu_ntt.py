@@ -39,7 +39,7 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
     assert np.array_equal(P.to_host(d2), oc.nwt_backward(x, L, 0))
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 5, 8, 9, 17, 25, 97], ids=["ept16", "ept8", "ept16-pipelined", "ept8-pipelined", "ept8-hoisted", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-ahead"])
+@pytest.fixture(params=[0, 1, 8, 9, 17, 25], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int"])
 def ntt_variant(request):
     """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
     import phantom_fhe_amd as P

@@ -1,0 +1,69 @@
+"""pyPhantom (pybind11 over host/phantom.h): the reference's Python names for the hot path
+(python/src/binding.cu:8-166 subset), checked against the oracle like python/examples/ckks.py's flow
+(multiply_and_relin, rescale_to_next, rotate, hoisting) but with synthetic ciphertexts and keys."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import oracle_ctx, primes_of, rng_for, uniform_poly
+
+
+def test_module_surface():
+    from phantom_fhe_amd import pyPhantom as ph
+    for name in ("scheme_type", "mul_tech_type", "modulus", "params", "context", "ciphertext", "relin_key",
+                 "galois_key", "create_coeff_modulus", "get_elt_from_step", "get_elts_from_steps", "negate", "add",
+                 "sub", "multiply", "multiply_and_relin", "relinearize", "rescale_to_next", "mod_switch_to_next",
+                 "apply_galois", "rotate", "hoisting"):
+        assert hasattr(ph, name), name
+    assert ph.get_elt_from_step(1, 4096) == 5 and ph.get_elt_from_step(0, 4096) == 8191
+    mods = ph.create_coeff_modulus(1 << 14, [60] + [40] * 6 + [60])
+    assert mods[0].value() == 1152921504606683137          # SURVEY.md 8(c) known answer
+
+
+@pytest.mark.gpu
+def test_ckks_flow(gpu):
+    from phantom_fhe_amd import pyPhantom as ph
+    name = "hyb12_a2"
+    log_n, primes, size_p = primes_of(name)
+    n, size_q = 1 << log_n, len(primes) - size_p
+    parms = ph.params(ph.scheme_type.ckks)
+    parms.set_poly_modulus_degree(n)
+    parms.set_special_modulus_size(size_p)
+    parms.set_coeff_modulus(ph.create_coeff_modulus(n, [60, 40, 40, 40, 40, 40, 60, 60]))
+    ctx = ph.context(parms)
+    assert ctx.total_parm_size() == 1 + size_q and ctx.coeff_modulus_size(1) == size_q
+    oc = oracle_ctx(name)
+    tool = O.Tool(oc, size_q)
+    r = rng_for(90)
+    dnum = size_q // size_p
+
+    def keys():
+        return np.stack([np.stack([uniform_poly(r, primes, n), uniform_poly(r, primes, n)]) for _ in range(dnum)])
+
+    evk, g1, g2 = keys(), keys(), keys()
+    rlk = ph.relin_key(); rlk.load(ctx, evk)
+    e1, e2 = ph.get_elt_from_step(1, n), ph.get_elt_from_step(2, n)
+    glk = ph.galois_key(); glk.load(ctx, e1, g1); glk.load(ctx, e2, g2)
+    h1 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    h2 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    a, b = ph.ciphertext(), ph.ciphertext()
+    a.load(ctx, 1, h1); b.load(ctx, 1, h2)
+    a.set_scale(2.0 ** 40); b.set_scale(2.0 ** 40)
+    assert np.array_equal(ph.add(ctx, a, b).to_numpy(), np.stack([oc.add(h1[i], h2[i], size_q) for i in range(2)]))
+    prod = ph.multiply_and_relin(ctx, a, b, rlk)
+    t3 = oc.tensor_prod_2x2(h1, h2, size_q)
+    ref = tool.keyswitch_inplace(t3[:2], t3[2], [evk[i] for i in range(tool.beta)], O.CKKS)
+    assert np.array_equal(prod.to_numpy(), ref) and prod.scale() == 2.0 ** 80
+    res = ph.rescale_to_next(ctx, prod)
+    assert np.array_equal(res.to_numpy(), tool.rescale_ntt(ref, 2)) and res.chain_index() == 2
+    rot = ph.rotate(ctx, a, 1, glk)
+    tab = O.galois_ntt_table(log_n, e1)
+    c0 = O.apply_galois_ntt(h1[0], tab, n, size_q)
+    c1 = O.apply_galois_ntt(h1[1], tab, n, size_q)
+    want = tool.keyswitch_inplace(np.stack([c0, np.zeros_like(c0)]), c1, [g1[i] for i in range(tool.beta)], O.CKKS)
+    assert np.array_equal(rot.to_numpy(), want)
+    hs = ph.hoisting(ctx, a, glk, [1, 2])
+    assert np.array_equal(hs.to_numpy(), tool.hoisting(h1, [e1, e2], [[g1[i] for i in range(tool.beta)],
+                                                                     [g2[i] for i in range(tool.beta)]], O.CKKS))
+    with pytest.raises(ValueError):
+        ph.relinearize(ctx, a, rlk)          # std::invalid_argument -> ValueError, as pybind does for the reference
