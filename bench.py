@@ -157,6 +157,22 @@ def main():
     elapsed = pdist.max_over_ranks(elapsed, device=None if share else dev)
     ntt_per_s = world * args.steps * size_q / elapsed
 
+    # ---- informational: the same transform over a batch of 4 polynomials in one launch (extension API) ----
+    batch = 4
+    polys = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(batch)])
+    for _ in range(5):
+        ctx.nwt_2d_radix8_forward_inplace_batched(polys, size_q, 0, batch, size_q * n)
+    torch.cuda.synchronize()
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b_steps = max(10, args.steps // 4)
+    b0.record()
+    for _ in range(b_steps):
+        ctx.nwt_2d_radix8_forward_inplace_batched(polys, size_q, 0, batch, size_q * n)
+    b1.record()
+    torch.cuda.synchronize()
+    batched_ms = b0.elapsed_time(b1) / b_steps
+    del polys
+
     # ---- HomMul + relinearize + rescale (secondary figure, same parameter set) -------------------------
     ct1 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
     ct2 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
@@ -201,6 +217,10 @@ def main():
                          "traffic_source": "profiles/r01e_pmc_fetch.csv + r01e_pmc_write.csv (rocprofv3 PMC, per launch pair)",
                          "kernel": "ntt_pass_kernel pair (strided pass + contiguous pass)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms},
+            "batched_ntt": {"polynomials_per_launch": batch, "ms_per_launch": batched_ms,
+                            "value": batch * size_q / (batched_ms * 1e-3), "unit": "NTT/s (this rank)",
+                            "frac_of_peak": batch * alg_bytes / (batched_ms * 1e-3) / PEAK_HBM,
+                            "note": "pha_nwt_2d_radix8_forward_inplace_batched: 4 x 45 limbs per launch pair"},
             "hommul_relin_rescale": {"value": world * hm_steps / hm_elapsed, "unit": "ops/s",
                                      "ms_per_op": 1e3 * hm_elapsed / hm_steps, "steps": hm_steps},
         }
