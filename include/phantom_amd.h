@@ -44,6 +44,11 @@ int pha_coeff_modulus_create(uint64_t poly_modulus_degree, const int *bit_sizes,
 int pha_context_create(pha_context_t *out, uint32_t log_n, const uint64_t *primes_qp, uint32_t size_qp,
                        uint32_t size_p, int device_id);
 void pha_context_destroy(pha_context_t ctx);
+/* EncryptionParameters::set_plain_modulus as seen by DRNSTool's constructor (argument `t`, src/rns.cu:11-26;
+ * BGV constants :196-285).  0 = none.  Call before the first evaluation call: cached per-level tools are
+ * dropped and rebuilt.  Errors: plain_modulus == 1 or >= 2^60 -> invalid_argument; not coprime with
+ * the chain -> logic_error ("invalid rns bases", rns.cu:207-208,274-275). */
+int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus);
 uint32_t pha_context_log_n(pha_context_t ctx);
 uint32_t pha_context_size_qp(pha_context_t ctx);
 uint32_t pha_context_size_p(pha_context_t ctx);
@@ -131,8 +136,9 @@ int pha_modup(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *
  * pointers, each key [2][size_QP][N]; p_cx [2][Ql+P][N] */
 int pha_key_switch_inner_prod(pha_context_t ctx, size_t size_Ql, uint64_t *p_cx, const uint64_t *p_t_mod_up,
                               const uint64_t *const *rlk, void *stream);
-/* DRNSTool::moddown_from_NTT (rns_bconv.cu:776-828): cx_i [Ql+P][N] (P limbs are clobbered,
- * exactly as in the reference) -> ct_i [Ql][N]; ct_i may alias cx_i */
+/* DRNSTool::moddown_from_NTT (rns_bconv.cu:776-828): cx_i [Ql+P][N] (ckks: P limbs clobbered; bfv / bgv:
+ * every limb left in coefficient form and the first P limb overwritten -- scratch, exactly as in the
+ * reference) -> ct_i [Ql][N]; ct_i may alias cx_i.  bgv needs pha_context_set_plain_modulus. */
 int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint64_t *cx_i, int scheme,
                          void *stream);
 /* phantom::keyswitch_inplace (eval_key_switch.cu:95-182) on raw buffers: ct [2][Ql][N] += KS(c2) */
@@ -144,6 +150,10 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
  * element's key).  One mod-up, one fused gather + inner-product kernel, one pair of mod-downs. */
 int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                  const uint64_t *const *const *glk, int scheme, void *stream);
+/* DRNSTool::mod_t_and_divide_q_last_ntt (rns.cu:1210-1236), the BGV modulus switch: src [cipher][Ql][N]
+ * in NTT form (left in coefficient form, as in the reference) -> dst [cipher][Ql-1][N] in NTT form */
+int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,
+                                    uint64_t *dst, void *stream);
 /* DRNSTool::divide_and_round_q_last_ntt (rns.cu:1160-1184): src [cipher][Ql][N] (last limb is
  * clobbered, as in the reference) -> dst [cipher][Ql-1][N] */
 int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,

@@ -467,6 +467,13 @@ struct orc_tool {
     bconv_t p_to_ql;                    /* base_P_to_Ql_conv rns.cu:196-198 */
     u64 *pinv, *pinv_s;                 /* bigPInv_mod_q rns.cu:110-123 */
     u64 *inv_q_last, *inv_q_last_s;     /* rns.cu:66-80 */
+    /* plain-modulus constants, BGV (rns.cu:196-285); plain_t == 0 until orc_tool_set_plain_modulus */
+    u64 plain_t, t_mu[2];
+    u64 *q_last_mod_q, *q_last_mod_q_s; /* rns.cu:68-75 */
+    u64 inv_q_last_mod_t, inv_q_last_mod_t_s; /* rns.cu:205-212 */
+    u64 *p_mod_q, *p_mod_q_s;           /* bigP_mod_q rns.cu:110-123 */
+    u64 pinv_mod_t, pinv_mod_t_s;       /* bigPInv_mod_t rns.cu:272-280 */
+    bconv_t p_to_t;                     /* base_P_to_t_conv rns.cu:283-284 */
 };
 
 orc_tool *orc_tool_create(const orc_ctx *c, size_t size_ql) {
@@ -527,8 +534,56 @@ void orc_tool_destroy(orc_tool *t) {
         for (size_t b = 0; b < t->beta; b++) bconv_free(&t->digit_conv[b]);
         free(t->digit_conv);
         bconv_free(&t->p_to_ql);
+        if (t->plain_t) bconv_free(&t->p_to_t);
     }
+    free(t->q_last_mod_q); free(t->q_last_mod_q_s); free(t->p_mod_q); free(t->p_mod_q_s);
     free(t);
+}
+
+int orc_tool_set_plain_modulus(orc_tool *t, u64 plain_t) {
+    /* DRNSTool ctor, plain-modulus part: rns.cu:200-212 (q_last^-1 mod t), :270-284 (P^-1 mod t, P -> {t}) */
+    const orc_ctx *c = t->c;
+    const size_t ql = t->size_ql;
+    if (plain_t < 2 || t->plain_t) return -1;
+    orc_const_ratio(plain_t, t->t_mu);
+    u64 g = c->q[ql - 1] % plain_t;
+    if (g == 0) return -1;
+    /* t need not be prime: extended Euclid */
+    {
+        __int128 r0 = plain_t, r1 = g, s0 = 0, s1 = 1;
+        while (r1) { __int128 qq = r0 / r1, tmp = r0 - qq * r1; r0 = r1; r1 = tmp; tmp = s0 - qq * s1; s0 = s1; s1 = tmp; }
+        if (r0 != 1) return -1;
+        t->inv_q_last_mod_t = (u64)((s0 % (__int128)plain_t + plain_t) % plain_t);
+    }
+    t->inv_q_last_mod_t_s = orc_compute_shoup(t->inv_q_last_mod_t, plain_t);
+    if (ql > 1) {
+        t->q_last_mod_q = (u64 *)malloc(sizeof(u64) * (ql - 1));
+        t->q_last_mod_q_s = (u64 *)malloc(sizeof(u64) * (ql - 1));
+        for (size_t i = 0; i + 1 < ql; i++) {
+            t->q_last_mod_q[i] = c->q[ql - 1] % c->q[i];
+            t->q_last_mod_q_s[i] = orc_compute_shoup(t->q_last_mod_q[i], c->q[i]);
+        }
+    }
+    if (t->size_p) {
+        t->p_mod_q = (u64 *)malloc(sizeof(u64) * ql);
+        t->p_mod_q_s = (u64 *)malloc(sizeof(u64) * ql);
+        for (size_t i = 0; i < ql; i++) {
+            u64 p = 1;
+            for (size_t k = 0; k < t->size_p; k++) p = orc_mulmod(p, c->q[t->size_q + k] % c->q[i], c->q[i]);
+            t->p_mod_q[i] = p;
+            t->p_mod_q_s[i] = orc_compute_shoup(p, c->q[i]);
+        }
+        u64 pt = 1 % plain_t;
+        for (size_t k = 0; k < t->size_p; k++) pt = orc_mulmod(pt, c->q[t->size_q + k] % plain_t, plain_t);
+        __int128 r0 = plain_t, r1 = pt, s0 = 0, s1 = 1;
+        while (r1) { __int128 qq = r0 / r1, tmp = r0 - qq * r1; r0 = r1; r1 = tmp; tmp = s0 - qq * s1; s0 = s1; s1 = tmp; }
+        if (r0 != 1) return -1;
+        t->pinv_mod_t = (u64)((s0 % (__int128)plain_t + plain_t) % plain_t);
+        t->pinv_mod_t_s = orc_compute_shoup(t->pinv_mod_t, plain_t);
+        bconv_init(&t->p_to_t, c->q + t->size_q, t->size_p, &plain_t, 1);
+    }
+    t->plain_t = plain_t;
+    return 0;
 }
 size_t orc_tool_beta(const orc_tool *t) { return t->beta; }
 
@@ -623,6 +678,25 @@ void orc_moddown_from_ntt(const orc_tool *t, u64 *ct, u64 *cx, int scheme) {
         bconv_matmul(&t->p_to_ql, tmp, delta, n, ql, 0);
         free(tmp);
     }
+    if (scheme == ORC_BGV) {
+        /* bgv_moddown_kernel rns_bconv.cu:636-652 with temp_t = bConv(P -> {t}) (:805-807), then NTT (:815) */
+        const u64 pt = t->plain_t;
+        u64 *tmp = (u64 *)malloc(sizeof(u64) * t->size_p * n);
+        u64 *cp_t = (u64 *)malloc(sizeof(u64) * n);
+        bconv_mult(&t->p_to_t, cx + ql * n, tmp, n);
+        bconv_matmul(&t->p_to_t, tmp, cp_t, n, 1, 0);
+        for (size_t j = 0; j < ql; j++)
+            for (size_t k = 0; k < n; k++) {
+                u64 v = shoup(cp_t[k], t->pinv_mod_t, t->pinv_mod_t_s, pt);
+                u64 corr = shoup(v, t->p_mod_q[j], t->p_mod_q_s[j], c->q[j]);
+                u64 d = submod(cx[j * n + k], delta[j * n + k], c->q[j]);
+                d = addmod(d, corr, c->q[j]);
+                ct[j * n + k] = shoup(d, t->pinv[j], t->pinv_s[j], c->q[j]);
+            }
+        orc_nwt_forward(c, ct, ql, 0);
+        free(tmp); free(cp_t); free(delta);
+        return;
+    }
     if (scheme == ORC_CKKS) orc_nwt_forward(c, delta, ql, 0); /* fused in ntt_moddown.cu:106-261 */
     /* (cx - delta) * P^-1 mod q : sub_negate_const_mult uintmodmath.cuh:233-241 / moddown_kernel :680-689 */
     for (size_t j = 0; j < ql; j++)
@@ -665,6 +739,28 @@ void orc_rescale_ntt(const orc_tool *t, u64 *src, size_t cipher_size, u64 *dst) 
                 u64 d = submod(in[j * n + k], out[j * n + k], c->q[j]);
                 out[j * n + k] = shoup(d, t->inv_q_last[j], t->inv_q_last_s[j], c->q[j]);
             }
+    }
+}
+
+void orc_mod_t_divide_q_last_ntt(const orc_tool *t, u64 *src, size_t cipher_size, u64 *dst) {
+    /* DRNSTool::mod_t_and_divide_q_last_ntt rns.cu:1186-1236 (BGV modulus switching; src is clobbered) */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, nl = ql - 1;
+    const u64 pt = t->plain_t;
+    for (size_t p = 0; p < cipher_size; p++) {
+        u64 *in = src + p * ql * n, *out = dst + p * nl * n;
+        orc_nwt_backward(c, in, ql, 0);
+        for (size_t j = 0; j < nl; j++)
+            for (size_t k = 0; k < n; k++) {
+                u64 last = in[nl * n + k];
+                u64 delta = barrett64(last, c->q[j], c->mu[j][1]);
+                u64 last_t = barrett64(last, pt, t->t_mu[1]);
+                u64 v = shoup(last_t, t->inv_q_last_mod_t, t->inv_q_last_mod_t_s, pt);
+                u64 corr = shoup(v, t->q_last_mod_q[j], t->q_last_mod_q_s[j], c->q[j]);
+                u64 d = addmod(submod(in[j * n + k], delta, c->q[j]), corr, c->q[j]);
+                out[j * n + k] = shoup(d, t->inv_q_last[j], t->inv_q_last_s[j], c->q[j]);
+            }
+        orc_nwt_forward(c, out, nl, 0);
     }
 }
 

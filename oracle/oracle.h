@@ -87,6 +87,8 @@ typedef struct orc_tool orc_tool;
 orc_tool *orc_tool_create(const orc_ctx *c, size_t size_ql);
 void orc_tool_destroy(orc_tool *t);
 size_t orc_tool_beta(const orc_tool *t);
+/* plain-modulus (BGV) constants of the tool, rns.cu:196-285; returns 0 on success, -1 when t is not invertible */
+int orc_tool_set_plain_modulus(orc_tool *t, uint64_t plain_t);
 /* scheme: 1 = bfv, 2 = ckks (include/host/encryptionparams.h:19-27 uses bfv=1,ckks=2,bgv=3) */
 enum { ORC_BFV = 1, ORC_CKKS = 2, ORC_BGV = 3 };
 /* DRNSTool::modup rns_bconv.cu:530-627: cks [size_ql][N] -> dst [beta][size_ql+alpha][N] */
@@ -102,6 +104,8 @@ void orc_hoisting(const orc_tool *t, uint64_t *ct, const uint32_t *galois_elts, 
                   const uint64_t *const *const *glk, int scheme);
 /* divide_and_round_q_last_ntt rns.cu:1128-1184: src [cipher][size_ql][N] (clobbered) -> dst [cipher][size_ql-1][N] */
 void orc_rescale_ntt(const orc_tool *t, uint64_t *src, size_t cipher_size, uint64_t *dst);
+/* mod_t_and_divide_q_last_ntt rns.cu:1186-1236 (BGV modulus switch; needs orc_tool_set_plain_modulus) */
+void orc_mod_t_divide_q_last_ntt(const orc_tool *t, uint64_t *src, size_t cipher_size, uint64_t *dst);
 /* divide_and_round_q_last rns.cu:1082-1126 (BFV coefficient-domain mod switch) */
 void orc_divide_and_round_q_last(const orc_tool *t, const uint64_t *src, size_t cipher_size, uint64_t *dst);
 

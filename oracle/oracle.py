@@ -83,6 +83,9 @@ def lib(path=None):
     L.orc_keyswitch_inplace.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p), C.c_int]
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+    L.orc_tool_set_plain_modulus.restype = C.c_int
+    L.orc_tool_set_plain_modulus.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_mod_t_divide_q_last_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_divide_and_round_q_last.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_galois_ntt_table.argtypes = [C.c_int, C.c_uint32, u32p]
     L.orc_apply_galois_ntt.argtypes = [u64p, u64p, u32p, C.c_size_t, C.c_size_t]
@@ -324,6 +327,19 @@ class Tool:
         outer = (C.POINTER(u64p) * len(tabs))(*[C.cast(a, C.POINTER(u64p)) for a in tabs])
         self.L.orc_hoisting(self.h, _p(ct), _p32(elts), len(elts), outer, scheme)
         return ct.reshape(2, self.size_ql, self.n)
+
+    def set_plain_modulus(self, t):
+        """BGV constants of the tool (rns.cu:196-285)."""
+        if self.L.orc_tool_set_plain_modulus(self.h, int(t)) != 0:
+            raise ValueError("plain modulus not invertible modulo the chain")
+        self.plain_t = int(t)
+        return self
+
+    def mod_t_divide_q_last_ntt(self, src, cipher_size):
+        src = np.array(src, dtype=np.uint64, copy=True).reshape(-1)
+        dst = np.zeros(cipher_size * (self.size_ql - 1) * self.n, dtype=np.uint64)
+        self.L.orc_mod_t_divide_q_last_ntt(self.h, _p(src), cipher_size, _p(dst))
+        return dst.reshape(cipher_size, self.size_ql - 1, self.n)
 
     def rescale_ntt(self, src, cipher_size):
         src = np.array(src, dtype=np.uint64, copy=True).reshape(-1)

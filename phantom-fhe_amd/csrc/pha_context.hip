@@ -361,6 +361,43 @@ Tool &Context::tool(uint32_t size_ql) {
         for (uint32_t i = 0; i < t->size_qlp; i++)
             if (primes[t->qlp_prime[i]] >> 60) t->split_ok = false;
     }
+    if (plain_t) {
+        // rns.cu:200-212 (q_last, q_last^-1 mod t), :270-284 (P, P^-1 mod t; P -> {t} converter row)
+        const u64 pt = plain_t;
+        t->t_mod = h_modulus(pt);
+        const u64 iq = h_invmod(primes[size_ql - 1] % pt, pt);
+        t->inv_q_last_mod_t = u64x2{iq, h_shoup(iq, pt)};
+        if (size_ql > 1) {
+            std::vector<u64x2> v(size_ql - 1);
+            for (uint32_t i = 0; i + 1 < size_ql; i++) {
+                const u64 r = primes[size_ql - 1] % primes[i];
+                v[i] = u64x2{r, h_shoup(r, primes[i])};
+            }
+            t->q_last_mod_q2.upload(v);
+        }
+        if (size_p) {
+            std::vector<u64x2> v(size_ql);
+            for (uint32_t i = 0; i < size_ql; i++) {
+                u64 p = 1;
+                for (uint32_t k = 0; k < size_p; k++) p = h_mulmod(p, primes[size_q + k] % primes[i], primes[i]);
+                v[i] = u64x2{p, h_shoup(p, primes[i])};
+            }
+            t->p_mod_q2.upload(v);
+            u64 p_t = 1 % pt;
+            std::vector<u64> hat(size_p);
+            for (uint32_t k = 0; k < size_p; k++) {
+                p_t = h_mulmod(p_t, primes[size_q + k] % pt, pt);
+                u64 h = 1 % pt;
+                for (uint32_t j = 0; j < size_p; j++)
+                    if (j != k) h = h_mulmod(h, primes[size_q + j] % pt, pt);
+                hat[k] = h;
+            }
+            const u64 ip = h_invmod(p_t, pt);
+            t->pinv_mod_t = u64x2{ip, h_shoup(ip, pt)};
+            t->p_hat_mod_t.upload(hat);
+        }
+        t->bgv_ready = true;
+    }
     Tool &ref = *t;
     tools[size_ql] = std::move(t);
     return ref;
@@ -446,6 +483,27 @@ void pha_context_destroy(pha_context_t ctx) {
 uint32_t pha_context_log_n(pha_context_t ctx) { return ctx->c.log_n; }
 uint32_t pha_context_size_qp(pha_context_t ctx) { return ctx->c.size_qp; }
 uint32_t pha_context_size_p(pha_context_t ctx) { return ctx->c.size_p; }
+
+int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus) {
+    PHA_API_BEGIN
+    if (!ctx) throw std::invalid_argument("null context");
+    Context &c = ctx->c;
+    if (plain_modulus == 1 || (plain_modulus >> 60)) throw std::invalid_argument("plain_modulus is not valid");
+    auto gcd = [](u64 a, u64 b) {
+        while (b) { const u64 r = a % b; a = b; b = r; }
+        return a;
+    };
+    for (u64 q : c.primes)  // every q_i and p_j must be invertible modulo t (rns.cu:207,274)
+        if (plain_modulus && gcd(q, plain_modulus) != 1) throw std::logic_error("invalid rns bases");
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.plain_t != plain_modulus) {
+        PHA_HIP(hipSetDevice(c.device));
+        PHA_HIP(hipDeviceSynchronize());  // per-level tools are rebuilt lazily with the new constants
+        c.tools.clear();
+        c.plain_t = plain_modulus;
+    }
+    PHA_API_END
+}
 
 int pha_context_prime_info(pha_context_t ctx, uint32_t i, uint64_t *value, uint64_t ratio[2], uint64_t *root,
                            uint64_t *n_inv) {

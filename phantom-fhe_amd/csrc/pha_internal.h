@@ -111,6 +111,12 @@ struct Tool {
     DevBuf<u64> inv_q_last, inv_q_last_shoup;      // rns.cu:66-80
     DevBuf<u64x2> inv_q_last2;                     // same, interleaved
     DevBuf<u64x2> pinv2;
+    // plain-modulus constants of the BGV branches (rns.cu:196-285); built when the context has a plain modulus
+    bool bgv_ready = false;
+    DModulus t_mod{};
+    u64x2 inv_q_last_mod_t{}, pinv_mod_t{};        // (value, Shoup) modulo t
+    DevBuf<u64x2> q_last_mod_q2, p_mod_q2;         // [ql-1], [ql]  (value, Shoup) modulo q_i
+    DevBuf<u64> p_hat_mod_t;                       // [alpha] row of base_P_to_t_conv
 };
 
 // ---- scratch arena: one per (context, stream), grown on demand, never freed until destroy ----
@@ -127,6 +133,7 @@ struct Context {
     int num_cus = 256;
     uint32_t log_n = 0, size_qp = 0, size_p = 0, size_q = 0;
     size_t n = 0;
+    u64 plain_t = 0;  // 0 = none (ckks); set by pha_context_set_plain_modulus
     std::vector<u64> primes, roots, n_inv;
     std::vector<DModulus> mods;
     // device tables

@@ -313,6 +313,74 @@ __global__ __launch_bounds__(256) void sub_mul_kernel(const SubMulArgs k) {
     k.dst[(size_t)limb * k.n + coeff] = shoup(t, cst, m.value);
 }
 
+// ---- BGV (plain modulus t): base_P_to_t_conv (rns.cu:283) as one thread per coefficient, writing over
+//      the first P limb it has just read; bgv_moddown_kernel rns_bconv.cu:636-652;
+//      bgv_mod_t_divide_q_kernel rns.cu:1186-1208 ---------------------------------------------------
+struct PToTArgs {
+    u64 *cx_p;                 // P block of polynomial 0: [alpha][N]; limb 0 receives [.]_t
+    size_t stride;             // elements between polynomials (blockIdx.y)
+    const u64x2 *hat_inv;      // [alpha] phat_i^-1 mod p_i
+    const uint32_t *iprime;    // [alpha] rows of the QP table
+    const u64 *hat_mod_t;      // [alpha] phat_i mod t
+    const DModulus *mod;
+    DModulus t;
+    uint32_t isz, n;
+};
+__global__ __launch_bounds__(256) void p_to_t_kernel(const PToTArgs k) {
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    u64 *p = k.cx_p + (size_t)blockIdx.y * k.stride + coeff;
+    u64 lo = 0, hi = 0;
+    for (uint32_t i = 0; i < k.isz; i++) {
+        const u64 x = shoup(p[(size_t)i * k.n], k.hat_inv[i], k.mod[k.iprime[i]].value);
+        mac128(x, k.hat_mod_t[i], lo, hi);
+    }
+    p[0] = barrett128(lo, hi, k.t);
+}
+
+struct BgvDownArgs {
+    u64 *dst;
+    const u64 *cx, *delta, *cp_t;
+    const u64x2 *p_mod_q, *pinv;
+    const DModulus *mod;
+    u64x2 pinv_t;
+    u64 t;
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void bgv_moddown_kernel(const BgvDownArgs k) {
+    const uint32_t limb = blockIdx.y;
+    const u64 q = k.mod[limb].value;
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = (size_t)limb * k.n + coeff;
+    const u64 u = shoup(k.cp_t[coeff], k.pinv_t, k.t);
+    const u64 corr = shoup(u, k.p_mod_q[limb], q);
+    const u64 d = add_mod(sub_mod(k.cx[id], k.delta[id], q), corr, q);
+    k.dst[id] = shoup(d, k.pinv[limb], q);
+}
+
+struct BgvSwitchArgs {
+    u64 *dst;
+    const u64 *src;            // polynomial 0: [ql][N] in coefficient form
+    const u64x2 *q_last_mod_q, *inv_q_last;
+    const DModulus *mod;
+    u64x2 inv_q_last_t;
+    DModulus t;
+    uint32_t n, nl;
+    size_t src_stride, dst_stride;
+};
+__global__ __launch_bounds__(256) void bgv_switch_kernel(const BgvSwitchArgs k) {
+    const uint32_t limb = blockIdx.y;
+    const DModulus m = k.mod[limb];
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    const u64 *in = k.src + (size_t)blockIdx.z * k.src_stride;
+    const u64 last = in[(size_t)k.nl * k.n + coeff];
+    const u64 delta = barrett64(last, m.value, m.ratio1);
+    const u64 last_t = barrett64(last, k.t.value, k.t.ratio1);
+    const u64 u = shoup(last_t, k.inv_q_last_t, k.t.value);
+    const u64 corr = shoup(u, k.q_last_mod_q[limb], m.value);
+    const u64 d = add_mod(sub_mod(in[(size_t)limb * k.n + coeff], delta, m.value), corr, m.value);
+    k.dst[(size_t)blockIdx.z * k.dst_stride + (size_t)limb * k.n + coeff] = shoup(d, k.inv_q_last[limb], m.value);
+}
+
 // divide_and_round_reduce_q_last_kernel rns.cu:1128-1139: dst[j] = last mod q_j
 struct ReduceArgs {
     u64 *dst;
@@ -422,10 +490,12 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
     xb.poly_stride = cx_stride;
     if (scheme == PHA_SCHEME_CKKS)
         ntt_inverse(c, cx, cx, cx, special_sel(ql, c.size_p, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
-    else if (scheme == PHA_SCHEME_BFV)
+    else if (scheme == PHA_SCHEME_BFV || scheme == PHA_SCHEME_BGV)
         ntt_inverse(c, cx, cx, cx, special_sel(0, qlp, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
     else
-        throw std::invalid_argument("unsupported scheme (bgv mod-down is not on the accelerated path yet)");
+        throw std::invalid_argument("unsupported scheme");
+    if (scheme == PHA_SCHEME_BGV && !t.bgv_ready)
+        throw std::invalid_argument("bgv needs a plain modulus (pha_context_set_plain_modulus)");
     const size_t d_stride = (size_t)ql * n;
     if (t.alpha == 1) {
         for (uint32_t z = 0; z < polys; z++) {
@@ -438,7 +508,28 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         launch_bconv(c, t.d_p_to_ql_conv.p, 0, polys, t.alpha, ql, t.split_ok, delta, d_stride, cx, cx_stride,
                      nullptr, true, s);
     }
-    if (scheme == PHA_SCHEME_CKKS) {
+    if (scheme == PHA_SCHEME_BGV) {
+        // [cx_P]_t lands in the first P limb of each polynomial, then the t-corrected division and the NTT
+        PToTArgs pk{cx + (size_t)ql * n, cx_stride, t.p_to_ql.hat_inv.p, t.p_to_ql.d_iprime.p, t.p_hat_mod_t.p,
+                    c.d_mod.p, t.t_mod, t.alpha, (uint32_t)n};
+        hipLaunchKernelGGL(p_to_t_kernel, dim3((unsigned)(n / 256), polys), dim3(256), 0, s, pk);
+        check_launch();
+        for (uint32_t z = 0; z < polys; z++) {
+            u64 *out = accumulate ? delta + z * d_stride : ct + z * ct_stride;
+            BgvDownArgs k{out, cx + z * cx_stride, delta + z * d_stride, cx + z * cx_stride + (size_t)ql * n,
+                          t.p_mod_q2.p, t.pinv2.p, c.d_mod.p, t.pinv_mod_t, t.t_mod.value, (uint32_t)n};
+            hipLaunchKernelGGL(bgv_moddown_kernel, dim3((unsigned)(n / 256), ql), dim3(256), 0, s, k);
+            check_launch();
+        }
+        NttExtra x;
+        x.batch = polys;
+        x.poly_stride = accumulate ? d_stride : ct_stride;
+        u64 *buf = accumulate ? delta : ct;
+        ntt_forward(c, buf, buf, buf, plain_sel(0, ql), EPI_FWD_CANON, x, s);
+        if (accumulate)
+            for (uint32_t z = 0; z < polys; z++)
+                launch_add(c, ct + z * ct_stride, delta + z * d_stride, ct + z * ct_stride, ql, 0, s);
+    } else if (scheme == PHA_SCHEME_CKKS) {
         NttExtra x;  // NTT(delta) fused with (cx - .) * P^-1 (ntt_moddown.cu:106-261)
         x.scale = t.pinv.p;
         x.scale_shoup = t.pinv_shoup.p;
@@ -630,6 +721,35 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
     x.out_stride = nl * n;
     x.aux_stride = size_Ql * n;
     ntt_forward(c, tmp, tmp, dst, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
+    PHA_API_END
+}
+
+int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,
+                                    uint64_t *dst, void *stream) {
+    PHA_API_BEGIN
+    need(src); need(dst);
+    Context &c = ctx->c;
+    check_level(c, size_Ql, false);
+    if (size_Ql < 2) throw std::invalid_argument("cannot switch down the last remaining modulus");
+    Tool &t = c.tool((uint32_t)size_Ql);
+    if (!t.bgv_ready) throw std::invalid_argument("bgv needs a plain modulus (pha_context_set_plain_modulus)");
+    if (cipher_size == 0) return 0;
+    if (cipher_size > 65535) throw std::invalid_argument("cipher_size out of range");
+    hipStream_t s = as_stream(stream);
+    const size_t n = c.n, nl = size_Ql - 1;
+    NttExtra xi;
+    xi.batch = (uint32_t)cipher_size;
+    xi.poly_stride = size_Ql * n;
+    ntt_inverse(c, src, src, src, plain_sel(0, size_Ql), EPI_INV_CANON, xi, s);  // rns.cu:1221
+    BgvSwitchArgs k{dst, src, t.q_last_mod_q2.p, t.inv_q_last2.p, c.d_mod.p, t.inv_q_last_mod_t, t.t_mod,
+                    (uint32_t)n, (uint32_t)nl, size_Ql * n, nl * n};
+    hipLaunchKernelGGL(bgv_switch_kernel, dim3((unsigned)(n / 256), (unsigned)nl, (unsigned)cipher_size), dim3(256), 0,
+                       s, k);
+    check_launch();
+    NttExtra xo;
+    xo.batch = (uint32_t)cipher_size;
+    xo.poly_stride = nl * n;
+    ntt_forward(c, dst, dst, dst, plain_sel(0, nl), EPI_FWD_CANON, xo, s);  // rns.cu:1234
     PHA_API_END
 }
 

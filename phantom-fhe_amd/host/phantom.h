@@ -5,7 +5,7 @@
 // keeps those names, members, argument meaning, pre-condition checks and exception types for everything
 // that sits on the RNS hot path, so code written against the reference's evaluate.* API compiles against
 // it for: negate / add / sub / multiply (CKKS, BGV tensor) / relinearize / multiply_and_relin /
-// rescale_to_next / mod_switch_to_next (drop) / apply_galois / rotate / hoisting / keyswitch_inplace.
+// rescale_to_next / mod_switch_to_next / apply_galois / rotate / hoisting / keyswitch_inplace.
 // Out of scope here exactly as in SURVEY.md section 8: key generation, encryption, decryption, encoders,
 // BFV BEHZ/HPS multiply (those callers are not on the accelerated path yet and throw).
 //
@@ -246,6 +246,9 @@ public:
         int log_n = 0;
         while ((size_t(1) << log_n) < n) log_n++;
         util::check_pha(pha_context_create(&amd_, log_n, primes.data(), primes.size(), sp, device));
+        // DRNSTool receives the plain modulus for BFV / BGV (src/context.cu:200-216 -> src/rns.cu:196-285)
+        if (params.scheme() == scheme_type::bgv && params.plain_modulus().value() != 0)
+            util::check_pha(pha_context_set_plain_modulus(amd_, params.plain_modulus().value()));
     }
     PhantomContext(const PhantomContext &) = delete;
     PhantomContext &operator=(const PhantomContext &) = delete;
@@ -450,6 +453,10 @@ inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &e
     if (square) util::check_pha(pha_tensor_square_2x2_rns_poly(context.amd(), encrypted1.data(), encrypted1.data(), L, s));
     else util::check_pha(pha_tensor_prod_2x2_rns_poly(context.amd(), encrypted1.data(), encrypted2.data(), encrypted1.data(), L, s));
     if (parms.scheme() == scheme_type::ckks) encrypted1.set_scale(encrypted1.scale() * encrypted2.scale());
+    if (parms.scheme() == scheme_type::bgv)  // evaluate.cu:392-396
+        encrypted1.set_correction_factor(static_cast<uint64_t>(
+            (static_cast<unsigned __int128>(encrypted1.correction_factor()) * encrypted2.correction_factor()) %
+            parms.plain_modulus().value()));
 }
 
 // relinearize_inplace (src/evaluate.cu:1342-1374)
@@ -494,21 +501,49 @@ inline void rescale_to_next_inplace(const PhantomContext &context, PhantomCipher
     encrypted = rescale_to_next(context, encrypted);
 }
 
-// mod_switch_to_next for CKKS = drop the last limb (src/evaluate.cu:1429-1470 mod_switch_drop_to_next)
+// mod_switch_to_next (src/evaluate.cu:1506-1543): CKKS drops the last limb (mod_switch_drop_to_next
+// :1429-1470); BFV / BGV divide by q_last (mod_switch_scale_to_next :1376-1427)
 [[nodiscard]] inline PhantomCiphertext mod_switch_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted) {
+    const auto &first = context.get_context_data(context.get_first_index()).parms();
+    const auto scheme = first.scheme();
+    if (encrypted.chain_index() == first.coeff_modulus().size())
+        throw std::invalid_argument("end of modulus switching chain reached");
+    if (scheme == scheme_type::bfv && encrypted.is_ntt_form()) throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+    if (scheme == scheme_type::bgv && !encrypted.is_ntt_form()) throw std::invalid_argument("BGV encrypted must be in NTT form");
+    if (scheme == scheme_type::ckks && !encrypted.is_ntt_form()) throw std::invalid_argument("CKKS encrypted must be in NTT form");
     const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
-    if (parms.scheme() != scheme_type::ckks)
-        throw std::invalid_argument("BFV/BGV modulus switching is not on the accelerated path");
     const auto &s = cudaStreamPerThread;
     const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree(), size = encrypted.size();
     const size_t next = context.get_next_index(encrypted.chain_index());
     PhantomCiphertext destination;
     destination.resize(context, next, size, s);
-    for (size_t i = 0; i < size; i++)
-        util::check_hip(hipMemcpyAsync(destination.data() + i * (L - 1) * n, encrypted.data() + i * L * n, (L - 1) * n * 8,
-                                       hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
     destination.set_ntt_form(encrypted.is_ntt_form());
     destination.set_scale(encrypted.scale());
+    if (scheme == scheme_type::ckks) {
+        for (size_t i = 0; i < size; i++)
+            util::check_hip(hipMemcpyAsync(destination.data() + i * (L - 1) * n, encrypted.data() + i * L * n, (L - 1) * n * 8,
+                                           hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        return destination;
+    }
+    if (scheme == scheme_type::bfv) {
+        util::check_pha(pha_divide_and_round_q_last(context.amd(), L, encrypted.data(), size, destination.data(), s));
+        return destination;
+    }
+    if (scheme != scheme_type::bgv) throw std::invalid_argument("unsupported scheme");
+    auto copy = util::make_cuda_auto_ptr<uint64_t>(size * L * n, s);  // the switch works on a copy (:1392-1395)
+    util::check_hip(hipMemcpyAsync(copy.get(), encrypted.data(), size * L * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    util::check_pha(pha_mod_t_and_divide_q_last_ntt(context.amd(), L, copy.get(), size, destination.data(), s));
+    // correction factor *= q_last^-1 mod t (:1421-1425)
+    const uint64_t t = parms.plain_modulus().value();
+    const uint64_t q_last_t = parms.coeff_modulus().back().value() % t;
+    __int128 r0 = t, r1 = q_last_t, s0 = 0, s1 = 1;
+    while (r1 != 0) {
+        const __int128 k = r0 / r1, r2 = r0 - k * r1, s2 = s0 - k * s1;
+        r0 = r1; r1 = r2; s0 = s1; s1 = s2;
+    }
+    const uint64_t inv = static_cast<uint64_t>(((s0 % static_cast<__int128>(t)) + t) % t);
+    destination.set_correction_factor(
+        static_cast<uint64_t>((static_cast<unsigned __int128>(encrypted.correction_factor()) * inv) % t));
     return destination;
 }
 inline void mod_switch_to_next_inplace(const PhantomContext &context, PhantomCiphertext &encrypted) {

@@ -83,6 +83,12 @@ class PhantomContext:
                                                   self.size_QP, self.size_P, self.device.index or 0))
         self._h = h
 
+    def set_plain_modulus(self, plain_modulus):
+        """EncryptionParameters::set_plain_modulus as DRNSTool sees it (src/rns.cu:196-285, BGV constants)."""
+        _lib.check(self._L.pha_context_set_plain_modulus(self._h, int(plain_modulus)))
+        self.plain_modulus = int(plain_modulus)
+        return self
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
@@ -209,6 +215,11 @@ class PhantomContext:
 
     def divide_and_round_q_last_ntt(self, size_Ql, src, cipher_size, dst):
         _lib.check(self._L.pha_divide_and_round_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
+                                                           _stream()))
+
+    def mod_t_and_divide_q_last_ntt(self, size_Ql, src, cipher_size, dst):
+        """BGV modulus switch (DRNSTool::mod_t_and_divide_q_last_ntt, src/rns.cu:1210-1236)."""
+        _lib.check(self._L.pha_mod_t_and_divide_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
                                                            _stream()))
 
     def divide_and_round_q_last(self, size_Ql, src, cipher_size, dst):

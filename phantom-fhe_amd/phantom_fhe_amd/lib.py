@@ -18,6 +18,7 @@ sz = C.c_size_t
 _SIGS = {
     "pha_coeff_modulus_create": [C.c_uint64, C.POINTER(C.c_int), sz, u64p],
     "pha_context_create": [C.POINTER(vp), C.c_uint32, u64p, C.c_uint32, C.c_uint32, C.c_int],
+    "pha_context_set_plain_modulus": [vp, C.c_uint64],
     "pha_context_prime_info": [vp, C.c_uint32, u64p, u64p, u64p, u64p],
     "pha_context_download_twiddle": [vp, C.c_uint32, C.c_int, u64p],
     "pha_tool_beta": [vp, C.c_uint32, C.POINTER(C.c_uint32)],
@@ -48,6 +49,7 @@ _SIGS = {
     "pha_keyswitch_inplace": [vp, sz, vp, vp, vp, C.c_int, vp],
     "pha_hoisting": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.c_int, vp],
     "pha_divide_and_round_q_last_ntt": [vp, sz, vp, sz, vp, vp],
+    "pha_mod_t_and_divide_q_last_ntt": [vp, sz, vp, sz, vp, vp],
     "pha_divide_and_round_q_last": [vp, sz, vp, sz, vp, vp],
     "pha_apply_galois_ntt": [vp, vp, vp, C.c_uint32, sz, vp],
     "pha_apply_galois": [vp, vp, vp, C.c_uint32, sz, sz, vp],

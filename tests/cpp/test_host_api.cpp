@@ -195,6 +195,43 @@ int main() {
         while (last.coeff_modulus_size() > 1) mod_switch_to_next_inplace(context, last);
         REQUIRE(throws_invalid([&] { rescale_to_next_inplace(context, last); }));         // no next parameters
     }
+    // BGV: multiply -> relinearize -> mod_switch_to_next (examples/2_bgv.cu flow) with plain modulus 65537
+    {
+        EncryptionParameters bp(scheme_type::bgv);
+        bp.set_poly_modulus_degree(n);
+        bp.set_special_modulus_size(alpha);
+        bp.set_coeff_modulus(parms.coeff_modulus());
+        bp.set_plain_modulus(Modulus(65537));
+        PhantomContext bctx(bp);
+        orc_tool *bt = orc_tool_create(oc, size_q);
+        REQUIRE(orc_tool_set_plain_modulus(bt, 65537) == 0);
+        PhantomRelinKey brlk;
+        {
+            std::vector<uint64_t> flat;
+            for (auto &k : rlk_host) flat.insert(flat.end(), k.begin(), k.end());
+            brlk.load_from_host(bctx, flat.data(), dnum);
+        }
+        PhantomCiphertext b1, b2;
+        b1.load_from_host(bctx, 1, 2, h1.data());
+        b2.load_from_host(bctx, 1, 2, h2.data());
+        b1.set_correction_factor(3);
+        b2.set_correction_factor(5);
+        PhantomCiphertext bprod = multiply_and_relin(bctx, b1, b2, brlk);
+        REQUIRE(bprod.size() == 2 && bprod.correction_factor() == 15);
+        std::vector<uint64_t> r2(ref3.begin(), ref3.begin() + 2 * ln), got(2 * ln);
+        orc_keyswitch_inplace(bt, r2.data(), ref3.data() + 2 * ln, rlk_ptrs.data(), ORC_BGV);
+        bprod.store_to_host(got.data());
+        REQUIRE(got == r2);
+        PhantomCiphertext bnext = mod_switch_to_next(bctx, bprod);
+        REQUIRE(bnext.chain_index() == 2 && bnext.coeff_modulus_size() == size_q - 1 && bnext.is_ntt_form());
+        std::vector<uint64_t> src = r2, ref((size_q - 1) * n * 2), out((size_q - 1) * n * 2);
+        orc_mod_t_divide_q_last_ntt(bt, src.data(), 2, ref.data());
+        bnext.store_to_host(out.data());
+        REQUIRE(out == ref);
+        const uint64_t inv = orc_invmod(q.back() % 65537, 65537);   // 65537 is prime
+        REQUIRE(bnext.correction_factor() == 15 * inv % 65537);
+        orc_tool_destroy(bt);
+    }
     phantom::util::check_hip(hipDeviceSynchronize(), "sync");
     orc_tool_destroy(tool);
     orc_ctx_destroy(oc);

@@ -73,7 +73,11 @@ KS_CASES = [
     ("c1_bfv4096", O.CKKS, [2, 1]),
     ("c4_bfv15", O.BFV, [30]),
     ("c3_ckks16", O.CKKS, [45, 31]),
+    ("hyb12_a2", O.BGV, [6, 5, 1]),      # t-corrected mod-down (bgv_moddown_kernel rns_bconv.cu:636-652)
+    ("hyb13_a3", O.BGV, [9, 7]),
+    ("c1_bfv4096", O.BGV, [2]),
 ]
+BGV_T = 65537
 
 
 @pytest.mark.parametrize("name,scheme,levels", KS_CASES)
@@ -86,8 +90,12 @@ def test_keyswitch_stages(name, scheme, levels, gpu):
     r = rng_for(20)
     evk = _keys(oc, r, primes, n, size_q, size_p)
     rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    if scheme == O.BGV:
+        ctx.set_plain_modulus(BGV_T)
     for ql in levels:
         tool = O.Tool(oc, ql)
+        if scheme == O.BGV:
+            tool.set_plain_modulus(BGV_T)
         qlp = ql + size_p
         beta = tool.beta
         assert ctx.beta(ql) == beta
@@ -143,6 +151,26 @@ def test_rescale(name, ql, gpu):
     assert np.array_equal(P.to_host(dst), tool.divide_and_round_q_last(ct, 2))
 
 
+@pytest.mark.parametrize("name,ql,plain_t", [("hyb12_a2", 6, 65537), ("hyb12_a2", 2, 1 << 20), ("c4_bfv15", 30, 786433)])
+def test_bgv_mod_switch(name, ql, plain_t, gpu):
+    """mod_t_and_divide_q_last_ntt (src/rns.cu:1186-1236)."""
+    import phantom_fhe_amd as P
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(45)
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(3)])
+    dst = P.to_device(np.zeros((3, ql - 1, n), dtype=np.uint64), gpu)
+    with pytest.raises(ValueError):                       # no plain modulus yet
+        ctx.mod_t_and_divide_q_last_ntt(ql, P.to_device(ct, gpu), 3, dst)
+    ctx.set_plain_modulus(plain_t)
+    tool = O.Tool(oc, ql).set_plain_modulus(plain_t)
+    ctx.mod_t_and_divide_q_last_ntt(ql, P.to_device(ct, gpu), 3, dst)
+    assert np.array_equal(P.to_host(dst), tool.mod_t_divide_q_last_ntt(ct, 3))
+    with pytest.raises((ArithmeticError, ValueError)):    # shares a factor with the chain: logic_error
+        ctx.set_plain_modulus(int(primes[1]))
+
+
 def test_galois(gpu):
     import phantom_fhe_amd as P
     name = "hyb12_a2"
@@ -164,6 +192,7 @@ def test_galois(gpu):
 
 @pytest.mark.parametrize("name,scheme,ql,elts", [("hyb12_a2", O.CKKS, 6, [5, 25, 125]), ("hyb12_a2", O.CKKS, 3, [5]),
                                                  ("hyb12_a2", O.BFV, 6, [5, 8191]), ("c1_bfv4096", O.CKKS, 2, [5, 25]),
+                                                 ("hyb12_a2", O.BGV, 6, [5, 25]),
                                                  ("c3_ckks16", O.CKKS, 45, [5, 25, 125, 625])])
 def test_hoisting(name, scheme, ql, elts, gpu):
     """hoisting_inplace (src/evaluate.cu:1670-1866): ct <- sum_e rotate_e(ct) with one shared mod-up."""
@@ -173,6 +202,9 @@ def test_hoisting(name, scheme, ql, elts, gpu):
     size_q = len(primes) - size_p
     oc, ctx = oracle_ctx(name), _ctx(name, gpu)
     tool = O.Tool(oc, ql)
+    if scheme == O.BGV:
+        ctx.set_plain_modulus(BGV_T)
+        tool.set_plain_modulus(BGV_T)
     r = rng_for(70)
     glk = [_keys(oc, r, primes, n, size_q, size_p) for _ in elts]
     ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])

@@ -177,6 +177,67 @@ def test_relinearize_decrypts_correctly(name, ql):
     assert worst.bit_length() < Q.bit_length() - 20
 
 
+@pytest.mark.parametrize("name,ql,plain_t", [("hyb12_a2", 6, 65537), ("hyb12_a2", 4, 786433), ("hyb13_a3", 9, 65537)])
+def test_bgv_relinearize_keeps_the_plaintext_mod_t(name, ql, plain_t):
+    """BGV mod-down (bgv_moddown_kernel rns_bconv.cu:636-652): with genuine BGV keys (error scaled by t,
+    secretkey.cu:268-273) the key-switched phase differs from the old one by t * small, i.e. mod t nothing moves."""
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc = oracle_ctx(name)
+    r = rng_for(37)
+    s_small = r.integers(-1, 2, n)
+    sk = np.stack([np.array([int(v) % int(q) for v in s_small], dtype=np.uint64) for q in primes])
+    sk_ntt = oc.nwt_forward(sk, len(primes), 0)
+    s2_ntt = oc.multiply(sk_ntt[:size_q], sk_ntt[:size_q], size_q)
+    dnum = size_q // size_p
+    a = np.stack([uniform_poly(r, primes, n) for _ in range(dnum)])
+    e_small = r.integers(-3, 4, (dnum, n))
+    e = np.stack([np.stack([np.array([int(v) * plain_t % int(q) for v in e_small[d]], dtype=np.uint64) for q in primes])
+                  for d in range(dnum)])
+    e_ntt = np.stack([oc.nwt_forward(e[d], len(primes), 0) for d in range(dnum)])
+    evk = oc.gen_kswitch_key(sk_ntt, s2_ntt, a, e_ntt)
+    tool = O.Tool(oc, ql).set_plain_modulus(plain_t)
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(3)])
+    out = tool.keyswitch_inplace(ct[:2], ct[2], [evk[i] for i in range(tool.beta)], O.BGV)
+    s1, s2 = sk_ntt[:ql], s2_ntt[:ql]
+    before = oc.add(oc.add(ct[0], oc.multiply(ct[1], s1, ql), ql), oc.multiply(ct[2], s2, ql), ql)
+    after = oc.add(out[0], oc.multiply(out[1], s1, ql), ql)
+    diff = oc.nwt_backward(oc.sub(after, before, ql), ql)
+    Q = 1
+    for q in primes[:ql]:
+        Q *= int(q)
+    worst = 0
+    for k in range(0, n, 97):
+        v, _ = crt_compose([diff[l, k] for l in range(ql)], primes[:ql])
+        v = v - Q if v > Q // 2 else v
+        assert v % plain_t == 0
+        worst = max(worst, abs(v))
+    assert worst < plain_t * n * 64 * (dnum + ql + size_p)
+    assert worst.bit_length() < Q.bit_length() - 20
+
+
+@pytest.mark.parametrize("plain_t", [65537, 1032193, 1 << 20])
+def test_bgv_mod_switch_is_exact_division_and_fixes_the_residue_mod_t(plain_t):
+    """mod_t_and_divide_q_last_ntt (rns.cu:1186-1236): dst * q_last = c - d with d = c mod q_last, d = 0 mod t."""
+    name, ql = "hyb12_a2", 4
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc = oracle_ctx(name)
+    tool = O.Tool(oc, ql).set_plain_modulus(plain_t)
+    c = uniform_poly(rng_for(43), primes[:ql], n)
+    c_ntt = oc.nwt_forward(c, ql, 0)
+    out = oc.nwt_backward(tool.mod_t_divide_q_last_ntt(c_ntt.reshape(1, ql, n), 1)[0], ql - 1)
+    q_last = int(primes[ql - 1])
+    inv_t = pow(q_last, -1, plain_t)
+    for k in range(0, n, 131):
+        v, _ = crt_compose([c[l, k] for l in range(ql)], primes[:ql])
+        last = int(c[ql - 1, k])
+        num = v - last + q_last * ((last % plain_t) * inv_t % plain_t)
+        assert num % q_last == 0 and (num - v) % plain_t == 0
+        assert [int(out[l, k]) for l in range(ql - 1)] == [(num // q_last) % int(q) for q in primes[:ql - 1]]
+
+
 def test_rescale_is_floor_division_by_q_last():
     """divide_and_round_q_last_ntt floors (rns.cu:1118 comment notwithstanding): dst = (c - [c]_qlast)/qlast."""
     name, ql = "hyb12_a2", 4
