@@ -19,7 +19,7 @@ for name, limbs in CASES:
     # limbs > #primes: several polynomials back to back would need a limb map; time a 60-limb launch x reps instead
     lim = min(limbs, len(primes))
     x = P.to_device(uniform_poly(rng_for(1), primes[:lim], n), "cuda:0")
-    for variant in (33, 97, 37):
+    for variant in (33,):
         P.set_tuning(0, variant)
         ctx.time_forward_ntt(x, lim, 20)
         best = min(ctx.time_forward_ntt(x, lim, 200) for _ in range(5))
