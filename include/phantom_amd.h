@@ -150,6 +150,16 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
  * element's key).  One mod-up, one fused gather + inner-product kernel, one pair of mod-downs. */
 int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                  const uint64_t *const *const *glk, int scheme, void *stream);
+/* PhantomSecretKey::generate_one_kswitch_key (src/secretkey.cu:297-341 with encrypt_zero_symmetric :232-295),
+ * arithmetic part; the randomness comes from the caller because the PRNG (sample_uniform_poly /
+ * sample_error_poly, src/prng.cu) is outside the accelerated path.  All buffers on the device:
+ *   sk_ntt [QP][N] secret key, NTT form;  new_key_ntt [Q][N] key to switch from (s^2 or galois(s)), NTT form;
+ *   a [dnum][QP][N] uniform residues (used as the NTT-form c1, as the reference samples it);
+ *   e [dnum][QP][N] noise residues in COEFFICIENT form -- clobbered (scaled by t for bgv, then NTT in place);
+ *   evk: device array of dnum device pointers, key d receives [2][QP][N] = (-(a_d s + e_d) + P new_key on the
+ *   digit's limbs, a_d), the layout key_switch_inner_prod consumes. */
+int pha_generate_one_kswitch_key(pha_context_t ctx, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,
+                                 const uint64_t *a, uint64_t *e, uint64_t *const *evk, int scheme, void *stream);
 /* DRNSTool::mod_t_and_divide_q_last_ntt (rns.cu:1210-1236), the BGV modulus switch: src [cipher][Ql][N]
  * in NTT form (left in coefficient form, as in the reference) -> dst [cipher][Ql-1][N] in NTT form */
 int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,

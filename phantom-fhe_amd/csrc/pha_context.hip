@@ -321,6 +321,15 @@ Tool &Context::tool(uint32_t size_ql) {
         t->pinv.upload(v);
         t->pinv_shoup.upload(vs);
         t->pinv2.upload(v2);
+        {   // P mod q_i (bigP_mod_q, rns.cu:110-123): key generation and the bgv mod-down
+            std::vector<u64x2> pm(size_ql);
+            for (uint32_t i = 0; i < size_ql; i++) {
+                u64 p = 1;
+                for (uint32_t k = 0; k < size_p; k++) p = h_mulmod(p, primes[size_q + k] % primes[i], primes[i]);
+                pm[i] = u64x2{p, h_shoup(p, primes[i])};
+            }
+            t->p_mod_q2.upload(pm);
+        }
         // digits (rns.cu:152-190)
         t->beta = (size_ql + t->alpha - 1) / t->alpha;
         t->digit.resize(t->beta);
@@ -376,13 +385,6 @@ Tool &Context::tool(uint32_t size_ql) {
             t->q_last_mod_q2.upload(v);
         }
         if (size_p) {
-            std::vector<u64x2> v(size_ql);
-            for (uint32_t i = 0; i < size_ql; i++) {
-                u64 p = 1;
-                for (uint32_t k = 0; k < size_p; k++) p = h_mulmod(p, primes[size_q + k] % primes[i], primes[i]);
-                v[i] = u64x2{p, h_shoup(p, primes[i])};
-            }
-            t->p_mod_q2.upload(v);
             u64 p_t = 1 % pt;
             std::vector<u64> hat(size_p);
             for (uint32_t k = 0; k < size_p; k++) {

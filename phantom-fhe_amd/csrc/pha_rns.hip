@@ -381,6 +381,37 @@ __global__ __launch_bounds__(256) void bgv_switch_kernel(const BgvSwitchArgs k) 
     k.dst[(size_t)blockIdx.z * k.dst_stride + (size_t)limb * k.n + coeff] = shoup(d, k.inv_q_last[limb], m.value);
 }
 
+// ---- key-switching key generation, arithmetic part (src/secretkey.cu:232-341): per digit d and limb j of QP
+//      b = -(a*s + u) [multiply_and_add_negate_rns_poly polymath.cu:234-251], and on the digit's own limbs
+//      b += P * new_key [multiply_temp_mod_and_add_rns_poly polymath.cu:318-338]; the key is (b, a). ----
+struct KeyGenArgs {
+    u64 *const *evk;        // device array [dnum] of keys [2][QP][N]
+    const u64 *sk;          // [QP][N] NTT form
+    const u64 *new_key;     // [Q][N] NTT form
+    const u64 *a, *u;       // [dnum][QP][N]: uniform part, noise in NTT form
+    const u64x2 *p_mod_q;   // [Q]
+    const DModulus *mod;
+    uint32_t n, size_qp, alpha;
+};
+__global__ __launch_bounds__(256) void kswitch_key_kernel(const KeyGenArgs k) {
+    const uint32_t limb = blockIdx.y, d = blockIdx.z;
+    const DModulus m = k.mod[limb];
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = (size_t)limb * k.n + coeff, did = (size_t)d * k.size_qp * k.n + id;
+    const u64 a = k.a[did];
+    u64 b = neg_mod(add_mod(mul_mod(a, k.sk[id], m), k.u[did], m.value), m.value);
+    if (limb >= d * k.alpha && limb < (d + 1) * k.alpha)
+        b = add_mod(b, shoup(k.new_key[id], k.p_mod_q[limb], m.value), m.value);
+    u64 *key = k.evk[d];
+    key[id] = b;
+    key[(size_t)k.size_qp * k.n + id] = a;
+}
+__global__ __launch_bounds__(256) void scale_by_t_kernel(u64 *e, const DModulus *mod, u64 t, uint32_t n, size_t stride) {
+    const DModulus m = mod[blockIdx.y];
+    const size_t id = (size_t)blockIdx.z * stride + (size_t)blockIdx.y * n + blockIdx.x * 256 + threadIdx.x;
+    e[id] = mul_mod(e[id], barrett64(t, m.value, m.ratio1), m);
+}
+
 // divide_and_round_reduce_q_last_kernel rns.cu:1128-1139: dst[j] = last mod q_j
 struct ReduceArgs {
     u64 *dst;
@@ -721,6 +752,34 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
     x.out_stride = nl * n;
     x.aux_stride = size_Ql * n;
     ntt_forward(c, tmp, tmp, dst, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
+    PHA_API_END
+}
+
+int pha_generate_one_kswitch_key(pha_context_t ctx, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,
+                                 const uint64_t *a, uint64_t *e, uint64_t *const *evk, int scheme, void *stream) {
+    PHA_API_BEGIN
+    need(sk_ntt); need(new_key_ntt); need(a); need(e); need(evk);
+    Context &c = ctx->c;
+    if (c.size_p == 0) throw std::invalid_argument("context has no special modulus");
+    if (c.size_q % c.size_p) throw std::invalid_argument("#Q must be a multiple of special_modulus_size");
+    ntt_domain_scheme(scheme);  // validates the scheme
+    Tool &t = c.tool(c.size_q);
+    hipStream_t s = as_stream(stream);
+    const uint32_t dnum = c.size_q / c.size_p, n = (uint32_t)c.n;
+    const size_t qp_n = (size_t)c.size_qp * n;
+    if (scheme == PHA_SCHEME_BGV) {  // noise = t*e (secretkey.cu:268-273)
+        if (!t.bgv_ready) throw std::invalid_argument("bgv needs a plain modulus (pha_context_set_plain_modulus)");
+        hipLaunchKernelGGL(scale_by_t_kernel, dim3(n / 256, c.size_qp, dnum), dim3(256), 0, s, e, c.d_mod.p,
+                           t.t_mod.value, n, qp_n);
+        check_launch();
+    }
+    NttExtra x;  // e -> NTT form, every digit in one launch (secretkey.cu:275)
+    x.batch = dnum;
+    x.poly_stride = qp_n;
+    ntt_forward(c, e, e, e, plain_sel(0, c.size_qp), EPI_FWD_CANON, x, s);
+    KeyGenArgs k{evk, sk_ntt, new_key_ntt, a, e, t.p_mod_q2.p, c.d_mod.p, n, c.size_qp, c.size_p};
+    hipLaunchKernelGGL(kswitch_key_kernel, dim3(n / 256, c.size_qp, dnum), dim3(256), 0, s, k);
+    check_launch();
     PHA_API_END
 }
 

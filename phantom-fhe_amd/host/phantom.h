@@ -22,6 +22,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <istream>
+#include <ostream>
 #include <vector>
 
 // the reference spells the stream type cudaStream_t in every signature
@@ -321,6 +323,48 @@ public:
     [[nodiscard]] uint64_t correction_factor() const { return correction_factor_; }
     [[nodiscard]] uint64_t *data() const { return data_.get(); }
 
+    // On-disk format of include/ciphertext.h:173-214: the nine metadata fields as raw host-endian values, then
+    // size * coeff_modulus_size * poly_modulus_degree words.  Files are interchangeable with the reference's.
+    void save(std::ostream &stream) const {
+        stream.write(reinterpret_cast<const char *>(&chain_index_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&size_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&poly_modulus_degree_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&coeff_modulus_size_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&scale_), sizeof(double));
+        stream.write(reinterpret_cast<const char *>(&correction_factor_), sizeof(std::uint64_t));
+        stream.write(reinterpret_cast<const char *>(&noiseScaleDeg_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&is_ntt_form_), sizeof(bool));
+        stream.write(reinterpret_cast<const char *>(&is_asymmetric_), sizeof(bool));
+        std::vector<uint64_t> host(size_ * coeff_modulus_size_ * poly_modulus_degree_);
+        if (!host.empty()) store_to_host(host.data());
+        stream.write(reinterpret_cast<const char *>(host.data()), static_cast<std::streamsize>(host.size() * sizeof(uint64_t)));
+    }
+    void load(std::istream &stream) {
+        size_t size = 0, degree = 0, limbs = 0;
+        stream.read(reinterpret_cast<char *>(&chain_index_), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&size), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&degree), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&limbs), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&scale_), sizeof(double));
+        stream.read(reinterpret_cast<char *>(&correction_factor_), sizeof(std::uint64_t));
+        stream.read(reinterpret_cast<char *>(&noiseScaleDeg_), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&is_ntt_form_), sizeof(bool));
+        stream.read(reinterpret_cast<char *>(&is_asymmetric_), sizeof(bool));
+        if (!stream || size > 16 || limbs > 4096 || degree > (size_t(1) << 17))
+            throw std::invalid_argument("ciphertext stream is not valid");
+        std::vector<uint64_t> host(size * limbs * degree);
+        stream.read(reinterpret_cast<char *>(host.data()), static_cast<std::streamsize>(host.size() * sizeof(uint64_t)));
+        if (!stream) throw std::invalid_argument("ciphertext stream is truncated");
+        const auto &s = cudaStreamPerThread;
+        data_.reset();
+        size_ = coeff_modulus_size_ = poly_modulus_degree_ = 0;
+        resize(size, limbs, degree, s);
+        if (!host.empty()) {
+            phantom::util::check_hip(hipMemcpyAsync(data_.get(), host.data(), host.size() * 8, hipMemcpyHostToDevice, s), "hipMemcpyAsync");
+            phantom::util::check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+    }
+
     // test / interop helpers (the reference fills ciphertexts by encryption, which is out of scope)
     void load_from_host(const PhantomContext &context, size_t chain_index, size_t size, const uint64_t *host,
                         const cudaStream_t &stream = cudaStreamPerThread) {
@@ -335,33 +379,75 @@ public:
     }
 };
 
-// PhantomRelinKey (include/secretkey.h:102-165): dnum public keys [2][#QP][N] + device pointer table
+// PhantomRelinKey (include/secretkey.h:102-165): dnum public keys, each a size-2 ciphertext [2][#QP][N] at chain
+// index 0, + the device pointer table the inner product reads
 class PhantomRelinKey {
-    std::vector<phantom::util::cuda_auto_ptr<uint64_t>> public_keys_;
+    std::vector<PhantomCiphertext> public_keys_;
     phantom::util::cuda_auto_ptr<uint64_t *> public_keys_ptr_;
     bool gen_flag_ = false;
 
+    void allocate(const PhantomContext &context, size_t dnum, const cudaStream_t &stream) {
+        public_keys_.clear();
+        public_keys_.resize(dnum);
+        for (auto &pk : public_keys_) {
+            pk.resize(context, 0, 2, stream);
+            pk.set_ntt_form(true);
+        }
+        upload_pointers(stream);
+    }
+    void upload_pointers(const cudaStream_t &stream) {
+        std::vector<uint64_t *> ptrs;
+        for (auto &pk : public_keys_) ptrs.push_back(pk.data());
+        public_keys_ptr_ = phantom::util::make_cuda_auto_ptr<uint64_t *>(ptrs.size(), stream);
+        phantom::util::check_hip(hipMemcpyAsync(public_keys_ptr_.get(), ptrs.data(), ptrs.size() * sizeof(uint64_t *),
+                                                hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+        phantom::util::check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    }
+
 public:
     PhantomRelinKey() = default;
-    // keys come from outside (key generation is out of scope): evk = [dnum][2][#QP][N] on the host
+    // keys from outside: evk = [dnum][2][#QP][N] on the host
     void load_from_host(const PhantomContext &context, const uint64_t *evk, size_t dnum,
                         const cudaStream_t &stream = cudaStreamPerThread) {
         const size_t words = 2 * context.coeff_mod_size() * context.poly_degree();
-        public_keys_.clear();
-        std::vector<uint64_t *> ptrs;
-        for (size_t d = 0; d < dnum; d++) {
-            public_keys_.emplace_back(words, stream);
-            phantom::util::check_hip(hipMemcpyAsync(public_keys_.back().get(), evk + d * words, words * 8,
+        allocate(context, dnum, stream);
+        for (size_t d = 0; d < dnum; d++)
+            phantom::util::check_hip(hipMemcpyAsync(public_keys_[d].data(), evk + d * words, words * 8,
                                                     hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
-            ptrs.push_back(public_keys_.back().get());
-        }
-        public_keys_ptr_ = phantom::util::make_cuda_auto_ptr<uint64_t *>(dnum, stream);
-        phantom::util::check_hip(hipMemcpyAsync(public_keys_ptr_.get(), ptrs.data(), dnum * sizeof(uint64_t *),
-                                                hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
         phantom::util::check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
         gen_flag_ = true;
     }
+    // PhantomSecretKey::generate_one_kswitch_key (src/secretkey.cu:297-341) with the randomness handed in (device
+    // buffers, see pha_generate_one_kswitch_key): sk_ntt [QP][N], new_key_ntt [Q][N], a / e [dnum][QP][N]
+    void generate(const PhantomContext &context, const uint64_t *sk_ntt, const uint64_t *new_key_ntt, const uint64_t *a,
+                  uint64_t *e, const cudaStream_t &stream = cudaStreamPerThread) {
+        const auto &parms = context.get_context_data(0).parms();
+        const size_t size_p = parms.special_modulus_size();
+        if (!context.using_keyswitching() || size_p == 0) throw std::invalid_argument("keyswitching is not supported by the context");
+        allocate(context, (parms.coeff_modulus().size() - size_p) / size_p, stream);
+        phantom::util::check_pha(pha_generate_one_kswitch_key(context.amd(), sk_ntt, new_key_ntt, a, e, public_keys_ptr_.get(),
+                                                              static_cast<int>(parms.scheme()), stream));
+        gen_flag_ = true;
+    }
+    // include/secretkey.h:129-163: dnum, then every public key as a ciphertext dump
+    void save(std::ostream &stream) const {
+        if (!gen_flag_) throw std::invalid_argument("PhantomRelinKey has not been generated");
+        const size_t dnum = public_keys_.size();
+        stream.write(reinterpret_cast<const char *>(&dnum), sizeof(std::size_t));
+        for (const auto &pk : public_keys_) pk.save(stream);
+    }
+    void load(std::istream &stream) {
+        size_t dnum = 0;
+        stream.read(reinterpret_cast<char *>(&dnum), sizeof(std::size_t));
+        if (!stream || dnum == 0 || dnum > 4096) throw std::invalid_argument("relin key stream is not valid");
+        public_keys_.clear();
+        public_keys_.resize(dnum);
+        for (auto &pk : public_keys_) pk.load(stream);
+        upload_pointers(cudaStreamPerThread);
+        gen_flag_ = true;
+    }
     [[nodiscard]] uint64_t **public_keys_ptr() const { return public_keys_ptr_.get(); }
+    [[nodiscard]] const PhantomCiphertext &public_key(size_t d) const { return public_keys_.at(d); }
     [[nodiscard]] size_t dnum() const { return public_keys_.size(); }
     [[nodiscard]] bool generated() const { return gen_flag_; }
 };
@@ -378,6 +464,23 @@ public:
     }
     [[nodiscard]] const std::vector<uint32_t> &galois_elts() const { return galois_elts_; }
     [[nodiscard]] const PhantomRelinKey &get_relin_keys(size_t index) const { return relin_keys_.at(index); }
+    // include/secretkey.h:196-220: the number of keys, then every relin key.  The file does not name the Galois
+    // elements (the reference pairs key i with the context's i-th element), so load() takes them.
+    void save(std::ostream &stream) const {
+        if (relin_keys_.empty()) throw std::invalid_argument("PhantomGaloisKey has not been generated");
+        const size_t rlk_num = relin_keys_.size();
+        stream.write(reinterpret_cast<const char *>(&rlk_num), sizeof(std::size_t));
+        for (const auto &rlk : relin_keys_) rlk.save(stream);
+    }
+    void load(std::istream &stream, const std::vector<uint32_t> &galois_elts) {
+        size_t rlk_num = 0;
+        stream.read(reinterpret_cast<char *>(&rlk_num), sizeof(std::size_t));
+        if (!stream || rlk_num != galois_elts.size()) throw std::invalid_argument("galois key stream does not match the elements");
+        galois_elts_ = galois_elts;
+        relin_keys_.clear();
+        relin_keys_.resize(rlk_num);
+        for (auto &rlk : relin_keys_) rlk.load(stream);
+    }
 };
 
 namespace phantom {

@@ -217,6 +217,16 @@ class PhantomContext:
         _lib.check(self._L.pha_divide_and_round_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
                                                            _stream()))
 
+    def generate_one_kswitch_key(self, sk_ntt, new_key_ntt, a, e, scheme):
+        """PhantomSecretKey::generate_one_kswitch_key (src/secretkey.cu:297-341), randomness (a, e) supplied by
+        the caller; e is in coefficient form and is clobbered.  Returns a PhantomRelinKey."""
+        dnum = self.size_Q // self.size_P
+        keys = [torch.empty((2, self.size_QP, self.n), dtype=torch.int64, device=self.device) for _ in range(dnum)]
+        rlk = PhantomRelinKey(keys)
+        _lib.check(self._L.pha_generate_one_kswitch_key(self._h, _ptr(sk_ntt), _ptr(new_key_ntt), _ptr(a), _ptr(e),
+                                                        _ptr(rlk.public_keys_ptr), int(scheme), _stream()))
+        return rlk
+
     def mod_t_and_divide_q_last_ntt(self, size_Ql, src, cipher_size, dst):
         """BGV modulus switch (DRNSTool::mod_t_and_divide_q_last_ntt, src/rns.cu:1210-1236)."""
         _lib.check(self._L.pha_mod_t_and_divide_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),

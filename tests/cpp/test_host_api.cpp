@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <sstream>
 
 extern "C" {
 #include "../../oracle/oracle.h"
@@ -195,6 +196,78 @@ int main() {
         while (last.coeff_modulus_size() > 1) mod_switch_to_next_inplace(context, last);
         REQUIRE(throws_invalid([&] { rescale_to_next_inplace(context, last); }));         // no next parameters
     }
+    // key generation with caller-supplied randomness (src/secretkey.cu:297-341) + on-disk formats
+    // (include/secretkey.h:129-163, include/ciphertext.h:173-214)
+    {
+        std::vector<uint64_t> sk(size_qp * n), e(dnum * size_qp * n), a;
+        for (size_t k = 0; k < n; k++) {
+            const int v = static_cast<int>(g() % 3) - 1;
+            for (size_t j = 0; j < size_qp; j++) sk[j * n + k] = v < 0 ? qp[j] - 1 : static_cast<uint64_t>(v);
+        }
+        for (size_t d = 0; d < dnum; d++) {
+            auto part = uniform(g, qp, n);
+            a.insert(a.end(), part.begin(), part.end());
+            for (size_t k = 0; k < n; k++) {
+                const int v = static_cast<int>(g() % 7) - 3;
+                for (size_t j = 0; j < size_qp; j++)
+                    e[(d * size_qp + j) * n + k] = v < 0 ? qp[j] - static_cast<uint64_t>(-v) : static_cast<uint64_t>(v);
+            }
+        }
+        orc_nwt_forward(oc, sk.data(), size_qp, 0);
+        std::vector<uint64_t> s2(size_q * n), e_ntt = e, ref(dnum * 2 * size_qp * n);
+        orc_multiply_rns_poly(oc, sk.data(), sk.data(), s2.data(), size_q, 0);
+        for (size_t d = 0; d < dnum; d++) orc_nwt_forward(oc, e_ntt.data() + d * size_qp * n, size_qp, 0);
+        orc_gen_kswitch_key(oc, sk.data(), s2.data(), a.data(), e_ntt.data(), ref.data());
+        const auto &st = cudaStreamPerThread;
+        auto up = [&](const std::vector<uint64_t> &h) {
+            auto d = util::make_cuda_auto_ptr<uint64_t>(h.size(), st);
+            util::check_hip(hipMemcpyAsync(d.get(), h.data(), h.size() * 8, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+            return d;
+        };
+        auto d_sk = up(sk), d_s2 = up(s2), d_a = up(a), d_e = up(e);
+        PhantomRelinKey gen;
+        gen.generate(context, d_sk.get(), d_s2.get(), d_a.get(), d_e.get());
+        REQUIRE(gen.generated() && gen.dnum() == dnum);
+        std::vector<uint64_t> got(2 * size_qp * n);
+        for (size_t d = 0; d < dnum; d++) {
+            gen.public_key(d).store_to_host(got.data());
+            REQUIRE(std::memcmp(got.data(), ref.data() + d * 2 * size_qp * n, got.size() * 8) == 0);
+        }
+        std::stringstream file;
+        gen.save(file);
+        const size_t header = 4 * sizeof(size_t) + sizeof(double) + sizeof(uint64_t) + sizeof(size_t) + 2 * sizeof(bool);
+        REQUIRE(file.str().size() == sizeof(size_t) + dnum * (header + 2 * size_qp * n * 8));
+        {
+            size_t w[5];
+            std::memcpy(w, file.str().data(), sizeof(w));   // dnum | chain_index, size, degree, limbs of key 0
+            REQUIRE(w[0] == dnum && w[1] == 0 && w[2] == 2 && w[3] == n && w[4] == size_qp);
+        }
+        PhantomRelinKey back;
+        back.load(file);
+        for (size_t d = 0; d < dnum; d++) {
+            back.public_key(d).store_to_host(got.data());
+            REQUIRE(std::memcmp(got.data(), ref.data() + d * 2 * size_qp * n, got.size() * 8) == 0);
+        }
+        // the reloaded key relinearizes like the oracle's copy of it
+        std::vector<const uint64_t *> ptrs;
+        for (size_t d = 0; d < dnum; d++) ptrs.push_back(ref.data() + d * 2 * size_qp * n);
+        PhantomCiphertext p3 = multiply(context, ct1, ct2);
+        relinearize_inplace(context, p3, back);
+        std::vector<uint64_t> r2(ref3.begin(), ref3.begin() + 2 * ln), out(2 * ln);
+        orc_keyswitch_inplace(tool, r2.data(), ref3.data() + 2 * ln, ptrs.data(), ORC_CKKS);
+        p3.store_to_host(out.data());
+        REQUIRE(out == r2);
+        std::stringstream cfile;
+        p3.save(cfile);
+        PhantomCiphertext p4;
+        p4.load(cfile);
+        REQUIRE(p4.chain_index() == 1 && p4.size() == 2 && p4.scale() == p3.scale() && p4.is_ntt_form());
+        p4.store_to_host(out.data());
+        REQUIRE(out == r2);
+        std::stringstream bad("xx");
+        REQUIRE(throws_invalid([&] { PhantomRelinKey k; k.load(bad); }));
+    }
+
     // BGV: multiply -> relinearize -> mod_switch_to_next (examples/2_bgv.cu flow) with plain modulus 65537
     {
         EncryptionParameters bp(scheme_type::bgv);

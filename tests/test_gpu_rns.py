@@ -239,3 +239,100 @@ def test_hommul_relin_rescale_c3(gpu):
     dst = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
     ctx.divide_and_round_q_last_ntt(ql, buf[:2].contiguous(), 2, dst)                 # rescale_to_next
     assert np.array_equal(P.to_host(dst), tool.rescale_ntt(ref2, 2))
+
+
+def _ternary_sk(oc, rng, primes, n):
+    s_small = rng.integers(-1, 2, n)
+    sk = np.stack([(s_small % int(q)).astype(np.uint64) for q in primes])
+    return oc.nwt_forward(sk, len(primes), 0)
+
+
+def _noise(rng, primes, n, count):
+    e_small = rng.integers(-3, 4, (count, n))
+    return np.stack([np.stack([(e_small[d] % int(q)).astype(np.uint64) for q in primes]) for d in range(count)])
+
+
+@pytest.mark.parametrize("name,scheme", [("hyb12_a2", O.CKKS), ("hyb12_a2", O.BGV), ("hyb13_a3", O.CKKS),
+                                         ("c1_bfv4096", O.BFV)])
+def test_generate_one_kswitch_key(name, scheme, gpu):
+    """generate_one_kswitch_key (src/secretkey.cu:297-341) with caller-supplied randomness vs the oracle."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    dnum = size_q // size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(80)
+    sk_ntt = _ternary_sk(oc, r, primes, n)
+    new_key = oc.multiply(sk_ntt[:size_q], sk_ntt[:size_q], size_q)
+    a = np.stack([uniform_poly(r, primes, n) for _ in range(dnum)])
+    e = _noise(r, primes, n, dnum)
+    e_ref = e
+    if scheme == O.BGV:
+        ctx.set_plain_modulus(BGV_T)
+        e_ref = np.stack([np.stack([(e[d, j].astype(object) * BGV_T % int(q)).astype(np.uint64)
+                                    for j, q in enumerate(primes)]) for d in range(dnum)])
+    e_ntt = np.stack([oc.nwt_forward(e_ref[d], len(primes), 0) for d in range(dnum)])
+    ref = oc.gen_kswitch_key(sk_ntt, new_key, a, e_ntt)
+    rlk = ctx.generate_one_kswitch_key(P.to_device(sk_ntt, gpu), P.to_device(new_key, gpu), P.to_device(a, gpu),
+                                       P.to_device(e, gpu), scheme)
+    for d in range(dnum):
+        assert np.array_equal(P.to_host(rlk.public_keys[d]), ref[d]), f"digit {d}"
+
+
+def test_c3_hommul_decrypts_with_generated_keys(gpu):
+    """SURVEY 8(0) C3 criterion: with keys generated by the build itself, HomMul -> relinearize -> rescale
+    of two genuine encryptions decrypts to m1*m2/q_last (negacyclic product) up to noise, at N=2^16, 45 limbs."""
+    import phantom_fhe_amd as P
+    from util import crt_compose
+    name = "c3_ckks16"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    ql, dnum = size_q, size_q // size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(90)
+    sk_ntt = _ternary_sk(oc, r, primes, n)
+    d_sk = P.to_device(sk_ntt, gpu)
+    d_s2 = P.to_device(np.zeros((size_q, n), dtype=np.uint64), gpu)
+    ctx.multiply_rns_poly(d_sk, d_sk, d_s2, size_q)
+    a = np.stack([uniform_poly(r, primes, n) for _ in range(dnum)])
+    rlk = ctx.generate_one_kswitch_key(d_sk, d_s2, P.to_device(a, gpu), P.to_device(_noise(r, primes, n, dnum), gpu),
+                                       O.CKKS)
+    q = primes[:ql]
+
+    def encrypt(m_small):
+        m = np.stack([(m_small % int(p)).astype(np.uint64) for p in q])
+        c1 = uniform_poly(r, q, n)
+        e = _noise(r, q, n, 1)[0]
+        me_ntt = oc.nwt_forward(oc.add(m, e, ql), ql, 0)
+        c0 = oc.sub(me_ntt, oc.multiply(c1, sk_ntt[:ql], ql), ql)       # c0 = m + e - c1*s
+        return np.stack([c0, c1]), oc.nwt_forward(m, ql, 0)
+
+    m1 = r.integers(-(1 << 30), 1 << 30, n)
+    m2 = r.integers(-(1 << 30), 1 << 30, n)
+    ct1, m1_ntt = encrypt(m1)
+    ct2, m2_ntt = encrypt(m2)
+    buf = P.to_device(np.concatenate([ct1, np.zeros((1, ql, n), dtype=np.uint64)]), gpu)
+    ctx.tensor_prod_2x2_rns_poly(buf, P.to_device(ct2, gpu), buf, ql)
+    ctx.keyswitch_inplace(ql, buf[:2], buf[2], rlk.public_keys_ptr, O.CKKS)
+    out = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+    ctx.divide_and_round_q_last_ntt(ql, buf[:2].contiguous(), 2, out)
+    res = P.to_host(out)
+    nl = ql - 1
+    phase = oc.nwt_backward(oc.add(res[0], oc.multiply(res[1], sk_ntt[:nl], nl), nl), nl)
+    prod = oc.nwt_backward(oc.multiply(m1_ntt, m2_ntt, ql), ql)          # exact m1*m2 mod (X^N+1), in RNS
+    Q, Qn = 1, 1
+    for p in q:
+        Q *= int(p)
+    for p in q[:nl]:
+        Qn *= int(p)
+    q_last = int(q[nl])
+    worst = 0
+    for k in range(0, n, 1021):
+        want, _ = crt_compose([prod[l, k] for l in range(ql)], q)
+        want = want - Q if want > Q // 2 else want
+        got, _ = crt_compose([phase[l, k] for l in range(nl)], q[:nl])
+        got = got - Qn if got > Qn // 2 else got
+        worst = max(worst, abs(got - want // q_last))
+    assert worst < 1 << 30, worst.bit_length()       # signal is ~2^36..2^38; fresh-noise x message terms ~2^22
