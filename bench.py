@@ -90,6 +90,8 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     import phantom_fhe_amd as P
+    if os.environ.get("PHA_NTT_VARIANT"):   # A/B experiments only (pha_set_tuning key 0); results never change
+        P.set_tuning(0, int(os.environ["PHA_NTT_VARIANT"]))
     n = 1 << LOG_N
     primes = [int(p) for p in P.coeff_modulus_create(n, BITS)]
     size_q = len(primes) - SIZE_P

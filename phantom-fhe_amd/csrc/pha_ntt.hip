@@ -13,8 +13,8 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles
-std::atomic<int> g_ntt_variant{1 | 32};  // default: 8 coefficients per thread, per-round twiddle loads (best at 45 limbs, r01b)
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4)
+std::atomic<int> g_ntt_variant{1 | 32 | 64};  // default: 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_wg_times[2048];
@@ -81,8 +81,13 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
     a.aux = (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) ? k.aux + (size_t)twr * n : nullptr;
 }
 
+#if defined(PHA_PASS_OCC)
+#define PHA_PASS_ATTR __attribute__((amdgpu_waves_per_eu(PHA_PASS_OCC, PHA_PASS_OCC)))
+#else
+#define PHA_PASS_ATTR
+#endif
 template <class C, bool FWD, int EPI, bool FOLD, int HOIST>
-__global__ __launch_bounds__(C::THREADS) void ntt_pass_kernel(const NttKArgs k) {
+__global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(const NttKArgs k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *lds = reinterpret_cast<u64 *>(smem);
 
@@ -142,7 +147,7 @@ template <class C, bool FWD, int EPI, bool FOLD>
 static void launch_pass(const NttKArgs &k, hipStream_t s) {
     const size_t n = (size_t)1 << k.log_n;
     const size_t lds_bytes = (size_t)C::LDS_WORDS * sizeof(u64);
-    const unsigned tiles_per_limb = (unsigned)(n / kTileElems);
+    const unsigned tiles_per_limb = (unsigned)(n >> C::LOGTILE);
     const unsigned total = k.active * tiles_per_limb;
     // (a persistent software-pipelined form and twiddle-prefetch policies were measured and dropped:
     //  DESIGN.md section 7)
@@ -244,14 +249,15 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
     // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
-    const int v = ((vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024)) ? 2 : (vv & 1);
+    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
+    const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
     switch (c.log_n) {
-        case 12: if (v == 2) forward_impl<12, 2>(k, epi, s); else if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
-        case 13: if (v == 2) forward_impl<13, 2>(k, epi, s); else if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
-        case 14: if (v == 2) forward_impl<14, 2>(k, epi, s); else if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
-        case 15: if (v == 2) forward_impl<15, 2>(k, epi, s); else if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
-        case 16: if (v == 2) forward_impl<16, 2>(k, epi, s); else if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
-        case 17: if (v == 2) forward_impl<17, 2>(k, epi, s); else if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
+        case 12: if (v == 4) forward_impl<12, 4>(k, epi, s); else if (v == 3) forward_impl<12, 3>(k, epi, s); else if (v == 2) forward_impl<12, 2>(k, epi, s); else if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
+        case 13: if (v == 4) forward_impl<13, 4>(k, epi, s); else if (v == 3) forward_impl<13, 3>(k, epi, s); else if (v == 2) forward_impl<13, 2>(k, epi, s); else if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
+        case 14: if (v == 4) forward_impl<14, 4>(k, epi, s); else if (v == 3) forward_impl<14, 3>(k, epi, s); else if (v == 2) forward_impl<14, 2>(k, epi, s); else if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
+        case 15: if (v == 4) forward_impl<15, 4>(k, epi, s); else if (v == 3) forward_impl<15, 3>(k, epi, s); else if (v == 2) forward_impl<15, 2>(k, epi, s); else if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
+        case 16: if (v == 4) forward_impl<16, 4>(k, epi, s); else if (v == 3) forward_impl<16, 3>(k, epi, s); else if (v == 2) forward_impl<16, 2>(k, epi, s); else if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
+        case 17: if (v == 4) forward_impl<17, 4>(k, epi, s); else if (v == 3) forward_impl<17, 3>(k, epi, s); else if (v == 2) forward_impl<17, 2>(k, epi, s); else if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -265,14 +271,15 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
     // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
-    const int v = ((vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024)) ? 2 : (vv & 1);
+    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
+    const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
     switch (c.log_n) {
-        case 12: if (v == 2) inverse_impl<12, 2>(k, epi, s); else if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
-        case 13: if (v == 2) inverse_impl<13, 2>(k, epi, s); else if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
-        case 14: if (v == 2) inverse_impl<14, 2>(k, epi, s); else if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
-        case 15: if (v == 2) inverse_impl<15, 2>(k, epi, s); else if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
-        case 16: if (v == 2) inverse_impl<16, 2>(k, epi, s); else if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
-        case 17: if (v == 2) inverse_impl<17, 2>(k, epi, s); else if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
+        case 12: if (v == 4) inverse_impl<12, 4>(k, epi, s); else if (v == 3) inverse_impl<12, 3>(k, epi, s); else if (v == 2) inverse_impl<12, 2>(k, epi, s); else if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
+        case 13: if (v == 4) inverse_impl<13, 4>(k, epi, s); else if (v == 3) inverse_impl<13, 3>(k, epi, s); else if (v == 2) inverse_impl<13, 2>(k, epi, s); else if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
+        case 14: if (v == 4) inverse_impl<14, 4>(k, epi, s); else if (v == 3) inverse_impl<14, 3>(k, epi, s); else if (v == 2) inverse_impl<14, 2>(k, epi, s); else if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
+        case 15: if (v == 4) inverse_impl<15, 4>(k, epi, s); else if (v == 3) inverse_impl<15, 3>(k, epi, s); else if (v == 2) inverse_impl<15, 2>(k, epi, s); else if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
+        case 16: if (v == 4) inverse_impl<16, 4>(k, epi, s); else if (v == 3) inverse_impl<16, 3>(k, epi, s); else if (v == 2) inverse_impl<16, 2>(k, epi, s); else if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
+        case 17: if (v == 4) inverse_impl<17, 4>(k, epi, s); else if (v == 3) inverse_impl<17, 3>(k, epi, s); else if (v == 2) inverse_impl<17, 2>(k, epi, s); else if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -413,7 +420,7 @@ int pha_exp_read_wg_times(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 63 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 127 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

@@ -47,20 +47,27 @@ enum Epilogue {
 // i.e. one per-row factor and one entry of the first T2/2 table slots shared by every row; the
 // butterfly multiplies by the two factors in turn.  Costs one extra modular multiply per butterfly in
 // that round, removes most of the twiddle traffic of the memory-bound contiguous pass.
-template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16, bool OT_ = false>
+// LOGTILE_: log2 of the coefficients one workgroup owns.  12 = the 4096-coefficient tile (32 KiB of LDS).
+// A contiguous pass may use 9: 512 coefficients = 64 threads x 8, i.e. one wavefront per workgroup that owns
+// whole rows, so the exchanges between rounds stay inside the wavefront and its barriers compile away.
+template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16, bool OT_ = false, int LOGTILE_ = 12>
 struct PassCfg {
     static constexpr int EPT = EPT_;
     static constexpr bool OT = OT_ && !STRIDED_;
-    static constexpr int THREADS = kTileElems / EPT_;
+    static constexpr int LOGTILE = LOGTILE_;
+    static constexpr int TILE = 1 << LOGTILE_;
+    static constexpr int THREADS = TILE / EPT_;
+    static_assert(LOGTILE_ >= LOGT_ && LOGTILE_ <= 12, "a tile holds whole transforms and fits the LDS budget");
     static_assert((1 << R0_) <= EPT_ && (1 << R1_) <= EPT_ && (1 << R2_) <= EPT_, "radix exceeds registers");
     static constexpr int LOGT = LOGT_;
     static constexpr int T = 1 << LOGT_;
-    static constexpr int LOGV = 12 - LOGT_;  // tile = 4096 elements
+    static constexpr int LOGV = LOGTILE_ - LOGT_;
     static constexpr int V = 1 << LOGV;
     static constexpr bool STRIDED = STRIDED_;
     static constexpr int NR = R2_ ? 3 : 2;
     static_assert(R0_ + R1_ + R2_ == LOGT_, "round schedule must cover all stages");
     static_assert(LOGT_ >= 4 && LOGT_ <= 12, "tile transform length out of range");
+    static_assert(THREADS >= 64, "a workgroup is at least one wavefront");
     static constexpr int r(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : R2_; }
     // twiddle registers per thread: round i holds G_i groups x (2^r_i - 1) pairs
     static constexpr bool ot_round(int i) { return OT && i == NR - 1; }
@@ -536,5 +543,19 @@ template <> struct NttPlan<14, 2> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  us
 template <> struct NttPlan<15, 2> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true>; };
 template <> struct NttPlan<16, 2> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true>; };
 template <> struct NttPlan<17, 2> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, true>; };
+// VARIANT 3: variant 1 with one-wavefront workgroups (512-coefficient tiles) in the contiguous pass
+template <> struct NttPlan<12, 3> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<6, false, 3, 3, 0, 8, false, 9>; };
+template <> struct NttPlan<13, 3> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8, false, 9>; };
+template <> struct NttPlan<14, 3> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8, false, 9>; };
+template <> struct NttPlan<15, 3> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, false, 9>; };
+template <> struct NttPlan<16, 3> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, false, 9>; };
+template <> struct NttPlan<17, 3> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, false, 9>; };
+// VARIANT 4: variant 2 (on-the-fly twiddles) with one-wavefront workgroups in the contiguous pass
+template <> struct NttPlan<12, 4> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<6, false, 3, 3, 0, 8, true, 9>; };
+template <> struct NttPlan<13, 4> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8, true, 9>; };
+template <> struct NttPlan<14, 4> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<7, false, 3, 2, 2, 8, true, 9>; };
+template <> struct NttPlan<15, 4> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true, 9>; };
+template <> struct NttPlan<16, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true, 9>; };
+template <> struct NttPlan<17, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, true, 9>; };
 
 }  // namespace pha

@@ -29,7 +29,7 @@ template <class C, bool FWD, int EPI, bool FOLD>
 static void run_pass(PassArgs a, size_t n) {
     std::vector<u64> lds(C::LDS_WORDS);
     static u64 regs[512][16];
-    const u32 tiles = (u32)(n / kTileElems);
+    const u32 tiles = (u32)(n >> C::LOGTILE);
     for (u32 t = 0; t < tiles; t++) {
         a.tile = t;
         run_segments<PassProgram<C, FWD, EPI, FOLD, 2>, 0>(a, lds.data(), regs);
@@ -71,7 +71,7 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
     const u64 *ax = reinterpret_cast<const u64 *>(aux);
     const int log_n = log_n_and_variant & 0xff, variant = (log_n_and_variant >> 8) & 0xff;
     const bool fp = (log_n_and_variant >> 16) & 1;
-#define EMU_CASE(N) case N: if (variant == 2) emu<N, 2>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;
+#define EMU_CASE(N) case N: if (variant == 4) emu<N, 4>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 3) emu<N, 3>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 2) emu<N, 2>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;
     switch (log_n) {
         EMU_CASE(12)
         EMU_CASE(13)

@@ -34,7 +34,7 @@ def pair(v, q):
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("bits", [40, 50, 60, 61])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_thread_program_matches_oracle(emu, log_n, bits, variant):
     n = 1 << log_n
     code = log_n | (variant << 8)   # variant 1 = 8 coefficients per thread (512-thread workgroups); 2 = 1 + on-the-fly twiddles

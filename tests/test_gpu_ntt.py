@@ -39,13 +39,13 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
     assert np.array_equal(P.to_host(d2), oc.nwt_backward(x, L, 0))
 
 
-@pytest.fixture(params=[0, 1, 8, 9, 17, 25], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int"])
+@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave"])
 def ntt_variant(request):
     """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
     import phantom_fhe_amd as P
     P.set_tuning(0, request.param)
     yield request.param
-    P.set_tuning(0, 1 | 32)
+    P.set_tuning(0, 1 | 32 | 64)
 
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])

@@ -128,8 +128,62 @@ __global__ __launch_bounds__(256) void rw_kernel(uint4 *__restrict__ buf, size_t
     }
 }
 
+// Memory floor of the NTT's access patterns with the butterflies removed: one workgroup of 512 threads per
+// 4096-coefficient tile, 8 coefficients per thread, in-place read-modify-write of a [limbs][65536] buffer.
+// MODE 0: strided pass (tile = 16 adjacent columns x 256 rows of the 256x256 view, 8 B per lane)
+// MODE 1: contiguous pass, 8 B per lane (thread t touches t + 512 j)
+// MODE 2: contiguous pass, 16 B per lane (thread t touches the pairs 2t + 1024 j)
+template <int MODE>
+__global__ __launch_bounds__(512) void tile_rw_kernel(u64 *buf) {
+    u64 *limb = buf + (size_t)blockIdx.y * 65536;
+    const uint32_t t = threadIdx.x, tile = blockIdx.x;
+    u64 v[8];
+    if (MODE == 0) {
+        const uint32_t c = tile * 16 + (t & 15), r0 = t >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = limb[(r0 + 32 * j) * 256 + c];
+#pragma unroll
+        for (int j = 0; j < 8; j++) limb[(r0 + 32 * j) * 256 + c] = v[j] + 1;
+    } else if (MODE == 1) {
+        u64 *p = limb + tile * 4096 + t;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = p[512 * j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[512 * j] = v[j] + 1;
+    } else {
+        uint4 *p = reinterpret_cast<uint4 *>(limb + tile * 4096) + t;
+        uint4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = p[512 * j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { w[j].x += 1; p[512 * j] = w[j]; }
+    }
+}
+template <int MODE>
+static int run_tile(u64 *buf, int limbs, const char *name) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 50;
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL(tile_rw_kernel<MODE>, dim3(16, limbs), dim3(512), 0, 0, buf);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(tile_rw_kernel<MODE>, dim3(16, limbs), dim3(512), 0, 0, buf);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = 2.0 * limbs * 65536 * 8;
+    printf("tile pattern %-34s limbs %3d: %6.2f us/launch  %5.2f TB/s (r+w)\n", name, limbs, ms * 1000 / reps, bytes * reps / ms / 1e9);
+    return 0;
+}
+
 int main() {
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    if (getenv("MB_PATTERN")) {
+        u64 *buf; CK(hipMalloc(&buf, (size_t)180 * 65536 * 8)); CK(hipMemset(buf, 1, (size_t)180 * 65536 * 8));
+        for (int limbs : {45, 180}) {
+            run_tile<0>(buf, limbs, "strided, 8 B/lane");
+            run_tile<1>(buf, limbs, "contiguous, 8 B/lane");
+            run_tile<2>(buf, limbs, "contiguous, 16 B/lane");
+        }
+        return 0;
+    }
     const double clk = p.clockRate / 1e6;
     printf("device %s  CUs %d  clock %.2f GHz  L2 %d KiB\n", p.name, p.multiProcessorCount, clk, p.l2CacheSize / 1024);
     const int blocks = p.multiProcessorCount * 8;  // 8 blocks x 4 waves = 32 waves/CU = 8/SIMD
