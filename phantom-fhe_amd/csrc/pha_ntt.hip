@@ -123,12 +123,12 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
     Prog::load_twiddles(a, tid, twreg);
     Prog::template run<0>(a, lds, tid, reg, twreg);
     PHA_STAMP(1);
-    __syncthreads();
+    tile_sync<C>();
     PHA_STAMP(2);
     Prog::template run<1>(a, lds, tid, reg, twreg);
     PHA_STAMP(3);
     if constexpr (Prog::NSEG == 3) {
-        __syncthreads();
+        tile_sync<C>();
         PHA_STAMP(4);
         Prog::template run<2>(a, lds, tid, reg, twreg);
         PHA_STAMP(5);

@@ -50,6 +50,8 @@ enum Epilogue {
 // LOGTILE_: log2 of the coefficients one workgroup owns.  12 = the 4096-coefficient tile (32 KiB of LDS).
 // A contiguous pass may use 9: 512 coefficients = 64 threads x 8, i.e. one wavefront per workgroup that owns
 // whole rows, so the exchanges between rounds stay inside the wavefront and its barriers compile away.
+// (Splitting the STRIDED pass by columns between the wavefronts makes it barrier-free too; measured r01g:
+// 16-byte runs per row cost more than the barriers, 45 limbs 29.1 -> 34.1 us, so that form was dropped.)
 template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16, bool OT_ = false, int LOGTILE_ = 12>
 struct PassCfg {
     static constexpr int EPT = EPT_;
@@ -58,6 +60,8 @@ struct PassCfg {
     static constexpr int TILE = 1 << LOGTILE_;
     static constexpr int THREADS = TILE / EPT_;
     static_assert(LOGTILE_ >= LOGT_ && LOGTILE_ <= 12, "a tile holds whole transforms and fits the LDS budget");
+    // one wavefront per workgroup: every exchange between rounds stays inside it, no workgroup barrier
+    static constexpr bool WAVE_LOCAL = TILE / EPT_ == 64;
     static_assert((1 << R0_) <= EPT_ && (1 << R1_) <= EPT_ && (1 << R2_) <= EPT_, "radix exceeds registers");
     static constexpr int LOGT = LOGT_;
     static constexpr int T = 1 << LOGT_;
@@ -447,6 +451,21 @@ PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
 // HOIST: 0 = every round requests its own twiddles when it starts; 1 = all rounds up front (one exposed
 // memory latency per tile, most registers); 2 = one round ahead (round k+1's twiddles are requested when
 // round k starts, so their latency hides behind round k's butterflies and the barrier).
+// Hand-over between two rounds: a workgroup barrier, or -- when no wavefront reads another's LDS words --
+// only an ordering point for the compiler (LDS operations of one wavefront execute in order).
+template <class C>
+PHA_HD void tile_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (C::WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+#endif
+}
+
 template <class C, bool FWD, int EPI, bool FOLD, int HOIST = 1>
 struct PassProgram {
     static constexpr int NSEG = C::NR;

@@ -60,6 +60,53 @@ static void emu(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *
     }
 }
 
+// Wave-locality proof for the barrier-free configurations: over all rounds, every LDS word a thread touches
+// must belong to the words of its own wavefront (tid / 64) only.  Returns the number of violations.
+template <class C, int RI>
+static int check_round_owner(std::vector<int> &owner) {
+    constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r, s0 = C::s0(RI), LOGD = C::LOGT - s0 - r;
+    int bad = 0;
+    if constexpr (r > 0) {
+        for (int tid = 0; tid < C::THREADS; tid++)
+            for (int gi = 0; gi < G; gi++) {
+                int v, hi, lo;
+                decode_group<C, RI>(tid + C::THREADS * gi, v, hi, lo);
+                const int e0 = (hi << (LOGD + r)) + lo;
+                for (int k = 0; k < K; k++) {
+                    const int idx = C::lds_index(e0 + (k << LOGD), v);
+                    if (idx < 0 || idx >= C::LDS_WORDS) { bad++; continue; }
+                    if (owner[idx] < 0) owner[idx] = tid >> 6;
+                    else if (owner[idx] != (tid >> 6)) bad++;
+                }
+            }
+    }
+    return bad;
+}
+template <class C>
+static int check_wave_local() {
+    if (!C::WAVE_LOCAL) return 0;
+    std::vector<int> owner(C::LDS_WORDS, -1);
+    int bad = check_round_owner<C, 0>(owner) + check_round_owner<C, 1>(owner);
+    if constexpr (C::NR == 3) bad += check_round_owner<C, 2>(owner);
+    int used = 0;
+    for (int o : owner) used += o >= 0;
+    if (used != C::TILE) bad += 1000000;   // every coefficient of the tile has exactly one slot
+    return bad;
+}
+template <int LOGN, int VARIANT>
+static int check_plan() {
+    return check_wave_local<typename NttPlan<LOGN, VARIANT>::P1>() + check_wave_local<typename NttPlan<LOGN, VARIANT>::P2>();
+}
+extern "C" int emu_check_wave_local(int log_n, int variant) {
+#define CHK(N) case N: return variant == 4 ? check_plan<N, 4>() : variant == 3 ? check_plan<N, 3>() : 0;
+    switch (log_n) { CHK(12) CHK(13) CHK(14) CHK(15) CHK(16) CHK(17) default: return -1; }
+}
+extern "C" int emu_plan_is_wave_local(int log_n, int variant) {   // bit 0: pass 1, bit 1: pass 2
+#define WL(N, V) ((NttPlan<N, V>::P1::WAVE_LOCAL ? 1 : 0) | (NttPlan<N, V>::P2::WAVE_LOCAL ? 2 : 0))
+#define WLC(N) case N: return variant == 4 ? WL(N, 4) : variant == 3 ? WL(N, 3) : variant == 2 ? WL(N, 2) : variant == 1 ? WL(N, 1) : WL(N, 0);
+    switch (log_n) { WLC(12) WLC(13) WLC(14) WLC(15) WLC(16) WLC(17) default: return -1; }
+}
+
 // bit 16 of log_n_and_variant: FP64 path (tw / ninv / w1ninv then carry (W, W/q) double bit patterns)
 extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *in, uint64_t *out, uint64_t q,
                        const uint64_t *tw_interleaved, const uint64_t *ninv, const uint64_t *w1ninv,

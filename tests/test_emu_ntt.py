@@ -89,3 +89,12 @@ def test_thread_program_matches_oracle(emu, log_n, bits, variant):
         assert emu.emu_ntt(code, 1, 2, p(x), p(out), q, p(twi), p(z), p(z), p(pair(s, q)), p(cx)) == 0
         want = c.multiply_scalar(c.sub(cx.reshape(1, n), ref.reshape(1, n), 1), np.array([s], dtype=np.uint64), 1)[0]
         assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
+def test_barrier_free_plans_are_wave_local(emu, log_n):
+    """The plans whose rounds hand over without a workgroup barrier (one-wavefront contiguous tiles) may only do so if no wavefront touches another wavefront's LDS words in any round."""
+    assert emu.emu_plan_is_wave_local(log_n, 1) == 0           # the barrier plans do not claim it
+    assert emu.emu_plan_is_wave_local(log_n, 3) == 2 and emu.emu_plan_is_wave_local(log_n, 4) == 2
+    for variant in (3, 4):
+        assert emu.emu_check_wave_local(log_n, variant) == 0

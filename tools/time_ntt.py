@@ -7,7 +7,7 @@ import torch
 import phantom_fhe_amd as P
 from util import primes_of, rng_for, uniform_poly
 
-CASES = [("c3_ckks16", 45), ("c3_ckks16", 60), ("c3_ckks16", 180)]
+CASES = [("c2_ntt14", 8), ("c4_bfv15", 30), ("c3_ckks16", 1), ("c3_ckks16", 45), ("c3_ckks16", 60)]
 ctxs = {}
 for name, limbs in CASES:
     log_n, primes, size_p = primes_of(name)
