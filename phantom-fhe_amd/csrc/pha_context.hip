@@ -354,6 +354,15 @@ Tool &Context::tool(uint32_t size_ql) {
         for (uint32_t i = 0; i < size_p; i++) ip.push_back(size_q + i);
         for (uint32_t i = 0; i < size_ql; i++) op.push_back(i);
         build_bconv(*this, t->p_to_ql, ip, op);
+        {   // the P -> Ql converter's phase-1 factors, addressable by the limb index of a [Ql || P] buffer
+            std::vector<u64x2> hi(size_p);
+            PHA_HIP(hipMemcpy(hi.data(), t->p_to_ql.hat_inv.p, size_p * sizeof(u64x2), hipMemcpyDeviceToHost));
+            std::vector<u64> v(t->size_qlp, 1), vs(t->size_qlp);
+            for (uint32_t i = 0; i < t->size_qlp; i++) vs[i] = h_shoup(1, primes[t->qlp_prime[i]]);
+            for (uint32_t i = 0; i < size_p; i++) { v[size_ql + i] = hi[i].x; vs[size_ql + i] = hi[i].y; }
+            t->p_hat_inv_by_limb.upload(v);
+            t->p_hat_inv_by_limb_shoup.upload(vs);
+        }
         // device descriptors for the batched launches
         auto describe = [](const BConv &b, uint32_t pad_start, uint32_t pad_len, uint32_t src_limb, uint32_t copy_own) {
             return BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.isz, b.osz,

@@ -111,6 +111,7 @@ struct Tool {
     DevBuf<u64> inv_q_last, inv_q_last_shoup;      // rns.cu:66-80
     DevBuf<u64x2> inv_q_last2;                     // same, interleaved
     DevBuf<u64x2> pinv2;
+    DevBuf<u64> p_hat_inv_by_limb, p_hat_inv_by_limb_shoup;  // [QlP]: phat_i^-1 mod p_i at limb Ql + i, 1 elsewhere
     // plain-modulus constants of the BGV branches (rns.cu:196-285); built when the context has a plain modulus
     bool bgv_ready = false;
     DModulus t_mod{};

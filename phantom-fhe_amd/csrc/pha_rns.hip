@@ -26,7 +26,7 @@ void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, si
 std::atomic<int> g_bconv_split{1};
 
 constexpr int kBcThreads = 256;
-constexpr int kBcOutPerBlock = 8;
+constexpr int kBcOutPerBlock = 16;  // output primes per workgroup: inputs are re-read ceil(osz / 16) times
 
 struct BConvLaunch {
     const BConvDev *convs;       // device array
@@ -53,14 +53,14 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     const uint32_t isz = d.isz;
     const uint32_t j0 = blockIdx.y * kBcOutPerBlock;
     const uint32_t j1 = min(j0 + kBcOutPerBlock, d.osz);
-    // SPLIT: this block's kBcOutPerBlock matrix rows (8 x 16 x 2 dwords = one dword per thread) go through
+    // SPLIT: this block's kBcOutPerBlock matrix rows (16 x 16 x 2 dwords = two dwords per thread) go through
     // LDS once; the MAC loop then reads them as broadcast ds_read_b64 instead of stalling on scalar loads
     __shared__ uint2 s_rows[kBcOutPerBlock * kBcRowPad];
     if (SPLIT) {
-        static_assert(kBcOutPerBlock * kBcRowPad * 2 == kBcThreads, "one dword per thread");
-        const size_t base = (size_t)j0 * kBcRowPad * 2 + threadIdx.x;
-        const uint32_t limit = d.osz * kBcRowPad * 2;
-        reinterpret_cast<uint32_t *>(s_rows)[threadIdx.x] = base < limit ? d.mat30[base] : 0u;
+        static_assert(kBcOutPerBlock * kBcRowPad == kBcThreads, "one matrix entry (two dwords) per thread");
+        const size_t base = (size_t)j0 * kBcRowPad + threadIdx.x;
+        const uint32_t limit = d.osz * kBcRowPad;
+        s_rows[threadIdx.x] = base < limit ? reinterpret_cast<const uint2 *>(d.mat30)[base] : uint2{0u, 0u};
         __syncthreads();
     }
     if (j0 >= d.osz) return;  // (after the barrier) nothing to produce for this group
@@ -170,6 +170,7 @@ static void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, 
     if (max_isz <= 2) PHA_BC(2);
     else if (max_isz <= 4) PHA_BC(4);
     else if (max_isz <= 8) PHA_BC(8);
+    else if (max_isz == 15) PHA_BC(15);  // alpha = 15 (C3 / C4): no padded sixteenth term
     else if (max_isz <= 16) PHA_BC(16);
     else if (scale_in) hipLaunchKernelGGL((bconv_wide_kernel<true>), grid, block, 0, s, L);
     else hipLaunchKernelGGL((bconv_wide_kernel<false>), grid, block, 0, s, L);
@@ -519,7 +520,14 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
     NttExtra xb;
     xb.batch = polys;
     xb.poly_stride = cx_stride;
-    if (scheme == PHA_SCHEME_CKKS)
+    // ckks, alpha > 1: bconv phase 1 (x phat_i^-1 mod p_i, bconv_mult_kernel rns_bconv.cu:22-33) rides on the
+    // inverse NTT's last round, exactly as mod-up does (:558-559); the conversion then skips its own scaling
+    const bool prescaled = scheme == PHA_SCHEME_CKKS && t.alpha > 1;
+    if (prescaled) {
+        xb.scale = t.p_hat_inv_by_limb.p;
+        xb.scale_shoup = t.p_hat_inv_by_limb_shoup.p;
+        ntt_inverse(c, cx, cx, cx, special_sel(ql, c.size_p, c.size_qp, c.size_p), EPI_INV_SCALE, xb, s);
+    } else if (scheme == PHA_SCHEME_CKKS)
         ntt_inverse(c, cx, cx, cx, special_sel(ql, c.size_p, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
     else if (scheme == PHA_SCHEME_BFV || scheme == PHA_SCHEME_BGV)
         ntt_inverse(c, cx, cx, cx, special_sel(0, qlp, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
@@ -537,7 +545,7 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         }
     } else {
         launch_bconv(c, t.d_p_to_ql_conv.p, 0, polys, t.alpha, ql, t.split_ok, delta, d_stride, cx, cx_stride,
-                     nullptr, true, s);
+                     nullptr, !prescaled, s);
     }
     if (scheme == PHA_SCHEME_BGV) {
         // [cx_P]_t lands in the first P limb of each polynomial, then the t-corrected division and the NTT
