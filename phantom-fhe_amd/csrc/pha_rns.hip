@@ -26,7 +26,7 @@ void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, si
 std::atomic<int> g_bconv_split{1};
 
 constexpr int kBcThreads = 256;
-constexpr int kBcOutPerBlock = 16;  // output primes per workgroup: inputs are re-read ceil(osz / 16) times
+constexpr int kBcMaxOutPerBlock = 24;  // output primes per workgroup (upper bound; the launch balances the groups)
 
 struct BConvLaunch {
     const BConvDev *convs;       // device array
@@ -37,6 +37,7 @@ struct BConvLaunch {
     size_t dst_stride, src_stride;
     const DModulus *mod;
     uint32_t n;
+    uint32_t out_per_block;      // output primes per workgroup (<= kBcMaxOutPerBlock)
 };
 
 // bconv_mult (+) bconv_matmul (src/rns_bconv.cu:22-60,109-170; padded variant :455-485).
@@ -51,16 +52,17 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)d.src_limb * n;
     u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
     const uint32_t isz = d.isz;
-    const uint32_t j0 = blockIdx.y * kBcOutPerBlock;
-    const uint32_t j1 = min(j0 + kBcOutPerBlock, d.osz);
-    // SPLIT: this block's kBcOutPerBlock matrix rows (16 x 16 x 2 dwords = two dwords per thread) go through
-    // LDS once; the MAC loop then reads them as broadcast ds_read_b64 instead of stalling on scalar loads
-    __shared__ uint2 s_rows[kBcOutPerBlock * kBcRowPad];
+    const uint32_t j0 = blockIdx.y * L.out_per_block;
+    const uint32_t j1 = min(j0 + L.out_per_block, d.osz);
+    // SPLIT: this block's matrix rows (out_per_block x 16 entries of two dwords) go through LDS once; the MAC
+    // loop then reads them as broadcast ds_read_b64 instead of stalling on scalar loads
+    __shared__ uint2 s_rows[kBcMaxOutPerBlock * kBcRowPad];
     if (SPLIT) {
-        static_assert(kBcOutPerBlock * kBcRowPad == kBcThreads, "one matrix entry (two dwords) per thread");
-        const size_t base = (size_t)j0 * kBcRowPad + threadIdx.x;
         const uint32_t limit = d.osz * kBcRowPad;
-        s_rows[threadIdx.x] = base < limit ? reinterpret_cast<const uint2 *>(d.mat30)[base] : uint2{0u, 0u};
+        for (uint32_t e = threadIdx.x; e < L.out_per_block * kBcRowPad; e += kBcThreads) {
+            const uint32_t base = j0 * kBcRowPad + e;
+            s_rows[e] = base < limit ? reinterpret_cast<const uint2 *>(d.mat30)[base] : uint2{0u, 0u};
+        }
         __syncthreads();
     }
     if (j0 >= d.osz) return;  // (after the barrier) nothing to produce for this group
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
         for (uint32_t i = 0; i < d.isz; i++)
             dst[(size_t)(d.src_limb + i) * n + coeff] = L.own[(size_t)(d.src_limb + i) * n + coeff];
     }
-    const uint32_t j0 = blockIdx.y * kBcOutPerBlock;
-    const uint32_t j1 = min(j0 + kBcOutPerBlock, d.osz);
+    const uint32_t j0 = blockIdx.y * L.out_per_block;
+    const uint32_t j1 = min(j0 + L.out_per_block, d.osz);
     for (uint32_t j = j0; j < j1; j++) {
         const DModulus m = L.mod[d.oprime[j]];
         const u64 *row = d.mat + (size_t)j * d.isz;
@@ -157,7 +159,10 @@ static void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, 
     BConvLaunch L{};
     L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;
     L.dst_stride = dst_stride; L.src_stride = src_stride; L.mod = c.d_mod.p; L.n = (uint32_t)c.n;
-    dim3 grid((unsigned)(c.n / kBcThreads), (max_osz + kBcOutPerBlock - 1) / kBcOutPerBlock, batch);
+    // balanced output groups: 45 outputs -> 2 groups of 23 (6 wavefronts per SIMD at C3 mod-up: one resident round)
+    const uint32_t groups = (max_osz + kBcMaxOutPerBlock - 1) / kBcMaxOutPerBlock;
+    L.out_per_block = (max_osz + groups - 1) / groups;
+    dim3 grid((unsigned)(c.n / kBcThreads), groups, batch);
     dim3 block(kBcThreads);
     const bool split = split_ok && g_bconv_split.load(std::memory_order_relaxed);
 #define PHA_BC(P)                                                                                        \
