@@ -194,6 +194,8 @@ struct NttExtra {
     uint32_t batch = 1;                                  // polynomials per launch (blockIdx.z)
     size_t poly_stride = 0;                              // elements between consecutive polynomials of in / mid
     size_t out_stride = 0, aux_stride = 0;               // same for out and aux (0 = poly_stride)
+    const u64 *pro_src = nullptr;                        // forward only: every limb of polynomial z transforms
+    size_t pro_stride = 0;                               //   (pro_src + z * pro_stride) mod its own prime; `in` unused
     uint32_t excl_step = 0;                              // polynomial z skips [excl_start + z*step, min(+len, limit))
     uint32_t excl_limit = 0xffffffffu;
 };

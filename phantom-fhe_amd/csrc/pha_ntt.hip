@@ -43,6 +43,8 @@ struct NttKArgs {
     uint32_t batch;          // polynomials per launch (blockIdx.z)
     size_t poly_stride, out_stride, aux_stride;
     uint32_t excl_step, excl_limit;
+    const u64 *pro_src;      // rescale prologue: every limb of polynomial z reads pro_src + z * pro_stride instead
+    size_t pro_stride;
 };
 
 // Per-tile arguments of limb `twr` (absolute limb index in the buffer), tile `tile`.
@@ -61,6 +63,8 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
         a.ninv = k.ninv[prime];
         a.w1ninv = k.w1ninv[prime];
     }
+    a.pro_reduce = false;
+    a.pro_ratio1 = 0;
     a.fp = false;
     if (k.fpinfo) {  // primes below 2^50 take the FP64 butterflies (uniform per workgroup)
         const FpInfo fi = k.fpinfo[prime];
@@ -105,6 +109,12 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
         a.in += (size_t)blockIdx.z * k.poly_stride;
         a.out += (size_t)blockIdx.z * k.out_stride;
         if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) a.aux += (size_t)blockIdx.z * k.aux_stride;
+    }
+    if (FWD && C::STRIDED && k.pro_src) {  // rescale prologue: transform (the last limb of polynomial z) mod this prime
+        const uint32_t prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
+        a.in = k.pro_src + (size_t)blockIdx.z * k.pro_stride;
+        a.pro_reduce = true;
+        a.pro_ratio1 = k.mod[prime].ratio1;
     }
 
     u64 reg[C::EPT];
@@ -221,6 +231,8 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.aux_stride = x.aux_stride ? x.aux_stride : x.poly_stride;
     k.excl_step = x.excl_step;
     k.excl_limit = x.excl_limit;
+    k.pro_src = fwd ? x.pro_src : nullptr;
+    k.pro_stride = x.pro_stride;
     uint32_t excl = 0;
     if (sel.excl_end > sel.excl_start) {
         const uint32_t lo = sel.excl_start > sel.start ? sel.excl_start : sel.start;

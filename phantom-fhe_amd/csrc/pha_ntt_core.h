@@ -110,6 +110,10 @@ struct PassArgs {
     // inter-pass buffer carry doubles; global inputs and outputs stay canonical integers
     bool fp;
     FpMod fpm;
+    // rescale prologue (first pass of a forward transform): `in` is ANOTHER limb's coefficients, which are
+    // first reduced modulo this limb's prime (divide_and_round_reduce_q_last_kernel rns.cu:1128-1139)
+    bool pro_reduce;
+    u64 pro_ratio1;    // floor(2^64 / q)
 };
 
 template <class C>
@@ -513,6 +517,10 @@ struct PassProgram {
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
         segment_twiddles<SEG>(a, tid, twreg);
         round_load<C, RI, first>(a, lds, tid, reg);
+        if (first && FWD && FIRST_PASS && a.pro_reduce) {  // uniform per workgroup
+#pragma unroll
+            for (int i = 0; i < C::EPT; i++) reg[i] = barrett64(reg[i], a.q, a.pro_ratio1);
+        }
         if (first) fp_after_global_load(a, reg);
         round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
         if (last) fp_before_global_store(a, reg);

@@ -418,22 +418,6 @@ __global__ __launch_bounds__(256) void scale_by_t_kernel(u64 *e, const DModulus 
     e[id] = mul_mod(e[id], barrett64(t, m.value, m.ratio1), m);
 }
 
-// divide_and_round_reduce_q_last_kernel rns.cu:1128-1139: dst[j] = last mod q_j
-struct ReduceArgs {
-    u64 *dst;
-    const u64 *last;
-    const DModulus *mod;
-    uint32_t n;
-    size_t dst_stride, last_stride;  // per polynomial (blockIdx.z)
-};
-__global__ __launch_bounds__(256) void reduce_last_kernel(const ReduceArgs k) {
-    const uint32_t limb = blockIdx.y;
-    const DModulus m = k.mod[limb];
-    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
-    const u64 v = k.last[(size_t)blockIdx.z * k.last_stride + coeff];
-    k.dst[(size_t)blockIdx.z * k.dst_stride + (size_t)limb * k.n + coeff] = barrett64(v, m.value, m.ratio1);
-}
-
 // ---- Galois (src/galois.cu:11-39) ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void galois_ntt_kernel(u64 *dst, const u64 *src, const uint32_t *table, uint32_t n) {
     const uint32_t limb = blockIdx.y;
@@ -745,17 +729,14 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
     const size_t n = c.n, nl = size_Ql - 1;
     if (cipher_size == 0) return 0;
     if (cipher_size > 65535) throw std::invalid_argument("cipher_size out of range");
-    u64 *tmp = c.scratch(stream, cipher_size * nl * n);
     // all polynomials of the ciphertext in one launch each (blockIdx.z = polynomial)
     NttExtra xi;
     xi.batch = (uint32_t)cipher_size;
     xi.poly_stride = size_Ql * n;
     ntt_inverse(c, src, src, src, plain_sel(nl, 1), EPI_INV_CANON, xi, s);  // ci[last] -> coefficients (rns.cu:1171)
-    ReduceArgs k{tmp, src + nl * n, c.d_mod.p, (uint32_t)n, nl * n, size_Ql * n};
-    hipLaunchKernelGGL(reduce_last_kernel, dim3((unsigned)(n / 256), (unsigned)nl, (unsigned)cipher_size), dim3(256), 0,
-                       s, k);
-    check_launch();
-    // NTT(ci[last] mod qj) fused with (ci[j] - .) * q_last^-1 (rns.cu:1178-1182)
+    // NTT(ci[last] mod qj) fused with (ci[j] - .) * q_last^-1 (rns.cu:1173-1182): the reduction modulo qj
+    // (divide_and_round_reduce_q_last_kernel) happens as the first pass loads ci[last]; dst doubles as the
+    // buffer between the two passes
     NttExtra x;
     x.scale = t.inv_q_last.p;
     x.scale_shoup = t.inv_q_last_shoup.p;
@@ -764,7 +745,9 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
     x.poly_stride = nl * n;
     x.out_stride = nl * n;
     x.aux_stride = size_Ql * n;
-    ntt_forward(c, tmp, tmp, dst, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
+    x.pro_src = src + nl * n;
+    x.pro_stride = size_Ql * n;
+    ntt_forward(c, dst, dst, dst, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
     PHA_API_END
 }
 
