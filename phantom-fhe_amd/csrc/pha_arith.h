@@ -166,7 +166,13 @@ PHA_HD double as_f64(u64 x) { return __builtin_bit_cast(double, x); }
 PHA_HD u64 as_u64(double x) { return __builtin_bit_cast(u64, x); }
 struct FpMod {
     double q, qinv;  // q and fl(1/q)
+    // Light butterflies (no re-centring inside a pass) are exact while every magnitude stays below 2^52.6:
+    //   forward: |t| <= q (0.5 + |Y| 2^-52) per stage, 8 stages per pass  -> q < 2^48 suffices (|x| < 9.5 q)
+    //   inverse: sums double per stage, 8 stages per pass                  -> q < 2^43 suffices (|x| < 2^8 q)
+    // (a pass = at most 9 stages for N = 2^17; the thresholds below keep one more bit of margin for that)
+    bool ct_light, gs_light;
 };
+PHA_HD FpMod make_fpmod(u64 q) { return FpMod{(double)q, 1.0 / (double)q, (q >> 47) == 0, (q >> 42) == 0}; }
 // x - rint(x/q)*q : |result| <= q/2 + 1 for |x| < 2^52.6
 PHA_HD double fp_reduce(double x, FpMod m) { return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x); }
 // Y*W mod q, centred. W in [0,q), Wi = fl(W/q), |Y| < 2^52.6
@@ -176,6 +182,14 @@ PHA_HD double fp_mulmod(double Y, double W, double Wi, FpMod m) {
     const double c = __builtin_rint(Y * Wi);
     const double r = __builtin_fma(-c, m.q, h) + l;
     return fp_reduce(r, m);
+}
+// Y*W - c*q with c = rint(fl(Y * Wi)): == Y*W (mod q), |result| <= q (0.5 + |Y| 2^-52): already centred when
+// |Y| << 2^52, so small primes skip fp_mulmod's second step (3 of its 10 operations, all on the dependent chain)
+PHA_HD double fp_mulmod_light(double Y, double W, double Wi, FpMod m) {
+    const double h = Y * W;
+    const double l = __builtin_fma(Y, W, -h);
+    const double c = __builtin_rint(Y * Wi);
+    return __builtin_fma(-c, m.q, h) + l;
 }
 // CT butterfly: (X, Y) -> (X + Y*W, X - Y*W); magnitudes grow by at most q/2 + 1 per stage
 PHA_HD void fp_ct_bfly(double &X, double &Y, double W, double Wi, FpMod m) {

@@ -168,7 +168,8 @@ static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, s
     w1ninv[i] = u64x2{w1, h_shoup(w1, q)};
     // FP64 tables (q < 2^50 only; see pha_arith.h)
     const bool ok = (q >> 50) == 0;
-    fp.info[i] = FpInfo{(double)q, 1.0 / (double)q, ok ? 1u : 0u, 0u};
+    const FpMod fm = make_fpmod(q);  // ok: bit 0 usable, bit 1 light forward butterflies, bit 2 light inverse ones
+    fp.info[i] = FpInfo{fm.q, fm.qinv, ok ? (1u | (fm.ct_light ? 2u : 0u) | (fm.gs_light ? 4u : 0u)) : 0u, 0u};
     if (ok) {
         u64x2 *tf = fp.tw.data() + (size_t)i * n, *itf = fp.itw.data() + (size_t)i * n;
         for (size_t k = 0; k < n; k++) {

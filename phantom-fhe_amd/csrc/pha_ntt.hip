@@ -70,7 +70,7 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
         const FpInfo fi = k.fpinfo[prime];
         if (fi.ok) {
             a.fp = true;
-            a.fpm = FpMod{fi.q, fi.qinv};
+            a.fpm = FpMod{fi.q, fi.qinv, (fi.ok & 2) != 0, (fi.ok & 4) != 0};
             a.tw = k.twf + (size_t)prime * n;
             if (!FWD && FOLD) {
                 a.ninv = k.ninvf[prime];

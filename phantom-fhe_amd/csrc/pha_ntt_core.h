@@ -191,7 +191,7 @@ PHA_HD void ot_round_int(u64 *v, const u64x2 *tc, const u64x2 *tr, u64 q4, u64 n
         }
     }
 }
-template <int R, bool FWD>
+template <int R, bool FWD, bool LIGHT>
 PHA_HD void ot_round_fp(u64 *v, const u64x2 *tc, const u64x2 *tr, FpMod m) {
 #pragma unroll
     for (int jj = 0; jj < R; jj++) {
@@ -203,14 +203,16 @@ PHA_HD void ot_round_fp(u64 *v, const u64x2 *tc, const u64x2 *tr, FpMod m) {
             const u64x2 wc = tc[(1 << j) - 1 + (k >> (R - j))], wr = tr[j];
             double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
             if (FWD) {
-                const double t = fp_mulmod(fp_mulmod(Y, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
+                const double t = LIGHT ? fp_mulmod_light(fp_mulmod_light(Y, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m)
+                                       : fp_mulmod(fp_mulmod(Y, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
                 const double x = X;
                 X = x + t;
                 Y = x - t;
             } else {
                 const double s = X + Y, d = X - Y;
-                X = fp_reduce(s, m);
-                Y = fp_mulmod(fp_mulmod(d, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
+                X = LIGHT ? s : fp_reduce(s, m);
+                Y = LIGHT ? fp_mulmod_light(fp_mulmod_light(d, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m)
+                          : fp_mulmod(fp_mulmod(d, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
             }
             v[k] = as_u64(X);
             v[k + dist] = as_u64(Y);
@@ -219,7 +221,7 @@ PHA_HD void ot_round_fp(u64 *v, const u64x2 *tc, const u64x2 *tr, FpMod m) {
 }
 
 // FP64 forms of the two rounds (same twiddle order; t[i].x = W, t[i].y = W/q as doubles)
-template <int R>
+template <int R, bool LIGHT>
 PHA_HD void fp_ct_round(u64 *v, const u64x2 *t, FpMod m) {
 #pragma unroll
     for (int j = 0; j < R; j++) {
@@ -229,13 +231,19 @@ PHA_HD void fp_ct_round(u64 *v, const u64x2 *t, FpMod m) {
             if (k & dist) continue;
             const u64x2 w = t[(1 << j) - 1 + (k >> (R - j))];
             double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
-            fp_ct_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+            if (LIGHT) {
+                const double tt = fp_mulmod_light(Y, as_f64(w.x), as_f64(w.y), m), x = X;
+                X = x + tt;
+                Y = x - tt;
+            } else {
+                fp_ct_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+            }
             v[k] = as_u64(X);
             v[k + dist] = as_u64(Y);
         }
     }
 }
-template <int R, bool FOLD>
+template <int R, bool FOLD, bool LIGHT>
 PHA_HD void fp_gs_round(u64 *v, const u64x2 *t, FpMod m, u64x2 ninv, u64x2 w1ninv) {
 #pragma unroll
     for (int j = R - 1; j >= 0; j--) {
@@ -250,7 +258,13 @@ PHA_HD void fp_gs_round(u64 *v, const u64x2 *t, FpMod m, u64x2 ninv, u64x2 w1nin
                 Y = fp_mulmod(d, as_f64(w1ninv.x), as_f64(w1ninv.y), m);
             } else {
                 const u64x2 w = t[(1 << j) - 1 + (k >> (R - j))];
-                fp_gs_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+                if (LIGHT) {
+                    const double s = X + Y, d = X - Y;
+                    X = s;
+                    Y = fp_mulmod_light(d, as_f64(w.x), as_f64(w.y), m);
+                } else {
+                    fp_gs_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+                }
             }
             v[k] = as_u64(X);
             v[k + dist] = as_u64(Y);
@@ -385,8 +399,12 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
         for (int gi = 0; gi < G; gi++) {
             u64 *rg = reg + gi * K;
             const u64x2 *tr = tc + (K - 1) + gi * r;
-            if (a.fp) ot_round_fp<r, FWD>(rg, tc, tr, a.fpm);
-            else ot_round_int<r, FWD>(rg, tc, tr, q4, nq);
+            if (a.fp) {
+                if (FWD ? a.fpm.ct_light : a.fpm.gs_light) ot_round_fp<r, FWD, true>(rg, tc, tr, a.fpm);
+                else ot_round_fp<r, FWD, false>(rg, tc, tr, a.fpm);
+            } else {
+                ot_round_int<r, FWD>(rg, tc, tr, q4, nq);
+            }
         }
         return;
     }
@@ -395,8 +413,13 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
         for (int gi = 0; gi < G; gi++) {
             u64 *rg = reg + gi * K;
             const u64x2 *t = twreg + C::tw_off(RI) + gi * (K - 1);
-            if (FWD) fp_ct_round<r>(rg, t, a.fpm);
-            else fp_gs_round<r, FOLD>(rg, t, a.fpm, a.ninv, a.w1ninv);
+            if (FWD) {
+                if (a.fpm.ct_light) fp_ct_round<r, true>(rg, t, a.fpm);
+                else fp_ct_round<r, false>(rg, t, a.fpm);
+            } else {
+                if (a.fpm.gs_light) fp_gs_round<r, FOLD, true>(rg, t, a.fpm, a.ninv, a.w1ninv);
+                else fp_gs_round<r, FOLD, false>(rg, t, a.fpm, a.ninv, a.w1ninv);
+            }
         }
         return;
     }

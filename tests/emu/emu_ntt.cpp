@@ -44,7 +44,7 @@ static void emu(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *
     const size_t n = (size_t)1 << LOGN;
     PassArgs a{};
     a.tw = tw; a.q = q; a.rho0 = P1::T; a.stride = P2::T; a.ninv = ninv; a.w1ninv = w1ninv; a.scale = scale; a.aux = aux;
-    a.fp = fp; a.fpm = FpMod{(double)q, 1.0 / (double)q};
+    a.fp = fp; a.fpm = make_fpmod(q);
     if (fwd) {
         a.in = in; a.out = out;
         run_pass<P1, true, EPI_NONE, false>(a, n);
