@@ -163,3 +163,33 @@ def test_invalid_arguments(gpu):
         P.PhantomContext(12, [97, 193], 0, device=gpu)  # not NTT primes for N=4096
     with pytest.raises(ValueError):
         P.PhantomContext(9, [0xffffee001], 0, device=gpu)
+
+
+def test_empty_and_full_size_properties(gpu):
+    """Edge cases and size-independent properties at the largest supported shape (N = 2^17, 60 limbs):
+    zero limbs is a no-op; inverse(forward(x)) = x; forward is linear; forward of 0 is 0."""
+    import phantom_fhe_amd as P
+    log_n, n = 17, 1 << 17
+    primes = [int(p) for p in P.coeff_modulus_create(n, [60] * 16 + [40] * 44)]
+    ctx = P.PhantomContext(log_n, primes, 15, device=gpu)
+    r = rng_for(97)
+    a = uniform_poly(r, primes, n)
+    b = uniform_poly(r, primes, n)
+    b[:, :64] = np.array(primes, dtype=np.uint64)[:, None] - 1          # q - 1 runs
+    da, db = P.to_device(a, gpu), P.to_device(b, gpu)
+    ctx.nwt_2d_radix8_forward_inplace(da, 0, 0)                           # empty limb range
+    assert np.array_equal(P.to_host(da), a)
+    dsum = P.to_device(np.zeros_like(a), gpu)
+    ctx.add_rns_poly(da, db, dsum, 60)
+    for t in (da, db, dsum):
+        ctx.nwt_2d_radix8_forward_inplace(t, 60, 0)
+    lin = P.to_device(np.zeros_like(a), gpu)
+    ctx.add_rns_poly(da, db, lin, 60)
+    assert np.array_equal(P.to_host(lin), P.to_host(dsum))               # NTT(a) + NTT(b) == NTT(a + b)
+    ha = P.to_host(da)
+    assert all(int(ha[l].max()) < primes[l] for l in range(60))          # canonical outputs
+    ctx.nwt_2d_radix8_backward_inplace(da, 60, 0)
+    assert np.array_equal(P.to_host(da), a)
+    dz = P.to_device(np.zeros_like(a), gpu)
+    ctx.nwt_2d_radix8_forward_inplace(dz, 60, 0)
+    assert not P.to_host(dz).any()

@@ -336,3 +336,36 @@ def test_c3_hommul_decrypts_with_generated_keys(gpu):
         got = got - Qn if got > Qn // 2 else got
         worst = max(worst, abs(got - want // q_last))
     assert worst < 1 << 30, worst.bit_length()       # signal is ~2^36..2^38; fresh-noise x message terms ~2^22
+
+
+def test_extreme_residues_and_empty_calls(gpu):
+    """All-(q-1) and all-zero inputs through mod-up / inner product / mod-down / rescale (largest accumulators of
+    the carry-free base-conversion MAC and of the 128-bit inner product), and empty ciphertexts."""
+    import phantom_fhe_amd as P
+    name, ql = "c4_bfv15", 30
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    top = lambda ps: np.stack([np.full(n, int(q) - 1, dtype=np.uint64) for q in ps])
+    evk = np.stack([np.stack([top(primes), top(primes)]) for _ in range(size_q // size_p)])
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    for scheme in (O.CKKS, O.BFV):
+        for c2 in (top(primes[:ql]), np.zeros((ql, n), dtype=np.uint64)):
+            ct = np.stack([top(primes[:ql]), top(primes[:ql])])
+            d_ct = P.to_device(ct, gpu)
+            ctx.keyswitch_inplace(ql, d_ct, P.to_device(c2, gpu), rlk.public_keys_ptr, scheme)
+            ref = tool.keyswitch_inplace(ct, c2, [evk[i] for i in range(tool.beta)], scheme)
+            assert np.array_equal(P.to_host(d_ct), ref)
+    ct = np.stack([top(primes[:ql]) for _ in range(2)])
+    dst = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+    ctx.divide_and_round_q_last_ntt(ql, P.to_device(ct, gpu), 2, dst)
+    assert np.array_equal(P.to_host(dst), tool.rescale_ntt(ct, 2))
+    before = P.to_host(dst).copy()
+    ctx.divide_and_round_q_last_ntt(ql, P.to_device(ct, gpu), 0, dst)     # empty ciphertext: nothing happens
+    assert np.array_equal(P.to_host(dst), before)
+    with pytest.raises(ValueError):
+        ctx.divide_and_round_q_last_ntt(1, P.to_device(ct, gpu), 2, dst)  # no modulus left to drop
+    with pytest.raises(ValueError):
+        ctx.keyswitch_inplace(size_q + 1, P.to_device(ct, gpu), P.to_device(ct[0], gpu), rlk.public_keys_ptr, O.CKKS)
