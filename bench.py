@@ -229,6 +229,30 @@ def main():
     torch.cuda.synchronize()
     hm_lanes_elapsed = time.perf_counter() - t0
 
+    # the same operation on a batch of B ciphertext pairs through the batched entry points (one set of launches:
+    # key limbs read once, NTT / base-conversion launches B times larger).  Informational (this rank).
+    del lanes
+    B = int(os.environ.get("PHA_BENCH_BATCH", "8"))
+    bt1 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
+    bt2 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
+    b01 = torch.zeros_like(bt1)
+    b2 = torch.zeros((B, size_q, n), dtype=torch.int64, device=dev)
+    bout = torch.zeros((B, 2, size_q - 1, n), dtype=torch.int64, device=dev)
+
+    def hommul_batched():
+        ctx.tensor_prod_2x2_batched(bt1, bt2, b01, b2, size_q, B)
+        ctx.keyswitch_inplace_batched(size_q, b01, b2, B, rlk.public_keys_ptr, P.scheme_type.ckks)
+        ctx.divide_and_round_q_last_ntt(size_q, b01, 2 * B, bout)
+
+    for _ in range(2):
+        hommul_batched()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(hm_steps):
+        hommul_batched()
+    torch.cuda.synchronize()
+    hm_batched_elapsed = time.perf_counter() - t0
+
     if rank == 0:
         alg_bytes = 16.0 * n * size_q                  # 8 B read + 8 B write per coefficient
         achieved = alg_bytes / (kernel_ms * 1e-3)
@@ -255,6 +279,9 @@ def main():
             "hommul_relin_rescale_4_streams": {"value": S * hm_steps / hm_lanes_elapsed, "unit": "ops/s (this rank)",
                                                "ms_per_op": 1e3 * hm_lanes_elapsed / (S * hm_steps),
                                                "note": "4 independent ciphertext pairs, one HIP stream each"},
+            "hommul_relin_rescale_batched": {"value": B * hm_steps / hm_batched_elapsed, "unit": "ops/s (this rank)",
+                                             "ms_per_op": 1e3 * hm_batched_elapsed / (B * hm_steps), "batch": B,
+                                             "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_inplace_batched + rescale of the batch"},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(primes, n)

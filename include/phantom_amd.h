@@ -144,6 +144,15 @@ int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint
 /* phantom::keyswitch_inplace (eval_key_switch.cu:95-182) on raw buffers: ct [2][Ql][N] += KS(c2) */
 int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
                           const uint64_t *const *rlk, int scheme, void *stream);
+/* Extension (the reference loops over ciphertexts): `batch` independent ciphertexts through ONE set of launches.
+ * ct [batch][2][Ql][N] += KS(c2[b]) with c2 [batch][Ql][N]; the key limbs are read once per launch, the NTT and
+ * base-conversion launches are batch times larger (the throughput regime of the kernels). */
+int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2, size_t batch,
+                                  const uint64_t *const *rlk, int scheme, void *stream);
+/* tensor_prod_2x2_rns_poly for `batch` ciphertext pairs in the layout above: operands [batch][2][L][N],
+ * res01 [batch][2][L][N] receives (c0, c1), res2 [batch][L][N] receives c2; res01 may alias operand1 */
+int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2, uint64_t *res01,
+                                uint64_t *res2, size_t coeff_mod_size, size_t batch, void *stream);
 /* phantom::hoisting_inplace (include/evaluate.cuh:233-241, src/evaluate.cu:1670-1866) on raw buffers:
  * ct [2][Ql][N] <- sum over the n_elts Galois elements of rotate(ct).  galois_elts is a HOST array;
  * glk is a HOST array of n_elts DEVICE pointer tables (PhantomRelinKey::public_keys_ptr() of each

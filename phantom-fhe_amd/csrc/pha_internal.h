@@ -198,6 +198,7 @@ struct NttExtra {
     size_t pro_stride = 0;                               //   (pro_src + z * pro_stride) mod its own prime; `in` unused
     uint32_t excl_step = 0;                              // polynomial z skips [excl_start + z*step, min(+len, limit))
     uint32_t excl_limit = 0xffffffffu;
+    uint32_t excl_mod = 0;                               // != 0: the skipped range follows z % excl_mod (batches of ciphertexts)
 };
 void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
                  hipStream_t s);

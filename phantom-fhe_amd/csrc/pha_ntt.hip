@@ -42,7 +42,7 @@ struct NttKArgs {
     uint32_t active;         // processed limbs = sel.count minus the excluded range (pipelined kernel)
     uint32_t batch;          // polynomials per launch (blockIdx.z)
     size_t poly_stride, out_stride, aux_stride;
-    uint32_t excl_step, excl_limit;
+    uint32_t excl_step, excl_limit, excl_mod;
     const u64 *pro_src;      // rescale prologue: every limb of polynomial z reads pro_src + z * pro_stride instead
     size_t pro_stride;
 };
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
     const uint32_t twr = k.sel.start + blockIdx.y;  // limb in the buffer (uniform)
     {
         // polynomial z skips its own digit: [excl_start + z*step, min(that + len, limit))  (ntt_modup.cu:422)
-        const uint32_t es = k.sel.excl_start + blockIdx.z * k.excl_step;
+        const uint32_t zd = k.excl_mod ? blockIdx.z % k.excl_mod : blockIdx.z;
+        const uint32_t es = k.sel.excl_start + zd * k.excl_step;
         uint32_t ee = es + (k.sel.excl_end - k.sel.excl_start);
         ee = ee < k.excl_limit ? ee : k.excl_limit;
         if (twr >= es && twr < ee) return;
@@ -231,6 +232,7 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.aux_stride = x.aux_stride ? x.aux_stride : x.poly_stride;
     k.excl_step = x.excl_step;
     k.excl_limit = x.excl_limit;
+    k.excl_mod = x.excl_mod;
     k.pro_src = fwd ? x.pro_src : nullptr;
     k.pro_stride = x.pro_stride;
     uint32_t excl = 0;

@@ -14,6 +14,7 @@ constexpr int kEwPerThread = 2;
 struct EwArgs {
     const u64 *a, *b, *d;
     u64 *r;
+    u64 *r2;             // tensor product: where c2 goes (null = r + 2 * limbs * n, the reference layout)
     const u64 *s0, *s1;  // per-limb scalars (Shoup pair)
     const DModulus *mod;
     uint32_t n, limbs, mod_start;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
         d1.y = csub(csub(d1.y + 2 * q - d0.y - d2.y, q), q);
         st2(k.r + idx, d0);
         st2(k.r + idx + rc, d1);
-        st2(k.r + idx + 2 * rc, d2);
+        st2(k.r2 ? k.r2 + idx : k.r + idx + 2 * rc, d2);
     } else if (OP == EW_SQUARE) {  // tensor_square_2x2_rns_poly :500-529
         u64x2 c0 = ld2(k.a + idx), c1 = ld2(k.a + idx + rc);
         u64x2 d0, d1, d2;
@@ -175,6 +176,18 @@ int pha_tensor_prod_2x2_rns_poly(pha_context_t ctx, const uint64_t *op1, const u
     EwArgs k{};
     k.a = op1; k.b = op2; k.r = res;
     launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream));
+    PHA_API_END
+}
+int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *res01,
+                                uint64_t *res2, size_t cms, size_t batch, void *stream) {
+    PHA_API_BEGIN
+    need(op1); need(op2); need(res01); need(res2);
+    const size_t ln = cms * ctx->c.n;
+    for (size_t b = 0; b < batch; b++) {  // HBM-streaming kernel: one launch per ciphertext loses nothing
+        EwArgs k{};
+        k.a = op1 + b * 2 * ln; k.b = op2 + b * 2 * ln; k.r = res01 + b * 2 * ln; k.r2 = res2 + b * ln;
+        launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream));
+    }
     PHA_API_END
 }
 int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *op, uint64_t *res, size_t cms,

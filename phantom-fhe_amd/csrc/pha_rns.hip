@@ -38,7 +38,18 @@ struct BConvLaunch {
     const DModulus *mod;
     uint32_t n;
     uint32_t out_per_block;      // output primes per workgroup (<= kBcMaxOutPerBlock)
+    // batches of ciphertexts (mod-up): polynomial z = (ciphertext z / conv_count, digit z % conv_count);
+    // conv_count = 0: every z has its own converter index z (one ciphertext) or shares converter 0 (conv_step 0)
+    uint32_t conv_count;
+    size_t src_group_stride, own_group_stride;  // per ciphertext
 };
+struct BConvWho {
+    uint32_t ci, grp;
+};
+__device__ __forceinline__ BConvWho bconv_who(const BConvLaunch &L) {
+    const uint32_t z = blockIdx.z;
+    return L.conv_count ? BConvWho{z % L.conv_count, z / L.conv_count} : BConvWho{z, 0u};
+}
 
 // bconv_mult (+) bconv_matmul (src/rns_bconv.cu:22-60,109-170; padded variant :455-485).
 // SPLIT: carry-free MAC -- inputs and matrix entries are cut into 30-bit halves, the four partial
@@ -46,10 +57,12 @@ struct BConvLaunch {
 // v_mad_u64_u32 each and are recombined once per output; valid for primes <= 60 bits, isz <= 16.
 template <int ISZ_PAD, bool SCALE_IN, bool SPLIT>
 __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) {
-    const BConvDev &d = L.convs[blockIdx.z * L.conv_step];
+    const BConvWho who = bconv_who(L);
+    const BConvDev &d = L.convs[who.ci * L.conv_step];
     const uint32_t coeff = blockIdx.x * kBcThreads + threadIdx.x;
     const uint32_t n = L.n;
-    const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)d.src_limb * n;
+    const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)who.grp * L.src_group_stride + (size_t)d.src_limb * n;
+    const u64 *own = L.own + (size_t)who.grp * L.own_group_stride;
     u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
     const uint32_t isz = d.isz;
     const uint32_t j0 = blockIdx.y * L.out_per_block;
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     }
     if (d.copy_own && blockIdx.y == 0) {  // modup_copy_partQl_kernel rns_bconv.cu:522-528
         for (uint32_t i = 0; i < isz; i++)
-            dst[(size_t)(d.src_limb + i) * n + coeff] = L.own[(size_t)(d.src_limb + i) * n + coeff];
+            dst[(size_t)(d.src_limb + i) * n + coeff] = own[(size_t)(d.src_limb + i) * n + coeff];
     }
     for (uint32_t j = j0; j < j1; j++) {
         const DModulus m = L.mod[d.oprime[j]];
@@ -127,14 +140,16 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
 // generic fallback for very wide input bases (isz > 16): inputs are re-read per output prime
 template <bool SCALE_IN>
 __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunch L) {
-    const BConvDev &d = L.convs[blockIdx.z * L.conv_step];
+    const BConvWho who = bconv_who(L);
+    const BConvDev &d = L.convs[who.ci * L.conv_step];
     const uint32_t coeff = blockIdx.x * kBcThreads + threadIdx.x;
     const uint32_t n = L.n;
-    const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)d.src_limb * n;
+    const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)who.grp * L.src_group_stride + (size_t)d.src_limb * n;
+    const u64 *own = L.own + (size_t)who.grp * L.own_group_stride;
     u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
     if (d.copy_own && blockIdx.y == 0) {
         for (uint32_t i = 0; i < d.isz; i++)
-            dst[(size_t)(d.src_limb + i) * n + coeff] = L.own[(size_t)(d.src_limb + i) * n + coeff];
+            dst[(size_t)(d.src_limb + i) * n + coeff] = own[(size_t)(d.src_limb + i) * n + coeff];
     }
     const uint32_t j0 = blockIdx.y * L.out_per_block;
     const uint32_t j1 = min(j0 + L.out_per_block, d.osz);
@@ -155,8 +170,10 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
 // convs: device array; max_isz / max_osz over the converters used; split_ok: all primes <= 60 bits
 static void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                          uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src,
-                         size_t src_stride, const u64 *own, bool scale_in, hipStream_t s) {
+                         size_t src_stride, const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0,
+                         size_t group_stride = 0) {
     BConvLaunch L{};
+    L.conv_count = conv_count; L.src_group_stride = group_stride; L.own_group_stride = group_stride;
     L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;
     L.dst_stride = dst_stride; L.src_stride = src_stride; L.mod = c.d_mod.p; L.n = (uint32_t)c.n;
     // balanced output groups: 45 outputs -> 2 groups of 23 (6 wavefronts per SIMD at C3 mod-up: one resident round)
@@ -239,6 +256,40 @@ __global__ __launch_bounds__(256) void inner_prod_kernel(const InnerArgs k) {
     u64x2 r1{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
     *reinterpret_cast<u64x2 *>(k.cx + c2_id) = r0;
     *reinterpret_cast<u64x2 *>(k.cx + c2_id + k.qlp_n) = r1;
+}
+
+// Batch of ciphertexts against ONE key: the key limbs are read once and stay in registers while the kernel
+// walks the ciphertexts (the inner product is HBM-bound and 2/3 of its bytes are the key).
+template <int BETA>
+__global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs k, uint32_t batch) {
+    const uint32_t nid = blockIdx.y;
+    const uint32_t twr = k.qlp_prime[nid];
+    const DModulus m = k.mod[twr];
+    const size_t coeff = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t c2_id = (size_t)nid * k.n + coeff;
+    const size_t evk_id = (size_t)twr * k.n + coeff;
+    u64x2 kb[BETA], ka[BETA];
+#pragma unroll
+    for (int i = 0; i < BETA; i++) {
+        const u64 *key = k.evks[i];
+        kb[i] = *reinterpret_cast<const u64x2 *>(key + evk_id);
+        ka[i] = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+    }
+    for (uint32_t b = 0; b < batch; b++) {
+        const u64 *mu = k.t_mod_up + (size_t)b * BETA * k.qlp_n + c2_id;
+        u64 *cx = k.cx + (size_t)b * 2 * k.qlp_n + c2_id;
+        u64 a0l = 0, a0h = 0, a1l = 0, a1h = 0, b0l = 0, b0h = 0, b1l = 0, b1h = 0;
+#pragma unroll
+        for (int i = 0; i < BETA; i++) {
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n);
+            mac128(v.x, kb[i].x, a0l, a0h);
+            mac128(v.y, kb[i].y, a1l, a1h);
+            mac128(v.x, ka[i].x, b0l, b0h);
+            mac128(v.y, ka[i].y, b1l, b1h);
+        }
+        *reinterpret_cast<u64x2 *>(cx) = u64x2{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
+        *reinterpret_cast<u64x2 *>(cx + k.qlp_n) = u64x2{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
+    }
 }
 
 // ---- hoisted rotations (src/evaluate.cu:1670-1866): for every output coefficient, sum over the Galois
@@ -447,56 +498,79 @@ static bool ntt_domain_scheme(int scheme) {
 
 // DRNSTool::modup rns_bconv.cu:530-627.  All beta digits go through ONE base-conversion launch and ONE
 // forward-NTT launch pair (blockIdx.z = digit; digit z skips its own limbs, ntt_modup.cu:422).
-static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64 *t_cks, hipStream_t s) {
+// `batch` ciphertexts at once: cks / t_cks are [batch][Ql][N], dst is [batch][beta][QlP][N].
+static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64 *t_cks, hipStream_t s,
+                  uint32_t batch = 1) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp, alpha = t.alpha;
     const bool ntt_dom = ntt_domain_scheme(scheme);
     if (ntt_dom) {
+        NttExtra x;
+        x.batch = batch;
+        x.poly_stride = (size_t)ql * n;
         if (alpha == 1) {
-            ntt_inverse(c, cks, t_cks, t_cks, plain_sel(0, ql), EPI_INV_CANON, NttExtra{}, s);
+            ntt_inverse(c, cks, t_cks, t_cks, plain_sel(0, ql), EPI_INV_CANON, x, s);
         } else {
-            NttExtra x;  // iNTT fused with x partQlHatInv (bconv phase 1), :558-559
+            // iNTT fused with x partQlHatInv (bconv phase 1), :558-559
             x.scale = t.part_hat_inv.p;
             x.scale_shoup = t.part_hat_inv_shoup.p;
             ntt_inverse(c, cks, t_cks, t_cks, plain_sel(0, ql), EPI_INV_SCALE, x, s);
         }
     }
     if (alpha == 1) {
-        for (uint32_t b = 0; b < t.beta; b++) {
-            u64 *out = dst + (size_t)b * qlp * n;
-            SinglePArgs k{out, cks + (size_t)b * n, (ntt_dom ? t_cks : cks) + (size_t)b * n, c.d_mod.p,
-                          t.d_qlp_prime.p, b, (uint32_t)n};
-            hipLaunchKernelGGL(single_p_kernel, dim3((unsigned)(n / 256), qlp), dim3(256), 0, s, k);
-            check_launch();
-        }
+        for (uint32_t g = 0; g < batch; g++)
+            for (uint32_t b = 0; b < t.beta; b++) {
+                const size_t off = (size_t)g * ql * n + (size_t)b * n;
+                u64 *out = dst + ((size_t)g * t.beta + b) * qlp * n;
+                SinglePArgs k{out, cks + off, (ntt_dom ? t_cks : cks) + off, c.d_mod.p, t.d_qlp_prime.p, b, (uint32_t)n};
+                hipLaunchKernelGGL(single_p_kernel, dim3((unsigned)(n / 256), qlp), dim3(256), 0, s, k);
+                check_launch();
+            }
     } else {
         // own limbs are copied verbatim by the same kernel (modup_copy_partQl_kernel :522-528);
         // BFV still needs the q-hat^-1 scaling (bconv_mult_kernel :603-607), ckks/bgv got it in the iNTT
         uint32_t max_osz = 0;
         for (const BConv &b : t.digit) max_osz = b.osz > max_osz ? b.osz : max_osz;
-        launch_bconv(c, t.d_digit_convs.p, 1, t.beta, alpha, max_osz, t.split_ok, dst, (size_t)qlp * n,
-                     ntt_dom ? t_cks : cks, 0, cks, !ntt_dom, s);
+        launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.split_ok, dst, (size_t)qlp * n,
+                     ntt_dom ? t_cks : cks, 0, cks, !ntt_dom, s, batch > 1 ? t.beta : 0, (size_t)ql * n);
     }
     LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);
     NttExtra x;
-    x.batch = t.beta;
+    x.batch = t.beta * batch;
     x.poly_stride = (size_t)qlp * n;
-    if (ntt_dom) {  // digit z skips [z*alpha, min((z+1)*alpha, ql))
+    if (ntt_dom) {  // digit z % beta skips [d*alpha, min((d+1)*alpha, ql))
         sel.excl_start = 0;
         sel.excl_end = alpha;
         x.excl_step = alpha;
         x.excl_limit = ql;
+        x.excl_mod = batch > 1 ? t.beta : 0;
     }
     ntt_forward(c, dst, dst, dst, sel, EPI_FWD_CANON, x, s);
 }
 
 // phantom::key_switch_inner_prod eval_key_switch.cu:71-92
-static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s) {
+static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s,
+                       uint32_t batch = 1) {
     InnerArgs k{};
     k.cx = cx; k.t_mod_up = t_mod_up; k.evks = rlk; k.mod = c.d_mod.p; k.qlp_prime = t.d_qlp_prime.p;
     k.n = (uint32_t)c.n; k.beta = t.beta; k.qlp_n = (size_t)t.size_qlp * c.n; k.qp_n = (size_t)c.size_qp * c.n;
-    hipLaunchKernelGGL(inner_prod_kernel, dim3((unsigned)(c.n / 512), t.size_qlp), dim3(256), 0, s, k);
-    check_launch();
+    const dim3 grid((unsigned)(c.n / 512), t.size_qlp), block(256);
+    if (batch > 1 && t.beta <= 4) {  // key limbs stay in registers across the ciphertexts
+        switch (t.beta) {
+            case 1: hipLaunchKernelGGL(inner_prod_batched_kernel<1>, grid, block, 0, s, k, batch); break;
+            case 2: hipLaunchKernelGGL(inner_prod_batched_kernel<2>, grid, block, 0, s, k, batch); break;
+            case 3: hipLaunchKernelGGL(inner_prod_batched_kernel<3>, grid, block, 0, s, k, batch); break;
+            default: hipLaunchKernelGGL(inner_prod_batched_kernel<4>, grid, block, 0, s, k, batch); break;
+        }
+        check_launch();
+        return;
+    }
+    for (uint32_t b = 0; b < batch; b++) {
+        hipLaunchKernelGGL(inner_prod_kernel, grid, block, 0, s, k);
+        check_launch();
+        k.t_mod_up += (size_t)t.beta * k.qlp_n;
+        k.cx += 2 * k.qlp_n;
+    }
 }
 
 // DRNSTool::moddown_from_NTT rns_bconv.cu:776-828 for `polys` polynomials cx + z*cx_stride at once.
@@ -654,6 +728,29 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     inner_prod(c, t, cx, t_mod_up, rlk, s);
     // both polynomials at once; ct += moddown(cx) with the add fused into the NTT epilogue
     moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2, scheme, true, tmp, s);
+    PHA_API_END
+}
+
+int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2, size_t batch,
+                                  const uint64_t *const *rlk, int scheme, void *stream) {
+    PHA_API_BEGIN
+    need(ct); need(c2); need(rlk);
+    if (batch == 0) return 0;
+    if (batch > 1024) throw std::invalid_argument("batch out of range");
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    Tool &t = c.tool((uint32_t)size_Ql);
+    if ((size_t)t.beta * batch > 65535 || 2 * batch > 65535) throw std::invalid_argument("batch out of range");
+    hipStream_t s = as_stream(stream);
+    const uint32_t B = (uint32_t)batch;
+    const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
+    // scratch: t_cks / delta [B][2][Ql][N] | t_mod_up [B][beta][QlP][N] | cx [B][2][QlP][N]
+    u64 *base = c.scratch(stream, B * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n));
+    u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n;
+    modup(c, t, t_mod_up, c2, scheme, tmp, s, B);
+    inner_prod(c, t, cx, t_mod_up, rlk, s, B);
+    // 2B polynomials: ct [B][2][Ql][N] and cx [B][2][QlP][N] are uniformly strided
+    moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2 * B, scheme, true, tmp, s);
     PHA_API_END
 }
 

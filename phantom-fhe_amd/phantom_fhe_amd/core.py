@@ -206,6 +206,15 @@ class PhantomContext:
         _lib.check(self._L.pha_keyswitch_inplace(self._h, size_Ql, _ptr(ct), _ptr(c2), _ptr(rlk_ptrs),
                                                  int(scheme), _stream()))
 
+    def keyswitch_inplace_batched(self, size_Ql, ct, c2, batch, rlk_ptrs, scheme):
+        """`batch` ciphertexts through one set of launches: ct [batch][2][Ql][N] += KS(c2 [batch][Ql][N])."""
+        _lib.check(self._L.pha_keyswitch_inplace_batched(self._h, size_Ql, _ptr(ct), _ptr(c2), batch, _ptr(rlk_ptrs),
+                                                         int(scheme), _stream()))
+
+    def tensor_prod_2x2_batched(self, op1, op2, res01, res2, cms, batch):
+        _lib.check(self._L.pha_tensor_prod_2x2_batched(self._h, _ptr(op1), _ptr(op2), _ptr(res01), _ptr(res2), cms,
+                                                       batch, _stream()))
+
     def hoisting(self, size_Ql, ct, galois_elts, galois_keys, scheme):
         """hoisting_inplace (src/evaluate.cu:1670-1866): ct <- sum_e rotate_e(ct); galois_keys[e] is the
         PhantomRelinKey of Galois element galois_elts[e]."""

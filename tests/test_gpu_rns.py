@@ -369,3 +369,41 @@ def test_extreme_residues_and_empty_calls(gpu):
         ctx.divide_and_round_q_last_ntt(1, P.to_device(ct, gpu), 2, dst)  # no modulus left to drop
     with pytest.raises(ValueError):
         ctx.keyswitch_inplace(size_q + 1, P.to_device(ct, gpu), P.to_device(ct[0], gpu), rlk.public_keys_ptr, O.CKKS)
+
+
+@pytest.mark.parametrize("name,scheme,ql,batch", [("hyb12_a2", O.CKKS, 6, 3), ("hyb12_a2", O.CKKS, 5, 2), ("hyb13_a3", O.CKKS, 7, 4),
+                                                  ("hyb12_a2", O.BFV, 6, 2), ("hyb12_a2", O.BGV, 6, 2), ("c1_bfv4096", O.CKKS, 2, 3),
+                                                  ("c4_bfv15", O.BFV, 30, 4), ("c3_ckks16", O.CKKS, 45, 2)])
+def test_batched_keyswitch_and_tensor(name, scheme, ql, batch, gpu):
+    """pha_keyswitch_inplace_batched / pha_tensor_prod_2x2_batched: every ciphertext of the batch must equal the
+    single-ciphertext result (oracle), including short last digits and the alpha = 1 path."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    if scheme == O.BGV:
+        ctx.set_plain_modulus(BGV_T)
+        tool.set_plain_modulus(BGV_T)
+    r = rng_for(110)
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    ct1 = np.stack([np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)]) for _ in range(batch)])
+    ct2 = np.stack([np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)]) for _ in range(batch)])
+    d01 = P.to_device(ct1, gpu)
+    d2 = P.to_device(np.zeros((batch, ql, n), dtype=np.uint64), gpu)
+    ctx.tensor_prod_2x2_batched(d01, P.to_device(ct2, gpu), d01, d2, ql, batch)     # in place on operand 1
+    ref3 = [oc.tensor_prod_2x2(ct1[b], ct2[b], ql) for b in range(batch)]
+    assert np.array_equal(P.to_host(d01), np.stack([t[:2] for t in ref3]))
+    assert np.array_equal(P.to_host(d2), np.stack([t[2] for t in ref3]))
+    ctx.keyswitch_inplace_batched(ql, d01, d2, batch, rlk.public_keys_ptr, scheme)
+    got = P.to_host(d01)
+    for b in range(batch):
+        ref = tool.keyswitch_inplace(ref3[b][:2], ref3[b][2], [evk[i] for i in range(tool.beta)], scheme)
+        assert np.array_equal(got[b], ref), f"ciphertext {b}"
+    if scheme == O.CKKS and ql > 1:
+        out = P.to_device(np.zeros((batch, 2, ql - 1, n), dtype=np.uint64), gpu)
+        ctx.divide_and_round_q_last_ntt(ql, d01, 2 * batch, out)                     # rescale of the whole batch
+        assert np.array_equal(P.to_host(out).reshape(2 * batch, ql - 1, n), tool.rescale_ntt(got.reshape(2 * batch, ql, n), 2 * batch))
+    ctx.keyswitch_inplace_batched(ql, d01, d2, 0, rlk.public_keys_ptr, scheme)       # empty batch: no-op
