@@ -157,9 +157,11 @@ PHA_HD void gs_bfly4(u64 &X, u64 &Y, u64x2 w, u64 q4, u64 nq) {
 // multiply needs 9 of them with no carry chains or zero-extensions (52.8 vs 87.7 cycles per
 // wave-butterfly, profiles/r01_microbench_gfx950.txt).  Residues are held as doubles with integer values,
 // |x| < 2^52.6, so sums/differences are exact; products are exact through the fma error term:
-//   h = Y*W (rounded), l = fma(Y, W, -h) = Y*W - h exactly, c = rint(Y * (W/q)) is the quotient to
-//   within 2, r = fma(-c, q, h) + l = Y*W - c*q exactly (an integer below 2^52), and one more
-//   rint/fma step centres it: result == Y*W (mod q), |result| <= q/2 + 1.
+//   h = Y*W (rounded), l = fma(Y, W, -h) = Y*W - h exactly, c = rint(h * fl(1/q)) is the quotient to
+//   within 3 (three roundings of relative size 2^-53 on a value below 2^52.6), r = fma(-c, q, h) + l =
+//   Y*W - c*q exactly (an integer below 2^52), and one more rint/fma step centres it:
+//   result == Y*W (mod q), |result| <= q/2 + 1.  The twiddle tables of this path therefore hold W alone
+//   (8 bytes per entry; the integer path needs 16 for W and its Shoup quotient).
 // Every stored output is converted back to the canonical integer residue, so results are bit-identical
 // to the integer path.
 PHA_HD double as_f64(u64 x) { return __builtin_bit_cast(double, x); }
@@ -167,7 +169,7 @@ PHA_HD u64 as_u64(double x) { return __builtin_bit_cast(u64, x); }
 struct FpMod {
     double q, qinv;  // q and fl(1/q)
     // Light butterflies (no re-centring inside a pass) are exact while every magnitude stays below 2^52.6:
-    //   forward: |t| <= q (0.5 + |Y| 2^-52) per stage, 8 stages per pass  -> q < 2^48 suffices (|x| < 9.5 q)
+    //   forward: |t| <= q (0.5 + 1.5 |Y| 2^-52) per stage, 8 stages per pass -> q < 2^47 keeps |x| < 11 q < 2^50.5
     //   inverse: sums double per stage, 8 stages per pass                  -> q < 2^43 suffices (|x| < 2^8 q)
     // (a pass = at most 9 stages for N = 2^17; the thresholds below keep one more bit of margin for that)
     bool ct_light, gs_light;
@@ -175,34 +177,35 @@ struct FpMod {
 PHA_HD FpMod make_fpmod(u64 q) { return FpMod{(double)q, 1.0 / (double)q, (q >> 47) == 0, (q >> 42) == 0}; }
 // x - rint(x/q)*q : |result| <= q/2 + 1 for |x| < 2^52.6
 PHA_HD double fp_reduce(double x, FpMod m) { return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x); }
-// Y*W mod q, centred. W in [0,q), Wi = fl(W/q), |Y| < 2^52.6
-PHA_HD double fp_mulmod(double Y, double W, double Wi, FpMod m) {
+// Y*W mod q, centred. W in [0,q), |Y| < 2^52.6
+PHA_HD double fp_mulmod(double Y, double W, FpMod m) {
     const double h = Y * W;
     const double l = __builtin_fma(Y, W, -h);
-    const double c = __builtin_rint(Y * Wi);
+    const double c = __builtin_rint(h * m.qinv);
     const double r = __builtin_fma(-c, m.q, h) + l;
     return fp_reduce(r, m);
 }
-// Y*W - c*q with c = rint(fl(Y * Wi)): == Y*W (mod q), |result| <= q (0.5 + |Y| 2^-52): already centred when
-// |Y| << 2^52, so small primes skip fp_mulmod's second step (3 of its 10 operations, all on the dependent chain)
-PHA_HD double fp_mulmod_light(double Y, double W, double Wi, FpMod m) {
+// Y*W - c*q with c = rint(h * fl(1/q)): == Y*W (mod q), |result| <= q (0.5 + 1.5 |Y| 2^-52): already centred
+// when |Y| << 2^52, so small primes skip fp_mulmod's second step (3 of its 10 operations, all on the dependent
+// chain)
+PHA_HD double fp_mulmod_light(double Y, double W, FpMod m) {
     const double h = Y * W;
     const double l = __builtin_fma(Y, W, -h);
-    const double c = __builtin_rint(Y * Wi);
+    const double c = __builtin_rint(h * m.qinv);
     return __builtin_fma(-c, m.q, h) + l;
 }
 // CT butterfly: (X, Y) -> (X + Y*W, X - Y*W); magnitudes grow by at most q/2 + 1 per stage
-PHA_HD void fp_ct_bfly(double &X, double &Y, double W, double Wi, FpMod m) {
-    const double t = fp_mulmod(Y, W, Wi, m);
+PHA_HD void fp_ct_bfly(double &X, double &Y, double W, FpMod m) {
+    const double t = fp_mulmod(Y, W, m);
     const double x = X;
     X = x + t;
     Y = x - t;
 }
 // GS butterfly: (X, Y) -> ((X + Y) mod q, (X - Y)*W mod q), both centred (inputs |.| <= 2q)
-PHA_HD void fp_gs_bfly(double &X, double &Y, double W, double Wi, FpMod m) {
+PHA_HD void fp_gs_bfly(double &X, double &Y, double W, FpMod m) {
     const double s = X + Y, d = X - Y;
     X = fp_reduce(s, m);
-    Y = fp_mulmod(d, W, Wi, m);
+    Y = fp_mulmod(d, W, m);
 }
 // canonical integer residue [0,q) (q < 2^50) <-> double, via the 2^52 mantissa trick
 PHA_HD double fp_from_canon(u64 x) { return as_f64(x | 0x4330000000000000ull) - 4503599627370496.0; }

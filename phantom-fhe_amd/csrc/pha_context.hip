@@ -137,13 +137,11 @@ static void get_primes(u64 ntt_size, int bit_size, size_t count, std::vector<u64
 // context
 // ------------------------------------------------------------------------------------------------
 struct FpTables {
-    std::vector<u64x2> tw, itw, ninv, w1ninv;
+    std::vector<u64> tw, itw;
+    std::vector<u64x2> ninv, w1ninv;
     std::vector<FpInfo> info;
 };
-static u64x2 fp_pair(u64 w, u64 q) {  // (W, fl(W/q)) as bit patterns
-    const double wd = (double)w, wi = (double)w / (double)q;
-    return u64x2{as_u64(wd), as_u64(wi)};
-}
+static u64 fp_bits(u64 w) { return as_u64((double)w); }  // W as a double (exact: W < 2^50)
 
 static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, std::vector<u64x2> &itw,
                                std::vector<u64x2> &ninv, std::vector<u64x2> &w1ninv, FpTables &fp) {
@@ -171,13 +169,13 @@ static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, s
     const FpMod fm = make_fpmod(q);  // ok: bit 0 usable, bit 1 light forward butterflies, bit 2 light inverse ones
     fp.info[i] = FpInfo{fm.q, fm.qinv, ok ? (1u | (fm.ct_light ? 2u : 0u) | (fm.gs_light ? 4u : 0u)) : 0u, 0u};
     if (ok) {
-        u64x2 *tf = fp.tw.data() + (size_t)i * n, *itf = fp.itw.data() + (size_t)i * n;
+        u64 *tf = fp.tw.data() + (size_t)i * n, *itf = fp.itw.data() + (size_t)i * n;
         for (size_t k = 0; k < n; k++) {
-            tf[k] = fp_pair(t[k].x, q);
-            itf[k] = fp_pair(it[k].x, q);
+            tf[k] = fp_bits(t[k].x);
+            itf[k] = fp_bits(it[k].x);
         }
-        fp.ninv[i] = fp_pair(ni, q);
-        fp.w1ninv[i] = fp_pair(w1, q);
+        fp.ninv[i] = u64x2{fp_bits(ni), 0};
+        fp.w1ninv[i] = u64x2{fp_bits(w1), 0};
     }
 }
 
@@ -211,8 +209,8 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
     }
     std::vector<u64x2> tw((size_t)size_qp * c.n), itw((size_t)size_qp * c.n), ninv(size_qp), w1ninv(size_qp);
     FpTables fp;
-    fp.tw.assign((size_t)size_qp * c.n, u64x2{0, 0});
-    fp.itw.assign((size_t)size_qp * c.n, u64x2{0, 0});
+    fp.tw.assign((size_t)size_qp * c.n, 0);
+    fp.itw.assign((size_t)size_qp * c.n, 0);
     fp.ninv.assign(size_qp, u64x2{0, 0});
     fp.w1ninv.assign(size_qp, u64x2{0, 0});
     fp.info.resize(size_qp);

@@ -143,9 +143,10 @@ struct Context {
     DevBuf<u64x2> d_itw;      // [size_qp][n] inverse (psi^-brev(k), Shoup), slot 1 NOT folded
     DevBuf<u64x2> d_ninv;     // [size_qp] (N^-1, Shoup)
     DevBuf<u64x2> d_w1ninv;   // [size_qp] (itw[1] * N^-1, Shoup)
-    // FP64 path for primes below 2^50: the same tables as (W, W/q) doubles (bit patterns), rows of the
+    // FP64 path for primes below 2^50: the same tables as doubles W (bit patterns, 8 bytes per entry), rows of the
     // other primes are zero; d_fpinfo[prime] = (q, 1/q, usable flag)
-    DevBuf<u64x2> d_twf, d_itwf, d_ninvf, d_w1ninvf;
+    DevBuf<u64> d_twf, d_itwf;        // [size_qp][n] doubles W (bit patterns)
+    DevBuf<u64x2> d_ninvf, d_w1ninvf;  // .x = the constant as a double
     DevBuf<FpInfo> d_fpinfo;
     // host copies kept for pha_context_download_twiddle and tool construction
     std::mutex mu;

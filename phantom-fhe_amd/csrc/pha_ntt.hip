@@ -30,7 +30,7 @@ struct NttKArgs {
     const DModulus *mod;     // [prime]
     const u64x2 *ninv;       // [prime]
     const u64x2 *w1ninv;     // [prime]
-    const u64x2 *twf;        // FP64 path: table base [prime][n] of (W, W/q) doubles (forward or inverse)
+    const u64 *twf;          // FP64 path: table base [prime][n] of doubles W (forward or inverse)
     const u64x2 *ninvf, *w1ninvf;
     const FpInfo *fpinfo;    // [prime]; null = FP64 path off
     const u64 *scale;        // [limb] or null
@@ -55,6 +55,7 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
     a.in = k.in + (size_t)twr * n;
     a.out = k.out + (size_t)twr * n;
     a.tw = k.tw + (size_t)prime * n;
+    a.twd = nullptr;
     a.q = k.mod[prime].value;
     a.tile = tile;
     a.rho0 = k.t1;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
         if (fi.ok) {
             a.fp = true;
             a.fpm = FpMod{fi.q, fi.qinv, (fi.ok & 2) != 0, (fi.ok & 4) != 0};
-            a.tw = k.twf + (size_t)prime * n;
+            a.twd = k.twf + (size_t)prime * n;
             if (!FWD && FOLD) {
                 a.ninv = k.ninvf[prime];
                 a.w1ninv = k.w1ninvf[prime];

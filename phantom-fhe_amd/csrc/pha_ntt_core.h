@@ -96,7 +96,8 @@ struct PassCfg {
 struct PassArgs {
     const u64 *in;     // limb base to read (first round only)
     u64 *out;          // limb base to write (last round only)
-    const u64x2 *tw;   // this prime's twiddle row: forward table or inverse table
+    const u64x2 *tw;   // this prime's twiddle row: forward table or inverse table (integer path: W and Shoup quotient)
+    const u64 *twd;    // FP64 path: the same row as doubles (W only, 8 bytes per entry)
     u64 q;             // modulus
     u32 tile;          // tile index inside the limb
     u32 rho0;          // contiguous pass: T1 (root index of row r is T1 + r); strided pass: unused
@@ -106,7 +107,7 @@ struct PassArgs {
     // epilogue operands
     u64x2 scale;       // EPI_INV_SCALE: per-limb scale ; EPI_FWD_MODDOWN: PInv mod q
     const u64 *aux;    // EPI_FWD_MODDOWN: cx limb base
-    // FP64 path (q < 2^50): tw / ninv / w1ninv then hold (W, W/q) doubles; registers, LDS and the
+    // FP64 path (q < 2^50): twd / ninv.x / w1ninv.x then hold W as a double; registers, LDS and the
     // inter-pass buffer carry doubles; global inputs and outputs stay canonical integers
     bool fp;
     FpMod fpm;
@@ -142,12 +143,24 @@ PHA_HD void decode_group(int g, int &v, int &hi, int &lo) {
 
 // Twiddles of one radix-2^R group, preloaded in heap order: stage j, sub-group kk -> t[(1 << j) - 1 + kk],
 // taken from tw[(base0 << j) + kk] (base0 = rho * 2^s0 + hi, see round_compute).
+// One table entry: the integer path reads the (W, W') pair, the FP64 path the double W (a.fp is uniform).
+PHA_HD u64x2 tw_entry(const PassArgs &a, u32 idx) {
+    if (a.fp) return u64x2{a.twd[idx], 0};
+    return a.tw[idx];
+}
 template <int R>
-PHA_HD void load_group_twiddles(u64x2 *t, const u64x2 *tw, u32 base0) {
+PHA_HD void load_group_twiddles(u64x2 *t, const PassArgs &a, u32 base0) {
+    if (a.fp) {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+#pragma unroll
+            for (int kk = 0; kk < (1 << j); kk++) t[(1 << j) - 1 + kk].x = a.twd[(base0 << j) + kk];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < R; j++)
 #pragma unroll
-        for (int kk = 0; kk < (1 << j); kk++) t[(1 << j) - 1 + kk] = tw[(base0 << j) + kk];
+        for (int kk = 0; kk < (1 << j); kk++) t[(1 << j) - 1 + kk] = a.tw[(base0 << j) + kk];
 }
 
 // r forward stages on 2^r registers; stage j uses tw[(base0 << j) + (k >> (r - j))].
@@ -203,16 +216,16 @@ PHA_HD void ot_round_fp(u64 *v, const u64x2 *tc, const u64x2 *tr, FpMod m) {
             const u64x2 wc = tc[(1 << j) - 1 + (k >> (R - j))], wr = tr[j];
             double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
             if (FWD) {
-                const double t = LIGHT ? fp_mulmod_light(fp_mulmod_light(Y, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m)
-                                       : fp_mulmod(fp_mulmod(Y, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
+                const double t = LIGHT ? fp_mulmod_light(fp_mulmod_light(Y, as_f64(wr.x), m), as_f64(wc.x), m)
+                                       : fp_mulmod(fp_mulmod(Y, as_f64(wr.x), m), as_f64(wc.x), m);
                 const double x = X;
                 X = x + t;
                 Y = x - t;
             } else {
                 const double s = X + Y, d = X - Y;
                 X = LIGHT ? s : fp_reduce(s, m);
-                Y = LIGHT ? fp_mulmod_light(fp_mulmod_light(d, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m)
-                          : fp_mulmod(fp_mulmod(d, as_f64(wr.x), as_f64(wr.y), m), as_f64(wc.x), as_f64(wc.y), m);
+                Y = LIGHT ? fp_mulmod_light(fp_mulmod_light(d, as_f64(wr.x), m), as_f64(wc.x), m)
+                          : fp_mulmod(fp_mulmod(d, as_f64(wr.x), m), as_f64(wc.x), m);
             }
             v[k] = as_u64(X);
             v[k + dist] = as_u64(Y);
@@ -232,11 +245,11 @@ PHA_HD void fp_ct_round(u64 *v, const u64x2 *t, FpMod m) {
             const u64x2 w = t[(1 << j) - 1 + (k >> (R - j))];
             double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
             if (LIGHT) {
-                const double tt = fp_mulmod_light(Y, as_f64(w.x), as_f64(w.y), m), x = X;
+                const double tt = fp_mulmod_light(Y, as_f64(w.x), m), x = X;
                 X = x + tt;
                 Y = x - tt;
             } else {
-                fp_ct_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+                fp_ct_bfly(X, Y, as_f64(w.x), m);
             }
             v[k] = as_u64(X);
             v[k + dist] = as_u64(Y);
@@ -254,16 +267,16 @@ PHA_HD void fp_gs_round(u64 *v, const u64x2 *t, FpMod m, u64x2 ninv, u64x2 w1nin
             double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
             if (FOLD && j == 0) {
                 const double s = X + Y, d = X - Y;
-                X = fp_mulmod(s, as_f64(ninv.x), as_f64(ninv.y), m);
-                Y = fp_mulmod(d, as_f64(w1ninv.x), as_f64(w1ninv.y), m);
+                X = fp_mulmod(s, as_f64(ninv.x), m);
+                Y = fp_mulmod(d, as_f64(w1ninv.x), m);
             } else {
                 const u64x2 w = t[(1 << j) - 1 + (k >> (R - j))];
                 if (LIGHT) {
                     const double s = X + Y, d = X - Y;
                     X = s;
-                    Y = fp_mulmod_light(d, as_f64(w.x), as_f64(w.y), m);
+                    Y = fp_mulmod_light(d, as_f64(w.x), m);
                 } else {
-                    fp_gs_bfly(X, Y, as_f64(w.x), as_f64(w.y), m);
+                    fp_gs_bfly(X, Y, as_f64(w.x), m);
                 }
             }
             v[k] = as_u64(X);
@@ -363,13 +376,13 @@ PHA_HD void round_load_tw(const PassArgs &a, int tid, u64x2 *twreg) {
         u64x2 *base = twreg + C::tw_off(RI);
         int v, hi, lo;
         decode_group<C, RI>(tid, v, hi, lo);
-        load_group_twiddles<r>(base, a.tw, (u32)hi);
+        load_group_twiddles<r>(base, a, (u32)hi);
 #pragma unroll
         for (int gi = 0; gi < G; gi++) {
             decode_group<C, RI>(tid + C::THREADS * gi, v, hi, lo);
             const u32 rho = a.rho0 + a.tile * C::V + (u32)v;
 #pragma unroll
-            for (int j = 0; j < r; j++) base[(K - 1) + gi * r + j] = a.tw[rho << (s0 + j)];
+            for (int j = 0; j < r; j++) base[(K - 1) + gi * r + j] = tw_entry(a, rho << (s0 + j));
         }
         return;
     }
@@ -384,7 +397,7 @@ PHA_HD void round_load_tw(const PassArgs &a, int tid, u64x2 *twreg) {
 #else
         const u32 base0 = (rho << s0) + (u32)hi;
 #endif
-        load_group_twiddles<r>(twreg + C::tw_off(RI) + gi * (K - 1), a.tw, base0);
+        load_group_twiddles<r>(twreg + C::tw_off(RI) + gi * (K - 1), a, base0);
     }
 }
 

@@ -43,7 +43,7 @@ static void emu(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *
     using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     const size_t n = (size_t)1 << LOGN;
     PassArgs a{};
-    a.tw = tw; a.q = q; a.rho0 = P1::T; a.stride = P2::T; a.ninv = ninv; a.w1ninv = w1ninv; a.scale = scale; a.aux = aux;
+    a.tw = tw; a.twd = reinterpret_cast<const u64 *>(tw); a.q = q; a.rho0 = P1::T; a.stride = P2::T; a.ninv = ninv; a.w1ninv = w1ninv; a.scale = scale; a.aux = aux;
     a.fp = fp; a.fpm = make_fpmod(q);
     if (fwd) {
         a.in = in; a.out = out;
@@ -107,7 +107,8 @@ extern "C" int emu_plan_is_wave_local(int log_n, int variant) {   // bit 0: pass
     switch (log_n) { WLC(12) WLC(13) WLC(14) WLC(15) WLC(16) WLC(17) default: return -1; }
 }
 
-// bit 16 of log_n_and_variant: FP64 path (tw / ninv / w1ninv then carry (W, W/q) double bit patterns)
+// bit 16 of log_n_and_variant: FP64 path (tw_interleaved is then a plain array of doubles W; ninv / w1ninv carry
+// the constant as a double in their first word)
 extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *in, uint64_t *out, uint64_t q,
                        const uint64_t *tw_interleaved, const uint64_t *ninv, const uint64_t *w1ninv,
                        const uint64_t *scale, const uint64_t *aux) {

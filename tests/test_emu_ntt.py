@@ -63,12 +63,11 @@ def test_thread_program_matches_oracle(emu, log_n, bits, variant):
     assert emu.emu_ntt(code, 0, 3, p(ref), p(back), q, p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q)), p(z), p(z)) == 0
     assert np.array_equal(back, x)
     if bits <= 50:
-        # FP64 path (primes below 2^50): tables of (W, W/q) doubles; results must stay bit-identical
+        # FP64 path (primes below 2^50): tables of doubles W (8 bytes per entry); results must stay bit-identical
         def fpairs(w):
-            wd = w.astype(np.float64)
-            return np.ascontiguousarray(np.stack([wd.view(np.uint64), (wd / float(q)).view(np.uint64)], axis=1).reshape(-1))
+            return np.ascontiguousarray(w.astype(np.float64)).view(np.uint64).copy()
         def fpair1(v):
-            d = np.array([float(v), float(v) / float(q)], dtype=np.float64)
+            d = np.array([float(v), 0.0], dtype=np.float64)
             return d.view(np.uint64).copy()
         fcode = code | (1 << 16)
         out_f = np.zeros(n, dtype=np.uint64)
