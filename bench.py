@@ -30,11 +30,11 @@ LOG_N = 16
 BITS = [60] + [50] * 44 + [60] * 15   # 45 data primes + 15 special primes
 SIZE_P = 15
 PEAK_HBM = 8.0e12                     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
-# HBM-side bytes of one 45-limb forward NTT from the PMC passes of profiles/r01h_pmc_{fetch,write}.csv
+# HBM-side bytes of one 45-limb forward NTT from the PMC passes of profiles/r01j_pmc_{fetch,write}.csv
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction of
-# MI355X_MICROARCH.md): strided pass 2*12356 + 23040 KiB, contiguous pass 2*35042 + 23041 KiB (it streams the
-# 45 MiB twiddle table).  Not measurable inside this process, hence a recorded constant.
-NTT_TRAFFIC_BYTES = (2 * (12356 + 35042) + 23040 + 23041) * 1024
+# MI355X_MICROARCH.md): strided pass 2*12023 + 23040 KiB, contiguous pass 2*24142 + 23040 KiB (it streams the
+# twiddle table: 8-byte entries for the 44 FP64 limbs, 16-byte pairs for the 60-bit limb).  Not measurable inside this process, hence a recorded constant.
+NTT_TRAFFIC_BYTES = (2 * (12023 + 24142) + 23040 + 23040) * 1024
 
 
 def uniform_residues(primes, n, device, gen):
@@ -267,7 +267,7 @@ def main():
                        "launch": "hipGraph replay of the K steps" if graph is not None else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM, "traffic": NTT_TRAFFIC_BYTES,
-                         "traffic_source": "profiles/r01h_pmc_fetch.csv + r01h_pmc_write.csv (rocprofv3 PMC, per launch pair)",
+                         "traffic_source": "profiles/r01j_pmc_fetch.csv + r01j_pmc_write.csv (rocprofv3 PMC, per launch pair)",
                          "kernel": "ntt_pass_kernel pair (strided pass + contiguous pass)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms},
             "batched_ntt": {"polynomials_per_launch": batch, "ms_per_launch": batched_ms,
