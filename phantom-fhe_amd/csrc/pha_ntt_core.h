@@ -256,11 +256,20 @@ PHA_HD void fp_ct_round(u64 *v, const u64x2 *t, FpMod m) {
         }
     }
 }
-template <int R, bool FOLD, bool LIGHT>
+// Which inverse stages must re-centre the sum X + Y (primes up to 2^50, magnitudes must stay below 2^52.6 ~ 6q):
+// with inputs bounded by b*q a stage forms |X - Y| <= 2b q for the multiply (needs 2b <= 6) and leaves X + Y
+// <= 2b q behind, so the sum may stay unreduced while 2b <= 3.  From centred inputs (b = 1/2: every pass but the
+// first, and anything a multiply produced) that is two stages in three; canonical inputs in [0, q) (b = 1, first
+// pass) allow one first.  `i` counts the stages of the pass in execution order.
+constexpr bool gs_stage_reduces(int i, bool canon_in) { return canon_in ? (i % 3 == 1) : (i % 3 == 2); }
+
+// STAGE0: how many stages of this pass ran before this round; CANON_IN: the pass started from canonical integers
+template <int R, bool FOLD, bool LIGHT, int STAGE0 = 0, bool CANON_IN = true>
 PHA_HD void fp_gs_round(u64 *v, const u64x2 *t, FpMod m, u64x2 ninv, u64x2 w1ninv) {
 #pragma unroll
     for (int j = R - 1; j >= 0; j--) {
         const int dist = 1 << (R - 1 - j);
+        const bool reduce_sum = gs_stage_reduces(STAGE0 + (R - 1 - j), CANON_IN);
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) {
             if (k & dist) continue;
@@ -275,8 +284,12 @@ PHA_HD void fp_gs_round(u64 *v, const u64x2 *t, FpMod m, u64x2 ninv, u64x2 w1nin
                     const double s = X + Y, d = X - Y;
                     X = s;
                     Y = fp_mulmod_light(d, as_f64(w.x), m);
-                } else {
+                } else if (reduce_sum) {
                     fp_gs_bfly(X, Y, as_f64(w.x), m);
+                } else {
+                    const double s = X + Y, d = X - Y;
+                    X = s;
+                    Y = fp_mulmod(d, as_f64(w.x), m);
                 }
             }
             v[k] = as_u64(X);
@@ -430,8 +443,11 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
                 if (a.fpm.ct_light) fp_ct_round<r, true>(rg, t, a.fpm);
                 else fp_ct_round<r, false>(rg, t, a.fpm);
             } else {
+                // stages of this pass already done (inverse order: rounds NR-1 .. 0), and whether it began canonical
+                constexpr int stage0 = C::LOGT - C::s0(RI) - r;
+                constexpr bool canon_in = !C::STRIDED;  // the inverse's first pass is the contiguous one
                 if (a.fpm.gs_light) fp_gs_round<r, FOLD, true>(rg, t, a.fpm, a.ninv, a.w1ninv);
-                else fp_gs_round<r, FOLD, false>(rg, t, a.fpm, a.ninv, a.w1ninv);
+                else fp_gs_round<r, FOLD, false, stage0, canon_in>(rg, t, a.fpm, a.ninv, a.w1ninv);
             }
         }
         return;
