@@ -46,7 +46,9 @@ def uniform_residues(primes, n, device, gen):
 
 
 def cpu_baseline(primes, n, seconds=12.0):
-    """Time the oracle's forward NTT (scalar C port of the reference semantics) on one host core."""
+    """Time the oracle's forward NTT (C port of the reference semantics) on the host: one core (the reported
+    baseline) and, informational, OpenMP over the 45 limbs on every core of the box."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # idle OpenMP threads must not spin on a shared box
     from oracle import oracle as O
     path = O.build(native=True)
     oc = O.Ctx(LOG_N, [int(p) for p in primes[:45]], 0, libpath=path)
@@ -54,16 +56,37 @@ def cpu_baseline(primes, n, seconds=12.0):
     x = np.stack([rng.integers(0, int(q), n, dtype=np.uint64) for q in primes[:45]]).reshape(-1)
     import ctypes as C
     ptr = x.ctypes.data_as(C.POINTER(C.c_uint64))
-    oc.L.orc_nwt_forward(oc.h, ptr, 45, 0)
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < seconds:
+
+    def run(threads, budget):
+        oc.L.orc_set_threads(threads)
         oc.L.orc_nwt_forward(oc.h, ptr, 45, 0)
-        reps += 1
-    dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget:
+            oc.L.orc_nwt_forward(oc.h, ptr, 45, 0)
+            reps += 1
+        return reps, time.perf_counter() - t0
+
+    reps, dt = run(1, seconds)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:   # a cgroup CPU quota caps what the visible cores can deliver
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    threads = min(cores, 45)
+    reps_all, dt_all = run(threads, 4.0)
+    oc.L.orc_set_threads(1)
     return {"value": 45 * reps / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
             "sample": f"{reps} forward NTTs of 45 limbs at N=2^16 ({dt:.1f} s, oracle/oracle.c -O3 -march=native, 1 thread)",
-            "host_cpus": os.cpu_count()}
+            "host_cpus": cores,
+            "all_cores": {"value": 45 * reps_all / dt_all, "unit": "NTT/s", "cores": threads,
+                          "sample": f"{reps_all} x 45 limbs, OpenMP over limbs ({threads} threads, one limb each), "
+                                    f"{dt_all:.1f} s; cores = min(affinity, cgroup quota, 45)"}}
 
 
 def main():
@@ -253,6 +276,22 @@ def main():
     torch.cuda.synchronize()
     hm_batched_elapsed = time.perf_counter() - t0
 
+    # device-to-device copy of 512 MiB (read + write), the calibrated counterpart of the nominal 8 TB/s
+    cal_a = torch.empty(64 << 20, dtype=torch.int64, device=dev)
+    cal_b = torch.empty_like(cal_a)
+    for _ in range(3):
+        cal_b.copy_(cal_a)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        cal_b.copy_(cal_a)
+    ev1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 10 * 2 * cal_a.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del cal_a, cal_b
+    # minimal per-stage traffic of one HomMul + relinearize + rescale at C3: 929 MiB
+    hm_alg_bytes = 929.0 * (1 << 20)
+
     if rank == 0:
         alg_bytes = 16.0 * n * size_q                  # 8 B read + 8 B write per coefficient
         achieved = alg_bytes / (kernel_ms * 1e-3)
@@ -269,18 +308,23 @@ def main():
                          "frac": achieved / PEAK_HBM, "traffic": NTT_TRAFFIC_BYTES,
                          "traffic_source": "profiles/r01j_pmc_fetch.csv + r01j_pmc_write.csv (rocprofv3 PMC, per launch pair)",
                          "kernel": "ntt_pass_kernel pair (strided pass + contiguous pass)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
+                         "calibrated_copy_GBps": copy_gbps,
+                         "calibrated_note": "512 MiB device-to-device copy, read + write bytes / time, this run"},
             "batched_ntt": {"polynomials_per_launch": batch, "ms_per_launch": batched_ms,
                             "value": batch * size_q / (batched_ms * 1e-3), "unit": "NTT/s (this rank)",
                             "frac_of_peak": batch * alg_bytes / (batched_ms * 1e-3) / PEAK_HBM,
                             "note": "pha_nwt_2d_radix8_forward_inplace_batched: 4 x 45 limbs per launch pair"},
             "hommul_relin_rescale": {"value": world * hm_steps / hm_elapsed, "unit": "ops/s",
-                                     "ms_per_op": 1e3 * hm_elapsed / hm_steps, "steps": hm_steps},
+                                     "ms_per_op": 1e3 * hm_elapsed / hm_steps, "steps": hm_steps,
+                                     "algorithmic_bytes_per_op": hm_alg_bytes,
+                                     "frac_of_peak": hm_alg_bytes / (hm_elapsed / hm_steps) / PEAK_HBM},
             "hommul_relin_rescale_4_streams": {"value": S * hm_steps / hm_lanes_elapsed, "unit": "ops/s (this rank)",
                                                "ms_per_op": 1e3 * hm_lanes_elapsed / (S * hm_steps),
                                                "note": "4 independent ciphertext pairs, one HIP stream each"},
             "hommul_relin_rescale_batched": {"value": B * hm_steps / hm_batched_elapsed, "unit": "ops/s (this rank)",
                                              "ms_per_op": 1e3 * hm_batched_elapsed / (B * hm_steps), "batch": B,
+                                             "frac_of_peak": hm_alg_bytes / (hm_batched_elapsed / (B * hm_steps)) / PEAK_HBM,
                                              "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_inplace_batched + rescale of the batch"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -10,6 +10,9 @@
 #include "oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
@@ -311,16 +314,28 @@ static void fwd1(const orc_ctx *c, u64 *x, size_t p) {
 static void inv1(const orc_ctx *c, u64 *x, size_t p) {
     orc_ntt_inverse(x, c->log_n, c->q[p], c->itw + p * c->n, c->itws + p * c->n, c->n_inv[p], c->n_inv_s[p]);
 }
+/* limbs are independent: OpenMP over limbs (the all-cores CPU baseline of bench.py; orc_set_threads(1) = scalar) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+    (void)n;
+#endif
+}
 void orc_nwt_forward(const orc_ctx *c, u64 *d, size_t limbs, size_t start) {
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < limbs; i++) fwd1(c, d + i * c->n, start + i);
 }
 void orc_nwt_backward(const orc_ctx *c, u64 *d, size_t limbs, size_t start) {
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < limbs; i++) inv1(c, d + i * c->n, start + i);
 }
 void orc_nwt_forward_map(const orc_ctx *c, u64 *d, const uint32_t *map, size_t limbs) {
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < limbs; i++) fwd1(c, d + i * c->n, map[i]);
 }
 void orc_nwt_backward_map(const orc_ctx *c, u64 *d, const uint32_t *map, size_t limbs) {
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < limbs; i++) inv1(c, d + i * c->n, map[i]);
 }
 

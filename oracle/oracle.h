@@ -58,6 +58,8 @@ size_t orc_ctx_n(const orc_ctx *c);
 const uint64_t *orc_ctx_twiddle(const orc_ctx *c, size_t prime_idx, int which); /* 0 tw,1 tw_shoup,2 itw,3 itw_shoup */
 uint64_t orc_ctx_n_inv(const orc_ctx *c, size_t prime_idx);
 
+/* threads used by the limb-parallel loops (0 = all cores); test / baseline knob only */
+void orc_set_threads(int n);
 /* limb-batched transforms; prime index of data limb i is start_idx+i (nwt_2d_radix8_forward_inplace
  * fntt_2d.cu:620-653 / backward intt_2d.cu:724-757) */
 void orc_nwt_forward(const orc_ctx *c, uint64_t *data, size_t limbs, size_t start_idx);

@@ -83,6 +83,8 @@ def lib(path=None):
     L.orc_keyswitch_inplace.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p), C.c_int]
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_threads.restype = None
     L.orc_tool_set_plain_modulus.restype = C.c_int
     L.orc_tool_set_plain_modulus.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_mod_t_divide_q_last_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
