@@ -1,0 +1,69 @@
+"""Seeded random parameter sets through the whole key-switch path on the GPU vs the oracle: mixed prime sizes
+(30..60 bits: FP64 light / FP64 / integer NTT paths side by side), alpha 1..4, dnum 1..4, every level including
+short last digits, all three schemes, plus rescale / modulus switch and hoisted rotations."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import rng_for, uniform_poly
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain(rng, n, count):
+    """`count` distinct NTT primes with random bit sizes (largest first within a size, like CoeffModulus::Create)."""
+    sizes = [int(rng.choice([30, 36, 40, 42, 43, 45, 47, 48, 50, 55, 60])) for _ in range(count)]
+    pools = {b: [int(p) for p in O.get_primes(n, b, sizes.count(b))] for b in set(sizes)}
+    return [pools[b].pop(0) for b in sizes]
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_parameter_sets(case, gpu):
+    import phantom_fhe_amd as P
+    rng = rng_for(5000 + case)
+    log_n = int(rng.choice([12, 12, 13]))
+    n = 1 << log_n
+    alpha = int(rng.integers(1, 5))
+    dnum = int(rng.integers(1, 5))
+    size_q = alpha * dnum
+    primes = _chain(rng, n, size_q + alpha)
+    scheme = [O.CKKS, O.BFV, O.BGV][case % 3]
+    ql = int(rng.integers(1, size_q + 1))
+    oc = O.Ctx(log_n, primes, alpha)
+    ctx = P.PhantomContext(log_n, primes, alpha, device=gpu)
+    tool = O.Tool(oc, ql)
+    if scheme == O.BGV:
+        t = 65537
+        ctx.set_plain_modulus(t)
+        tool.set_plain_modulus(t)
+    evk = np.stack([np.stack([uniform_poly(rng, primes, n), uniform_poly(rng, primes, n)]) for _ in range(dnum)])
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    ct = np.stack([uniform_poly(rng, primes[:ql], n) for _ in range(2)])
+    c2 = uniform_poly(rng, primes[:ql], n)
+    d_ct = P.to_device(ct, gpu)
+    ctx.keyswitch_inplace(ql, d_ct, P.to_device(c2, gpu), rlk.public_keys_ptr, scheme)
+    ref = tool.keyswitch_inplace(ct, c2, [evk[i] for i in range(tool.beta)], scheme)
+    assert np.array_equal(P.to_host(d_ct), ref), f"keyswitch {primes} alpha={alpha} ql={ql} scheme={scheme}"
+    # batch of two through the batched entry point: same answers
+    d_b = P.to_device(np.stack([ct, ref]), gpu)
+    d_c2 = P.to_device(np.stack([c2, ct[0]]), gpu)
+    ctx.keyswitch_inplace_batched(ql, d_b, d_c2, 2, rlk.public_keys_ptr, scheme)
+    got = P.to_host(d_b)
+    assert np.array_equal(got[0], ref)
+    assert np.array_equal(got[1], tool.keyswitch_inplace(ref, ct[0], [evk[i] for i in range(tool.beta)], scheme))
+    if ql > 1:
+        dst = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+        if scheme == O.CKKS:
+            ctx.divide_and_round_q_last_ntt(ql, P.to_device(ref, gpu), 2, dst)
+            assert np.array_equal(P.to_host(dst), tool.rescale_ntt(ref, 2))
+        elif scheme == O.BGV:
+            ctx.mod_t_and_divide_q_last_ntt(ql, P.to_device(ref, gpu), 2, dst)
+            assert np.array_equal(P.to_host(dst), tool.mod_t_divide_q_last_ntt(ref, 2))
+        else:
+            ctx.divide_and_round_q_last(ql, P.to_device(ref, gpu), 2, dst)
+            assert np.array_equal(P.to_host(dst), tool.divide_and_round_q_last(ref, 2))
+    elts = [5, 2 * n - 1]
+    glk = [np.stack([np.stack([uniform_poly(rng, primes, n), uniform_poly(rng, primes, n)]) for _ in range(dnum)]) for _ in elts]
+    d_h = P.to_device(ct, gpu)
+    ctx.hoisting(ql, d_h, elts, [P.PhantomRelinKey.from_numpy(k, gpu) for k in glk], scheme)
+    assert np.array_equal(P.to_host(d_h), tool.hoisting(ct, elts, [[k[i] for i in range(tool.beta)] for k in glk], scheme))
