@@ -13,6 +13,9 @@
 
 #include <phantom.h>
 
+#include <fstream>
+#include <sstream>
+
 namespace py = pybind11;
 using namespace phantom;
 using namespace phantom::arith;
@@ -68,6 +71,17 @@ PYBIND11_MODULE(pyPhantom, m) {
             u64_array out({ct.size(), ct.coeff_modulus_size(), ct.poly_modulus_degree()});
             ct.store_to_host(out.mutable_data());
             return out;
+        })
+        // the reference's on-disk format (include/ciphertext.h:173-214)
+        .def("save", [](const PhantomCiphertext &ct, const std::string &path) {
+            std::ofstream f(path, std::ios::binary);
+            if (!f) throw std::runtime_error("cannot open " + path);
+            ct.save(f);
+        })
+        .def("load_file", [](PhantomCiphertext &ct, const std::string &path) {
+            std::ifstream f(path, std::ios::binary);
+            if (!f) throw std::runtime_error("cannot open " + path);
+            ct.load(f);
         });
 
     py::class_<PhantomRelinKey>(m, "relin_key")
@@ -75,6 +89,37 @@ PYBIND11_MODULE(pyPhantom, m) {
         .def("load", [](PhantomRelinKey &k, const PhantomContext &c, u64_array evk) {
             if (evk.ndim() != 4) throw std::invalid_argument("expected [dnum][2][QP][N]");
             k.load_from_host(c, evk.data(), static_cast<size_t>(evk.shape(0)));
+        })
+        // generate_one_kswitch_key (src/secretkey.cu:297-341) with caller-supplied randomness: sk [QP][N] and
+        // new_key [Q][N] in NTT form, a [dnum][QP][N] uniform, e [dnum][QP][N] noise in coefficient form
+        .def("generate", [](PhantomRelinKey &k, const PhantomContext &c, u64_array sk, u64_array new_key, u64_array a, u64_array e) {
+            const auto &s = cudaStreamPerThread;
+            auto up = [&](const u64_array &h) {
+                auto d = util::make_cuda_auto_ptr<uint64_t>(static_cast<size_t>(h.size()), s);
+                util::check_hip(hipMemcpyAsync(d.get(), h.data(), static_cast<size_t>(h.size()) * 8, hipMemcpyHostToDevice, s), "hipMemcpyAsync");
+                return d;
+            };
+            auto d_sk = up(sk), d_nk = up(new_key), d_a = up(a), d_e = up(e);
+            k.generate(c, d_sk.get(), d_nk.get(), d_a.get(), d_e.get(), s);
+            util::check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        })
+        .def("to_numpy", [](const PhantomRelinKey &k) {
+            const auto &pk0 = k.public_key(0);
+            u64_array out({k.dnum(), size_t(2), pk0.coeff_modulus_size(), pk0.poly_modulus_degree()});
+            const size_t words = 2 * pk0.coeff_modulus_size() * pk0.poly_modulus_degree();
+            for (size_t d = 0; d < k.dnum(); d++) k.public_key(d).store_to_host(out.mutable_data() + d * words);
+            return out;
+        })
+        // the reference's on-disk format (include/secretkey.h:129-163)
+        .def("save", [](const PhantomRelinKey &k, const std::string &path) {
+            std::ofstream f(path, std::ios::binary);
+            if (!f) throw std::runtime_error("cannot open " + path);
+            k.save(f);
+        })
+        .def("load_file", [](PhantomRelinKey &k, const std::string &path) {
+            std::ifstream f(path, std::ios::binary);
+            if (!f) throw std::runtime_error("cannot open " + path);
+            k.load(f);
         });
     py::class_<PhantomGaloisKey>(m, "galois_key")
         .def(py::init<>())

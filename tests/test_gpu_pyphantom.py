@@ -67,3 +67,47 @@ def test_ckks_flow(gpu):
                                                                      [g2[i] for i in range(tool.beta)]], O.CKKS))
     with pytest.raises(ValueError):
         ph.relinearize(ctx, a, rlk)          # std::invalid_argument -> ValueError, as pybind does for the reference
+
+
+@pytest.mark.gpu
+def test_keygen_and_files(gpu, tmp_path):
+    """relin_key.generate (caller-supplied randomness) vs the oracle, and the reference's on-disk formats."""
+    from phantom_fhe_amd import pyPhantom as ph
+    name = "hyb12_a2"
+    log_n, primes, size_p = primes_of(name)
+    n, size_q = 1 << log_n, len(primes) - size_p
+    parms = ph.params(ph.scheme_type.ckks)
+    parms.set_poly_modulus_degree(n)
+    parms.set_special_modulus_size(size_p)
+    parms.set_coeff_modulus(ph.create_coeff_modulus(n, [60, 40, 40, 40, 40, 40, 60, 60]))
+    ctx = ph.context(parms)
+    oc = oracle_ctx(name)
+    r = rng_for(91)
+    dnum = size_q // size_p
+    s_small = r.integers(-1, 2, n)
+    sk = oc.nwt_forward(np.stack([(s_small % int(q)).astype(np.uint64) for q in primes]), len(primes), 0)
+    s2 = oc.multiply(sk[:size_q], sk[:size_q], size_q)
+    a = np.stack([uniform_poly(r, primes, n) for _ in range(dnum)])
+    e_small = r.integers(-3, 4, (dnum, n))
+    e = np.stack([np.stack([(e_small[d] % int(q)).astype(np.uint64) for q in primes]) for d in range(dnum)])
+    ref = oc.gen_kswitch_key(sk, s2, a, np.stack([oc.nwt_forward(e[d], len(primes), 0) for d in range(dnum)]))
+    rlk = ph.relin_key()
+    rlk.generate(ctx, sk, s2, a, e)
+    assert np.array_equal(rlk.to_numpy(), ref)
+    path = str(tmp_path / "rlk.bin")
+    rlk.save(path)
+    import os
+    header = 4 * 8 + 8 + 8 + 8 + 2
+    assert os.path.getsize(path) == 8 + dnum * (header + 2 * len(primes) * n * 8)
+    back = ph.relin_key()
+    back.load_file(path)
+    assert np.array_equal(back.to_numpy(), ref)
+    ct = ph.ciphertext()
+    h = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct.load(ctx, 1, h)
+    ct.set_scale(2.0 ** 40)
+    cpath = str(tmp_path / "ct.bin")
+    ct.save(cpath)
+    ct2 = ph.ciphertext()
+    ct2.load_file(cpath)
+    assert np.array_equal(ct2.to_numpy(), h) and ct2.scale() == 2.0 ** 40 and ct2.chain_index() == 1
