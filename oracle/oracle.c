@@ -793,6 +793,227 @@ void orc_divide_and_round_q_last(const orc_tool *t, const u64 *src, size_t ciphe
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * BFV multiply, BEHZ variant (src/evaluate.cu:404-548; constants src/rns.cu:392-560; kernels
+ * src/rns.cu:1249-1510, src/polymath.cu:606-634).  Top data level only (base q = every data prime).
+ * ---------------------------------------------------------------------------------------------- */
+static int inv_euclid(u64 a, u64 m, u64 *out) { /* a^-1 mod m for any m >= 2 (try_invert_uint_mod) */
+    __int128 r0 = m, r1 = a % m, s0 = 0, s1 = 1;
+    while (r1) { __int128 qq = r0 / r1, tmp = r0 - qq * r1; r0 = r1; r1 = tmp; tmp = s0 - qq * s1; s0 = s1; s1 = tmp; }
+    if (r0 != 1) return -1;
+    *out = (u64)((s0 % (__int128)m + m) % m);
+    return 0;
+}
+static u64 prod_mod(const u64 *v, size_t cnt, u64 m) {
+    u64 p = 1 % m;
+    for (size_t i = 0; i < cnt; i++) p = orc_mulmod(p, v[i] % m, m);
+    return p;
+}
+static int prod_bit_count(const u64 *v, size_t cnt) { /* get_significant_bit_count_uint(prod v) */
+    u64 *acc = (u64 *)calloc(cnt + 1, sizeof(u64));
+    size_t len = 1;
+    acc[0] = 1;
+    for (size_t i = 0; i < cnt; i++) {
+        u64 carry = 0;
+        for (size_t w = 0; w < len; w++) {
+            u128 t = (u128)acc[w] * v[i] + carry;
+            acc[w] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+        if (carry) acc[len++] = carry;
+    }
+    int bits = (int)(len - 1) * 64 + (64 - __builtin_clzll(acc[len - 1]));
+    free(acc);
+    return bits;
+}
+struct orc_behz {
+    const orc_ctx *c;
+    size_t n, size_q, size_b, size_bsk;
+    int log_n;
+    u64 plain_t, m_tilde, m_sk;
+    u64 *bsk;                 /* [size_bsk] = B primes then m_sk (rns.cu:413-431) */
+    u64 (*bsk_mu)[2];
+    u64 *tw, *tws, *itw, *itws, *n_inv, *n_inv_s; /* NTT tables of the Bsk primes (:433-448) */
+    u64 *mt_qhatinv, *mt_qhatinv_s;               /* m_tilde * QHatInv mod q (:450-465) */
+    bconv_t q_to_bsk, q_to_mtilde, b_to_q, b_to_msk;
+    u64 *inv_prod_q_mod_bsk, *inv_prod_q_mod_bsk_s, *prod_q_mod_bsk, *inv_mt_mod_bsk, *inv_mt_mod_bsk_s;
+    u64 neg_inv_prod_q_mod_mt, neg_inv_prod_q_mod_mt_s, inv_prod_b_mod_msk, inv_prod_b_mod_msk_s;
+    u64 *prod_b_mod_q;
+};
+size_t orc_behz_bsk_size(const orc_behz *b) { return b->size_bsk; }
+void orc_behz_base(const orc_behz *b, u64 *out) { memcpy(out, b->bsk, sizeof(u64) * b->size_bsk); }
+
+orc_behz *orc_behz_create(const orc_ctx *c, u64 plain_t) {
+    orc_behz *b = (orc_behz *)calloc(1, sizeof(*b));
+    b->c = c; b->n = c->n; b->log_n = c->log_n; b->size_q = c->size_q; b->plain_t = plain_t;
+    const size_t sq = c->size_q, n = c->n;
+    /* bit count of prod(q) and of t: base B grows by one prime when 32 + |t| + |Q| >= 61 * size_q + 61 (:398-406) */
+    int total_bits = prod_bit_count(c->q, sq), t_bits = 64 - __builtin_clzll(plain_t);
+    b->size_b = sq + ((32 + t_bits + total_bits >= 61 * (int)sq + 61) ? 1 : 0);
+    b->size_bsk = b->size_b + 1;
+    u64 *aux = (u64 *)malloc(sizeof(u64) * (b->size_b + 1));
+    if (orc_get_primes(n, 61, b->size_b + 1, aux)) { free(aux); free(b); return NULL; }
+    b->m_sk = aux[0];
+    b->m_tilde = (u64)1 << 32;
+    b->bsk = (u64 *)malloc(sizeof(u64) * b->size_bsk);
+    for (size_t i = 0; i < b->size_b; i++) b->bsk[i] = aux[1 + i];
+    b->bsk[b->size_b] = b->m_sk;
+    free(aux);
+    const size_t sk = b->size_bsk;
+    b->bsk_mu = malloc(sizeof(u64[2]) * sk);
+    b->tw = (u64 *)malloc(sizeof(u64) * sk * n); b->tws = (u64 *)malloc(sizeof(u64) * sk * n);
+    b->itw = (u64 *)malloc(sizeof(u64) * sk * n); b->itws = (u64 *)malloc(sizeof(u64) * sk * n);
+    b->n_inv = (u64 *)malloc(sizeof(u64) * sk); b->n_inv_s = (u64 *)malloc(sizeof(u64) * sk);
+    for (size_t i = 0; i < sk; i++) {
+        orc_const_ratio(b->bsk[i], b->bsk_mu[i]);
+        orc_ntt_tables(c->log_n, b->bsk[i], b->tw + i * n, b->tws + i * n, b->itw + i * n, b->itws + i * n,
+                       &b->n_inv[i], &b->n_inv_s[i]);
+    }
+    u64 *bskmt = (u64 *)malloc(sizeof(u64) * (sk + 1));
+    memcpy(bskmt, b->bsk, sizeof(u64) * sk);
+    bskmt[sk] = b->m_tilde;
+    bconv_init(&b->q_to_bsk, c->q, sq, b->bsk, sk);
+    bconv_init(&b->q_to_mtilde, c->q, sq, &b->m_tilde, 1);
+    bconv_init(&b->b_to_q, b->bsk, b->size_b, c->q, sq);
+    bconv_init(&b->b_to_msk, b->bsk, b->size_b, &b->m_sk, 1);
+    free(bskmt);
+    b->mt_qhatinv = (u64 *)malloc(sizeof(u64) * sq); b->mt_qhatinv_s = (u64 *)malloc(sizeof(u64) * sq);
+    for (size_t i = 0; i < sq; i++) {
+        b->mt_qhatinv[i] = orc_mulmod(b->m_tilde % c->q[i], b->q_to_bsk.hat_inv[i], c->q[i]);
+        b->mt_qhatinv_s[i] = orc_compute_shoup(b->mt_qhatinv[i], c->q[i]);
+    }
+    b->inv_prod_q_mod_bsk = (u64 *)malloc(sizeof(u64) * sk); b->inv_prod_q_mod_bsk_s = (u64 *)malloc(sizeof(u64) * sk);
+    b->prod_q_mod_bsk = (u64 *)malloc(sizeof(u64) * sk);
+    b->inv_mt_mod_bsk = (u64 *)malloc(sizeof(u64) * sk); b->inv_mt_mod_bsk_s = (u64 *)malloc(sizeof(u64) * sk);
+    for (size_t i = 0; i < sk; i++) {
+        const u64 p = b->bsk[i];
+        b->prod_q_mod_bsk[i] = prod_mod(c->q, sq, p);                         /* :548-553 */
+        inv_euclid(b->prod_q_mod_bsk[i], p, &b->inv_prod_q_mod_bsk[i]);        /* :508-518 */
+        b->inv_prod_q_mod_bsk_s[i] = orc_compute_shoup(b->inv_prod_q_mod_bsk[i], p);
+        inv_euclid(b->m_tilde % p, p, &b->inv_mt_mod_bsk[i]);                  /* :537-546 */
+        b->inv_mt_mod_bsk_s[i] = orc_compute_shoup(b->inv_mt_mod_bsk[i], p);
+    }
+    u64 inv = 0;
+    inv_euclid(prod_mod(c->q, sq, b->m_tilde), b->m_tilde, &inv);              /* -prod(q)^-1 mod m_tilde */
+    b->neg_inv_prod_q_mod_mt = (b->m_tilde - inv) % b->m_tilde;
+    b->neg_inv_prod_q_mod_mt_s = orc_compute_shoup(b->neg_inv_prod_q_mod_mt, b->m_tilde);
+    inv_euclid(prod_mod(b->bsk, b->size_b, b->m_sk), b->m_sk, &b->inv_prod_b_mod_msk); /* :526-535 */
+    b->inv_prod_b_mod_msk_s = orc_compute_shoup(b->inv_prod_b_mod_msk, b->m_sk);
+    b->prod_b_mod_q = (u64 *)malloc(sizeof(u64) * sq);
+    for (size_t i = 0; i < sq; i++) b->prod_b_mod_q[i] = prod_mod(b->bsk, b->size_b, c->q[i]);
+    return b;
+}
+void orc_behz_destroy(orc_behz *b) {
+    if (!b) return;
+    free(b->bsk); free(b->bsk_mu); free(b->tw); free(b->tws); free(b->itw); free(b->itws); free(b->n_inv); free(b->n_inv_s);
+    free(b->mt_qhatinv); free(b->mt_qhatinv_s);
+    bconv_free(&b->q_to_bsk); bconv_free(&b->q_to_mtilde); bconv_free(&b->b_to_q); bconv_free(&b->b_to_msk);
+    free(b->inv_prod_q_mod_bsk); free(b->inv_prod_q_mod_bsk_s); free(b->prod_q_mod_bsk);
+    free(b->inv_mt_mod_bsk); free(b->inv_mt_mod_bsk_s); free(b->prod_b_mod_q);
+    free(b);
+}
+
+/* BEHZ_mul_1 evaluate.cu:404-441: one polynomial x [Q][N] (coefficient form) -> NTT(x) over q and the lifted,
+ * Montgomery-reduced polynomial over Bsk in NTT form */
+static void behz_lift(const orc_behz *b, const u64 *x, u64 *out_q, u64 *out_bsk) {
+    const orc_ctx *c = b->c;
+    const size_t n = b->n, sq = b->size_q, sk = b->size_bsk;
+    memcpy(out_q, x, sizeof(u64) * sq * n);
+    orc_nwt_forward(c, out_q, sq, 0);
+    /* fastbconv_m_tilde rns.cu:1249-1278: phase 1 with m_tilde * QHatInv, then Q -> Bsk and Q -> {m_tilde} */
+    u64 *y = (u64 *)malloc(sizeof(u64) * sq * n);
+    u64 *lift = (u64 *)malloc(sizeof(u64) * (sk + 1) * n);
+    for (size_t i = 0; i < sq; i++)
+        for (size_t k = 0; k < n; k++) y[i * n + k] = shoup(x[i * n + k], b->mt_qhatinv[i], b->mt_qhatinv_s[i], c->q[i]);
+    bconv_matmul(&b->q_to_bsk, y, lift, n, sk, 0);
+    bconv_matmul(&b->q_to_mtilde, y, lift + sk * n, n, 1, 0);
+    /* sm_mrq_kernel rns.cu:1290-1320 */
+    const u64 mt = b->m_tilde;
+    for (size_t j = 0; j < sk; j++) {
+        const u64 p = b->bsk[j];
+        for (size_t k = 0; k < n; k++) {
+            u64 r = shoup(lift[sk * n + k], b->neg_inv_prod_q_mod_mt, b->neg_inv_prod_q_mod_mt_s, mt);
+            if (r >= (mt >> 1)) r += p - mt;
+            u128 t = (u128)r * b->prod_q_mod_bsk[j] + lift[j * n + k];
+            u64 v = barrett128(t, p, b->bsk_mu[j]);
+            out_bsk[j * n + k] = shoup(v, b->inv_mt_mod_bsk[j], b->inv_mt_mod_bsk_s[j], p);
+        }
+        orc_ntt_forward(out_bsk + j * n, b->log_n, p, b->tw + j * n, b->tws + j * n);
+    }
+    free(y); free(lift);
+}
+static void tensor_generic(const u64 *a, const u64 *bb, u64 *r, const u64 *q, u64 (*const mu)[2], size_t limbs, size_t n) {
+    /* tensor_prod_2x2_rns_poly polymath.cu:463-496 over an arbitrary base; r may alias a */
+    const size_t rc = limbs * n;
+    for (size_t l = 0; l < limbs; l++)
+        for (size_t k = 0; k < n; k++) {
+            const size_t id = l * n + k;
+            u64 c00 = a[id], c01 = a[id + rc], c10 = bb[id], c11 = bb[id + rc];
+            u64 d0 = barrett128((u128)c00 * c10, q[l], mu[l]);
+            u64 d2 = barrett128((u128)c01 * c11, q[l], mu[l]);
+            u64 d1 = barrett128((u128)(c00 + c01) * (c10 + c11), q[l], mu[l]);
+            d1 = csub(csub(d1 + 2 * q[l] - d0 - d2, q[l]), q[l]);
+            r[id] = d0; r[id + rc] = d1; r[id + 2 * rc] = d2;
+        }
+}
+void orc_bfv_multiply_behz(const orc_behz *b, const u64 *ct1, const u64 *ct2, u64 *dst) {
+    const orc_ctx *c = b->c;
+    const size_t n = b->n, sq = b->size_q, sk = b->size_bsk, sb = b->size_b;
+    u64 *q1 = (u64 *)calloc(3 * sq * n, 8), *b1 = (u64 *)calloc(3 * sk * n, 8);
+    u64 *q2 = (u64 *)calloc(2 * sq * n, 8), *b2 = (u64 *)calloc(2 * sk * n, 8);
+    for (int p = 0; p < 2; p++) {
+        behz_lift(b, ct1 + p * sq * n, q1 + p * sq * n, b1 + p * sk * n);
+        behz_lift(b, ct2 + p * sq * n, q2 + p * sq * n, b2 + p * sk * n);
+    }
+    /* step 4: dyadic tensor product in both bases (evaluate.cu:479-498) */
+    tensor_generic(q1, q2, q1, c->q, c->mu, sq, n);
+    tensor_generic(b1, b2, b1, b->bsk, b->bsk_mu, sk, n);
+    /* steps 5-6: inverse NTT fused with the multiplication by t, full Shoup reduce (:518-530) */
+    for (int p = 0; p < 3; p++) {
+        u64 *xq = q1 + p * sq * n, *xb = b1 + p * sk * n;
+        orc_nwt_backward(c, xq, sq, 0);
+        for (size_t i = 0; i < sq; i++) {
+            const u64 ts = orc_compute_shoup(b->plain_t, c->q[i]);
+            for (size_t k = 0; k < n; k++) xq[i * n + k] = shoup(xq[i * n + k], b->plain_t, ts, c->q[i]);
+        }
+        for (size_t j = 0; j < sk; j++) {
+            orc_ntt_inverse(xb + j * n, b->log_n, b->bsk[j], b->itw + j * n, b->itws + j * n, b->n_inv[j], b->n_inv_s[j]);
+            const u64 ts = orc_compute_shoup(b->plain_t, b->bsk[j]);
+            for (size_t k = 0; k < n; k++) xb[j * n + k] = shoup(xb[j * n + k], b->plain_t, ts, b->bsk[j]);
+        }
+        /* step 7 fast_floor rns.cu:1394-1419: (x_Bsk - FastBconv(x_q, q -> Bsk)) * prod(q)^-1 mod Bsk */
+        u64 *y = (u64 *)malloc(sizeof(u64) * sq * n), *conv = (u64 *)malloc(sizeof(u64) * sk * n);
+        u64 *fl = (u64 *)malloc(sizeof(u64) * sk * n);
+        bconv_mult(&b->q_to_bsk, xq, y, n);
+        bconv_matmul(&b->q_to_bsk, y, conv, n, sk, 0);
+        for (size_t j = 0; j < sk; j++)
+            for (size_t k = 0; k < n; k++) {
+                const u64 v = xb[j * n + k] + (b->bsk[j] - conv[j * n + k]);   /* not reduced before the multiply (:1376-1378) */
+                fl[j * n + k] = shoup(v, b->inv_prod_q_mod_bsk[j], b->inv_prod_q_mod_bsk_s[j], b->bsk[j]);
+            }
+        /* step 8 fastbconv_sk rns.cu:1470-1510 */
+        u64 *yb = (u64 *)malloc(sizeof(u64) * sb * n), *alpha = (u64 *)malloc(sizeof(u64) * n);
+        u64 *out = dst + p * sq * n;
+        bconv_mult(&b->b_to_q, fl, yb, n);
+        bconv_matmul(&b->b_to_msk, yb, alpha, n, 1, 0);
+        for (size_t k = 0; k < n; k++) {
+            const u64 v = alpha[k] + (b->m_sk - fl[sb * n + k]);
+            alpha[k] = shoup(v, b->inv_prod_b_mod_msk, b->inv_prod_b_mod_msk_s, b->m_sk);
+        }
+        bconv_matmul(&b->b_to_q, yb, out, n, sq, 0);
+        for (size_t i = 0; i < sq; i++)   /* multiply_and_negated_add_rns_poly polymath.cu:606-634 */
+            for (size_t k = 0; k < n; k++) {
+                u64 op1 = alpha[k], pb = b->prod_b_mod_q[i];
+                if (op1 > (b->m_sk >> 1)) op1 = b->m_sk - op1;
+                else pb = c->q[i] - pb;
+                op1 = barrett128((u128)op1 * pb, c->q[i], c->mu[i]);
+                out[i * n + k] = addmod(out[i * n + k], op1, c->q[i]);
+            }
+        free(y); free(conv); free(fl); free(yb); free(alpha);
+    }
+    free(q1); free(b1); free(q2); free(b2);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Galois (include/galois.cuh:98-130, src/galois.cu:11-39)
  * ---------------------------------------------------------------------------------------------- */
 void orc_galois_ntt_table(int log_n, uint32_t elt, uint32_t *table) {

@@ -111,6 +111,15 @@ void orc_mod_t_divide_q_last_ntt(const orc_tool *t, uint64_t *src, size_t cipher
 /* divide_and_round_q_last rns.cu:1082-1126 (BFV coefficient-domain mod switch) */
 void orc_divide_and_round_q_last(const orc_tool *t, const uint64_t *src, size_t cipher_size, uint64_t *dst);
 
+/* ---- BFV multiply, BEHZ (src/evaluate.cu:404-548; src/rns.cu:392-560,1249-1510); base q = all data primes ---- */
+typedef struct orc_behz orc_behz;
+orc_behz *orc_behz_create(const orc_ctx *c, uint64_t plain_t);
+void orc_behz_destroy(orc_behz *b);
+size_t orc_behz_bsk_size(const orc_behz *b);
+void orc_behz_base(const orc_behz *b, uint64_t *bsk_out);  /* B primes then m_sk */
+/* ct1, ct2 [2][Q][N] in coefficient form -> dst [3][Q][N] in coefficient form */
+void orc_bfv_multiply_behz(const orc_behz *b, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst);
+
 /* ---- Galois (include/galois.cuh:98-130, src/galois.cu:11-39) ---- */
 void orc_galois_ntt_table(int log_n, uint32_t galois_elt, uint32_t *table);
 void orc_apply_galois_ntt(const uint64_t *src, uint64_t *dst, const uint32_t *table, size_t n, size_t limbs);

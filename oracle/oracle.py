@@ -84,6 +84,13 @@ def lib(path=None):
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_behz_create.restype = C.c_void_p
+    L.orc_behz_create.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_behz_destroy.argtypes = [C.c_void_p]
+    L.orc_behz_bsk_size.restype = C.c_size_t
+    L.orc_behz_bsk_size.argtypes = [C.c_void_p]
+    L.orc_behz_base.argtypes = [C.c_void_p, u64p]
+    L.orc_bfv_multiply_behz.argtypes = [C.c_void_p, u64p, u64p, u64p]
     L.orc_set_threads.restype = None
     L.orc_tool_set_plain_modulus.restype = C.c_int
     L.orc_tool_set_plain_modulus.argtypes = [C.c_void_p, C.c_uint64]
@@ -267,6 +274,33 @@ def bconv(ibase, obase, src, n):
     dst = np.zeros(len(obase) * n, dtype=np.uint64)
     lib().orc_bconv(_p(ibase), len(ibase), _p(obase), len(obase), _p(src), _p(dst), n)
     return dst.reshape(len(obase), n)
+
+
+class Behz:
+    """BFV multiply, BEHZ variant, at the top data level (src/evaluate.cu:404-548)."""
+
+    def __init__(self, ctx, plain_t):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = self.L.orc_behz_create(ctx.h, int(plain_t))
+        if not self.h:
+            raise ValueError("cannot set up the BEHZ bases")
+        self.size_bsk = self.L.orc_behz_bsk_size(self.h)
+        bsk = np.zeros(self.size_bsk, dtype=np.uint64)
+        self.L.orc_behz_base(self.h, _p(bsk))
+        self.bsk = [int(v) for v in bsk]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_behz_destroy(self.h)
+            self.h = None
+
+    def multiply(self, ct1, ct2):
+        c = self.ctx
+        a = np.ascontiguousarray(ct1, dtype=np.uint64).reshape(-1)
+        b = np.ascontiguousarray(ct2, dtype=np.uint64).reshape(-1)
+        out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
+        self.L.orc_bfv_multiply_behz(self.h, _p(a), _p(b), _p(out))
+        return out.reshape(3, c.size_q, c.n)
 
 
 class Tool:

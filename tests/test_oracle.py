@@ -265,3 +265,50 @@ def test_galois_ntt_permutation_matches_coefficient_automorphism():
         via_coeff = oc.nwt_forward(oc.apply_galois_coeff(x, elt, 2), 2, 0)
         via_ntt = O.apply_galois_ntt(oc.nwt_forward(x, 2, 0), O.galois_ntt_table(log_n, elt), n, 2)
         assert np.array_equal(via_coeff, via_ntt)
+
+
+@pytest.mark.parametrize("name,plain_t", [("c1_bfv4096", 65537), ("hyb12_a2", 65537), ("hyb12_a2", 1032193)])
+def test_bfv_behz_multiply_decrypts_to_the_product(name, plain_t):
+    """BFV BEHZ multiply (src/evaluate.cu:404-548) pinned by its meaning: for encryptions of m1, m2 the three-part
+    result decrypts (d0 + d1 s + d2 s^2, scaled by t/Q and rounded) to m1 * m2 mod (X^N + 1, t)."""
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    q = [int(p) for p in primes[:size_q]]
+    oc = oracle_ctx(name)
+    behz = O.Behz(oc, plain_t)
+    assert behz.size_bsk in (size_q + 1, size_q + 2) and all(p.bit_length() == 61 for p in behz.bsk)
+    r = rng_for(77)
+    Q = 1
+    for p in q:
+        Q *= p
+    delta = Q // plain_t
+    s_small = r.integers(-1, 2, n)
+    sk = np.stack([(s_small % p).astype(np.uint64) for p in q])
+    sk_ntt = oc.nwt_forward(sk, size_q, 0)
+
+    def encrypt(m):
+        a = uniform_poly(r, q, n)
+        e = r.integers(-3, 4, n)
+        dm = np.stack([np.array([(delta * int(v) + int(ev)) % p for v, ev in zip(m, e)], dtype=np.uint64) for p in q])
+        a_s = oc.nwt_backward(oc.multiply(oc.nwt_forward(a, size_q, 0), sk_ntt, size_q), size_q)
+        return np.stack([oc.sub(dm, a_s, size_q), a])
+
+    m1 = r.integers(0, plain_t, n)
+    m2 = r.integers(0, plain_t, n)
+    d = behz.multiply(encrypt(m1), encrypt(m2))
+    d_ntt = [oc.nwt_forward(d[i], size_q, 0) for i in range(3)]
+    s2 = oc.multiply(sk_ntt, sk_ntt, size_q)
+    phase = oc.add(oc.add(d_ntt[0], oc.multiply(d_ntt[1], sk_ntt, size_q), size_q), oc.multiply(d_ntt[2], s2, size_q), size_q)
+    phase = oc.nwt_backward(phase, size_q)
+    # exact m1 * m2 mod (X^N + 1) over the integers through one 60-bit NTT prime (|coefficients| < N t^2 < 2^59)
+    big = int(O.get_primes(n, 60, 1)[0])
+    bc = O.Ctx(log_n, [big], 0)
+    pm = bc.nwt_backward(bc.multiply(bc.nwt_forward(m1.astype(np.uint64).reshape(1, n), 1, 0),
+                                     bc.nwt_forward(m2.astype(np.uint64).reshape(1, n), 1, 0), 1), 1)[0]
+    for k in range(0, n, 61):
+        v, _ = crt_compose([phase[l, k] for l in range(size_q)], q)
+        got = ((v * plain_t + Q // 2) // Q) % plain_t
+        w = int(pm[k])
+        w = w - big if w > big // 2 else w
+        assert got == w % plain_t, k
