@@ -169,6 +169,11 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
  *   digit's limbs, a_d), the layout key_switch_inner_prod consumes. */
 int pha_generate_one_kswitch_key(pha_context_t ctx, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,
                                  const uint64_t *a, uint64_t *e, uint64_t *const *evk, int scheme, void *stream);
+/* bfv_multiply_behz (src/evaluate.cu:447-548), the 2 x 2 case at the top data level: ct1, ct2 [2][Q][N] in
+ * coefficient form -> dst [3][Q][N] in coefficient form (ct1 == ct2 takes the squaring kernels, like the
+ * reference).  Needs pha_context_set_plain_modulus; the auxiliary base Bsk u {m_tilde} (src/rns.cu:392-560) and
+ * its NTT tables are built on first use.  dst must not alias the inputs. */
+int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst, void *stream);
 /* DRNSTool::mod_t_and_divide_q_last_ntt (rns.cu:1210-1236), the BGV modulus switch: src [cipher][Ql][N]
  * in NTT form (left in coefficient form, as in the reference) -> dst [cipher][Ql-1][N] in NTT form */
 int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,

@@ -1,0 +1,175 @@
+// pha_behz.hip -- BFV multiply, BEHZ variant, on gfx950.
+//
+// Reference: bfv_multiply_behz src/evaluate.cu:404-548; DRNSTool::fastbconv_m_tilde / sm_mrq / fast_floor /
+// fastbconv_sk src/rns.cu:1249-1510; multiply_and_negated_add_rns_poly src/polymath.cu:606-634; constants
+// src/rns.cu:392-560 (built in pha_context.hip, Context::behz).  The base conversions reuse the one-thread-per-
+// coefficient converter of pha_rns.hip (its 128-bit accumulate form: the auxiliary primes are 61 bits wide), the
+// transforms reuse the NTT kernels over the auxiliary table rows, and what remains are three element-wise kernels.
+#include "../../include/phantom_amd.h"
+#include "pha_internal.h"
+#include "pha_ntt_core.h"
+
+namespace pha {
+
+// sm_mrq_kernel rns.cu:1290-1320: (x + q * r) * m_tilde^-1 mod Bsk with r = -x_mtilde * q^-1 mod m_tilde, centred
+struct MrqArgs {
+    u64 *dst;                // [polys][Bsk][N]
+    const u64 *src;          // [polys][Bsk + 1][N], last limb modulo m_tilde
+    const DModulus *mod;     // table base; Bsk limb j is row aux0 + j
+    const u64 *prod_q_mod_bsk;
+    const u64x2 *inv_mt_mod_bsk;
+    u64x2 neg_inv_prod_q_mod_mt;
+    uint32_t aux0, size_bsk, n;
+};
+__global__ __launch_bounds__(256) void sm_mrq_kernel(const MrqArgs k) {
+    const uint32_t j = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    const DModulus m = k.mod[k.aux0 + j];
+    const u64 mt = (u64)1 << 32;
+    const u64 *in = k.src + (size_t)blockIdx.z * (k.size_bsk + 1) * k.n;
+    u64 r = shoup(in[(size_t)k.size_bsk * k.n + coeff], k.neg_inv_prod_q_mod_mt, mt);
+    if (r >= (mt >> 1)) r += m.value - mt;
+    u64 lo, hi;
+    mul128(r, k.prod_q_mod_bsk[j], lo, hi);
+    const u64 x = in[(size_t)j * k.n + coeff];
+    lo += x;
+    hi += lo < x;
+    k.dst[((size_t)blockIdx.z * k.size_bsk + j) * k.n + coeff] = shoup(barrett128(lo, hi, m), k.inv_mt_mod_bsk[j], m.value);
+}
+
+// second half of bconv_fuse_sub_mul_unroll2_kernel rns.cu:1343-1386: (x_Bsk + (p - conv)) * prod(q)^-1 mod p
+struct FloorArgs {
+    u64 *dst;
+    const u64 *x_bsk, *conv;
+    const DModulus *mod;
+    const u64x2 *scale;
+    uint32_t aux0, n;
+};
+__global__ __launch_bounds__(256) void fast_floor_kernel(const FloorArgs k) {
+    const uint32_t j = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    const u64 p = k.mod[k.aux0 + j].value;
+    const size_t id = (size_t)j * k.n + coeff;
+    k.dst[id] = shoup(k.x_bsk[id] + (p - k.conv[id]), k.scale[j], p);   // the sum is not reduced first (:1376-1378)
+}
+
+// alpha_sk (bconv_fuse_sub_mul_single_unroll2_kernel rns.cu:1421-1464) and the Shenoy-Kumaresan correction
+// (multiply_and_negated_add_rns_poly polymath.cu:606-634) in one kernel over the q limbs
+struct SkArgs {
+    u64 *out_q;              // [Q][N]: FastBconv(x, B -> q) on entry, the result on exit
+    const u64 *conv_msk;     // [N]   FastBconv(x, B -> {m_sk})
+    const u64 *x_msk;        // [N]   the m_sk limb of the Bsk polynomial
+    const DModulus *mod;
+    const u64 *prod_b_mod_q;
+    u64x2 inv_prod_b_mod_msk;
+    u64 m_sk;
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void sk_fix_kernel(const SkArgs k) {
+    const uint32_t i = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    const DModulus m = k.mod[i];
+    u64 a = shoup(k.conv_msk[coeff] + (k.m_sk - k.x_msk[coeff]), k.inv_prod_b_mod_msk, k.m_sk);
+    u64 pb = k.prod_b_mod_q[i];
+    if (a > (k.m_sk >> 1)) a = k.m_sk - a;   // alpha_sk in [-m_sk/2, 0): -alpha * B is positive
+    else pb = m.value - pb;                  // alpha_sk in [0, m_sk/2):  -alpha * B = alpha * (-B mod q)
+    const size_t id = (size_t)i * k.n + coeff;
+    k.out_q[id] = add_mod(k.out_q[id], mul_mod(a, pb, m), m.value);
+}
+
+// x * c_i mod q_i per limb (bconv_mult_kernel with the m_tilde-scaled factors, rns.cu:1259-1262)
+struct ScaleArgs {
+    u64 *dst;
+    const u64 *src;
+    const DModulus *mod;
+    const u64x2 *c;
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void scale_limbs_kernel(const ScaleArgs k) {
+    const uint32_t i = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = ((size_t)blockIdx.z * gridDim.y + i) * k.n + coeff;
+    k.dst[id] = shoup(k.src[id], k.c[i], k.mod[i].value);
+}
+
+static LimbSel aux_sel(uint32_t count, uint32_t aux0) {  // a buffer of `count` limbs whose table rows start at aux0
+    LimbSel s = plain_sel(0, count);
+    s.remap_from = 0;
+    s.remap_add = aux0;
+    return s;
+}
+
+// BEHZ_mul_1 evaluate.cu:404-441 for the two polynomials of one ciphertext
+static void behz_lift(Context &c, Behz &b, const u64 *ct, u64 *out_q, u64 *out_bsk, u64 *tmp, hipStream_t s) {
+    const uint32_t n = (uint32_t)c.n, sq = b.size_q, sk = b.size_bsk;
+    const size_t qn = (size_t)sq * n;
+    PHA_HIP(hipMemcpyAsync(out_q, ct, 2 * qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    NttExtra xq;
+    xq.batch = 2;
+    xq.poly_stride = qn;
+    ntt_forward(c, out_q, out_q, out_q, plain_sel(0, sq), EPI_FWD_CANON, xq, s);
+    // (1) q -> Bsk u {m_tilde}: phase 1 with m_tilde * qhat^-1, then one conversion for all Bsk + 1 outputs
+    u64 *y = tmp, *lift = tmp + 2 * qn;  // y [2][Q][N], lift [2][Bsk + 1][N]
+    ScaleArgs sa{y, ct, c.d_mod.p, b.mt_qhatinv.p, n};
+    hipLaunchKernelGGL(scale_limbs_kernel, dim3(n / 256, sq, 2), dim3(256), 0, s, sa);
+    check_launch();
+    launch_bconv(c, b.d_q_to_bskmt.p, 0, 2, sq, sk + 1, false, lift, (size_t)(sk + 1) * n, y, qn, nullptr, false, s);
+    // (2) small Montgomery reduction modulo q, switching to base Bsk
+    MrqArgs ma{out_bsk, lift, c.d_mod.p, b.prod_q_mod_bsk.p, b.inv_mt_mod_bsk.p, b.neg_inv_prod_q_mod_mt, b.aux0, sk, n};
+    hipLaunchKernelGGL(sm_mrq_kernel, dim3(n / 256, sk, 2), dim3(256), 0, s, ma);
+    check_launch();
+    NttExtra xb;
+    xb.batch = 2;
+    xb.poly_stride = (size_t)sk * n;
+    ntt_forward(c, out_bsk, out_bsk, out_bsk, aux_sel(sk, b.aux0), EPI_FWD_CANON, xb, s);
+}
+
+}  // namespace pha
+
+using namespace pha;
+
+extern "C" int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
+                                     void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    Behz &b = c.behz();
+    hipStream_t s = as_stream(stream);
+    const uint32_t n = (uint32_t)c.n, sq = b.size_q, sk = b.size_bsk, sb = b.size_b;
+    const size_t qn = (size_t)sq * n, bn = (size_t)sk * n;
+    const bool square = ct1 == ct2;
+    // scratch: q1 [3][Q] | b1 [3][Bsk] | q2 [2][Q] | b2 [2][Bsk] | tmp (y [2][Q] + lift [2][Bsk+1], later conv / floor)
+    const size_t tmp_words = 2 * qn + 2 * (bn + n) + 3 * bn;
+    u64 *base = c.scratch(stream, 3 * qn + 3 * bn + 2 * qn + 2 * bn + tmp_words);
+    u64 *q1 = base, *b1 = q1 + 3 * qn, *q2 = b1 + 3 * bn, *b2 = q2 + 2 * qn, *tmp = b2 + 2 * bn;
+    behz_lift(c, b, ct1, q1, b1, tmp, s);
+    if (!square) behz_lift(c, b, ct2, q2, b2, tmp, s);
+    // step 4: tensor product in both bases (evaluate.cu:479-498)
+    launch_tensor(c, q1, square ? q1 : q2, q1, sq, 0, square, s);
+    launch_tensor(c, b1, square ? b1 : b2, b1, sk, b.aux0, square, s);
+    // steps 5-6: inverse transforms fused with the multiplication by t (:518-530)
+    NttExtra xq;
+    xq.batch = 3;
+    xq.poly_stride = qn;
+    xq.scale = b.t_q.p;
+    xq.scale_shoup = b.t_q_shoup.p;
+    ntt_inverse(c, q1, q1, q1, plain_sel(0, sq), EPI_INV_SCALE, xq, s);
+    NttExtra xb;
+    xb.batch = 3;
+    xb.poly_stride = bn;
+    xb.scale = b.t_bsk.p;
+    xb.scale_shoup = b.t_bsk_shoup.p;
+    ntt_inverse(c, b1, b1, b1, aux_sel(sk, b.aux0), EPI_INV_SCALE, xb, s);
+    u64 *conv = tmp, *fl = tmp + 3 * bn;  // conv [3][Bsk][N] (re-used per polynomial), fl [Bsk][N]
+    for (uint32_t p = 0; p < 3; p++) {
+        u64 *xq_p = q1 + p * qn, *xb_p = b1 + p * bn, *out = dst + p * qn;
+        // step 7 fast_floor (rns.cu:1394-1419)
+        launch_bconv(c, b.d_q_to_bsk.p, 0, 1, sq, sk, false, conv, 0, xq_p, 0, nullptr, true, s);
+        FloorArgs fa{fl, xb_p, conv, c.d_mod.p, b.inv_prod_q_mod_bsk.p, b.aux0, n};
+        hipLaunchKernelGGL(fast_floor_kernel, dim3(n / 256, sk), dim3(256), 0, s, fa);
+        check_launch();
+        // step 8 fastbconv_sk (rns.cu:1470-1510)
+        launch_bconv(c, b.d_b_to_msk.p, 0, 1, sb, 1, false, conv, 0, fl, 0, nullptr, true, s);   // conv[0..N) = B -> m_sk
+        launch_bconv(c, b.d_b_to_q.p, 0, 1, sb, sq, false, out, 0, fl, 0, nullptr, true, s);
+        SkArgs ka{out, conv, fl + (size_t)sb * n, c.d_mod.p, b.prod_b_mod_q.p, b.inv_prod_b_mod_msk, b.m_sk, n};
+        hipLaunchKernelGGL(sk_fix_kernel, dim3(n / 256, sq), dim3(256), 0, s, ka);
+        check_launch();
+    }
+    PHA_API_END
+}

@@ -143,13 +143,15 @@ struct FpTables {
 };
 static u64 fp_bits(u64 w) { return as_u64((double)w); }  // W as a double (exact: W < 2^50)
 
-static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, std::vector<u64x2> &itw,
+// Tables of prime c.primes[row] written at position `i` of the output vectors (i == row for the QP chain;
+// auxiliary primes are built into short vectors and appended to the device arrays).
+static void build_prime_tables(Context &c, uint32_t row, uint32_t i, std::vector<u64x2> &tw, std::vector<u64x2> &itw,
                                std::vector<u64x2> &ninv, std::vector<u64x2> &w1ninv, FpTables &fp) {
-    const u64 q = c.primes[i];
+    const u64 q = c.primes[row];
     const size_t n = c.n;
     const u64 psi = h_minimal_primitive_root(2 * n, q);
     const u64 ipsi = h_invmod(psi, q);
-    c.roots[i] = psi;
+    c.roots[row] = psi;
     u64x2 *t = tw.data() + (size_t)i * n, *it = itw.data() + (size_t)i * n;
     u64 pw = 1, ipw = 1;
     for (size_t e = 0; e < n; e++) {  // slot brev(e) holds psi^e (src/host/ntt.cu:27-33)
@@ -160,7 +162,7 @@ static void build_prime_tables(Context &c, uint32_t i, std::vector<u64x2> &tw, s
         ipw = h_mulmod(ipw, ipsi, q);
     }
     const u64 ni = h_invmod((u64)(n % q), q);
-    c.n_inv[i] = ni;
+    c.n_inv[row] = ni;
     ninv[i] = u64x2{ni, h_shoup(ni, q)};
     const u64 w1 = h_mulmod(it[1].x, ni, q);  // what the reference stores in itwiddle[1] (ntt.cu:53-55)
     w1ninv[i] = u64x2{w1, h_shoup(w1, q)};
@@ -221,7 +223,7 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
         for (unsigned t = 0; t < nthreads; t++)
             pool.emplace_back([&, t] {
                 try {
-                    for (uint32_t i = t; i < size_qp; i += nthreads) build_prime_tables(c, i, tw, itw, ninv, w1ninv, fp);
+                    for (uint32_t i = t; i < size_qp; i += nthreads) build_prime_tables(c, i, i, tw, itw, ninv, w1ninv, fp);
                 } catch (const std::exception &e) { errs[t] = e.what(); }
             });
         for (auto &th : pool) th.join();
@@ -238,6 +240,150 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
     c.d_ninvf.upload(fp.ninv);
     c.d_w1ninvf.upload(fp.w1ninv);
     c.d_fpinfo.upload(fp.info);
+    c.rows = size_qp;
+}
+
+static void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
+
+// Append auxiliary moduli to the context's prime / table arrays: `ntt_primes` get full NTT tables, then one more
+// modulus without tables (m_tilde = 2^32 of BEHZ).  Returns the row of the first one.  Nothing may be in flight.
+uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_less_modulus) {
+    PHA_HIP(hipSetDevice(device));
+    PHA_HIP(hipDeviceSynchronize());
+    const uint32_t first = rows, cnt = (uint32_t)ntt_primes.size();
+    for (u64 q : ntt_primes) {
+        if (q >> 61) throw std::invalid_argument("modulus exceeds 61 bits");
+        if (!h_is_prime(q) || (q - 1) % (2 * n)) throw std::invalid_argument("modulus is not an NTT prime");
+        for (u64 p : primes)
+            if (p == q) throw std::invalid_argument("coeff_modulus is not coprime");
+        primes.push_back(q);
+        mods.push_back(h_modulus(q));
+    }
+    primes.push_back(table_less_modulus);
+    mods.push_back(h_modulus(table_less_modulus));
+    roots.resize(primes.size());
+    n_inv.resize(primes.size());
+    const uint32_t total = cnt + 1;
+    std::vector<u64x2> tw((size_t)total * n, u64x2{0, 0}), itw((size_t)total * n, u64x2{0, 0}), ninv(total, u64x2{0, 0}),
+        w1ninv(total, u64x2{0, 0});
+    FpTables fp;
+    fp.tw.assign((size_t)total * n, 0);
+    fp.itw.assign((size_t)total * n, 0);
+    fp.ninv.assign(total, u64x2{0, 0});
+    fp.w1ninv.assign(total, u64x2{0, 0});
+    fp.info.assign(total, FpInfo{0.0, 0.0, 0u, 0u});
+    for (uint32_t i = 0; i < cnt; i++) build_prime_tables(*this, first + i, i, tw, itw, ninv, w1ninv, fp);
+    d_mod.append(std::vector<DModulus>(mods.begin() + first, mods.end()));
+    d_tw.append(tw);
+    d_itw.append(itw);
+    d_ninv.append(ninv);
+    d_w1ninv.append(w1ninv);
+    d_twf.append(fp.tw);
+    d_itwf.append(fp.itw);
+    d_ninvf.append(fp.ninv);
+    d_w1ninvf.append(fp.w1ninv);
+    d_fpinfo.append(fp.info);
+    rows += total;
+    return first;
+}
+
+static void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
+    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.isz, b.osz, 0xffffffffu, 0, 0, 0}});
+}
+
+// DRNSTool constructor, BEHZ part (src/rns.cu:392-560).  Needs the plain modulus; top data level only.
+Behz &Context::behz() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (behz_tool) return *behz_tool;
+    if (!plain_t) throw std::invalid_argument("bfv multiply needs a plain modulus (pha_context_set_plain_modulus)");
+    auto b = std::make_unique<Behz>();
+    b->size_q = size_q;
+    b->plain_t = plain_t;
+    // |prod(q)| exactly (get_significant_bit_count_uint of the big modulus)
+    std::vector<u64> acc{1};
+    for (uint32_t i = 0; i < size_q; i++) {
+        u64 carry = 0;
+        for (auto &w : acc) {
+            const u128 t = (u128)w * primes[i] + carry;
+            w = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+        if (carry) acc.push_back(carry);
+    }
+    const int total_bits = (int)(acc.size() - 1) * 64 + (64 - __builtin_clzll(acc.back()));
+    const int t_bits = 64 - __builtin_clzll(plain_t);
+    b->size_b = size_q + ((32 + t_bits + total_bits >= 61 * (int)size_q + 61) ? 1 : 0);  // rns.cu:398-406
+    b->size_bsk = b->size_b + 1;
+    // get_primes(n, 61, size_b + 1): m_sk first, then B (rns.cu:413-419); descending from 2^61 - 2n + 1 in steps of 2n
+    std::vector<u64> found;
+    for (u64 v = ((u64)1 << 61) - 2 * n + 1; found.size() < b->size_b + 1 && v > ((u64)1 << 60); v -= 2 * n)
+        if (h_is_prime(v)) found.push_back(v);
+    if (found.size() < b->size_b + 1) throw std::logic_error("failed to find enough qualifying primes");
+    b->m_sk = found[0];
+    std::vector<u64> bsk(found.begin() + 1, found.end());
+    bsk.push_back(b->m_sk);
+    const u64 m_tilde = (u64)1 << 32;
+    b->aux0 = add_aux_moduli(bsk, m_tilde);
+    const uint32_t mt_row = b->aux0 + b->size_bsk;
+    std::vector<uint32_t> iq, ib, obskmt, obsk, omsk{b->aux0 + b->size_b};
+    for (uint32_t i = 0; i < size_q; i++) iq.push_back(i);
+    for (uint32_t i = 0; i < b->size_b; i++) ib.push_back(b->aux0 + i);
+    for (uint32_t i = 0; i < b->size_bsk; i++) obsk.push_back(b->aux0 + i);
+    obskmt = obsk;
+    obskmt.push_back(mt_row);
+    build_bconv(*this, b->q_to_bskmt, iq, obskmt);
+    build_bconv(*this, b->q_to_bsk, iq, obsk);
+    build_bconv(*this, b->b_to_q, ib, iq);
+    build_bconv(*this, b->b_to_msk, ib, omsk);
+    describe_conv(b->q_to_bskmt, b->d_q_to_bskmt);
+    describe_conv(b->q_to_bsk, b->d_q_to_bsk);
+    describe_conv(b->b_to_q, b->d_b_to_q);
+    describe_conv(b->b_to_msk, b->d_b_to_msk);
+    auto pair = [](u64 v, u64 q) { return u64x2{v, h_shoup(v, q)}; };
+    auto prod_mod = [&](uint32_t first, uint32_t cnt, u64 m) {
+        u64 p = 1 % m;
+        for (uint32_t i = 0; i < cnt; i++) p = h_mulmod(p, primes[first + i] % m, m);
+        return p;
+    };
+    {   // m_tilde * qhat_i^-1 mod q_i (:450-465)
+        std::vector<u64x2> hi(size_q), v(size_q);
+        PHA_HIP(hipMemcpy(hi.data(), b->q_to_bsk.hat_inv.p, size_q * sizeof(u64x2), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < size_q; i++) v[i] = pair(h_mulmod(m_tilde % primes[i], hi[i].x, primes[i]), primes[i]);
+        b->mt_qhatinv.upload(v);
+    }
+    {
+        std::vector<u64x2> ipq(b->size_bsk), imt(b->size_bsk);
+        std::vector<u64> pq(b->size_bsk), tb(b->size_bsk), tbs(b->size_bsk);
+        for (uint32_t j = 0; j < b->size_bsk; j++) {
+            const u64 p = primes[b->aux0 + j];
+            pq[j] = prod_mod(0, size_q, p);                         // :548-553
+            ipq[j] = pair(h_invmod(pq[j], p), p);                   // :508-518
+            imt[j] = pair(h_invmod(m_tilde % p, p), p);             // :537-546
+            tb[j] = plain_t;                                        // :467-479
+            tbs[j] = h_shoup(plain_t, p);
+        }
+        b->inv_prod_q_mod_bsk.upload(ipq);
+        b->inv_mt_mod_bsk.upload(imt);
+        b->prod_q_mod_bsk.upload(pq);
+        b->t_bsk.upload(tb);
+        b->t_bsk_shoup.upload(tbs);
+    }
+    {
+        std::vector<u64> pb(size_q), tq(size_q), tqs(size_q);
+        for (uint32_t i = 0; i < size_q; i++) {
+            pb[i] = prod_mod(b->aux0, b->size_b, primes[i]);
+            tq[i] = plain_t;
+            tqs[i] = h_shoup(plain_t, primes[i]);
+        }
+        b->prod_b_mod_q.upload(pb);
+        b->t_q.upload(tq);
+        b->t_q_shoup.upload(tqs);
+    }
+    const u64 inv_q_mt = h_invmod(prod_mod(0, size_q, m_tilde), m_tilde);
+    b->neg_inv_prod_q_mod_mt = pair((m_tilde - inv_q_mt) % m_tilde, m_tilde);
+    b->inv_prod_b_mod_msk = pair(h_invmod(prod_mod(b->aux0, b->size_b, b->m_sk), b->m_sk), b->m_sk);
+    behz_tool = std::move(b);
+    return *behz_tool;
 }
 
 // q-hat_i^-1 mod q_i and q-hat_i mod p_j for an (ibase -> obase) converter: src/host/rns.cu:282-337,438-457
@@ -510,6 +656,7 @@ int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus) {
         PHA_HIP(hipSetDevice(c.device));
         PHA_HIP(hipDeviceSynchronize());  // per-level tools are rebuilt lazily with the new constants
         c.tools.clear();
+        c.behz_tool.reset();   // (its auxiliary table rows stay; a later tool appends fresh ones)
         c.plain_t = plain_modulus;
     }
     PHA_API_END

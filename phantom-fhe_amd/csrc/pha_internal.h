@@ -62,6 +62,14 @@ struct DevBuf {
         if (h.size() != count) alloc(h.size());
         if (count) PHA_HIP(hipMemcpy(p, h.data(), count * sizeof(T), hipMemcpyHostToDevice));
     }
+    // keep the old contents, append `tail` (table rows of auxiliary primes)
+    void append(const std::vector<T> &tail) {
+        DevBuf<T> bigger(count + tail.size());
+        if (count) PHA_HIP(hipMemcpy(bigger.p, p, count * sizeof(T), hipMemcpyDeviceToDevice));
+        if (!tail.empty())
+            PHA_HIP(hipMemcpy(bigger.p + count, tail.data(), tail.size() * sizeof(T), hipMemcpyHostToDevice));
+        *this = std::move(bigger);
+    }
 };
 
 constexpr int kBcRowPad = 16;  // row pitch (entries) of the split base-conversion matrix
@@ -120,6 +128,22 @@ struct Tool {
     DevBuf<u64> p_hat_mod_t;                       // [alpha] row of base_P_to_t_conv
 };
 
+// ---- BFV BEHZ multiply at the top data level (src/rns.cu:392-560): auxiliary base Bsk = B u {m_sk}, m_tilde = 2^32.
+//      The auxiliary moduli live in rows [aux0, aux0 + size_bsk] of the context's prime / table arrays
+//      (B primes, m_sk, then m_tilde, which has a modulus entry but no NTT table).
+struct Behz {
+    uint32_t size_q = 0, size_b = 0, size_bsk = 0, aux0 = 0;
+    u64 plain_t = 0, m_sk = 0;
+    BConv q_to_bskmt, q_to_bsk, b_to_q, b_to_msk;      // Q -> Bsk u {m_tilde}; Q -> Bsk; B -> Q; B -> {m_sk}
+    DevBuf<BConvDev> d_q_to_bskmt, d_q_to_bsk, d_b_to_q, d_b_to_msk;
+    DevBuf<u64x2> mt_qhatinv;                            // [Q]   m_tilde * qhat_i^-1 mod q_i
+    DevBuf<u64x2> inv_prod_q_mod_bsk, inv_mt_mod_bsk;    // [Bsk]
+    DevBuf<u64> prod_q_mod_bsk;                          // [Bsk]
+    DevBuf<u64> prod_b_mod_q;                            // [Q]
+    DevBuf<u64> t_q, t_q_shoup, t_bsk, t_bsk_shoup;      // t with its Shoup quotient per limb (iNTT scale)
+    u64x2 neg_inv_prod_q_mod_mt{}, inv_prod_b_mod_msk{};
+};
+
 // ---- scratch arena: one per (context, stream), grown on demand, never freed until destroy ----
 struct Arena {
     DevBuf<u64> buf;
@@ -151,10 +175,14 @@ struct Context {
     // host copies kept for pha_context_download_twiddle and tool construction
     std::mutex mu;
     std::map<uint32_t, std::unique_ptr<Tool>> tools;
+    std::unique_ptr<Behz> behz_tool;
+    uint32_t rows = 0;  // table rows = size_qp + auxiliary moduli
     std::map<void *, std::unique_ptr<Arena>> arenas;
     std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
 
     Tool &tool(uint32_t size_ql);
+    Behz &behz();                                             // built on first use; needs the plain modulus
+    uint32_t add_aux_moduli(const std::vector<u64> &ntt_primes, u64 plain_modulus_like);
     u64 *scratch(void *stream, size_t words);
     const uint32_t *galois_table(uint32_t elt);
 };
@@ -205,6 +233,14 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
                  hipStream_t s);
 void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
                  hipStream_t s);
+
+// shared launchers (pha_rns.hip / pha_poly.hip)
+void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
+                  uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
+                  const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0);
+void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,
+                   hipStream_t s);
+void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline void check_launch() { PHA_HIP(hipGetLastError()); }

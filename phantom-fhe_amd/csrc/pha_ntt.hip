@@ -252,7 +252,7 @@ static void check_sel(Context &c, const LimbSel &sel) {
     if (sel.count == 0) return;
     const uint32_t last = sel.start + sel.count - 1;
     const uint32_t prime_last = last >= sel.remap_from ? last + sel.remap_add : last;
-    if (prime_last >= c.size_qp) throw std::invalid_argument("modulus index out of range of the NTT tables");
+    if (prime_last >= c.rows) throw std::invalid_argument("modulus index out of range of the NTT tables");
 }
 
 void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,

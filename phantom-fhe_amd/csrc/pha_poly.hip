@@ -99,6 +99,23 @@ static void launch_ew(Context &c, EwArgs k, size_t limbs, size_t mod_start, hipS
     check_launch();
 }
 
+// tensor product over table rows [mod_start, mod_start + limbs) (pha_behz.hip: base q and base Bsk)
+void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,
+                   hipStream_t s) {
+    EwArgs k{};
+    k.a = a; k.b = b; k.r = r;
+    if (limbs == 0) return;
+    if (mod_start + limbs > c.rows) throw std::invalid_argument("modulus index out of range");
+    k.mod = c.d_mod.p;
+    k.n = (uint32_t)c.n;
+    k.limbs = (uint32_t)limbs;
+    k.mod_start = (uint32_t)mod_start;
+    dim3 grid((unsigned)(c.n / (kEwThreads * kEwPerThread)), (unsigned)limbs);
+    if (square) hipLaunchKernelGGL((ew_kernel<EW_SQUARE>), grid, dim3(kEwThreads), 0, s, k);
+    else hipLaunchKernelGGL((ew_kernel<EW_TENSOR>), grid, dim3(kEwThreads), 0, s, k);
+    check_launch();
+}
+
 // used by pha_rns.hip
 void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s) {
     EwArgs k{};

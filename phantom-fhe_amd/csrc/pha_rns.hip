@@ -168,10 +168,10 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
 }
 
 // convs: device array; max_isz / max_osz over the converters used; split_ok: all primes <= 60 bits
-static void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
+void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                          uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src,
-                         size_t src_stride, const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0,
-                         size_t group_stride = 0) {
+                         size_t src_stride, const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count,
+                         size_t group_stride) {
     BConvLaunch L{};
     L.conv_count = conv_count; L.src_group_stride = group_stride; L.own_group_stride = group_stride;
     L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;

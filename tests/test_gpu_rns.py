@@ -407,3 +407,36 @@ def test_batched_keyswitch_and_tensor(name, scheme, ql, batch, gpu):
         ctx.divide_and_round_q_last_ntt(ql, d01, 2 * batch, out)                     # rescale of the whole batch
         assert np.array_equal(P.to_host(out).reshape(2 * batch, ql - 1, n), tool.rescale_ntt(got.reshape(2 * batch, ql, n), 2 * batch))
     ctx.keyswitch_inplace_batched(ql, d01, d2, 0, rlk.public_keys_ptr, scheme)       # empty batch: no-op
+
+
+@pytest.mark.parametrize("name,plain_t", [("c1_bfv4096", 65537), ("hyb12_a2", 65537), ("hyb12_a2", 1032193),
+                                          ("hyb13_a3", 786433), ("c4_bfv15", 1032193)])
+def test_bfv_multiply_behz(name, plain_t, gpu):
+    """bfv_multiply_behz (src/evaluate.cu:447-548) incl. the squaring path, vs the oracle; at C4 the conversions
+    run the wide (31-input) form."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(120)
+    ct1 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct2 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    dst = P.to_device(np.zeros((3, size_q, n), dtype=np.uint64), gpu)
+    with pytest.raises(ValueError):
+        ctx.bfv_multiply_behz(P.to_device(ct1, gpu), P.to_device(ct2, gpu), dst)    # no plain modulus yet
+    ctx.set_plain_modulus(plain_t)
+    behz = O.Behz(oc, plain_t)
+    d1, d2 = P.to_device(ct1, gpu), P.to_device(ct2, gpu)
+    ctx.bfv_multiply_behz(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), behz.multiply(ct1, ct2))
+    ctx.bfv_multiply_behz(d1, d1, dst)                                               # square
+    assert np.array_equal(P.to_host(dst), behz.multiply(ct1, ct1))
+    # the key-switch path still works after the table arrays grew (relinearize the product)
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    tool = O.Tool(oc, size_q)
+    prod = behz.multiply(ct1, ct1)
+    d_ct = P.to_device(prod[:2], gpu)
+    ctx.keyswitch_inplace(size_q, d_ct, P.to_device(prod[2], gpu), rlk.public_keys_ptr, O.BFV)
+    assert np.array_equal(P.to_host(d_ct), tool.keyswitch_inplace(prod[:2], prod[2], [evk[i] for i in range(tool.beta)], O.BFV))
