@@ -440,3 +440,77 @@ def test_bfv_multiply_behz(name, plain_t, gpu):
     d_ct = P.to_device(prod[:2], gpu)
     ctx.keyswitch_inplace(size_q, d_ct, P.to_device(prod[2], gpu), rlk.public_keys_ptr, O.BFV)
     assert np.array_equal(P.to_host(d_ct), tool.keyswitch_inplace(prod[:2], prod[2], [evk[i] for i in range(tool.beta)], O.BFV))
+
+
+def test_bfv_hommul_relinearize_decrypts_on_gpu(gpu):
+    """Config 0's operation (BFV HomAdd + HomMul at N = 4096, BFVDefault primes) on the GPU path: encryptions of m1, m2
+    -> add, BEHZ multiply, relinearize with a key generated by this build -> decrypts to m1 + m2 and m1 * m2 mod t."""
+    import phantom_fhe_amd as P
+    from util import crt_compose
+    name, plain_t = "c1_bfv4096", 65537
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    q = [int(p) for p in primes[:size_q]]
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    ctx.set_plain_modulus(plain_t)
+    r = rng_for(130)
+    Q = 1
+    for p in q:
+        Q *= p
+    delta = Q // plain_t
+    s_small = r.integers(-1, 2, n)
+    sk_ntt_full = _ternary_sk_from(oc, s_small, primes)
+    sk_ntt = sk_ntt_full[:size_q]
+    d_sk = P.to_device(sk_ntt_full, gpu)
+    d_s2 = P.to_device(np.zeros((size_q, n), dtype=np.uint64), gpu)
+    ctx.multiply_rns_poly(d_sk, d_sk, d_s2, size_q)
+    dnum = size_q // size_p
+    rlk = ctx.generate_one_kswitch_key(d_sk, d_s2, P.to_device(np.stack([uniform_poly(r, primes, n) for _ in range(dnum)]), gpu),
+                                       P.to_device(_noise(r, primes, n, dnum), gpu), O.BFV)
+
+    def encrypt(m):
+        a = uniform_poly(r, q, n)
+        e = r.integers(-3, 4, n)
+        dm = np.stack([np.array([(delta * int(v) + int(ev)) % p for v, ev in zip(m, e)], dtype=np.uint64) for p in q])
+        a_s = oc.nwt_backward(oc.multiply(oc.nwt_forward(a, size_q, 0), sk_ntt, size_q), size_q)
+        return np.stack([oc.sub(dm, a_s, size_q), a])
+
+    def decrypt(ct):      # ct [2][Q][N] coefficient form -> plaintext coefficients mod t
+        c1s = oc.nwt_backward(oc.multiply(oc.nwt_forward(ct[1], size_q, 0), sk_ntt, size_q), size_q)
+        phase = oc.add(ct[0], c1s, size_q)
+        out = []
+        for k in range(0, n, 53):
+            v, _ = crt_compose([phase[l, k] for l in range(size_q)], q)
+            out.append(((v * plain_t + Q // 2) // Q) % plain_t)
+        return out
+
+    m1 = r.integers(0, plain_t, n)
+    m2 = r.integers(0, plain_t, n)
+    c1, c2 = encrypt(m1), encrypt(m2)
+    d1, d2 = P.to_device(c1, gpu), P.to_device(c2, gpu)
+    # HomAdd
+    dsum = P.to_device(np.zeros_like(c1), gpu)
+    for i in range(2):
+        ctx.add_rns_poly(d1[i], d2[i], dsum[i], size_q)
+    assert decrypt(P.to_host(dsum)) == [int((int(m1[k]) + int(m2[k])) % plain_t) for k in range(0, n, 53)]
+    # HomMul + relinearize
+    d3 = P.to_device(np.zeros((3, size_q, n), dtype=np.uint64), gpu)
+    ctx.bfv_multiply_behz(d1, d2, d3)
+    ctx.keyswitch_inplace(size_q, d3[:2], d3[2], rlk.public_keys_ptr, O.BFV)
+    big = int(O.get_primes(n, 60, 1)[0])
+    bc = O.Ctx(log_n, [big], 0)
+    pm = bc.nwt_backward(bc.multiply(bc.nwt_forward(m1.astype(np.uint64).reshape(1, n), 1, 0),
+                                     bc.nwt_forward(m2.astype(np.uint64).reshape(1, n), 1, 0), 1), 1)[0]
+    want = []
+    for k in range(0, n, 53):
+        w = int(pm[k])
+        w = w - big if w > big // 2 else w
+        want.append(w % plain_t)
+    assert decrypt(P.to_host(d3[:2].contiguous())) == want
+
+
+def _ternary_sk_from(oc, s_small, primes):
+    n = len(s_small)
+    sk = np.stack([(s_small % int(p)).astype(np.uint64) for p in primes])
+    return oc.nwt_forward(sk, len(primes), 0)
