@@ -249,7 +249,7 @@ public:
         while ((size_t(1) << log_n) < n) log_n++;
         util::check_pha(pha_context_create(&amd_, log_n, primes.data(), primes.size(), sp, device));
         // DRNSTool receives the plain modulus for BFV / BGV (src/context.cu:200-216 -> src/rns.cu:196-285)
-        if (params.scheme() == scheme_type::bgv && params.plain_modulus().value() != 0)
+        if ((params.scheme() == scheme_type::bgv || params.scheme() == scheme_type::bfv) && params.plain_modulus().value() != 0)
             util::check_pha(pha_context_set_plain_modulus(amd_, params.plain_modulus().value()));
     }
     PhantomContext(const PhantomContext &) = delete;
@@ -541,8 +541,26 @@ inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encryp
 // multiply_inplace (src/evaluate.cu:1030-1079 -> bgv_ckks_multiply :345-397)
 inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2) {
     const auto &parms = context.get_context_data(encrypted1.chain_index()).parms();
-    if (parms.scheme() == scheme_type::bfv)
-        throw std::invalid_argument("BFV multiply (BEHZ/HPS) is not on the accelerated path");
+    if (parms.scheme() == scheme_type::bfv) {
+        // bfv_multiply (src/evaluate.cu:962-982) -> bfv_multiply_behz (:447-548); the HPS variants are not built
+        if (parms.mul_tech() != mul_tech_type::behz)
+            throw std::invalid_argument("only the BEHZ variant of BFV multiply is on the accelerated path");
+        if (encrypted1.is_ntt_form() || encrypted2.is_ntt_form())
+            throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
+        if (encrypted1.chain_index() != encrypted2.chain_index())
+            throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (encrypted1.size() != 2 || encrypted2.size() != 2)
+            throw std::invalid_argument("only 2x2 tensor products are on the accelerated path");
+        if (encrypted1.chain_index() != context.get_first_index())
+            throw std::invalid_argument("BFV multiply runs at the top data level");
+        const auto &s = cudaStreamPerThread;
+        const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree();
+        auto out = util::make_cuda_auto_ptr<uint64_t>(3 * L * n, s);
+        util::check_pha(pha_bfv_multiply_behz(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
+        encrypted1.resize(context, encrypted1.chain_index(), 3, s);
+        util::check_hip(hipMemcpyAsync(encrypted1.data(), out.get(), 3 * L * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        return;
+    }
     if (!(encrypted1.is_ntt_form() && encrypted2.is_ntt_form()))
         throw std::invalid_argument("encrypted1 and encrypted2 must be in NTT form");
     if (encrypted1.chain_index() != encrypted2.chain_index())

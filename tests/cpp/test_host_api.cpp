@@ -305,6 +305,47 @@ int main() {
         REQUIRE(bnext.correction_factor() == 15 * inv % 65537);
         orc_tool_destroy(bt);
     }
+    // BFV: multiply (BEHZ, evaluate.cu:447-548) -> relinearize, coefficient-form ciphertexts (examples/1_bfv.cu flow)
+    {
+        EncryptionParameters fp(scheme_type::bfv);
+        fp.set_poly_modulus_degree(n);
+        fp.set_special_modulus_size(alpha);
+        fp.set_coeff_modulus(parms.coeff_modulus());
+        fp.set_plain_modulus(Modulus(65537));
+        fp.set_mul_tech(mul_tech_type::behz);
+        PhantomContext fctx(fp);
+        orc_behz *ob = orc_behz_create(oc, 65537);
+        REQUIRE(ob != nullptr);
+        PhantomRelinKey frlk;
+        {
+            std::vector<uint64_t> flat;
+            for (auto &k : rlk_host) flat.insert(flat.end(), k.begin(), k.end());
+            frlk.load_from_host(fctx, flat.data(), dnum);
+        }
+        PhantomCiphertext f1, f2;
+        f1.load_from_host(fctx, 1, 2, h1.data());
+        f2.load_from_host(fctx, 1, 2, h2.data());
+        f1.set_ntt_form(false);
+        f2.set_ntt_form(false);
+        PhantomCiphertext fprod = multiply(fctx, f1, f2);
+        REQUIRE(fprod.size() == 3 && !fprod.is_ntt_form());
+        std::vector<uint64_t> r3(3 * ln), got3(3 * ln);
+        orc_bfv_multiply_behz(ob, h1.data(), h2.data(), r3.data());
+        fprod.store_to_host(got3.data());
+        REQUIRE(got3 == r3);
+        relinearize_inplace(fctx, fprod, frlk);
+        std::vector<uint64_t> r2(r3.begin(), r3.begin() + 2 * ln), got2(2 * ln);
+        orc_keyswitch_inplace(tool, r2.data(), r3.data() + 2 * ln, rlk_ptrs.data(), ORC_BFV);
+        fprod.store_to_host(got2.data());
+        REQUIRE(got2 == r2);
+        PhantomCiphertext fsq = f1;
+        multiply_inplace(fctx, fsq, fsq);                      // squaring path
+        orc_bfv_multiply_behz(ob, h1.data(), h1.data(), r3.data());
+        fsq.store_to_host(got3.data());
+        REQUIRE(got3 == r3);
+        REQUIRE(throws_invalid([&] { PhantomCiphertext c = f1; c.set_ntt_form(true); multiply_inplace(fctx, c, f2); }));
+        orc_behz_destroy(ob);
+    }
     phantom::util::check_hip(hipDeviceSynchronize(), "sync");
     orc_tool_destroy(tool);
     orc_ctx_destroy(oc);
