@@ -1014,6 +1014,173 @@ void orc_bfv_multiply_behz(const orc_behz *b, const u64 *ct1, const u64 *ct2, u6
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * BFV multiply, HPS variant (mul_tech_type::hps; src/evaluate.cu:674-818, bConv_HPS src/rns_bconv.cu:248-372,
+ * scaleAndRound_HPS_QR_R src/rns.cu:1700-1746, constants src/rns.cu:687-790, src/host/rns.cu:321-323,459-466).
+ * Floating point: the reference's kernels are built by nvcc with its default -fmad=true (no flag in its CMake
+ * files), so `acc += double(x) * c` is ONE fused multiply-add per term; the same fma chain is restated here.
+ * ---------------------------------------------------------------------------------------------- */
+#include <math.h>
+typedef struct { u64 *w; size_t len; } big_t;
+static big_t big_one(size_t cap) { big_t b; b.w = (u64 *)calloc(cap, sizeof(u64)); b.w[0] = 1; b.len = 1; return b; }
+static void big_mul_small(big_t *b, u64 m) {
+    u64 carry = 0;
+    for (size_t i = 0; i < b->len; i++) { u128 t = (u128)b->w[i] * m + carry; b->w[i] = (u64)t; carry = (u64)(t >> 64); }
+    if (carry) b->w[b->len++] = carry;
+}
+static u64 big_mod_small(const big_t *b, u64 m) {
+    u128 r = 0;
+    for (size_t i = b->len; i-- > 0;) r = ((r << 64) | b->w[i]) % m;
+    return (u64)r;
+}
+static void big_div_small(big_t *b, u64 m) { /* b = floor(b / m) */
+    u128 r = 0;
+    for (size_t i = b->len; i-- > 0;) { u128 cur = (r << 64) | b->w[i]; b->w[i] = (u64)(cur / m); r = cur % m; }
+    while (b->len > 1 && b->w[b->len - 1] == 0) b->len--;
+}
+typedef struct {
+    bconv_t conv;
+    double *inv;        /* 1 / q_i (src/host/rns.cu:321-323) */
+    u64 *alpha_q_mod_p; /* [isz + 1][osz]  alpha * Q mod p_j (:459-466) */
+} hpsconv_t;
+static void hpsconv_init(hpsconv_t *h, const u64 *ib, size_t isz, const u64 *ob, size_t osz) {
+    bconv_init(&h->conv, ib, isz, ob, osz);
+    h->inv = (double *)malloc(sizeof(double) * isz);
+    for (size_t i = 0; i < isz; i++) h->inv[i] = 1.0 / (double)ib[i];
+    h->alpha_q_mod_p = (u64 *)malloc(sizeof(u64) * (isz + 1) * osz);
+    for (size_t j = 0; j < osz; j++) {
+        const u64 qm = prod_mod(ib, isz, ob[j]);
+        for (size_t a = 0; a <= isz; a++) h->alpha_q_mod_p[a * osz + j] = orc_mulmod(a, qm, ob[j]);
+    }
+}
+static void hpsconv_free(hpsconv_t *h) { bconv_free(&h->conv); free(h->inv); free(h->alpha_q_mod_p); }
+/* DBaseConverter::bConv_HPS rns_bconv.cu:354-372 */
+static void hpsconv_apply(const hpsconv_t *h, const u64 *src, u64 *dst, size_t n) {
+    const bconv_t *b = &h->conv;
+    u64 *y = (u64 *)malloc(sizeof(u64) * b->isz * n);
+    bconv_mult(b, src, y, n);
+    for (size_t k = 0; k < n; k++) {
+        double frac = 0.0;
+        for (size_t i = 0; i < b->isz; i++) frac = fma((double)y[i * n + k], h->inv[i], frac);
+        const size_t v = (size_t)llround(frac);
+        for (size_t j = 0; j < b->osz; j++) {
+            u128 acc = 0;
+            for (size_t i = 0; i < b->isz; i++) acc += (u128)y[i * n + k] * b->mat[j * b->isz + i];
+            const u64 out = barrett128(acc, b->ob[j], b->omu[j]);
+            dst[j * n + k] = submod(out, h->alpha_q_mod_p[v * b->osz + j], b->ob[j]);
+        }
+    }
+    free(y);
+}
+struct orc_hps {
+    const orc_ctx *c;
+    size_t n, size_q, size_r;
+    int log_n;
+    u64 *r, *qr;                 /* R primes, then Q || R */
+    u64 (*qr_mu)[2];
+    u64 *tw, *tws, *itw, *itws, *n_inv, *n_inv_s; /* tables of Q || R */
+    hpsconv_t q_to_r, r_to_q;
+    double *frac;                /* [Q]  tRSHatInvModsDivsFrac */
+    u64 *div_mod_r;              /* [R][Q + 1] tRSHatInvModsDivsModr */
+};
+size_t orc_hps_r_size(const orc_hps *h) { return h->size_r; }
+void orc_hps_base(const orc_hps *h, u64 *out) { memcpy(out, h->r, sizeof(u64) * h->size_r); }
+orc_hps *orc_hps_create(const orc_ctx *c, u64 plain_t) {
+    orc_hps *h = (orc_hps *)calloc(1, sizeof(*h));
+    const size_t sq = c->size_q, sr = sq + 1, sqr = sq + sr, n = c->n;
+    h->c = c; h->n = n; h->log_n = c->log_n; h->size_q = sq; h->size_r = sr;
+    /* get_primes_below(n, min q, size_R) src/host/numth.cu:235-263 */
+    u64 minq = c->q[0];
+    for (size_t i = 1; i < sq; i++) if (c->q[i] < minq) minq = c->q[i];
+    h->r = (u64 *)malloc(sizeof(u64) * sr);
+    {
+        const u64 factor = 2 * (u64)n, lower = (u64)1 << (63 - __builtin_clzll(minq));
+        size_t found = 0;
+        for (u64 v = minq - factor; found < sr && v > lower; v -= factor)
+            if (orc_is_prime(v)) h->r[found++] = v;
+        if (found < sr) { free(h->r); free(h); return NULL; }
+    }
+    h->qr = (u64 *)malloc(sizeof(u64) * sqr);
+    memcpy(h->qr, c->q, sizeof(u64) * sq);
+    memcpy(h->qr + sq, h->r, sizeof(u64) * sr);
+    h->qr_mu = malloc(sizeof(u64[2]) * sqr);
+    h->tw = (u64 *)malloc(sizeof(u64) * sqr * n); h->tws = (u64 *)malloc(sizeof(u64) * sqr * n);
+    h->itw = (u64 *)malloc(sizeof(u64) * sqr * n); h->itws = (u64 *)malloc(sizeof(u64) * sqr * n);
+    h->n_inv = (u64 *)malloc(sizeof(u64) * sqr); h->n_inv_s = (u64 *)malloc(sizeof(u64) * sqr);
+    for (size_t i = 0; i < sqr; i++) {
+        orc_const_ratio(h->qr[i], h->qr_mu[i]);
+        orc_ntt_tables(c->log_n, h->qr[i], h->tw + i * n, h->tws + i * n, h->itw + i * n, h->itws + i * n, &h->n_inv[i], &h->n_inv_s[i]);
+    }
+    hpsconv_init(&h->q_to_r, c->q, sq, h->r, sr);
+    hpsconv_init(&h->r_to_q, h->r, sr, c->q, sq);
+    /* t/Q scale-and-round tables (rns.cu:727-790): S = Q || R, x_i = t * R * (S/s_i)^-1 mod s_i as big integers */
+    h->frac = (double *)malloc(sizeof(double) * sq);
+    h->div_mod_r = (u64 *)malloc(sizeof(u64) * sr * (sq + 1));
+    for (size_t i = 0; i < sqr; i++) {
+        u64 hat = 1;                                    /* (S / s_i) mod s_i, then its inverse */
+        for (size_t k = 0; k < sqr; k++) if (k != i) hat = orc_mulmod(hat, h->qr[k] % h->qr[i], h->qr[i]);
+        const u64 shat_inv = orc_invmod(hat, h->qr[i]);
+        big_t x = big_one(sr + 4);
+        for (size_t k = 0; k < sr; k++) big_mul_small(&x, h->r[k]);
+        big_mul_small(&x, plain_t);
+        big_mul_small(&x, shat_inv);
+        if (i < sq) h->frac[i] = (double)big_mod_small(&x, h->qr[i]) / (double)h->qr[i];
+        big_div_small(&x, h->qr[i]);
+        if (i < sq) {
+            for (size_t j = 0; j < sr; j++) h->div_mod_r[j * (sq + 1) + i] = big_mod_small(&x, h->r[j]);
+        } else {
+            const size_t j = i - sq;
+            h->div_mod_r[j * (sq + 1) + sq] = big_mod_small(&x, h->r[j]);
+        }
+        free(x.w);
+    }
+    return h;
+}
+void orc_hps_destroy(orc_hps *h) {
+    if (!h) return;
+    free(h->r); free(h->qr); free(h->qr_mu); free(h->tw); free(h->tws); free(h->itw); free(h->itws); free(h->n_inv); free(h->n_inv_s);
+    hpsconv_free(&h->q_to_r); hpsconv_free(&h->r_to_q); free(h->frac); free(h->div_mod_r); free(h);
+}
+void orc_bfv_multiply_hps(const orc_hps *h, const u64 *ct1, const u64 *ct2, u64 *dst) {
+    const size_t n = h->n, sq = h->size_q, sr = h->size_r, sqr = sq + sr;
+    u64 *x1 = (u64 *)calloc(3 * sqr * n, 8), *x2 = (u64 *)calloc(2 * sqr * n, 8);
+    for (int p = 0; p < 2; p++) {
+        const u64 *src[2] = {ct1 + p * sq * n, ct2 + p * sq * n};
+        u64 *dstp[2] = {x1 + p * sqr * n, x2 + p * sqr * n};
+        for (int w = 0; w < 2; w++) {
+            memcpy(dstp[w], src[w], sizeof(u64) * sq * n);
+            hpsconv_apply(&h->q_to_r, dstp[w], dstp[w] + sq * n, n);     /* evaluate.cu:716 */
+            for (size_t i = 0; i < sqr; i++)
+                orc_ntt_forward(dstp[w] + i * n, h->log_n, h->qr[i], h->tw + i * n, h->tws + i * n);
+        }
+    }
+    tensor_generic(x1, x2, x1, h->qr, h->qr_mu, sqr, n);
+    u64 *tmp = (u64 *)malloc(sizeof(u64) * sr * n);
+    for (int p = 0; p < 3; p++) {
+        u64 *x = x1 + p * sqr * n;
+        for (size_t i = 0; i < sqr; i++)
+            orc_ntt_inverse(x + i * n, h->log_n, h->qr[i], h->itw + i * n, h->itws + i * n, h->n_inv[i], h->n_inv_s[i]);
+        /* scaleAndRound_HPS_QR_R_kernel rns.cu:1700-1737 */
+        for (size_t k = 0; k < n; k++) {
+            double nu = 0.5;
+            for (size_t i = 0; i < sq; i++) nu = fma((double)x[i * n + k], h->frac[i], nu);
+            u64 alpha = (u64)nu;
+            for (size_t j = 0; j < sr; j++) {
+                const u64 rj = h->qr[sq + j];
+                const u64 *tab = h->div_mod_r + j * (sq + 1);
+                u128 cur = 0;
+                for (size_t i = 0; i < sq; i++) cur += (u128)x[i * n + k] * tab[i];
+                cur += (u128)x[(sq + j) * n + k] * tab[sq];
+                const u64 v = barrett128(cur, rj, h->qr_mu[sq + j]);
+                alpha = barrett64(alpha, rj, h->qr_mu[sq + j][1]);
+                tmp[j * n + k] = addmod(v, alpha, rj);
+            }
+        }
+        hpsconv_apply(&h->r_to_q, tmp, dst + p * sq * n, n);                /* evaluate.cu:806 */
+    }
+    free(tmp); free(x1); free(x2);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Galois (include/galois.cuh:98-130, src/galois.cu:11-39)
  * ---------------------------------------------------------------------------------------------- */
 void orc_galois_ntt_table(int log_n, uint32_t elt, uint32_t *table) {

@@ -120,6 +120,14 @@ void orc_behz_base(const orc_behz *b, uint64_t *bsk_out);  /* B primes then m_sk
 /* ct1, ct2 [2][Q][N] in coefficient form -> dst [3][Q][N] in coefficient form */
 void orc_bfv_multiply_behz(const orc_behz *b, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst);
 
+/* ---- BFV multiply, HPS (mul_tech hps; src/evaluate.cu:674-818, src/rns_bconv.cu:248-372, src/rns.cu:687-790,1700-1746) ---- */
+typedef struct orc_hps orc_hps;
+orc_hps *orc_hps_create(const orc_ctx *c, uint64_t plain_t);
+void orc_hps_destroy(orc_hps *h);
+size_t orc_hps_r_size(const orc_hps *h);
+void orc_hps_base(const orc_hps *h, uint64_t *r_out);
+void orc_bfv_multiply_hps(const orc_hps *h, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst);
+
 /* ---- Galois (include/galois.cuh:98-130, src/galois.cu:11-39) ---- */
 void orc_galois_ntt_table(int log_n, uint32_t galois_elt, uint32_t *table);
 void orc_apply_galois_ntt(const uint64_t *src, uint64_t *dst, const uint32_t *table, size_t n, size_t limbs);

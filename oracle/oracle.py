@@ -25,7 +25,7 @@ def build(native=False, out=None):
     if os.path.exists(out) and os.path.getmtime(out) >= max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "oracle.h"))):
         return out
-    cmd = ["gcc", "-O3", "-fPIC", "-std=c11", "-fopenmp", "-shared", "-o", out, src]
+    cmd = ["gcc", "-O3", "-fPIC", "-std=c11", "-fopenmp", "-ffp-contract=off", "-shared", "-o", out, src, "-lm"]
     if native:
         cmd.insert(2, "-march=native")
     subprocess.check_call(cmd)
@@ -84,6 +84,13 @@ def lib(path=None):
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_hps_create.restype = C.c_void_p
+    L.orc_hps_create.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_hps_destroy.argtypes = [C.c_void_p]
+    L.orc_hps_r_size.restype = C.c_size_t
+    L.orc_hps_r_size.argtypes = [C.c_void_p]
+    L.orc_hps_base.argtypes = [C.c_void_p, u64p]
+    L.orc_bfv_multiply_hps.argtypes = [C.c_void_p, u64p, u64p, u64p]
     L.orc_behz_create.restype = C.c_void_p
     L.orc_behz_create.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_behz_destroy.argtypes = [C.c_void_p]
@@ -300,6 +307,33 @@ class Behz:
         b = np.ascontiguousarray(ct2, dtype=np.uint64).reshape(-1)
         out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
         self.L.orc_bfv_multiply_behz(self.h, _p(a), _p(b), _p(out))
+        return out.reshape(3, c.size_q, c.n)
+
+
+class Hps:
+    """BFV multiply, HPS variant (mul_tech_type::hps), at the top data level (src/evaluate.cu:674-818)."""
+
+    def __init__(self, ctx, plain_t):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = self.L.orc_hps_create(ctx.h, int(plain_t))
+        if not self.h:
+            raise ValueError("cannot set up the HPS bases")
+        self.size_r = self.L.orc_hps_r_size(self.h)
+        r = np.zeros(self.size_r, dtype=np.uint64)
+        self.L.orc_hps_base(self.h, _p(r))
+        self.r = [int(v) for v in r]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_hps_destroy(self.h)
+            self.h = None
+
+    def multiply(self, ct1, ct2):
+        c = self.ctx
+        a = np.ascontiguousarray(ct1, dtype=np.uint64).reshape(-1)
+        b = np.ascontiguousarray(ct2, dtype=np.uint64).reshape(-1)
+        out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
+        self.L.orc_bfv_multiply_hps(self.h, _p(a), _p(b), _p(out))
         return out.reshape(3, c.size_q, c.n)
 
 

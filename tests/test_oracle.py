@@ -312,3 +312,63 @@ def test_bfv_behz_multiply_decrypts_to_the_product(name, plain_t):
         w = int(pm[k])
         w = w - big if w > big // 2 else w
         assert got == w % plain_t, k
+
+
+@pytest.mark.parametrize("name,plain_t", [("c1_bfv4096", 65537), ("bfv13_50", 65537), ("bfv13_50", 1032193)])
+def test_bfv_hps_multiply_decrypts_to_the_product(name, plain_t):
+    """BFV HPS multiply (mul_tech hps, src/evaluate.cu:674-818) pinned by its meaning, like the BEHZ test; the two
+    variants give different ciphertexts (different rounding) that decrypt to the same product.  The base R the
+    reference picks (|Q| + 1 primes below the smallest q_i, rns.cu:690-693) only covers t*N*Q when the data primes
+    have about the same size, hence the uniform chains here.  The reference's scale-and-round kernel reduces its
+    carry `alpha` in place across the R limbs (rns.cu:1733), which makes limbs j >= 1 wrong by a multiple of
+    (r_0 mod r_j): noise of about one prime's size, far below Q/t; restated as is."""
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    q = [int(p) for p in primes[:size_q]]
+    oc = oracle_ctx(name)
+    hps = O.Hps(oc, plain_t)
+    assert hps.size_r == size_q + 1 and all(p < min(q) and (p - 1) % (2 * n) == 0 for p in hps.r)
+    a_ct, b_ct = np.stack([uniform_poly(rng_for(5), q, n) for _ in range(2)]), np.stack([uniform_poly(rng_for(6), q, n) for _ in range(2)])
+    da, db = hps.multiply(a_ct, b_ct), O.Behz(oc, plain_t).multiply(a_ct, b_ct)
+    Qall = 1
+    for p in q:
+        Qall *= p
+    for k in range(0, n, 997):          # both variants approximate round(t/Q * tensor): they agree up to about one prime
+        va, _ = crt_compose([da[2, l, k] for l in range(size_q)], q)
+        vb, _ = crt_compose([db[2, l, k] for l in range(size_q)], q)
+        dd = (va - vb) % Qall
+        dd = dd - Qall if dd > Qall // 2 else dd
+        assert abs(dd).bit_length() <= max(p.bit_length() for p in q) + 4
+    r = rng_for(78)
+    Q = 1
+    for p in q:
+        Q *= p
+    delta = Q // plain_t
+    s_small = r.integers(-1, 2, n)
+    sk_ntt = oc.nwt_forward(np.stack([(s_small % p).astype(np.uint64) for p in q]), size_q, 0)
+
+    def encrypt(m):
+        a = uniform_poly(r, q, n)
+        e = r.integers(-3, 4, n)
+        dm = np.stack([np.array([(delta * int(v) + int(ev)) % p for v, ev in zip(m, e)], dtype=np.uint64) for p in q])
+        a_s = oc.nwt_backward(oc.multiply(oc.nwt_forward(a, size_q, 0), sk_ntt, size_q), size_q)
+        return np.stack([oc.sub(dm, a_s, size_q), a])
+
+    m1 = r.integers(0, plain_t, n)
+    m2 = r.integers(0, plain_t, n)
+    d = hps.multiply(encrypt(m1), encrypt(m2))
+    d_ntt = [oc.nwt_forward(d[i], size_q, 0) for i in range(3)]
+    s2 = oc.multiply(sk_ntt, sk_ntt, size_q)
+    phase = oc.add(oc.add(d_ntt[0], oc.multiply(d_ntt[1], sk_ntt, size_q), size_q), oc.multiply(d_ntt[2], s2, size_q), size_q)
+    phase = oc.nwt_backward(phase, size_q)
+    big = int(O.get_primes(n, 60, 1)[0])
+    bc = O.Ctx(log_n, [big], 0)
+    pm = bc.nwt_backward(bc.multiply(bc.nwt_forward(m1.astype(np.uint64).reshape(1, n), 1, 0),
+                                     bc.nwt_forward(m2.astype(np.uint64).reshape(1, n), 1, 0), 1), 1)[0]
+    for k in range(0, n, 61):
+        v, _ = crt_compose([phase[l, k] for l in range(size_q)], q)
+        got = ((v * plain_t + Q // 2) // Q) % plain_t
+        w = int(pm[k])
+        w = w - big if w > big // 2 else w
+        assert got == w % plain_t, k

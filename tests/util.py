@@ -16,6 +16,7 @@ CONFIGS = {
     "hyb13_a3": (13, [60] + [50] * 8 + [60] * 3, 3),  # 9 data limbs (dnum 3); lower levels have a short last digit
     "c3_ckks16": (16, [60] + [50] * 44 + [60] * 15, 15),  # examples/3_ckks.cu:729-739
     "c4_bfv15": (15, [60] + [50] * 29 + [60] * 15, 15),   # benchmark/keyswitch_bench.cu:25-34
+    "bfv13_50": (13, [50] * 4 + [60, 60], 2),             # uniform data primes: what the HPS variant of BFV multiply needs
 }
 
 
