@@ -174,6 +174,11 @@ int pha_generate_one_kswitch_key(pha_context_t ctx, const uint64_t *sk_ntt, cons
  * reference).  Needs pha_context_set_plain_modulus; the auxiliary base Bsk u {m_tilde} (src/rns.cu:392-560) and
  * its NTT tables are built on first use.  dst must not alias the inputs. */
 int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst, void *stream);
+/* bfv_multiply_hps with mul_tech_type::hps (src/evaluate.cu:674-818; bConv_HPS src/rns_bconv.cu:248-372;
+ * scaleAndRound_HPS_QR_R src/rns.cu:1700-1746): same shapes as pha_bfv_multiply_behz.  The base R (|Q| + 1 primes
+ * below the smallest q_i, src/rns.cu:687-693) and its tables are built on first use.  The double-precision
+ * sums are fused multiply-add chains, as nvcc builds the reference's kernels by default. */
+int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst, void *stream);
 /* DRNSTool::mod_t_and_divide_q_last_ntt (rns.cu:1210-1236), the BGV modulus switch: src [cipher][Ql][N]
  * in NTT form (left in coefficient form, as in the reference) -> dst [cipher][Ql-1][N] in NTT form */
 int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,

@@ -120,9 +120,143 @@ static void behz_lift(Context &c, Behz &b, const u64 *ct, u64 *out_q, u64 *out_b
     ntt_forward(c, out_bsk, out_bsk, out_bsk, aux_sel(sk, b.aux0), EPI_FWD_CANON, xb, s);
 }
 
+// ---- HPS variant (mul_tech_type::hps): bConv_HPS src/rns_bconv.cu:248-372, scaleAndRound_HPS_QR_R src/rns.cu:1700-1746.
+// Floating point: the reference is built by nvcc with its default -fmad=true, so every `acc += double(x) * c` of
+// its kernels is ONE fused multiply-add; the same fma chains are issued here (this file is compiled with
+// -ffp-contract=off, the fusions are explicit).
+struct HpsFixArgs {
+    u64 *out;                // [osz][N]: FastBconv(y) on entry, minus v * prod(ibase) mod p_j on exit
+    const u64 *y;            // [isz][N]  x_i * hat_i^-1 mod q_i
+    const double *inv;       // [isz]     1 / q_i
+    const u64 *alpha_mod;    // [isz + 1][osz]
+    const DModulus *mod;
+    const uint32_t *oprime;  // table rows of the output primes
+    uint32_t isz, osz, n;
+};
+__global__ __launch_bounds__(256) void hps_fix_kernel(const HpsFixArgs k) {
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    double frac = 0.0;
+    for (uint32_t i = 0; i < k.isz; i++) frac = __builtin_fma((double)k.y[(size_t)i * k.n + coeff], k.inv[i], frac);
+    const size_t v = (size_t)llround(frac);
+    for (uint32_t j = 0; j < k.osz; j++) {
+        const u64 p = k.mod[k.oprime[j]].value;
+        const size_t id = (size_t)j * k.n + coeff;
+        k.out[id] = sub_mod(k.out[id], k.alpha_mod[v * k.osz + j], p);
+    }
+}
+
+struct ScaleRoundArgs {
+    u64 *dst;                // [R][N]
+    const u64 *src;          // [Q + R][N] coefficient form
+    const double *frac;      // [Q]
+    const u64 *tab;          // [R][Q + 1]
+    const DModulus *mod;
+    uint32_t size_q, size_r, aux0, n;
+};
+__global__ __launch_bounds__(256) void hps_scale_round_kernel(const ScaleRoundArgs k) {
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    double nu = 0.5;
+    for (uint32_t i = 0; i < k.size_q; i++) nu = __builtin_fma((double)k.src[(size_t)i * k.n + coeff], k.frac[i], nu);
+    u64 alpha = (u64)nu;
+    for (uint32_t j = 0; j < k.size_r; j++) {
+        const DModulus m = k.mod[k.aux0 + j];
+        const u64 *tab = k.tab + (size_t)j * (k.size_q + 1);
+        u64 lo = 0, hi = 0;
+        for (uint32_t i = 0; i < k.size_q; i++) mac128(k.src[(size_t)i * k.n + coeff], tab[i], lo, hi);
+        mac128(k.src[(size_t)(k.size_q + j) * k.n + coeff], tab[k.size_q], lo, hi);
+        const u64 v = barrett128(lo, hi, m);
+        alpha = barrett64(alpha, m.value, m.ratio1);   // reduced IN PLACE across the R limbs, as rns.cu:1733 does
+        k.dst[(size_t)j * k.n + coeff] = add_mod(v, alpha, m.value);
+    }
+}
+
+void launch_bconv_phase1(Context &c, const BConv &conv, u64 *dst, const u64 *src, hipStream_t s);
+
+// DBaseConverter::bConv_HPS on one polynomial: dst [osz][N] <- src [isz][N]
+static void bconv_hps(Context &c, const BConv &conv, const BConvDev *d_conv, const double *inv, const u64 *alpha_mod,
+                      u64 *dst, const u64 *src, u64 *y, hipStream_t s) {
+    const uint32_t n = (uint32_t)c.n;
+    launch_bconv(c, d_conv, 0, 1, conv.isz, conv.osz, false, dst, 0, src, 0, nullptr, true, s);
+    launch_bconv_phase1(c, conv, y, src, s);   // the fix-up needs the phase-1 values themselves
+    HpsFixArgs fa{dst, y, inv, alpha_mod, c.d_mod.p, conv.d_oprime.p, conv.isz, conv.osz, n};
+    hipLaunchKernelGGL(hps_fix_kernel, dim3(n / 256), dim3(256), 0, s, fa);
+    check_launch();
+}
+
+// y_i = x_i * hat_i^-1 mod q_i for the input limbs of a converter (bconv_mult_kernel rns_bconv.cu:22-33)
+struct Phase1Args {
+    u64 *dst;
+    const u64 *src;
+    const DModulus *mod;
+    const uint32_t *iprime;
+    const u64x2 *hat_inv;
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void bconv_phase1_kernel(const Phase1Args k) {
+    const uint32_t i = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = (size_t)i * k.n + coeff;
+    k.dst[id] = shoup(k.src[id], k.hat_inv[i], k.mod[k.iprime[i]].value);
+}
+void launch_bconv_phase1(Context &c, const BConv &conv, u64 *dst, const u64 *src, hipStream_t s) {
+    Phase1Args k{dst, src, c.d_mod.p, conv.d_iprime.p, conv.hat_inv.p, (uint32_t)c.n};
+    hipLaunchKernelGGL(bconv_phase1_kernel, dim3((unsigned)(c.n / 256), conv.isz), dim3(256), 0, s, k);
+    check_launch();
+}
+
+static LimbSel qr_sel(uint32_t size_q, uint32_t size_r, uint32_t aux0) {  // [Q limbs || R limbs] buffers
+    LimbSel s = plain_sel(0, size_q + size_r);
+    s.remap_from = size_q;
+    s.remap_add = aux0 - size_q;
+    return s;
+}
+
 }  // namespace pha
 
 using namespace pha;
+
+extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
+                                    void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    Hps &h = c.hps();
+    hipStream_t s = as_stream(stream);
+    const uint32_t n = (uint32_t)c.n, sq = h.size_q, sr = h.size_r, sqr = sq + sr;
+    const size_t qn = (size_t)sq * n, rn = (size_t)sr * n, qrn = (size_t)sqr * n;
+    const bool square = ct1 == ct2;
+    // scratch: x1 [3][Q+R] | x2 [2][Q+R] | y [R] | tmp [R]
+    u64 *base = c.scratch(stream, 5 * qrn + 2 * rn);
+    u64 *x1 = base, *x2 = x1 + 3 * qrn, *y = x2 + 2 * qrn, *tmp = y + rn;
+    // lift every input polynomial from base Q to Q || R (evaluate.cu:702-716, :733-748)
+    for (int w = 0; w < (square ? 1 : 2); w++) {
+        const u64 *ct = w ? ct2 : ct1;
+        u64 *x = w ? x2 : x1;
+        for (uint32_t p = 0; p < 2; p++) {
+            PHA_HIP(hipMemcpyAsync(x + p * qrn, ct + p * qn, qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
+            bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x + p * qrn + qn, ct + p * qn, y, s);
+        }
+        NttExtra xf;
+        xf.batch = 2;
+        xf.poly_stride = qrn;
+        ntt_forward(c, x, x, x, qr_sel(sq, sr, h.aux0), EPI_FWD_CANON, xf, s);
+    }
+    // tensor product over Q || R: the Q limbs and the R limbs live in different table rows
+    const u64 *rhs = square ? x1 : x2;
+    launch_tensor(c, x1, rhs, x1, sq, 0, square, s, sqr);
+    launch_tensor(c, x1 + qn, rhs + qn, x1 + qn, sr, h.aux0, square, s, sqr);
+    NttExtra xi;
+    xi.batch = 3;
+    xi.poly_stride = qrn;
+    ntt_inverse(c, x1, x1, x1, qr_sel(sq, sr, h.aux0), EPI_INV_CANON, xi, s);
+    for (uint32_t p = 0; p < 3; p++) {
+        // scale by t/Q and round into base R, then R -> Q (evaluate.cu:800-808)
+        ScaleRoundArgs ka{tmp, x1 + p * qrn, h.frac.p, h.div_mod_r.p, c.d_mod.p, sq, sr, h.aux0, n};
+        hipLaunchKernelGGL(hps_scale_round_kernel, dim3(n / 256), dim3(256), 0, s, ka);
+        check_launch();
+        bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, dst + p * qn, tmp, y, s);
+    }
+    PHA_API_END
+}
 
 extern "C" int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
                                      void *stream) {

@@ -259,11 +259,14 @@ uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_l
         primes.push_back(q);
         mods.push_back(h_modulus(q));
     }
-    primes.push_back(table_less_modulus);
-    mods.push_back(h_modulus(table_less_modulus));
+    const uint32_t extra = table_less_modulus ? 1u : 0u;
+    if (extra) {
+        primes.push_back(table_less_modulus);
+        mods.push_back(h_modulus(table_less_modulus));
+    }
     roots.resize(primes.size());
     n_inv.resize(primes.size());
-    const uint32_t total = cnt + 1;
+    const uint32_t total = cnt + extra;
     std::vector<u64x2> tw((size_t)total * n, u64x2{0, 0}), itw((size_t)total * n, u64x2{0, 0}), ninv(total, u64x2{0, 0}),
         w1ninv(total, u64x2{0, 0});
     FpTables fp;
@@ -289,6 +292,99 @@ uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_l
 
 static void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
     out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.isz, b.osz, 0xffffffffu, 0, 0, 0}});
+}
+
+// DRNSTool constructor, HPS multiply part (src/rns.cu:687-790; converters src/host/rns.cu:282-337,438-466).
+Hps &Context::hps() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (hps_tool) return *hps_tool;
+    if (!plain_t) throw std::invalid_argument("bfv multiply needs a plain modulus (pha_context_set_plain_modulus)");
+    auto h = std::make_unique<Hps>();
+    const uint32_t sq = size_q, sr = size_q + 1;
+    h->size_q = sq;
+    h->size_r = sr;
+    // get_primes_below(n, min q, |R|) src/host/numth.cu:235-263
+    u64 minq = primes[0];
+    for (uint32_t i = 1; i < sq; i++) minq = std::min(minq, primes[i]);
+    std::vector<u64> r;
+    {
+        const u64 factor = 2 * (u64)n, lower = (u64)1 << (63 - __builtin_clzll(minq));
+        for (u64 v = minq - factor; r.size() < sr && v > lower; v -= factor)
+            if (h_is_prime(v)) r.push_back(v);
+        if (r.size() < sr) throw std::logic_error("failed to find enough qualifying primes 2");
+    }
+    h->aux0 = add_aux_moduli(r, 0);
+    std::vector<uint32_t> iq, ir;
+    for (uint32_t i = 0; i < sq; i++) iq.push_back(i);
+    for (uint32_t j = 0; j < sr; j++) ir.push_back(h->aux0 + j);
+    build_bconv(*this, h->q_to_r, iq, ir);
+    build_bconv(*this, h->r_to_q, ir, iq);
+    describe_conv(h->q_to_r, h->d_q_to_r);
+    describe_conv(h->r_to_q, h->d_r_to_q);
+    auto prod_mod = [&](const std::vector<uint32_t> &rows_, u64 m) {
+        u64 p = 1 % m;
+        for (uint32_t row : rows_) p = h_mulmod(p, primes[row] % m, m);
+        return p;
+    };
+    {
+        std::vector<double> qi(sq), ri(sr);
+        for (uint32_t i = 0; i < sq; i++) qi[i] = 1.0 / (double)primes[i];
+        for (uint32_t j = 0; j < sr; j++) ri[j] = 1.0 / (double)r[j];
+        h->q_inv.upload(qi);
+        h->r_inv.upload(ri);
+        std::vector<u64> aq((size_t)(sq + 1) * sr), ar((size_t)(sr + 1) * sq);
+        for (uint32_t j = 0; j < sr; j++) {
+            const u64 qm = prod_mod(iq, r[j]);
+            for (uint32_t a = 0; a <= sq; a++) aq[(size_t)a * sr + j] = h_mulmod(a, qm, r[j]);
+        }
+        for (uint32_t i = 0; i < sq; i++) {
+            const u64 rm = prod_mod(ir, primes[i]);
+            for (uint32_t a = 0; a <= sr; a++) ar[(size_t)a * sq + i] = h_mulmod(a, rm, primes[i]);
+        }
+        h->alpha_q_mod_r.upload(aq);
+        h->alpha_r_mod_q.upload(ar);
+    }
+    {   // t/Q scale-and-round tables (rns.cu:727-790): x_i = t * R * (S / s_i)^-1 mod s_i as big integers, S = Q || R
+        std::vector<u64> s_all(primes.begin(), primes.begin() + sq);
+        s_all.insert(s_all.end(), r.begin(), r.end());
+        std::vector<double> frac(sq);
+        std::vector<u64> tab((size_t)sr * (sq + 1));
+        auto mul_small = [](std::vector<u64> &b, u64 m) {
+            u64 carry = 0;
+            for (auto &w : b) { const u128 t = (u128)w * m + carry; w = (u64)t; carry = (u64)(t >> 64); }
+            if (carry) b.push_back(carry);
+        };
+        auto mod_small = [](const std::vector<u64> &b, u64 m) {
+            u128 rem = 0;
+            for (size_t i = b.size(); i-- > 0;) rem = ((rem << 64) | b[i]) % m;
+            return (u64)rem;
+        };
+        auto div_small = [](std::vector<u64> &b, u64 m) {
+            u128 rem = 0;
+            for (size_t i = b.size(); i-- > 0;) { const u128 cur = (rem << 64) | b[i]; b[i] = (u64)(cur / m); rem = cur % m; }
+        };
+        for (uint32_t i = 0; i < sq + sr; i++) {
+            u64 hat = 1;
+            for (uint32_t k = 0; k < sq + sr; k++)
+                if (k != i) hat = h_mulmod(hat, s_all[k] % s_all[i], s_all[i]);
+            const u64 shat_inv = h_invmod(hat, s_all[i]);
+            std::vector<u64> x{1};
+            for (u64 rj : r) mul_small(x, rj);
+            mul_small(x, plain_t);
+            mul_small(x, shat_inv);
+            if (i < sq) frac[i] = (double)mod_small(x, s_all[i]) / (double)s_all[i];
+            div_small(x, s_all[i]);
+            if (i < sq) {
+                for (uint32_t j = 0; j < sr; j++) tab[(size_t)j * (sq + 1) + i] = mod_small(x, r[j]);
+            } else {
+                tab[(size_t)(i - sq) * (sq + 1) + sq] = mod_small(x, r[i - sq]);
+            }
+        }
+        h->frac.upload(frac);
+        h->div_mod_r.upload(tab);
+    }
+    hps_tool = std::move(h);
+    return *hps_tool;
 }
 
 // DRNSTool constructor, BEHZ part (src/rns.cu:392-560).  Needs the plain modulus; top data level only.
@@ -656,7 +752,8 @@ int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus) {
         PHA_HIP(hipSetDevice(c.device));
         PHA_HIP(hipDeviceSynchronize());  // per-level tools are rebuilt lazily with the new constants
         c.tools.clear();
-        c.behz_tool.reset();   // (its auxiliary table rows stay; a later tool appends fresh ones)
+        c.behz_tool.reset();   // (their auxiliary table rows stay; a later tool appends fresh ones)
+        c.hps_tool.reset();
         c.plain_t = plain_modulus;
     }
     PHA_API_END

@@ -144,6 +144,18 @@ struct Behz {
     u64x2 neg_inv_prod_q_mod_mt{}, inv_prod_b_mod_msk{};
 };
 
+// ---- BFV HPS multiply (mul_tech hps) at the top data level (src/rns.cu:687-790): auxiliary base R = |Q| + 1 primes
+//      below the smallest q_i, in table rows [aux0, aux0 + size_r)
+struct Hps {
+    uint32_t size_q = 0, size_r = 0, aux0 = 0;
+    BConv q_to_r, r_to_q;
+    DevBuf<BConvDev> d_q_to_r, d_r_to_q;
+    DevBuf<double> q_inv, r_inv;                 // 1 / q_i, 1 / r_j (src/host/rns.cu:321-323)
+    DevBuf<u64> alpha_q_mod_r, alpha_r_mod_q;    // [|ibase| + 1][|obase|] alpha * prod(ibase) mod p_j (:459-466)
+    DevBuf<double> frac;                         // [Q]        tRSHatInvModsDivsFrac
+    DevBuf<u64> div_mod_r;                       // [R][Q + 1] tRSHatInvModsDivsModr
+};
+
 // ---- scratch arena: one per (context, stream), grown on demand, never freed until destroy ----
 struct Arena {
     DevBuf<u64> buf;
@@ -176,12 +188,14 @@ struct Context {
     std::mutex mu;
     std::map<uint32_t, std::unique_ptr<Tool>> tools;
     std::unique_ptr<Behz> behz_tool;
+    std::unique_ptr<Hps> hps_tool;
     uint32_t rows = 0;  // table rows = size_qp + auxiliary moduli
     std::map<void *, std::unique_ptr<Arena>> arenas;
     std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
 
     Tool &tool(uint32_t size_ql);
     Behz &behz();                                             // built on first use; needs the plain modulus
+    Hps &hps();
     uint32_t add_aux_moduli(const std::vector<u64> &ntt_primes, u64 plain_modulus_like);
     u64 *scratch(void *stream, size_t words);
     const uint32_t *galois_table(uint32_t elt);
@@ -239,7 +253,7 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
                   uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
                   const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0);
 void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,
-                   hipStream_t s);
+                   hipStream_t s, size_t poly_limbs = 0);
 void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -18,6 +18,7 @@ struct EwArgs {
     const u64 *s0, *s1;  // per-limb scalars (Shoup pair)
     const DModulus *mod;
     uint32_t n, limbs, mod_start;
+    uint32_t poly_limbs;  // limbs between two polynomials of a ciphertext (0 = limbs)
 };
 
 enum EwOp { EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_MULADD, EW_MULSCALAR, EW_TENSOR, EW_SQUARE };
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
     const DModulus m = k.mod[k.mod_start + limb];
     const u64 q = m.value;
     const size_t idx = (size_t)limb * k.n + ((size_t)blockIdx.x * kEwThreads + threadIdx.x) * kEwPerThread;
-    const size_t rc = (size_t)k.limbs * k.n;  // stride between the polynomials of a ciphertext
+    const size_t rc = (size_t)(k.poly_limbs ? k.poly_limbs : k.limbs) * k.n;  // stride between the polynomials of a ciphertext
 
     if (OP == EW_ADD) {  // add_rns_poly polymath.cu:41-56
         u64x2 x = ld2(k.a + idx), y = ld2(k.b + idx);
@@ -101,9 +102,10 @@ static void launch_ew(Context &c, EwArgs k, size_t limbs, size_t mod_start, hipS
 
 // tensor product over table rows [mod_start, mod_start + limbs) (pha_behz.hip: base q and base Bsk)
 void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,
-                   hipStream_t s) {
+                   hipStream_t s, size_t poly_limbs) {
     EwArgs k{};
     k.a = a; k.b = b; k.r = r;
+    k.poly_limbs = (uint32_t)poly_limbs;
     if (limbs == 0) return;
     if (mod_start + limbs > c.rows) throw std::invalid_argument("modulus index out of range");
     k.mod = c.d_mod.p;

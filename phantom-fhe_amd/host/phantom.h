@@ -542,9 +542,11 @@ inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encryp
 inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2) {
     const auto &parms = context.get_context_data(encrypted1.chain_index()).parms();
     if (parms.scheme() == scheme_type::bfv) {
-        // bfv_multiply (src/evaluate.cu:962-982) -> bfv_multiply_behz (:447-548); the HPS variants are not built
-        if (parms.mul_tech() != mul_tech_type::behz)
-            throw std::invalid_argument("only the BEHZ variant of BFV multiply is on the accelerated path");
+        // bfv_multiply (src/evaluate.cu:962-982) -> bfv_multiply_behz (:447-548) or bfv_multiply_hps with mul_tech hps
+        // (:674-818); the hps_overq variants are not built
+        const auto mul_tech = parms.mul_tech();
+        if (mul_tech != mul_tech_type::behz && mul_tech != mul_tech_type::hps)
+            throw std::invalid_argument("only the BEHZ and HPS variants of BFV multiply are on the accelerated path");
         if (encrypted1.is_ntt_form() || encrypted2.is_ntt_form())
             throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
         if (encrypted1.chain_index() != encrypted2.chain_index())
@@ -556,7 +558,10 @@ inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &e
         const auto &s = cudaStreamPerThread;
         const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree();
         auto out = util::make_cuda_auto_ptr<uint64_t>(3 * L * n, s);
-        util::check_pha(pha_bfv_multiply_behz(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
+        if (mul_tech == mul_tech_type::behz)
+            util::check_pha(pha_bfv_multiply_behz(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
+        else
+            util::check_pha(pha_bfv_multiply_hps(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
         encrypted1.resize(context, encrypted1.chain_index(), 3, s);
         util::check_hip(hipMemcpyAsync(encrypted1.data(), out.get(), 3 * L * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         return;

@@ -219,6 +219,10 @@ class PhantomContext:
         """bfv_multiply_behz (src/evaluate.cu:447-548): [2][Q][N] x [2][Q][N] -> [3][Q][N], coefficient form."""
         _lib.check(self._L.pha_bfv_multiply_behz(self._h, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
 
+    def bfv_multiply_hps(self, ct1, ct2, dst):
+        """bfv_multiply_hps, mul_tech hps (src/evaluate.cu:674-818): same shapes as bfv_multiply_behz."""
+        _lib.check(self._L.pha_bfv_multiply_hps(self._h, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
+
     def hoisting(self, size_Ql, ct, galois_elts, galois_keys, scheme):
         """hoisting_inplace (src/evaluate.cu:1670-1866): ct <- sum_e rotate_e(ct); galois_keys[e] is the
         PhantomRelinKey of Galois element galois_elts[e]."""

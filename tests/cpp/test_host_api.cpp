@@ -345,6 +345,22 @@ int main() {
         REQUIRE(got3 == r3);
         REQUIRE(throws_invalid([&] { PhantomCiphertext c = f1; c.set_ntt_form(true); multiply_inplace(fctx, c, f2); }));
         orc_behz_destroy(ob);
+        // the reference's default mul_tech (hps) on a second context
+        EncryptionParameters hp = fp;
+        hp.set_mul_tech(mul_tech_type::hps);
+        PhantomContext hctx(hp);
+        orc_hps *oh = orc_hps_create(oc, 65537);
+        REQUIRE(oh != nullptr);
+        PhantomCiphertext g1, g2;
+        g1.load_from_host(hctx, 1, 2, h1.data());
+        g2.load_from_host(hctx, 1, 2, h2.data());
+        g1.set_ntt_form(false);
+        g2.set_ntt_form(false);
+        PhantomCiphertext hprod = multiply(hctx, g1, g2);
+        orc_bfv_multiply_hps(oh, h1.data(), h2.data(), r3.data());
+        hprod.store_to_host(got3.data());
+        REQUIRE(got3 == r3);
+        orc_hps_destroy(oh);
     }
     phantom::util::check_hip(hipDeviceSynchronize(), "sync");
     orc_tool_destroy(tool);

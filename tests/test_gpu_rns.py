@@ -514,3 +514,31 @@ def _ternary_sk_from(oc, s_small, primes):
     n = len(s_small)
     sk = np.stack([(s_small % int(p)).astype(np.uint64) for p in primes])
     return oc.nwt_forward(sk, len(primes), 0)
+
+
+@pytest.mark.parametrize("name,plain_t", [("c1_bfv4096", 65537), ("bfv13_50", 65537), ("bfv13_50", 1032193), ("c4_bfv15", 1032193)])
+def test_bfv_multiply_hps(name, plain_t, gpu):
+    """bfv_multiply_hps, mul_tech hps (src/evaluate.cu:674-818) incl. the squaring path, vs the oracle (same fma chains,
+    same in-place carry reduction)."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    ctx.set_plain_modulus(plain_t)
+    hps = O.Hps(oc, plain_t)
+    r = rng_for(140)
+    ct1 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct2 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct2[:, :, :32] = np.array(primes[:size_q], dtype=np.uint64)[None, :, None] - 1       # extreme residues
+    dst = P.to_device(np.zeros((3, size_q, n), dtype=np.uint64), gpu)
+    d1, d2 = P.to_device(ct1, gpu), P.to_device(ct2, gpu)
+    ctx.bfv_multiply_hps(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), hps.multiply(ct1, ct2))
+    ctx.bfv_multiply_hps(d2, d2, dst)
+    assert np.array_equal(P.to_host(dst), hps.multiply(ct2, ct2))
+    # both variants on one context (two sets of auxiliary table rows)
+    ctx.bfv_multiply_behz(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), O.Behz(oc, plain_t).multiply(ct1, ct2))
+    ctx.bfv_multiply_hps(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), hps.multiply(ct1, ct2))
