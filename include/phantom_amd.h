@@ -179,6 +179,11 @@ int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, const uint64_t
  * below the smallest q_i, src/rns.cu:687-693) and its tables are built on first use.  The double-precision
  * sums are fused multiply-add chains, as nvcc builds the reference's kernels by default. */
 int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst, void *stream);
+/* Batched modular GEMM (benchmark/matmul_bench.cu:215-541): for z in [0, batch): C[z] = A[z] * B[z] mod q, q = the
+ * context prime mod_start_idx + z; row-major A [batch][m][lda], B [batch][k][ldb], C [batch][m][ldc], inputs
+ * canonical.  Exact (the reference's benchmark kernels lose the carries of the low product word, :231-232). */
+int pha_batched_modular_gemm(pha_context_t ctx, uint64_t *C, size_t ldc, const uint64_t *A, size_t lda, const uint64_t *B,
+                             size_t ldb, size_t m, size_t n, size_t k, size_t batch, size_t mod_start_idx, void *stream);
 /* DRNSTool::mod_t_and_divide_q_last_ntt (rns.cu:1210-1236), the BGV modulus switch: src [cipher][Ql][N]
  * in NTT form (left in coefficient form, as in the reference) -> dst [cipher][Ql-1][N] in NTT form */
 int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,

@@ -1181,6 +1181,37 @@ void orc_bfv_multiply_hps(const orc_hps *h, const u64 *ct1, const u64 *ct2, u64 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * batched modular GEMM (benchmark/matmul_bench.cu:215-541), exact: C = A * B mod q, row-major.
+ * (The reference's kernels add low and high product words separately and lose the low word's carries, :231-232;
+ * orc_gemm_mod_ref_quirk restates that arithmetic so that the difference can be shown on data.)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_gemm_mod(u64 q, const u64 *A, const u64 *B, u64 *C, size_t m, size_t n, size_t k) {
+    u64 mu[2];
+    orc_const_ratio(q, mu);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < n; j++) {
+            u64 acc = 0;
+            for (size_t l = 0; l < k; l++) acc = addmod(acc, barrett128((u128)A[i * k + l] * B[l * n + j], q, mu), q);
+            C[i * n + j] = acc;
+        }
+}
+void orc_gemm_mod_ref_quirk(u64 q, const u64 *A, const u64 *B, u64 *C, size_t m, size_t n, size_t k) {
+    u64 mu[2];
+    orc_const_ratio(q, mu);
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < n; j++) {
+            u64 lo = 0, hi = 0;
+            for (size_t l = 0; l < k; l++) {
+                const u128 p = (u128)A[i * k + l] * B[l * n + j];
+                lo += (u64)p;            /* no carry into hi: matmul_bench.cu:231-232 */
+                hi += (u64)(p >> 64);
+            }
+            C[i * n + j] = barrett128(((u128)hi << 64) | lo, q, mu);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Galois (include/galois.cuh:98-130, src/galois.cu:11-39)
  * ---------------------------------------------------------------------------------------------- */
 void orc_galois_ntt_table(int log_n, uint32_t elt, uint32_t *table) {

@@ -128,6 +128,10 @@ size_t orc_hps_r_size(const orc_hps *h);
 void orc_hps_base(const orc_hps *h, uint64_t *r_out);
 void orc_bfv_multiply_hps(const orc_hps *h, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst);
 
+/* ---- batched modular GEMM (benchmark/matmul_bench.cu:215-541), one modulus: row-major A [m][k], B [k][n], C [m][n] ---- */
+void orc_gemm_mod(uint64_t q, const uint64_t *A, const uint64_t *B, uint64_t *C, size_t m, size_t n, size_t k);
+void orc_gemm_mod_ref_quirk(uint64_t q, const uint64_t *A, const uint64_t *B, uint64_t *C, size_t m, size_t n, size_t k);
+
 /* ---- Galois (include/galois.cuh:98-130, src/galois.cu:11-39) ---- */
 void orc_galois_ntt_table(int log_n, uint32_t galois_elt, uint32_t *table);
 void orc_apply_galois_ntt(const uint64_t *src, uint64_t *dst, const uint32_t *table, size_t n, size_t limbs);

@@ -84,6 +84,8 @@ def lib(path=None):
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_gemm_mod.argtypes = [C.c_uint64, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.orc_gemm_mod_ref_quirk.argtypes = [C.c_uint64, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t]
     L.orc_hps_create.restype = C.c_void_p
     L.orc_hps_create.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_hps_destroy.argtypes = [C.c_void_p]
@@ -308,6 +310,18 @@ class Behz:
         out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
         self.L.orc_bfv_multiply_behz(self.h, _p(a), _p(b), _p(out))
         return out.reshape(3, c.size_q, c.n)
+
+
+def gemm_mod(q, A, B, quirk=False):
+    """C = A @ B mod q (exact), or with the reference benchmark kernel's dropped carries (quirk=True)."""
+    L = lib()
+    A = np.ascontiguousarray(A, dtype=np.uint64)
+    B = np.ascontiguousarray(B, dtype=np.uint64)
+    m, k = A.shape
+    n = B.shape[1]
+    out = np.zeros((m, n), dtype=np.uint64)
+    (L.orc_gemm_mod_ref_quirk if quirk else L.orc_gemm_mod)(int(q), _p(A.reshape(-1)), _p(B.reshape(-1)), _p(out.reshape(-1)), m, n, k)
+    return out
 
 
 class Hps:

@@ -223,6 +223,11 @@ class PhantomContext:
         """bfv_multiply_hps, mul_tech hps (src/evaluate.cu:674-818): same shapes as bfv_multiply_behz."""
         _lib.check(self._L.pha_bfv_multiply_hps(self._h, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
 
+    def batched_modular_gemm(self, C, A, B, m, n, k, batch, mod_start=0):
+        """C[z] = A[z] @ B[z] mod q_{mod_start + z}, row-major [batch][m][k] x [batch][k][n] (benchmark/matmul_bench.cu)."""
+        _lib.check(self._L.pha_batched_modular_gemm(self._h, _ptr(C), n, _ptr(A), k, _ptr(B), n, m, n, k, batch, mod_start,
+                                                    _stream()))
+
     def hoisting(self, size_Ql, ct, galois_elts, galois_keys, scheme):
         """hoisting_inplace (src/evaluate.cu:1670-1866): ct <- sum_e rotate_e(ct); galois_keys[e] is the
         PhantomRelinKey of Galois element galois_elts[e]."""

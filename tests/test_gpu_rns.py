@@ -542,3 +542,25 @@ def test_bfv_multiply_hps(name, plain_t, gpu):
     assert np.array_equal(P.to_host(dst), O.Behz(oc, plain_t).multiply(ct1, ct2))
     ctx.bfv_multiply_hps(d1, d2, dst)
     assert np.array_equal(P.to_host(dst), hps.multiply(ct1, ct2))
+
+
+@pytest.mark.parametrize("bits,m,n,k,batch", [(50, 256, 256, 256, 3), (50, 96, 40, 72, 2), (60, 128, 64, 100, 2), (36, 64, 32, 16, 1)])
+def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
+    """matmul_bench shape (256^3 per 50-bit modulus) and ragged shapes, wide (60-bit) and narrow paths, vs the oracle;
+    the benchmark's all-ones input gives k everywhere."""
+    import phantom_fhe_amd as P
+    primes = [int(p) for p in O.get_primes(4096, bits, batch)]
+    ctx = P.PhantomContext(12, primes, 0, device=gpu)
+    r = rng_for(150)
+    A = np.stack([r.integers(0, q, (m, k), dtype=np.uint64) for q in primes])
+    B = np.stack([r.integers(0, q, (k, n), dtype=np.uint64) for q in primes])
+    A[:, 0, :] = np.array(primes, dtype=np.uint64)[:, None] - 1       # a row and a column of q - 1
+    B[:, :, 0] = np.array(primes, dtype=np.uint64)[:, None] - 1
+    dC = P.to_device(np.zeros((batch, m, n), dtype=np.uint64), gpu)
+    ctx.batched_modular_gemm(dC, P.to_device(A, gpu), P.to_device(B, gpu), m, n, k, batch)
+    got = P.to_host(dC)
+    for z, q in enumerate(primes):
+        assert np.array_equal(got[z], O.gemm_mod(q, A[z], B[z])), f"modulus {z}"
+    ones_a, ones_b = np.ones_like(A), np.ones_like(B)
+    ctx.batched_modular_gemm(dC, P.to_device(ones_a, gpu), P.to_device(ones_b, gpu), m, n, k, batch)
+    assert (P.to_host(dC) == k).all()

@@ -372,3 +372,16 @@ def test_bfv_hps_multiply_decrypts_to_the_product(name, plain_t):
         w = int(pm[k])
         w = w - big if w > big // 2 else w
         assert got == w % plain_t, k
+
+
+def test_gemm_mod_against_python_ints():
+    q = int(O.get_primes(4096, 50, 1)[0])
+    r = rng_for(200)
+    A = r.integers(0, q, (5, 9), dtype=np.uint64)
+    B = r.integers(0, q, (9, 7), dtype=np.uint64)
+    want = [[sum(int(A[i, l]) * int(B[l, j]) for l in range(9)) % q for j in range(7)] for i in range(5)]
+    assert O.gemm_mod(q, A, B).tolist() == want
+    ones = np.ones((4, 256), dtype=np.uint64), np.ones((256, 4), dtype=np.uint64)
+    assert (O.gemm_mod(q, *ones) == 256).all() and (O.gemm_mod(q, *ones, quirk=True) == 256).all()  # the benchmark's input
+    big = r.integers(q // 2, q, (2, 256), dtype=np.uint64), r.integers(q // 2, q, (256, 2), dtype=np.uint64)
+    assert not np.array_equal(O.gemm_mod(q, *big), O.gemm_mod(q, *big, quirk=True))   # the dropped carries show
