@@ -153,7 +153,34 @@ struct ScaleRoundArgs {
     const DModulus *mod;
     uint32_t size_q, size_r, aux0, n;
 };
+template <int QPAD>   // QPAD >= size_q: the Q residues of the coefficient stay in registers across the R limbs
 __global__ __launch_bounds__(256) void hps_scale_round_kernel(const ScaleRoundArgs k) {
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    u64 x[QPAD];
+    double nu = 0.5;
+#pragma unroll
+    for (int i = 0; i < QPAD; i++) {
+        x[i] = 0;
+        if (i < (int)k.size_q) {
+            x[i] = k.src[(size_t)i * k.n + coeff];
+            nu = __builtin_fma((double)x[i], k.frac[i], nu);
+        }
+    }
+    u64 alpha = (u64)nu;
+    for (uint32_t j = 0; j < k.size_r; j++) {
+        const DModulus m = k.mod[k.aux0 + j];
+        const u64 *tab = k.tab + (size_t)j * (k.size_q + 1);
+        u64 lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < QPAD; i++)
+            if (i < (int)k.size_q) mac128(x[i], tab[i], lo, hi);
+        mac128(k.src[(size_t)(k.size_q + j) * k.n + coeff], tab[k.size_q], lo, hi);
+        const u64 v = barrett128(lo, hi, m);
+        alpha = barrett64(alpha, m.value, m.ratio1);   // reduced IN PLACE across the R limbs, as rns.cu:1733 does
+        k.dst[(size_t)j * k.n + coeff] = add_mod(v, alpha, m.value);
+    }
+}
+__global__ __launch_bounds__(256) void hps_scale_round_wide_kernel(const ScaleRoundArgs k) {  // size_q > 32
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
     double nu = 0.5;
     for (uint32_t i = 0; i < k.size_q; i++) nu = __builtin_fma((double)k.src[(size_t)i * k.n + coeff], k.frac[i], nu);
@@ -165,7 +192,7 @@ __global__ __launch_bounds__(256) void hps_scale_round_kernel(const ScaleRoundAr
         for (uint32_t i = 0; i < k.size_q; i++) mac128(k.src[(size_t)i * k.n + coeff], tab[i], lo, hi);
         mac128(k.src[(size_t)(k.size_q + j) * k.n + coeff], tab[k.size_q], lo, hi);
         const u64 v = barrett128(lo, hi, m);
-        alpha = barrett64(alpha, m.value, m.ratio1);   // reduced IN PLACE across the R limbs, as rns.cu:1733 does
+        alpha = barrett64(alpha, m.value, m.ratio1);
         k.dst[(size_t)j * k.n + coeff] = add_mod(v, alpha, m.value);
     }
 }
@@ -251,7 +278,10 @@ extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, cons
     for (uint32_t p = 0; p < 3; p++) {
         // scale by t/Q and round into base R, then R -> Q (evaluate.cu:800-808)
         ScaleRoundArgs ka{tmp, x1 + p * qrn, h.frac.p, h.div_mod_r.p, c.d_mod.p, sq, sr, h.aux0, n};
-        hipLaunchKernelGGL(hps_scale_round_kernel, dim3(n / 256), dim3(256), 0, s, ka);
+        if (sq <= 8) hipLaunchKernelGGL(hps_scale_round_kernel<8>, dim3(n / 256), dim3(256), 0, s, ka);
+        else if (sq <= 16) hipLaunchKernelGGL(hps_scale_round_kernel<16>, dim3(n / 256), dim3(256), 0, s, ka);
+        else if (sq <= 32) hipLaunchKernelGGL(hps_scale_round_kernel<32>, dim3(n / 256), dim3(256), 0, s, ka);
+        else hipLaunchKernelGGL(hps_scale_round_wide_kernel, dim3(n / 256), dim3(256), 0, s, ka);
         check_launch();
         bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, dst + p * qn, tmp, y, s);
     }

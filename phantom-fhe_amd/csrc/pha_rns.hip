@@ -181,7 +181,8 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
     L.out_per_block = (max_osz + groups - 1) / groups;
     dim3 grid((unsigned)(c.n / kBcThreads), groups, batch);
     dim3 block(kBcThreads);
-    const bool split = split_ok && g_bconv_split.load(std::memory_order_relaxed);
+    // the carry-free split accumulators hold at most 16 terms; wider bases take the 128-bit accumulate
+    const bool split = split_ok && max_isz <= 16 && g_bconv_split.load(std::memory_order_relaxed);
 #define PHA_BC(P)                                                                                        \
     do {                                                                                                 \
         if (scale_in && split) hipLaunchKernelGGL((bconv_kernel<P, true, true>), grid, block, 0, s, L);   \
@@ -194,6 +195,7 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
     else if (max_isz <= 8) PHA_BC(8);
     else if (max_isz == 15) PHA_BC(15);  // alpha = 15 (C3 / C4): no padded sixteenth term
     else if (max_isz <= 16) PHA_BC(16);
+    else if (max_isz <= 32) PHA_BC(32);  // BFV multiply at 30-limb chains: inputs still live in registers
     else if (scale_in) hipLaunchKernelGGL((bconv_wide_kernel<true>), grid, block, 0, s, L);
     else hipLaunchKernelGGL((bconv_wide_kernel<false>), grid, block, 0, s, L);
 #undef PHA_BC
