@@ -171,7 +171,11 @@ struct FpMod {
     // Light butterflies (no re-centring inside a pass) are exact while every magnitude stays below 2^52.6:
     //   forward: |t| <= q (0.5 + 1.5 |Y| 2^-52) per stage, 8 stages per pass -> q < 2^47 keeps |x| < 11 q < 2^50.5
     //   inverse: sums double per stage, 8 stages per pass                  -> q < 2^43 suffices (|x| < 2^8 q)
-    // (a pass = at most 9 stages for N = 2^17; the thresholds below keep one more bit of margin for that)
+    // (a pass = at most 9 stages for N = 2^17; the thresholds below keep one more bit of margin for that).
+    // The one-launch N = 4096 transform runs 12 stages in its single pass: forward light still fits (|x| < 10 q <
+    // 2^50.3), the full forward butterfly reaches q + 12 (q/2 + 1) < 7.1 q < 2^52.9 at q < 2^50 (integers below
+    // 2^53 are exact and fp_mulmod's quotient stays within 3 there), and the inverse only runs light below 2^40
+    // (round_compute in pha_ntt_core.h).
     bool ct_light, gs_light;
 };
 PHA_HD FpMod make_fpmod(u64 q) { return FpMod{(double)q, 1.0 / (double)q, (q >> 47) == 0, (q >> 42) == 0}; }

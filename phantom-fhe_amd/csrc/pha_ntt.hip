@@ -13,7 +13,7 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4)
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096 through the two-pass plans too (default: the whole transform in one launch)
 std::atomic<int> g_ntt_variant{1 | 32 | 64};  // default: 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
         a.out += (size_t)blockIdx.z * k.out_stride;
         if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) a.aux += (size_t)blockIdx.z * k.aux_stride;
     }
-    if (FWD && C::STRIDED && k.pro_src) {  // rescale prologue: transform (the last limb of polynomial z) mod this prime
+    if (FWD && (C::STRIDED || C::WHOLE) && k.pro_src) {  // rescale prologue: transform (the last limb of polynomial z) mod this prime
         const uint32_t prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
         a.in = k.pro_src + (size_t)blockIdx.z * k.pro_stride;
         a.pro_reduce = true;
@@ -167,6 +167,23 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     (void)total;
     hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, k);
     check_launch();
+}
+
+// N = 4096 as ONE pass (the transform fits a tile): T1 = 1, T2 = N
+static void forward_whole12(NttKArgs k, int epi, hipStream_t s) {
+    k.t1 = 1;
+    k.t2 = WholePlan12::T;
+    k.mid = k.out;
+    if (epi == EPI_FWD_MODDOWN) launch_pass<WholePlan12, true, EPI_FWD_MODDOWN, false>(k, s);
+    else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<WholePlan12, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
+    else launch_pass<WholePlan12, true, EPI_FWD_CANON, false>(k, s);
+}
+static void inverse_whole12(NttKArgs k, int epi, hipStream_t s) {
+    k.t1 = 1;
+    k.t2 = WholePlan12::T;
+    k.mid = k.out;
+    if (epi == EPI_INV_SCALE) launch_pass<WholePlan12, false, EPI_INV_SCALE, true>(k, s);
+    else launch_pass<WholePlan12, false, EPI_INV_CANON, true>(k, s);
 }
 
 template <int LOGN, int VARIANT>
@@ -266,6 +283,10 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
     const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
+    if (c.log_n == 12 && !(vv & 128)) {  // bit 7 clear (default): N = 4096 in one launch
+        forward_whole12(k, epi, s);
+        return;
+    }
     switch (c.log_n) {
         case 12: if (v == 4) forward_impl<12, 4>(k, epi, s); else if (v == 3) forward_impl<12, 3>(k, epi, s); else if (v == 2) forward_impl<12, 2>(k, epi, s); else if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
         case 13: if (v == 4) forward_impl<13, 4>(k, epi, s); else if (v == 3) forward_impl<13, 3>(k, epi, s); else if (v == 2) forward_impl<13, 2>(k, epi, s); else if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
@@ -288,6 +309,10 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
     const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
+    if (c.log_n == 12 && !(vv & 128)) {
+        inverse_whole12(k, epi, s);
+        return;
+    }
     switch (c.log_n) {
         case 12: if (v == 4) inverse_impl<12, 4>(k, epi, s); else if (v == 3) inverse_impl<12, 3>(k, epi, s); else if (v == 2) inverse_impl<12, 2>(k, epi, s); else if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
         case 13: if (v == 4) inverse_impl<13, 4>(k, epi, s); else if (v == 3) inverse_impl<13, 3>(k, epi, s); else if (v == 2) inverse_impl<13, 2>(k, epi, s); else if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
@@ -435,7 +460,7 @@ int pha_exp_read_wg_times(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 127 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 255 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

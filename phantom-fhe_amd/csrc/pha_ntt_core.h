@@ -52,7 +52,9 @@ enum Epilogue {
 // whole rows, so the exchanges between rounds stay inside the wavefront and its barriers compile away.
 // (Splitting the STRIDED pass by columns between the wavefronts makes it barrier-free too; measured r01g:
 // 16-byte runs per row cost more than the barriers, 45 limbs 29.1 -> 34.1 us, so that form was dropped.)
-template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16, bool OT_ = false, int LOGTILE_ = 12>
+// WHOLE_: the pass is the whole transform (N = 4096 fits one tile): it is both the first and the last pass.
+template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16, bool OT_ = false, int LOGTILE_ = 12,
+          bool WHOLE_ = false>
 struct PassCfg {
     static constexpr int EPT = EPT_;
     static constexpr bool OT = OT_ && !STRIDED_;
@@ -62,6 +64,7 @@ struct PassCfg {
     static_assert(LOGTILE_ >= LOGT_ && LOGTILE_ <= 12, "a tile holds whole transforms and fits the LDS budget");
     // one wavefront per workgroup: every exchange between rounds stays inside it, no workgroup barrier
     static constexpr bool WAVE_LOCAL = TILE / EPT_ == 64;
+    static constexpr bool WHOLE = WHOLE_ && !STRIDED_;
     static_assert((1 << R0_) <= EPT_ && (1 << R1_) <= EPT_ && (1 << R2_) <= EPT_, "radix exceeds registers");
     static constexpr int LOGT = LOGT_;
     static constexpr int T = 1 << LOGT_;
@@ -446,7 +449,10 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
                 // stages of this pass already done (inverse order: rounds NR-1 .. 0), and whether it began canonical
                 constexpr int stage0 = C::LOGT - C::s0(RI) - r;
                 constexpr bool canon_in = !C::STRIDED;  // the inverse's first pass is the contiguous one
-                if (a.fpm.gs_light) fp_gs_round<r, FOLD, true>(rg, t, a.fpm, a.ninv, a.w1ninv);
+                // unreduced sums double every stage: a 12-stage pass (N = 4096 in one launch) reaches 2^12 q, so it
+                // only runs light below 2^40 (2^52 worst case; all-(q-1) inputs do reach it)
+                const bool light = a.fpm.gs_light && (C::LOGT <= 9 || a.fpm.q < 0x1p40);
+                if (light) fp_gs_round<r, FOLD, true>(rg, t, a.fpm, a.ninv, a.w1ninv);
                 else fp_gs_round<r, FOLD, false, stage0, canon_in>(rg, t, a.fpm, a.ninv, a.w1ninv);
             }
         }
@@ -527,7 +533,8 @@ struct PassProgram {
     static constexpr int NSEG = C::NR;
     static constexpr int THREADS = C::THREADS;
     // the transform's first pass is the strided one going forward and the contiguous one going backward
-    static constexpr bool FIRST_PASS = FWD ? C::STRIDED : !C::STRIDED;
+    static constexpr bool FIRST_PASS = C::WHOLE || (FWD ? C::STRIDED : !C::STRIDED);
+    static constexpr bool LAST_PASS = C::WHOLE || !(FWD ? C::STRIDED : !C::STRIDED);
 
     // FP64 path: what just came from global memory becomes a small double.  First pass: canonical
     // integers -> doubles; second pass: the lazy doubles of the first pass are centred again.
@@ -539,7 +546,7 @@ struct PassProgram {
     }
     // FP64 path, last pass: doubles -> canonical integers (the integer epilogue then sees [0,q))
     PHA_HD static void fp_before_global_store(const PassArgs &a, u64 *reg) {
-        if (!a.fp || FIRST_PASS) return;
+        if (!a.fp || !LAST_PASS) return;
 #pragma unroll
         for (int i = 0; i < C::EPT; i++) reg[i] = fp_to_canon(as_f64(reg[i]), a.fpm);
     }
@@ -636,5 +643,7 @@ template <> struct NttPlan<14, 4> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  us
 template <> struct NttPlan<15, 4> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true, 9>; };
 template <> struct NttPlan<16, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true, 9>; };
 template <> struct NttPlan<17, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, true, 9>; };
+// N = 4096: the whole transform in one 4096-coefficient tile (three radix-16 rounds, one launch, no intermediate)
+using WholePlan12 = PassCfg<12, false, 4, 4, 4, 16, false, 12, true>;
 
 }  // namespace pha

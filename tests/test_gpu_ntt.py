@@ -39,7 +39,7 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
     assert np.array_equal(P.to_host(d2), oc.nwt_backward(x, L, 0))
 
 
-@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave"])
+@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave", "two-pass-4096"])
 def ntt_variant(request):
     """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
     import phantom_fhe_amd as P
@@ -193,3 +193,23 @@ def test_empty_and_full_size_properties(gpu):
     dz = P.to_device(np.zeros_like(a), gpu)
     ctx.nwt_2d_radix8_forward_inplace(dz, 60, 0)
     assert not P.to_host(dz).any()
+
+
+@pytest.mark.parametrize("log_n", [12, 13, 17])
+def test_large_residues_fp_thresholds(log_n, gpu, ntt_variant):
+    """Residues just below q everywhere (busy low bits): the unreduced FP64 sums of the light butterflies reach
+    their worst case, right at the prime sizes where the light / deferred variants switch."""
+    import phantom_fhe_amd as P
+    n = 1 << log_n
+    primes = [int(p) for p in O.coeff_modulus_create(n, [50, 47, 46, 42, 41, 40, 39, 30])]
+    oc = O.Ctx(log_n, primes, 0)
+    ctx = P.PhantomContext(log_n, primes, 0, device=gpu)
+    r = rng_for(700 + log_n)
+    x = np.stack([(q - 1 - r.integers(0, 1 << 16, n)).astype(np.uint64) for q in primes])
+    L = len(primes)
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_backward_inplace(d, L, 0)
+    assert np.array_equal(P.to_host(d), oc.nwt_backward(x, L, 0))
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace(d, L, 0)
+    assert np.array_equal(P.to_host(d), oc.nwt_forward(x, L, 0))
