@@ -159,6 +159,14 @@ int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *operand1, con
  * element's key).  One mod-up, one fused gather + inner-product kernel, one pair of mod-downs. */
 int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                  const uint64_t *const *const *glk, int scheme, void *stream);
+/* Weighted hoisted rotations -- BUILD-DEFINED (BASELINE config 5 "encrypted matmul"; the reference has no such
+ * entry point: its building blocks are hoisting_inplace src/evaluate.cu:1670-1866, multiply_plain_inplace :1297-1340
+ * and add_inplace :116-198):  ct [2][Ql][N] (NTT form, ckks / bgv) <- sum_e w_e (.) rotate_e(ct), i.e. the
+ * diagonal form of a plaintext-matrix x encrypted-vector product.  The weights are multiplied in before the one
+ * shared mod-down, so weights[e] (HOST array of DEVICE pointers) is the plaintext over [Q_l || P], NTT form,
+ * [Ql + size_P][N].  Galois element 1 (main diagonal) takes no key: glk[e] may be NULL there. */
+int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
+                          const uint64_t *const *const *glk, const uint64_t *const *weights, int scheme, void *stream);
 /* PhantomSecretKey::generate_one_kswitch_key (src/secretkey.cu:297-341 with encrypt_zero_symmetric :232-295),
  * arithmetic part; the randomness comes from the caller because the PRNG (sample_uniform_poly /
  * sample_error_poly, src/prng.cu) is outside the accelerated path.  All buffers on the device:

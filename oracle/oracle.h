@@ -104,6 +104,9 @@ void orc_keyswitch_inplace(const orc_tool *t, uint64_t *ct, const uint64_t *c2, 
 /* hoisting_inplace evaluate.cu:1670-1866: ct=[2][size_ql][N] <- sum_e rotate_e(ct); glk[e][digit] = key [2][size_QP][N] */
 void orc_hoisting(const orc_tool *t, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                   const uint64_t *const *const *glk, int scheme);
+/* build-defined: sum_e w_e (.) rotate_e(ct), weights over [Q_l || P] in NTT form (BASELINE config 5) */
+void orc_hoisting_weighted(const orc_tool *t, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
+                           const uint64_t *const *const *glk, const uint64_t *const *weights, int scheme);
 /* divide_and_round_q_last_ntt rns.cu:1128-1184: src [cipher][size_ql][N] (clobbered) -> dst [cipher][size_ql-1][N] */
 void orc_rescale_ntt(const orc_tool *t, uint64_t *src, size_t cipher_size, uint64_t *dst);
 /* mod_t_and_divide_q_last_ntt rns.cu:1186-1236 (BGV modulus switch; needs orc_tool_set_plain_modulus) */

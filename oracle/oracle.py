@@ -82,6 +82,7 @@ def lib(path=None):
     L.orc_moddown_from_ntt.argtypes = [C.c_void_p, u64p, u64p, C.c_int]
     L.orc_keyswitch_inplace.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p), C.c_int]
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
+    L.orc_hoisting_weighted.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.POINTER(u64p), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_gemm_mod.argtypes = [C.c_uint64, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t]
@@ -410,6 +411,24 @@ class Tool:
             tabs.append(arr)
         outer = (C.POINTER(u64p) * len(tabs))(*[C.cast(a, C.POINTER(u64p)) for a in tabs])
         self.L.orc_hoisting(self.h, _p(ct), _p32(elts), len(elts), outer, scheme)
+        return ct.reshape(2, self.size_ql, self.n)
+
+    def hoisting_weighted(self, ct, galois_elts, glk, weights, scheme):
+        """sum_e w_e (.) rotate_e(ct); weights[e] is [QlP][N] in NTT form; glk[e] may be None for element 1."""
+        ct = np.array(ct, dtype=np.uint64, copy=True).reshape(-1)
+        elts = np.ascontiguousarray(galois_elts, dtype=np.uint32)
+        keep, tabs = [], []
+        for keys in glk:
+            if keys is None:
+                tabs.append(None)
+                continue
+            arr, k = self._evk_ptrs(keys)
+            keep.append(k)
+            tabs.append(arr)
+        outer = (C.POINTER(u64p) * len(tabs))(*[C.cast(a, C.POINTER(u64p)) if a is not None else C.POINTER(u64p)() for a in tabs])
+        ws = [np.ascontiguousarray(w, dtype=np.uint64).reshape(-1) for w in weights]
+        warr = (u64p * len(ws))(*[_p(w) for w in ws])
+        self.L.orc_hoisting_weighted(self.h, _p(ct), _p32(elts), len(elts), outer, warr, scheme)
         return ct.reshape(2, self.size_ql, self.n)
 
     def set_plain_modulus(self, t):

@@ -352,6 +352,76 @@ __global__ __launch_bounds__(256) void hoist_c0_kernel(u64 *dst, const u64 *src,
     dst[(size_t)limb * n + coeff] = acc;
 }
 
+// ---- weighted hoisted rotations (BASELINE config 5, build-defined: no reference counterpart): as above with a
+//      plaintext weight per Galois element, multiplied in before the shared mod-down:
+//      cx[k] = sum_e w_e[k] * (sum_b modup_b[perm_e[k]] * key_{e,b}[k] mod q).  The per-element inner product
+//      is reduced once (Barrett) so that the weighted sum fits the 128-bit accumulator again. ----
+struct HoistWArgs {
+    HoistArgs h;
+    const u64 *const *weights;        // device array [n_elts] of weights [QlP][N] (NTT form)
+};
+__global__ __launch_bounds__(256) void hoist_weighted_inner_prod_kernel(const HoistWArgs kw) {
+    const HoistArgs &k = kw.h;
+    const uint32_t nid = blockIdx.y;
+    const uint32_t twr = k.qlp_prime[nid];
+    const DModulus m = k.mod[twr];
+    const size_t coeff = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t out_id = (size_t)nid * k.n + coeff;
+    const size_t evk_id = (size_t)twr * k.n + coeff;
+    u64 a0l = 0, a0h = 0, a1l = 0, a1h = 0, b0l = 0, b0h = 0, b1l = 0, b1h = 0;
+    if (k.accumulate) {
+        const u64x2 p0 = *reinterpret_cast<const u64x2 *>(k.cx + out_id);
+        const u64x2 p1 = *reinterpret_cast<const u64x2 *>(k.cx + out_id + k.qlp_n);
+        a0l = p0.x; a1l = p0.y; b0l = p1.x; b1l = p1.y;
+    }
+    for (uint32_t e = 0; e < k.n_elts; e++) {
+        const uint2 idx = *reinterpret_cast<const uint2 *>(k.tables[e] + coeff);
+        const u64 *const *keys = k.keys[e];
+        u64 s0l = 0, s0h = 0, s1l = 0, s1h = 0, t0l = 0, t0h = 0, t1l = 0, t1h = 0;
+        for (uint32_t i = 0; i < k.beta; i++) {
+            const u64 *digit = k.t_mod_up + (size_t)i * k.qlp_n + (size_t)nid * k.n;
+            const u64 v0 = digit[idx.x], v1 = digit[idx.y];
+            const u64 *key = keys[i];
+            const u64x2 kb = *reinterpret_cast<const u64x2 *>(key + evk_id);
+            const u64x2 ka = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+            mac128(v0, kb.x, s0l, s0h);
+            mac128(v1, kb.y, s1l, s1h);
+            mac128(v0, ka.x, t0l, t0h);
+            mac128(v1, ka.y, t1l, t1h);
+        }
+        const u64x2 w = *reinterpret_cast<const u64x2 *>(kw.weights[e] + out_id);
+        mac128(barrett128(s0l, s0h, m), w.x, a0l, a0h);
+        mac128(barrett128(s1l, s1h, m), w.y, a1l, a1h);
+        mac128(barrett128(t0l, t0h, m), w.x, b0l, b0h);
+        mac128(barrett128(t1l, t1h, m), w.y, b1l, b1h);
+    }
+    *reinterpret_cast<u64x2 *>(k.cx + out_id) = u64x2{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
+    *reinterpret_cast<u64x2 *>(k.cx + out_id + k.qlp_n) = u64x2{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
+}
+
+// dst[p][limb][k] = sum_e w_e[limb][k] * src[p][limb][perm_e[k]] mod q.  blockIdx.z = polynomial: c0 takes every
+// element, c1 only the main-diagonal ones (Galois element 1, identity permutation), whose list starts at first_c1.
+__global__ __launch_bounds__(256) void hoist_weighted_c_kernel(u64 *dst, const u64 *src, const uint32_t *const *tables,
+                                                               const u64 *const *weights, uint32_t n_elts,
+                                                               uint32_t first_c1, const DModulus *mod, uint32_t n,
+                                                               size_t poly_stride) {
+    const uint32_t limb = blockIdx.y, p = blockIdx.z;
+    const DModulus m = mod[limb];
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = (size_t)limb * n + coeff;
+    u64 lo = 0, hi = 0;
+    uint32_t terms = 0;
+    for (uint32_t e = p ? first_c1 : 0; e < n_elts; e++) {
+        mac128(src[p * poly_stride + (size_t)limb * n + tables[e][coeff]], weights[e][id], lo, hi);
+        if (++terms == 48) {           // products of two 61-bit residues: 48 * 2^122 stays below 2^128
+            lo = barrett128(lo, hi, m);
+            hi = 0;
+            terms = 1;
+        }
+    }
+    dst[p * poly_stride + id] = barrett128(lo, hi, m);
+}
+
 // ---- (cx - delta) * c element-wise: moddown_kernel rns_bconv.cu:680-689 and
 //      divide_and_round_q_last_kernel rns.cu:1082-1108 (REDUCE_LAST) ---------------------------------
 struct SubMulArgs {
@@ -813,6 +883,70 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
     }
     PHA_HIP(hipMemsetAsync(ct + ql_n, 0, ql_n * sizeof(u64), s));
     moddown_from_ntt(c, t, ct, ql_n, acc_cx, qlp_n, 2, scheme, true, tmp, s);
+    PHA_API_END
+}
+
+int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
+                          const uint64_t *const *const *glk, const uint64_t *const *weights, int scheme, void *stream) {
+    PHA_API_BEGIN
+    need(ct); need(galois_elts); need(glk); need(weights);
+    if (n_elts == 0) throw std::invalid_argument("steps must not be empty");
+    if (!ntt_domain_scheme(scheme)) throw std::invalid_argument("weighted hoisting takes NTT-form ciphertexts (ckks / bgv)");
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    Tool &t = c.tool((uint32_t)size_Ql);
+    hipStream_t s = as_stream(stream);
+    const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
+    // order the elements: key-switched ones first, main-diagonal ones (element 1, no key) last
+    std::vector<const void *> tabs, keys, w_ks, w_all;
+    std::vector<size_t> order;
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t e = 0; e < n_elts; e++) {
+            if (!weights[e]) throw std::invalid_argument("null weight");
+            if ((galois_elts[e] == 1) == (pass == 1)) order.push_back(e);
+        }
+    size_t n_ks = 0;
+    for (size_t e : order) {
+        tabs.push_back(c.galois_table(galois_elts[e]));
+        w_all.push_back(weights[e]);
+        if (galois_elts[e] != 1) {
+            if (!glk[e]) throw std::logic_error("Galois key not present in hoisting");
+            keys.push_back(glk[e]);
+            n_ks++;
+        }
+    }
+    // scratch: (c0, c1) copy [2][Ql][N] | tmp / delta [2][Ql][N] | mod-up [beta][QlP][N] | acc_cx [2][QlP][N] | pointers
+    const size_t ptr_words = 3 * n_elts;
+    u64 *base = c.scratch(stream, 4 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n + ptr_words);
+    u64 *cc = base, *tmp = cc + 2 * ql_n, *t_mod_up = tmp + 2 * ql_n, *acc_cx = t_mod_up + (size_t)t.beta * qlp_n;
+    u64 *d_ptrs = acc_cx + 2 * qlp_n;
+    PHA_HIP(hipMemcpyAsync(d_ptrs, tabs.data(), n_elts * sizeof(void *), hipMemcpyHostToDevice, s));
+    PHA_HIP(hipMemcpyAsync(d_ptrs + n_elts, w_all.data(), n_elts * sizeof(void *), hipMemcpyHostToDevice, s));
+    if (n_ks) PHA_HIP(hipMemcpyAsync(d_ptrs + 2 * n_elts, keys.data(), n_ks * sizeof(void *), hipMemcpyHostToDevice, s));
+    const uint32_t *const *d_tabs = reinterpret_cast<const uint32_t *const *>(d_ptrs);
+    const u64 *const *d_w = reinterpret_cast<const u64 *const *>(d_ptrs + n_elts);
+    const u64 *const *const *d_keys = reinterpret_cast<const u64 *const *const *>(d_ptrs + 2 * n_elts);
+    PHA_HIP(hipMemcpyAsync(cc, ct, 2 * ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    if (n_ks) {
+        modup(c, t, t_mod_up, ct + ql_n, scheme, tmp, s);
+        const size_t per_call = 63;    // weighted terms below 2^122 each (61-bit primes) in the 128-bit accumulator
+        for (size_t e0 = 0; e0 < n_ks; e0 += per_call) {
+            HoistWArgs kw{};
+            HoistArgs &k = kw.h;
+            k.cx = acc_cx; k.t_mod_up = t_mod_up; k.keys = d_keys + e0; k.tables = d_tabs + e0; k.mod = c.d_mod.p;
+            k.qlp_prime = t.d_qlp_prime.p; k.n = (uint32_t)n; k.beta = t.beta;
+            k.n_elts = (uint32_t)std::min(per_call, n_ks - e0); k.accumulate = e0 ? 1 : 0;
+            k.qlp_n = qlp_n; k.qp_n = (size_t)c.size_qp * n;
+            kw.weights = d_w + e0;
+            hipLaunchKernelGGL(hoist_weighted_inner_prod_kernel, dim3((unsigned)(n / 512), t.size_qlp), dim3(256), 0, s, kw);
+            check_launch();
+        }
+    }
+    // ct0 <- sum_e w_e galois_e(c0), ct1 <- sum over the main-diagonal elements of w_e c1; then both += moddown(acc_cx)
+    hipLaunchKernelGGL(hoist_weighted_c_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql, 2), dim3(256), 0, s, ct, cc,
+                       d_tabs, d_w, (uint32_t)n_elts, (uint32_t)n_ks, c.d_mod.p, (uint32_t)n, ql_n);
+    check_launch();
+    if (n_ks) moddown_from_ntt(c, t, ct, ql_n, acc_cx, qlp_n, 2, scheme, true, tmp, s);
     PHA_API_END
 }
 

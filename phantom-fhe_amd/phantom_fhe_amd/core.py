@@ -235,6 +235,15 @@ class PhantomContext:
         tabs = (C.c_void_p * len(galois_keys))(*[k.public_keys_ptr.data_ptr() for k in galois_keys])
         _lib.check(self._L.pha_hoisting(self._h, size_Ql, _ptr(ct), elts, len(galois_elts), tabs, int(scheme), _stream()))
 
+    def hoisting_weighted(self, size_Ql, ct, galois_elts, galois_keys, weights, scheme):
+        """Build-defined (BASELINE config 5): ct <- sum_e weights[e] (.) rotate_e(ct); weights[e] is a device
+        tensor [Ql + size_P][N] (the plaintext over [Q_l || P], NTT form); galois_keys[e] may be None for element 1."""
+        elts = (C.c_uint32 * len(galois_elts))(*[int(e) for e in galois_elts])
+        tabs = (C.c_void_p * len(galois_keys))(*[k.public_keys_ptr.data_ptr() if k is not None else None for k in galois_keys])
+        ws = (C.c_void_p * len(weights))(*[_ptr(w) for w in weights])
+        _lib.check(self._L.pha_hoisting_weighted(self._h, size_Ql, _ptr(ct), elts, len(galois_elts), tabs, ws, int(scheme),
+                                                 _stream()))
+
     def divide_and_round_q_last_ntt(self, size_Ql, src, cipher_size, dst):
         _lib.check(self._L.pha_divide_and_round_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
                                                            _stream()))

@@ -53,6 +53,7 @@ _SIGS = {
     "pha_bfv_multiply_hps": [vp, vp, vp, vp, vp],
     "pha_batched_modular_gemm": [vp, vp, sz, vp, sz, vp, sz, sz, sz, sz, sz, sz, vp],
     "pha_hoisting": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.c_int, vp],
+    "pha_hoisting_weighted": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.POINTER(vp), C.c_int, vp],
     "pha_divide_and_round_q_last_ntt": [vp, sz, vp, sz, vp, vp],
     "pha_generate_one_kswitch_key": [vp, vp, vp, vp, vp, vp, C.c_int, vp],
     "pha_mod_t_and_divide_q_last_ntt": [vp, sz, vp, sz, vp, vp],

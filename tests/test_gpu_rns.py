@@ -215,6 +215,55 @@ def test_hoisting(name, scheme, ql, elts, gpu):
     assert np.array_equal(P.to_host(d_ct), ref)
 
 
+@pytest.mark.parametrize("name,scheme,ql,n_rot,ident", [
+    ("hyb12_a2", O.CKKS, 6, 3, True), ("hyb12_a2", O.CKKS, 3, 2, False), ("hyb12_a2", O.BGV, 5, 3, True),
+    ("hyb13_a3", O.CKKS, 7, 4, True), ("hyb12_a2", O.CKKS, 2, 0, True),
+    ("hyb12_a2", O.CKKS, 4, 127, True),          # config 5 shape: 128 diagonals (the kernel folds every 63 / 48 terms)
+    ("c3_ckks16", O.CKKS, 45, 2, True)])
+def test_hoisting_weighted(name, scheme, ql, n_rot, ident, gpu):
+    """pha_hoisting_weighted (build-defined, BASELINE config 5): sum_e w_e (.) rotate_e(ct) vs the oracle's
+    composition; uniform random weights over [Q_l || P] (the arithmetic does not care that plaintexts are small)."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    if scheme == O.BGV:
+        ctx.set_plain_modulus(BGV_T)
+        tool.set_plain_modulus(BGV_T)
+    r = rng_for(170 + n_rot)
+    rot = [int(pow(5, i + 1, 2 * n)) for i in range(n_rot)]
+    elts = ([1] if ident else []) + rot
+    if n_rot > 8:                                    # many diagonals: a few distinct keys, reused
+        pool = [_keys(oc, r, primes, n, size_q, size_p) for _ in range(3)]
+        glk_rot = [pool[i % 3] for i in range(n_rot)]
+        pool_w = [uniform_poly(r, [primes[i] for i in list(range(ql)) + [size_q + j for j in range(size_p)]], n) for _ in range(5)]
+        weights = [pool_w[i % 5] for i in range(len(elts))]
+        dev_pool = [P.PhantomRelinKey.from_numpy(k, gpu) for k in pool]
+        dev_keys_rot = [dev_pool[i % 3] for i in range(n_rot)]
+        dev_pool_w = [P.to_device(w, gpu) for w in pool_w]
+        dev_w = [dev_pool_w[i % 5] for i in range(len(elts))]
+    else:
+        glk_rot = [_keys(oc, r, primes, n, size_q, size_p) for _ in rot]
+        qlp_primes = [primes[i] for i in list(range(ql)) + [size_q + j for j in range(size_p)]]
+        weights = [uniform_poly(r, qlp_primes, n) for _ in elts]
+        dev_keys_rot = [P.PhantomRelinKey.from_numpy(k, gpu) for k in glk_rot]
+        dev_w = [P.to_device(w, gpu) for w in weights]
+    glk = ([None] if ident else []) + [[k[i] for i in range(tool.beta)] for k in glk_rot]
+    dev_keys = ([None] if ident else []) + dev_keys_rot
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    d_ct = P.to_device(ct, gpu)
+    ctx.hoisting_weighted(ql, d_ct, elts, dev_keys, dev_w, scheme)
+    ref = tool.hoisting_weighted(ct, elts, glk, weights, scheme)
+    assert np.array_equal(P.to_host(d_ct), ref)
+    with pytest.raises(ValueError):
+        ctx.hoisting_weighted(ql, d_ct, elts, dev_keys, dev_w, O.BFV)       # NTT-form schemes only
+    if n_rot:
+        with pytest.raises(ArithmeticError):         # std::logic_error, like hoisting_inplace (evaluate.cu:1783)
+            ctx.hoisting_weighted(ql, d_ct, [rot[0]], [None], dev_w[:1], scheme)  # a rotation without its key
+
+
 def test_hommul_relin_rescale_c3(gpu):
     """CKKS HomMul + relinearize + rescale at N=2^16, 45 limbs, stage by stage."""
     import phantom_fhe_amd as P

@@ -267,6 +267,59 @@ def test_galois_ntt_permutation_matches_coefficient_automorphism():
         assert np.array_equal(via_coeff, via_ntt)
 
 
+def small_weight(r, primes_qlp, qlp_idx, oc, n, bound=1 << 10):
+    """A small integer polynomial as residues over [Q_l || P], NTT form: one weight of hoisting_weighted."""
+    w = r.integers(-bound, bound + 1, n)
+    res = np.stack([np.array([int(v) % int(q) for v in w], dtype=np.uint64) for q in primes_qlp])
+    return oc.nwt_forward_map(res, qlp_idx)
+
+
+@pytest.mark.parametrize("name,ql", [("hyb12_a2", 6), ("hyb12_a2", 3)])
+def test_weighted_hoisting_is_the_weighted_sum_of_rotations(name, ql):
+    """Config 5 composition (build-defined): with genuine Galois keys, phase(out) = sum_e w_e * galois_e(phase(ct))
+    + small, the main diagonal (element 1) included without a key."""
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc = oracle_ctx(name)
+    r = rng_for(61)
+    s_small = r.integers(-1, 2, n)
+    sk = np.stack([np.array([int(v) % int(q) for v in s_small], dtype=np.uint64) for q in primes])
+    sk_ntt = oc.nwt_forward(sk, len(primes), 0)
+    elts = [1, 3, 25, 2 * n - 1]
+    tabs = {e: O.galois_ntt_table(log_n, e) for e in elts}
+    glk = [None if e == 1 else _small_keys(oc, primes, n, size_q, size_p, r, O.apply_galois_ntt(sk_ntt[:size_q], tabs[e], n, size_q), sk_ntt)
+           for e in elts]
+    tool = O.Tool(oc, ql)
+    qlp_idx = list(range(ql)) + [size_q + i for i in range(size_p)]
+    primes_qlp = [primes[i] for i in qlp_idx]
+    weights = [small_weight(r, primes_qlp, qlp_idx, oc, n) for _ in elts]
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    out = tool.hoisting_weighted(ct, elts, [None if k is None else [k[i] for i in range(tool.beta)] for k in glk], weights, O.CKKS)
+    s1 = sk_ntt[:ql]
+    phase = oc.add(ct[0], oc.multiply(ct[1], s1, ql), ql)
+    want = np.zeros_like(phase)
+    for e, w in zip(elts, weights):
+        want = oc.add(want, oc.multiply(O.apply_galois_ntt(phase, tabs[e], n, ql), w[:ql], ql), ql)
+    after = oc.add(out[0], oc.multiply(out[1], s1, ql), ql)
+    diff = oc.nwt_backward(oc.sub(after, want, ql), ql)
+    Q = 1
+    for q in primes[:ql]:
+        Q *= int(q)
+    worst = 0
+    for k in range(0, n, 97):
+        v, _ = crt_compose([diff[l, k] for l in range(ql)], primes[:ql])
+        v = v - Q if v > Q // 2 else v
+        worst = max(worst, abs(v))
+    assert 0 < worst < len(elts) * (1 << 10) * n * n * 64 * (size_q // size_p + ql)
+    assert worst.bit_length() < Q.bit_length() - 20
+    # no weights but ones, no identity: the plain hoisting_inplace sum
+    one = np.ones((tool.size_qlp, n), dtype=np.uint64)       # NTT form of the constant 1
+    plain = tool.hoisting(ct, elts[1:], [[k[i] for i in range(tool.beta)] for k in glk[1:]], O.CKKS)
+    same = tool.hoisting_weighted(ct, elts[1:], [[k[i] for i in range(tool.beta)] for k in glk[1:]], [one] * 3, O.CKKS)
+    assert np.array_equal(plain, same)
+
+
 @pytest.mark.parametrize("name,plain_t", [("c1_bfv4096", 65537), ("hyb12_a2", 65537), ("hyb12_a2", 1032193)])
 def test_bfv_behz_multiply_decrypts_to_the_product(name, plain_t):
     """BFV BEHZ multiply (src/evaluate.cu:404-548) pinned by its meaning: for encryptions of m1, m2 the three-part
