@@ -1,0 +1,67 @@
+"""Host compositions of BASELINE.json configurations 4 and 5 over the C-ABI entry points, with the
+rank sharding of SURVEY.md 8(e): independent units (ciphertexts / matrix row blocks) are split into contiguous
+blocks per rank, every rank runs the same launches on its block, no collective on the data path -- so the
+results are bit-identical for every number of ranks.
+
+* config 4: relinearize + Galois rotate of a batch of ciphertexts -- the flows of
+  example_bfv_hybrid_key_switching / example_bfv_rotate_row (examples/1_bfv.cu:1269-1336, 1041-1157) at the
+  parameter set of benchmark/keyswitch_bench.cu:25-34; relinearize_inplace src/evaluate.cu:1028-1077,
+  apply_galois_inplace :1567-1624.
+* config 5: encrypted matrix-vector product in diagonal form from hoisted rotations.  The reference has no such
+  function (its matmul_bench is a plaintext modular GEMM); the composition is this build's, from the reference's
+  hoisting_inplace (src/evaluate.cu:1670-1866), multiply_plain_inplace (:1297-1340) and add_inplace (:116-198).
+"""
+import torch
+
+from . import dist as pdist
+from .core import scheme_type
+
+
+def relinearize_rotate_batch(ctx, size_Ql, ct3, relin_key, galois_key, galois_elt, scheme):
+    """ct3 [B][3][Ql][N] (a batch of size-3 ciphertexts) -> [B][2][Ql][N]: relinearize, then rotate by
+    galois_elt.  BFV ciphertexts are in coefficient form, CKKS / BGV in NTT form, as in the reference."""
+    B = ct3.shape[0]
+    ct = ct3[:, :2].clone(memory_format=torch.contiguous_format)   # never a view: the key switch works in place
+    ctx.keyswitch_inplace_batched(size_Ql, ct, ct3[:, 2].contiguous(), B, relin_key.public_keys_ptr, scheme)
+    g = torch.empty_like(ct)
+    for b in range(B):
+        for p in range(2):
+            if int(scheme) == int(scheme_type.bfv):
+                ctx.apply_galois(ct[b, p], g[b, p], galois_elt, size_Ql)
+            else:
+                ctx.apply_galois_ntt(ct[b, p], g[b, p], galois_elt, size_Ql)
+    rot = torch.zeros_like(ct)
+    rot[:, 0] = g[:, 0]
+    ctx.keyswitch_inplace_batched(size_Ql, rot, g[:, 1].contiguous(), B, galois_key.public_keys_ptr, scheme)
+    return rot
+
+
+def relinearize_rotate_sharded(ctx, size_Ql, ct3, relin_key, galois_key, galois_elt, scheme, rank=None, world=None):
+    """Config 4 on this rank: the contiguous block shard_range(B, rank, world) of the batch; returns
+    (index range, results of that block)."""
+    rank = pdist.rank() if rank is None else rank
+    world = pdist.world() if world is None else world
+    mine = pdist.shard_range(ct3.shape[0], rank, world)
+    if len(mine) == 0:
+        return mine, ct3[:0, :2].contiguous()
+    return mine, relinearize_rotate_batch(ctx, size_Ql, ct3[mine.start:mine.stop], relin_key, galois_key, galois_elt, scheme)
+
+
+def diag_matvec(ctx, size_Ql, ct, galois_elts, galois_keys, diagonals, scheme):
+    """One block of config 5: out = sum_k diagonals[k] (.) rotate_{galois_elts[k]}(ct) (Halevi-Shoup diagonal
+    form), all rotations hoisted behind one mod-up and one mod-down (pha_hoisting_weighted).  diagonals[k] is the
+    k-th generalised diagonal encoded over [Q_l || P] in NTT form, [Ql + size_P][N]; Galois element 1 (the main
+    diagonal) takes no key."""
+    out = ct.clone()
+    ctx.hoisting_weighted(size_Ql, out, galois_elts, galois_keys, diagonals, scheme)
+    return out
+
+
+def matvec_row_blocks_sharded(ctx, size_Ql, ct, galois_elts, galois_keys, blocks, scheme, rank=None, world=None):
+    """Config 5 on this rank: `blocks` is a list of row blocks of the matrix, each a list of encoded diagonals
+    (one output ciphertext per block); blocks are split contiguously over the ranks.  Returns (index range,
+    list of output ciphertexts of that range)."""
+    rank = pdist.rank() if rank is None else rank
+    world = pdist.world() if world is None else world
+    mine = pdist.shard_range(len(blocks), rank, world)
+    return mine, [diag_matvec(ctx, size_Ql, ct, galois_elts, galois_keys, blocks[i], scheme) for i in mine]

@@ -71,3 +71,74 @@ def test_shard_range_properties():
             parts = [list(shard_range(batch, r, world)) for r in range(world)]
             assert sum(parts, []) == list(range(batch))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+class _StubKey:
+    public_keys_ptr = None
+
+
+class _StubCtx:
+    """Stands in for PhantomContext on the CPU: deterministic tensor functions with the same call shapes, so that
+    only the host logic of phantom_fhe_amd.workloads (sharding, copies, aliasing) is under test here."""
+
+    def keyswitch_inplace_batched(self, ql, ct, c2, batch, keys, scheme):
+        assert ct.shape[0] == batch == c2.shape[0]
+        ct += c2[:, None] * 3
+
+    def apply_galois(self, src, dst, elt, ql, mod_start=0):
+        dst.copy_(src.flip(-1) + elt)
+
+    apply_galois_ntt = apply_galois
+
+    def hoisting_weighted(self, ql, ct, elts, keys, weights, scheme):
+        acc = sum(w[:ql] * int(e) for w, e in zip(weights, elts))
+        ct *= acc[None]
+
+
+def _workload_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "phantom-fhe_amd"))
+    from phantom_fhe_amd import workloads as W
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(99)
+        ql, n, batch = 3, 16, 5
+        ct3 = torch.randint(0, 1 << 40, (batch, 3, ql, n), dtype=torch.int64, generator=g)
+        keep = ct3.clone()
+        ctx = _StubCtx()
+        mine, res = W.relinearize_rotate_sharded(ctx, ql, ct3, _StubKey(), _StubKey(), 3, 1)   # rank / world from the group
+        assert torch.equal(ct3, keep)                                                         # inputs are not consumed
+        ct = torch.randint(0, 1 << 20, (2, ql, n), dtype=torch.int64, generator=g)
+        blocks = [[torch.randint(0, 1 << 20, (ql + 2, n), dtype=torch.int64, generator=g) for _ in range(3)] for _ in range(5)]
+        mine5, outs = W.matvec_row_blocks_sharded(ctx, ql, ct, [1, 5, 25], [None, _StubKey(), _StubKey()], blocks, 2)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (list(mine), res, list(mine5), outs))
+        if rank == 0:
+            full = W.relinearize_rotate_batch(ctx, ql, ct3, _StubKey(), _StubKey(), 3, 1)
+            _, full5 = W.matvec_row_blocks_sharded(ctx, ql, ct, [1, 5, 25], [None, _StubKey(), _StubKey()], blocks, 2, rank=0, world=1)
+            idx = sum((g_[0] for g_ in gathered), [])
+            ok4 = idx == list(range(batch)) and torch.equal(torch.cat([g_[1] for g_ in gathered]), full)
+            idx5 = sum((g_[2] for g_ in gathered), [])
+            outs5 = sum((g_[3] for g_ in gathered), [])
+            ok5 = idx5 == list(range(5)) and all(torch.equal(a, b) for a, b in zip(outs5, full5))
+            q.put((ok4, ok5))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_config4_and_config5_sharding_reproduces_one_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_workload_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok4, ok5 = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok4 and ok5

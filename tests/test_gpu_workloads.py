@@ -1,0 +1,91 @@
+"""BASELINE configs 4 and 5 as host compositions (phantom_fhe_amd/workloads.py) on the GPU vs the oracle's
+composition of the same reference steps, and: the union of the rank shards is bit-identical to the unsharded run
+for every world size ("identical results on 1/2/4/8 GPUs")."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import oracle_ctx, primes_of, rng_for, uniform_poly
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(name, gpu):
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    return P.PhantomContext(log_n, list(primes), size_p, device=gpu)
+
+
+def _keys(rng, primes, n, dnum):
+    return np.stack([np.stack([uniform_poly(rng, primes, n), uniform_poly(rng, primes, n)]) for _ in range(dnum)])
+
+
+@pytest.mark.parametrize("name,scheme,ql,batch", [("hyb12_a2", O.BFV, 6, 5), ("hyb12_a2", O.CKKS, 4, 3), ("c4_bfv15", O.BFV, 30, 2)])
+def test_config4_relinearize_rotate_batch(name, scheme, ql, batch, gpu):
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(800 + batch)
+    rlk, glk = _keys(r, primes, n, size_q // size_p), _keys(r, primes, n, size_q // size_p)
+    elt = 3
+    ct3 = np.stack([np.stack([uniform_poly(r, primes[:ql], n) for _ in range(3)]) for _ in range(batch)])
+    d_rlk, d_glk = P.PhantomRelinKey.from_numpy(rlk, gpu), P.PhantomRelinKey.from_numpy(glk, gpu)
+    d_ct3 = P.to_device(ct3, gpu)
+    full = P.to_host(W.relinearize_rotate_batch(ctx, ql, d_ct3, d_rlk, d_glk, elt, scheme))
+    # the oracle's composition of the same reference steps, ciphertext by ciphertext
+    table = O.galois_ntt_table(log_n, elt)
+    for b in range(batch):
+        ct = tool.keyswitch_inplace(ct3[b, :2], ct3[b, 2], [rlk[i] for i in range(tool.beta)], scheme)
+        if scheme == O.BFV:
+            g = [oc.apply_galois_coeff(ct[p], elt, ql) for p in range(2)]
+        else:
+            g = [O.apply_galois_ntt(ct[p], table, n, ql) for p in range(2)]
+        want = tool.keyswitch_inplace(np.stack([g[0], np.zeros_like(g[0])]), g[1], [glk[i] for i in range(tool.beta)], scheme)
+        assert np.array_equal(full[b], want)
+    for world in (2, 4, 8):
+        parts, covered = [], []
+        for rank in range(world):
+            mine, res = W.relinearize_rotate_sharded(ctx, ql, d_ct3, d_rlk, d_glk, elt, scheme, rank=rank, world=world)
+            covered += list(mine)
+            parts.append(P.to_host(res))
+        assert covered == list(range(batch))
+        assert np.array_equal(np.concatenate(parts), full)
+
+
+@pytest.mark.parametrize("name,ql,n_blocks,n_diag", [("hyb12_a2", 5, 3, 4), ("hyb13_a3", 9, 2, 16)])
+def test_config5_diagonal_matvec_row_blocks(name, ql, n_blocks, n_diag, gpu):
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(900 + n_diag)
+    elts = [1] + [int(pow(5, k, 2 * n)) for k in range(1, n_diag)]          # rotations by 0 .. n_diag-1 slots
+    glk = [None] + [_keys(r, primes, n, size_q // size_p) for _ in elts[1:]]
+    qlp_primes = [primes[i] for i in list(range(ql)) + [size_q + j for j in range(size_p)]]
+    blocks = [[uniform_poly(r, qlp_primes, n) for _ in elts] for _ in range(n_blocks)]
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    d_keys = [None] + [P.PhantomRelinKey.from_numpy(k, gpu) for k in glk[1:]]
+    d_blocks = [[P.to_device(w, gpu) for w in blk] for blk in blocks]
+    d_ct = P.to_device(ct, gpu)
+    mine, outs = W.matvec_row_blocks_sharded(ctx, ql, d_ct, elts, d_keys, d_blocks, O.CKKS, rank=0, world=1)
+    assert list(mine) == list(range(n_blocks))
+    assert np.array_equal(P.to_host(d_ct), ct)                               # the input vector is not consumed
+    full = [P.to_host(o) for o in outs]
+    okeys = [None] + [[k[i] for i in range(tool.beta)] for k in glk[1:]]
+    for i in range(n_blocks):
+        assert np.array_equal(full[i], tool.hoisting_weighted(ct, elts, okeys, blocks[i], O.CKKS))
+    for world in (2, 8):
+        got = {}
+        for rank in range(world):
+            mine, outs = W.matvec_row_blocks_sharded(ctx, ql, d_ct, elts, d_keys, d_blocks, O.CKKS, rank=rank, world=world)
+            for i, o in zip(mine, outs):
+                got[i] = P.to_host(o)
+        assert sorted(got) == list(range(n_blocks))
+        assert all(np.array_equal(got[i], full[i]) for i in range(n_blocks))
