@@ -91,6 +91,39 @@ int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context_t ctx, ui
                                                            size_t coeff_modulus_size, size_t start_modulus_idx,
                                                            size_t size_QP, size_t size_P, void *stream);
 
+/* nwt_2d_radix8_forward_inplace_include_temp_mod (include/ntt.cuh:182-185, src/ntt/fntt_2d.cu:200-405,655-693) and
+ * nwt_2d_radix8_backward_inplace_include_temp_mod_scale (include/ntt.cuh:222-226, src/ntt/intt_2d.cu:313-409,836-873):
+ * transforms over the BEHZ base Bsk = B u {m_sk} (callers src/evaluate.cu:434,528).  The reference passes
+ * rns_tool.gpu_Bsk_tables(); here the context owns those primes (pha_context_set_plain_modulus must have been
+ * called), so coeff_modulus_size must be |Bsk|, start_modulus_idx 0 and total_modulus_size |Bsk| + 1. */
+int pha_nwt_2d_radix8_forward_inplace_include_temp_mod(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                                       size_t start_modulus_idx, size_t total_modulus_size,
+                                                       void *stream);
+int pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale(pha_context_t ctx, uint64_t *inout,
+                                                              size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                              size_t total_modulus_size, const uint64_t *scale,
+                                                              const uint64_t *scale_shoup, void *stream);
+/* nwt_2d_radix8_forward_modup_fuse (include/ntt.cuh:199-201, src/ntt/ntt_keyswitch_old.cu:10-265): out[limb] = NTT
+ * modulo q_{modulus_index} of in[limb], limbs [start, start + coeff_modulus_size) -- how the reference lifts a
+ * plaintext modulo t into RNS limb modulus_index (src/evaluate.cu:1152,1210,1321).  Out of place. */
+int pha_nwt_2d_radix8_forward_modup_fuse(pha_context_t ctx, uint64_t *out, const uint64_t *in, size_t modulus_index,
+                                         size_t coeff_modulus_size, size_t start_modulus_idx, void *stream);
+/* fnwt_1d / fnwt_1d_opt / inwt_1d / inwt_1d_opt (include/ntt.cuh:157-171, src/ntt/ntt_1d.cu:17-292): single-workgroup
+ * transforms for dim <= 2048 over caller-built tables (the reference's NTT test and benchmark use them:
+ * test/ntt_test.cu:9-69, benchmark/ntt_bench.cu:8-79).  twiddles[limb * dim + k] / twiddles_shoup likewise; modulus is
+ * an array of {value, const_ratio[0], const_ratio[1]} triples (DModulus); the inverse multiplies the FIRST half of
+ * its outputs by scalar[limb] (the second half gets N^-1 through slot 1 of the inverse table, src/host/ntt.cu:53-55).
+ * fnwt_1d_opt ignores start_modulus_idx, as the reference's kernel does (ntt_1d.cu:92-93).  No context needed. */
+int pha_fnwt_1d(uint64_t *inout, const uint64_t *twiddles, const uint64_t *twiddles_shoup, const uint64_t *modulus,
+                size_t dim, size_t coeff_modulus_size, size_t start_modulus_idx, void *stream);
+int pha_fnwt_1d_opt(uint64_t *inout, const uint64_t *twiddles, const uint64_t *twiddles_shoup, const uint64_t *modulus,
+                    size_t dim, size_t coeff_modulus_size, size_t start_modulus_idx, void *stream);
+int pha_inwt_1d(uint64_t *inout, const uint64_t *itwiddles, const uint64_t *itwiddles_shoup, const uint64_t *modulus,
+                const uint64_t *scalar, const uint64_t *scalar_shoup, size_t dim, size_t coeff_modulus_size,
+                size_t start_modulus_idx, void *stream);
+int pha_inwt_1d_opt(uint64_t *inout, const uint64_t *itwiddles, const uint64_t *itwiddles_shoup, const uint64_t *modulus,
+                    const uint64_t *scalar, const uint64_t *scalar_shoup, size_t dim, size_t coeff_modulus_size,
+                    size_t start_modulus_idx, void *stream);
 /* Extension (no reference counterpart): the same limbs [start, start+size) of `batch` polynomials that
  * lie `poly_stride` elements apart (e.g. the polynomials of a ciphertext) in ONE launch. */
 int pha_nwt_2d_radix8_forward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size,

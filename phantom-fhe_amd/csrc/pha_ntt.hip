@@ -424,6 +424,63 @@ int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context_t ctx, ui
     PHA_API_END
 }
 
+// BEHZ base Bsk = B u {m_sk} (src/evaluate.cu:434,528).  The reference keeps the tables of Bsk u {m_tilde} in their own
+// DNTTTable and sends the last data limb (m_sk) to its last row (fntt_2d.cu:226, intt_2d.cu:334); here those primes
+// are auxiliary rows of the context's one table set, so the selector is a plain offset.
+static LimbSel temp_mod_sel(Context &c, size_t cms, size_t start, size_t total) {
+    Behz &b = c.behz();
+    if (start != 0 || cms != b.size_bsk || total != (size_t)b.size_bsk + 1)
+        throw std::invalid_argument("include_temp_mod transforms a whole Bsk buffer: coeff_modulus_size = |Bsk|, total = |Bsk| + 1");
+    LimbSel s = plain_sel(0, cms);
+    s.remap_from = 0;
+    s.remap_add = b.aux0;
+    return s;
+}
+
+int pha_nwt_2d_radix8_forward_inplace_include_temp_mod(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start,
+                                                       size_t total_modulus_size, void *stream) {
+    PHA_API_BEGIN
+    need(inout);
+    ntt_forward(ctx->c, inout, inout, inout, temp_mod_sel(ctx->c, cms, start, total_modulus_size), EPI_FWD_CANON, NttExtra{},
+                as_stream(stream));
+    PHA_API_END
+}
+
+int pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale(pha_context_t ctx, uint64_t *inout, size_t cms,
+                                                              size_t start, size_t total_modulus_size,
+                                                              const uint64_t *scale, const uint64_t *scale_shoup,
+                                                              void *stream) {
+    PHA_API_BEGIN
+    need(inout); need(scale); need(scale_shoup);
+    NttExtra x;
+    x.scale = scale;
+    x.scale_shoup = scale_shoup;
+    ntt_inverse(ctx->c, inout, inout, inout, temp_mod_sel(ctx->c, cms, start, total_modulus_size), EPI_INV_SCALE, x,
+                as_stream(stream));
+    PHA_API_END
+}
+
+// out[limb] = NTT modulo q_{modulus_index} of in[limb] for the limbs [start, start + cms): the reference lifts a
+// plaintext (coefficients below t < q) into one RNS limb at a time this way (ntt_keyswitch_old.cu:225-265, callers
+// evaluate.cu:1152,1210,1321).  Inputs are reduced modulo the prime as they are loaded (the reference leaves
+// that reduction commented out, :47-49: same results for its inputs below q).
+int pha_nwt_2d_radix8_forward_modup_fuse(pha_context_t ctx, uint64_t *out, const uint64_t *in, size_t modulus_index,
+                                         size_t cms, size_t start, void *stream) {
+    PHA_API_BEGIN
+    need(out); need(in);
+    Context &c = ctx->c;
+    if (modulus_index >= c.size_qp) throw std::invalid_argument("modulus_index out of range");
+    for (size_t limb = start; limb < start + cms; limb++) {
+        LimbSel sel = plain_sel(limb, 1);
+        sel.remap_from = (uint32_t)limb;
+        sel.remap_add = (uint32_t)modulus_index - (uint32_t)limb;
+        NttExtra x;
+        x.pro_src = in + limb * c.n;
+        ntt_forward(c, out, out, out, sel, EPI_FWD_CANON, x, as_stream(stream));
+    }
+    PHA_API_END
+}
+
 int pha_nwt_2d_radix8_forward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start,
                                               size_t batch, size_t poly_stride, void *stream) {
     PHA_API_BEGIN

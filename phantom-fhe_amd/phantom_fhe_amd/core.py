@@ -274,6 +274,18 @@ class PhantomContext:
     def apply_galois(self, src, dst, galois_elt, cms, mod_start=0):
         _lib.check(self._L.pha_apply_galois(self._h, _ptr(src), _ptr(dst), galois_elt, cms, mod_start, _stream()))
 
+    def nwt_2d_radix8_forward_inplace_include_temp_mod(self, inout, cms, start, total_modulus_size):
+        _lib.check(self._L.pha_nwt_2d_radix8_forward_inplace_include_temp_mod(self._h, _ptr(inout), cms, start,
+                                                                              total_modulus_size, _stream()))
+
+    def nwt_2d_radix8_backward_inplace_include_temp_mod_scale(self, inout, cms, start, total_modulus_size, scale, scale_shoup):
+        _lib.check(self._L.pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale(
+            self._h, _ptr(inout), cms, start, total_modulus_size, _ptr(scale), _ptr(scale_shoup), _stream()))
+
+    def nwt_2d_radix8_forward_modup_fuse(self, out, inp, modulus_index, cms, start=0):
+        _lib.check(self._L.pha_nwt_2d_radix8_forward_modup_fuse(self._h, _ptr(out), _ptr(inp), modulus_index, cms, start,
+                                                                _stream()))
+
     # -- measurement ------------------------------------------------------------------------------
     def time_forward_ntt(self, inout, cms, iters):
         ms = C.c_float()
@@ -293,3 +305,17 @@ class PhantomRelinKey:
     @classmethod
     def from_numpy(cls, evk, device="cuda:0"):
         return cls([to_device(evk[i], device) for i in range(evk.shape[0])])
+
+
+def fnwt_1d(inout, twiddles, twiddles_shoup, modulus, dim, cms, start=0, opt=False):
+    """fnwt_1d / fnwt_1d_opt (src/ntt/ntt_1d.cu): modulus is a device tensor of (value, const_ratio lo, hi) triples."""
+    L = _lib.load()
+    f = L.pha_fnwt_1d_opt if opt else L.pha_fnwt_1d
+    _lib.check(f(_ptr(inout), _ptr(twiddles), _ptr(twiddles_shoup), _ptr(modulus), dim, cms, start, _stream()))
+
+
+def inwt_1d(inout, itwiddles, itwiddles_shoup, modulus, scalar, scalar_shoup, dim, cms, start=0, opt=False):
+    L = _lib.load()
+    f = L.pha_inwt_1d_opt if opt else L.pha_inwt_1d
+    _lib.check(f(_ptr(inout), _ptr(itwiddles), _ptr(itwiddles_shoup), _ptr(modulus), _ptr(scalar), _ptr(scalar_shoup), dim,
+                 cms, start, _stream()))

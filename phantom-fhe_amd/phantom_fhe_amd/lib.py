@@ -52,6 +52,13 @@ _SIGS = {
     "pha_bfv_multiply_behz": [vp, vp, vp, vp, vp],
     "pha_bfv_multiply_hps": [vp, vp, vp, vp, vp],
     "pha_batched_modular_gemm": [vp, vp, sz, vp, sz, vp, sz, sz, sz, sz, sz, sz, vp],
+    "pha_nwt_2d_radix8_forward_inplace_include_temp_mod": [vp, vp, sz, sz, sz, vp],
+    "pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale": [vp, vp, sz, sz, sz, vp, vp, vp],
+    "pha_nwt_2d_radix8_forward_modup_fuse": [vp, vp, vp, sz, sz, sz, vp],
+    "pha_fnwt_1d": [vp, vp, vp, vp, sz, sz, sz, vp],
+    "pha_fnwt_1d_opt": [vp, vp, vp, vp, sz, sz, sz, vp],
+    "pha_inwt_1d": [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp],
+    "pha_inwt_1d_opt": [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp],
     "pha_hoisting": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.c_int, vp],
     "pha_hoisting_weighted": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.POINTER(vp), C.c_int, vp],
     "pha_divide_and_round_q_last_ntt": [vp, sz, vp, sz, vp, vp],

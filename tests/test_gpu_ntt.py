@@ -213,3 +213,107 @@ def test_large_residues_fp_thresholds(log_n, gpu, ntt_variant):
     d = P.to_device(x, gpu)
     ctx.nwt_2d_radix8_forward_inplace(d, L, 0)
     assert np.array_equal(P.to_host(d), oc.nwt_forward(x, L, 0))
+
+
+def test_temp_mod_variants_transform_the_behz_base(gpu):
+    """include_temp_mod / include_temp_mod_scale (fntt_2d.cu:200-405, intt_2d.cu:313-409): NTTs over Bsk = B u {m_sk}."""
+    import phantom_fhe_amd as P
+    name = "hyb12_a2"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    d = P.to_device(np.zeros((4, n), dtype=np.uint64), gpu)
+    with pytest.raises(ValueError):
+        ctx.nwt_2d_radix8_forward_inplace_include_temp_mod(d, 4, 0, 5)       # no plain modulus yet: no BEHZ base
+    ctx.set_plain_modulus(65537)
+    behz = O.Behz(oc, 65537)
+    sk = behz.size_bsk
+    ob = O.Ctx(log_n, behz.bsk, 0)
+    x = uniform_poly(rng_for(41), behz.bsk, n)
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_include_temp_mod(d, sk, 0, sk + 1)
+    fwd = ob.nwt_forward(x, sk, 0)
+    assert np.array_equal(P.to_host(d), fwd)
+    scale = np.array([65537 % q for q in behz.bsk], dtype=np.uint64)        # tModBsk (evaluate.cu:530)
+    shoup = np.array([O.compute_shoup(int(s), int(q)) for s, q in zip(scale, behz.bsk)], dtype=np.uint64)
+    ctx.nwt_2d_radix8_backward_inplace_include_temp_mod_scale(d, sk, 0, sk + 1, P.to_device(scale, gpu), P.to_device(shoup, gpu))
+    assert np.array_equal(P.to_host(d), ob.multiply_scalar(x, scale, sk, 0))
+    with pytest.raises(ValueError):
+        ctx.nwt_2d_radix8_forward_inplace_include_temp_mod(d, sk - 1, 0, sk + 1)
+
+
+@pytest.mark.parametrize("name", ["hyb12_a2", "hyb13_a3", "c2_ntt14"])
+def test_forward_modup_fuse(name, gpu, ntt_variant):
+    """nwt_2d_radix8_forward_modup_fuse (ntt_keyswitch_old.cu:225-265): a plaintext modulo t lifted into one RNS limb
+    at a time, the way add_plain / multiply_plain call it for BGV (evaluate.cu:1150-1154)."""
+    import phantom_fhe_amd as P
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L = min(len(primes), 5)
+    t = 65537
+    plain = rng_for(43).integers(0, t, (1, n), dtype=np.uint64)
+    d_plain = P.to_device(plain, gpu)
+    d_out = P.to_device(np.zeros((L, n), dtype=np.uint64), gpu)
+    for i in range(L):
+        ctx.nwt_2d_radix8_forward_modup_fuse(d_out[i:i + 1], d_plain, i, 1, 0)
+    want = oc.nwt_forward(np.repeat(plain, L, axis=0), L, 0)
+    assert np.array_equal(P.to_host(d_out), want)
+    assert np.array_equal(P.to_host(d_plain), plain)
+    # several limbs at once: limbs [1, 3) of `in`, all modulo prime 2; the rest of `out` is left alone
+    src = uniform_poly(rng_for(44), [primes[2]] * 4, n)
+    d_o = P.to_device(np.full((4, n), 7, dtype=np.uint64), gpu)
+    ctx.nwt_2d_radix8_forward_modup_fuse(d_o, P.to_device(src, gpu), 2, 2, 1)
+    got = P.to_host(d_o)
+    assert np.array_equal(got[1:3], oc.nwt_forward_map(src[1:3], [2, 2]))
+    assert (got[0] == 7).all() and (got[3] == 7).all()
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 10, 11])
+def test_single_workgroup_transforms(log_n, gpu):
+    """fnwt_1d(_opt) / inwt_1d(_opt) (src/ntt/ntt_1d.cu; test/ntt_test.cu:9-69 is the reference's own use): caller-built
+    tables, N <= 2048, round trip and values vs the oracle; the inverse scales only the first half of its outputs."""
+    import phantom_fhe_amd as P
+    n = 1 << log_n
+    primes = [int(p) for p in O.get_primes(max(n, 2), 50, 2)] + [int(O.get_primes(max(n, 2), 60, 1)[0])]
+    L = len(primes)
+    tabs = [O.ntt_tables(log_n, q) for q in primes]
+    tw = np.stack([t[0] for t in tabs]); tws = np.stack([t[1] for t in tabs])
+    itw = np.stack([t[2] for t in tabs]); itws = np.stack([t[3] for t in tabs])
+    ninv = np.array([t[4] for t in tabs], dtype=np.uint64); ninvs = np.array([t[5] for t in tabs], dtype=np.uint64)
+    mod = np.array([[q, O.const_ratio(q)[0], O.const_ratio(q)[1]] for q in primes], dtype=np.uint64)
+    x = uniform_poly(rng_for(900 + log_n), primes, n)
+    x[0, : n // 2] = primes[0] - 1
+    oc = O.Ctx(log_n, primes, 0)
+    want = oc.nwt_forward(x, L, 0)
+    dev = lambda a: P.to_device(np.ascontiguousarray(a), gpu)
+    d_tw, d_tws, d_itw, d_itws, d_mod = dev(tw), dev(tws), dev(itw), dev(itws), dev(mod)
+    for opt in ((False, True) if n >= 4 else (False,)):
+        d = dev(x)
+        P.fnwt_1d(d, d_tw, d_tws, d_mod, n, L, 0, opt=opt)
+        assert np.array_equal(P.to_host(d), want)
+        # the oracle's inverse table already has N^-1 folded into slot 1 (src/host/ntt.cu:53-55), so scalar = N^-1
+        # completes the inverse
+        P.inwt_1d(d, d_itw, d_itws, d_mod, dev(ninv), dev(ninvs), n, L, 0, opt=opt)
+        assert np.array_equal(P.to_host(d), x)
+    # a limb range, and the quirk of the _opt forward launcher (it ignores start_modulus_idx)
+    d = dev(x)
+    P.fnwt_1d(d, d_tw, d_tws, d_mod, n, 1, 2)
+    ref = x.copy(); ref[2] = want[2]
+    assert np.array_equal(P.to_host(d), ref)
+    if n >= 4:
+        d = dev(x)
+        P.fnwt_1d(d, d_tw, d_tws, d_mod, n, 1, 2, opt=True)
+        ref = x.copy(); ref[0] = want[0]
+        assert np.array_equal(P.to_host(d), ref)
+    # scalar = 1: the first half stays unscaled, i.e. N times the true inverse there
+    one = np.ones(L, dtype=np.uint64)
+    one_s = np.array([O.compute_shoup(1, q) for q in primes], dtype=np.uint64)
+    d = dev(want)
+    P.inwt_1d(d, d_itw, d_itws, d_mod, dev(one), dev(one_s), n, L, 0)
+    got = P.to_host(d)
+    nvec = np.array([n % q for q in primes], dtype=np.uint64)
+    assert np.array_equal(got[:, n // 2:], x[:, n // 2:])
+    assert np.array_equal(got[:, : n // 2], oc.multiply_scalar(x, nvec, L, 0)[:, : n // 2])
+    with pytest.raises(ValueError):
+        P.fnwt_1d(dev(np.zeros((1, 4096), dtype=np.uint64)), d_tw, d_tws, d_mod, 4096, 1, 0)
