@@ -160,6 +160,67 @@ int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *operand, u
 /* add_to_ct_kernel (src/rns_bconv.cu:763-769) */
 int pha_add_to_ct(pha_context_t ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, void *stream);
 
+/* ---- the rest of include/polymath.cuh:6-307 (src/polymath.cu): residue-wise kernels the reference's encryption,
+ *      decryption and plaintext layers launch around the hot path.  Same conventions: [limb][coeff] buffers,
+ *      table rows [mod_start, mod_start + coeff_mod_size) where a mod_start is given, canonical outputs. ---- */
+/* add_std_cipher :56-73 -- both polynomials of two size-2 ciphertexts */
+int pha_add_std_cipher(pha_context_t ctx, const uint64_t *cipher1, const uint64_t *cipher2, uint64_t *result,
+                       size_t coeff_mod_size, void *stream);
+/* add_and_negate_rns_poly :82-98 -- -(a + b) */
+int pha_add_and_negate_rns_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2, uint64_t *result,
+                                size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+/* add_many_rns_poly :126-147 -- result[poly_index] = sum of operands[e][poly_index]; operands is a HOST array of
+ * add_size DEVICE pointers (the reference takes the same table on the device) */
+int pha_add_many_rns_poly(pha_context_t ctx, const uint64_t *const *operands, size_t add_size, uint64_t *result,
+                          size_t poly_index, size_t coeff_mod_size, void *stream);
+/* multiply_scalar_rns_poly, the overload with ONE scalar for every limb :181-196 (Barrett) */
+int pha_multiply_uniform_scalar_rns_poly(pha_context_t ctx, const uint64_t *operand, uint64_t scale, uint64_t *result,
+                                         size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+/* multiply_scalar_and_add_rns_poly :246-264 -- operand1 + operand2 * scalar; _and_sub :266-283 -- operand1 - operand2 * scalar */
+int pha_multiply_scalar_and_add_rns_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2,
+                                         uint64_t scalar, uint64_t *result, size_t coeff_mod_size, size_t mod_start_idx,
+                                         void *stream);
+int pha_multiply_scalar_and_sub_rns_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2,
+                                         uint64_t scalar, uint64_t *result, size_t coeff_mod_size, size_t mod_start_idx,
+                                         void *stream);
+/* multiply_and_scale_add_rns_poly :294-315 -- operand1 * operand2 + operand3 * scale */
+int pha_multiply_and_scale_add_rns_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2,
+                                        const uint64_t *operand3, uint64_t scale, uint64_t *result,
+                                        size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+/* multiply_and_add_negate_rns_poly :350-371 -- -(operand1 * operand2 + operand3) (the b half of an RLWE sample) */
+int pha_multiply_and_add_negate_rns_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2,
+                                         const uint64_t *operand3, uint64_t *result, size_t coeff_mod_size,
+                                         size_t mod_start_idx, void *stream);
+/* sub_and_scale_rns_poly :392-411 -- (operand1 - operand2) * scale[limb]; _single_mod_poly :374-390 -- one limb, explicit modulus */
+int pha_sub_and_scale_rns_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2,
+                               const uint64_t *scale, const uint64_t *scale_shoup, uint64_t *result,
+                               size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+int pha_sub_and_scale_single_mod_poly(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2,
+                                      uint64_t scale, uint64_t scale_shoup, uint64_t modulus, uint64_t *result,
+                                      void *stream);
+/* bfv_add_timesQ_overt_kernel / bfv_sub_timesQ_overt_kernel :413-461 -- ct[limb] +- (pt * (-Ql mod t) mod t) * t^-1 mod q_limb,
+ * pt a single limb of N coefficients below t */
+int pha_bfv_add_timesQ_overt(pha_context_t ctx, uint64_t *ct, const uint64_t *pt, uint64_t negQl_mod_t,
+                             uint64_t negQl_mod_t_shoup, const uint64_t *tInv_mod_q, const uint64_t *tInv_mod_q_shoup,
+                             uint64_t t, size_t size_Ql, void *stream);
+int pha_bfv_sub_timesQ_overt(pha_context_t ctx, uint64_t *ct, const uint64_t *pt, uint64_t negQl_mod_t,
+                             uint64_t negQl_mod_t_shoup, const uint64_t *tInv_mod_q, const uint64_t *tInv_mod_q_shoup,
+                             uint64_t t, size_t size_Ql, void *stream);
+/* abs_plain_rns_poly :645-664 -- result[limb][i] = operand[i] (+ increment[limb] when operand[i] >= threshold) */
+int pha_abs_plain_rns_poly(pha_context_t ctx, const uint64_t *operand, uint64_t plain_upper_half_threshold,
+                           const uint64_t *plain_upper_half_increment, uint64_t *result, size_t coeff_mod_size,
+                           void *stream);
+/* tensor_prod_mxn_rns_poly :546-592 -- ciphertext product of sizes m x n (1..8 polynomials each; the operands sit in
+ * registers instead of the reference's per-thread device new[]) */
+int pha_tensor_prod_mxn_rns_poly(pha_context_t ctx, const uint64_t *operand1, size_t op1_size, const uint64_t *operand2,
+                                 size_t op2_size, uint64_t *result, size_t res_size, size_t coeff_mod_size,
+                                 void *stream);
+/* multiply_and_negated_add_rns_poly :606-634 -- BEHZ FastBconvSK fix-up: operand3 - alpha_sk * prod(B) with alpha_sk
+ * (one limb, modulo m_sk) taken centred */
+int pha_multiply_and_negated_add_rns_poly(pha_context_t ctx, const uint64_t *alpha_sk, uint64_t m_sk,
+                                          const uint64_t *prod_B_mod_q, const uint64_t *operand3, uint64_t *result,
+                                          size_t coeff_mod_size, void *stream);
+
 /* ---- RNS tool at level size_Ql (DRNSTool of context_data(chain) with size_Ql data limbs) ---- */
 /* DBaseConverter::bConv_BEHZ for base_P_to_Ql_conv (rns_bconv.cu:212-229): src [P][N] -> dst [Ql][N] */
 int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);

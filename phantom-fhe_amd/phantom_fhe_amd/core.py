@@ -178,6 +178,51 @@ class PhantomContext:
         _lib.check(self._L.pha_multiply_scalar_rns_poly(self._h, _ptr(a), _ptr(scalar), _ptr(scalar_shoup),
                                                         _ptr(r), cms, mod_start, _stream()))
 
+    # -- the rest of polymath.cu (kernels around the hot path: encryption / decryption / plaintext layers) --------
+    def add_std_cipher(self, c1, c2, r, cms):
+        _lib.check(self._L.pha_add_std_cipher(self._h, _ptr(c1), _ptr(c2), _ptr(r), cms, _stream()))
+
+    def add_and_negate_rns_poly(self, a, b, r, cms, mod_start=0):
+        _lib.check(self._L.pha_add_and_negate_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(r), cms, mod_start, _stream()))
+
+    def add_many_rns_poly(self, operands, r, poly_index, cms):
+        tab = (C.c_void_p * len(operands))(*[_ptr(o) for o in operands])
+        _lib.check(self._L.pha_add_many_rns_poly(self._h, tab, len(operands), _ptr(r), poly_index, cms, _stream()))
+
+    def multiply_uniform_scalar_rns_poly(self, a, scale, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_uniform_scalar_rns_poly(self._h, _ptr(a), int(scale), _ptr(r), cms, mod_start, _stream()))
+
+    def multiply_scalar_and_add_rns_poly(self, a, b, scalar, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_scalar_and_add_rns_poly(self._h, _ptr(a), _ptr(b), int(scalar), _ptr(r), cms, mod_start, _stream()))
+
+    def multiply_scalar_and_sub_rns_poly(self, a, b, scalar, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_scalar_and_sub_rns_poly(self._h, _ptr(a), _ptr(b), int(scalar), _ptr(r), cms, mod_start, _stream()))
+
+    def multiply_and_scale_add_rns_poly(self, a, b, d, scale, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_and_scale_add_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(d), int(scale), _ptr(r), cms, mod_start, _stream()))
+
+    def multiply_and_add_negate_rns_poly(self, a, b, d, r, cms, mod_start=0):
+        _lib.check(self._L.pha_multiply_and_add_negate_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(d), _ptr(r), cms, mod_start, _stream()))
+
+    def sub_and_scale_rns_poly(self, a, b, scale, scale_shoup, r, cms, mod_start=0):
+        _lib.check(self._L.pha_sub_and_scale_rns_poly(self._h, _ptr(a), _ptr(b), _ptr(scale), _ptr(scale_shoup), _ptr(r), cms, mod_start, _stream()))
+
+    def sub_and_scale_single_mod_poly(self, a, b, scale, scale_shoup, modulus, r):
+        _lib.check(self._L.pha_sub_and_scale_single_mod_poly(self._h, _ptr(a), _ptr(b), int(scale), int(scale_shoup), int(modulus), _ptr(r), _stream()))
+
+    def bfv_add_timesQ_overt(self, ct, pt, neg_ql_mod_t, neg_ql_mod_t_shoup, t_inv, t_inv_shoup, t, size_Ql, sub=False):
+        f = self._L.pha_bfv_sub_timesQ_overt if sub else self._L.pha_bfv_add_timesQ_overt
+        _lib.check(f(self._h, _ptr(ct), _ptr(pt), int(neg_ql_mod_t), int(neg_ql_mod_t_shoup), _ptr(t_inv), _ptr(t_inv_shoup), int(t), size_Ql, _stream()))
+
+    def abs_plain_rns_poly(self, operand, threshold, increment, r, cms):
+        _lib.check(self._L.pha_abs_plain_rns_poly(self._h, _ptr(operand), int(threshold), _ptr(increment), _ptr(r), cms, _stream()))
+
+    def tensor_prod_mxn_rns_poly(self, op1, m, op2, n_polys, r, cms):
+        _lib.check(self._L.pha_tensor_prod_mxn_rns_poly(self._h, _ptr(op1), m, _ptr(op2), n_polys, _ptr(r), m + n_polys - 1, cms, _stream()))
+
+    def multiply_and_negated_add_rns_poly(self, alpha_sk, m_sk, prod_b_mod_q, operand3, r, cms):
+        _lib.check(self._L.pha_multiply_and_negated_add_rns_poly(self._h, _ptr(alpha_sk), int(m_sk), _ptr(prod_b_mod_q), _ptr(operand3), _ptr(r), cms, _stream()))
+
     def tensor_prod_2x2_rns_poly(self, op1, op2, result, cms):
         _lib.check(self._L.pha_tensor_prod_2x2_rns_poly(self._h, _ptr(op1), _ptr(op2), _ptr(result), cms, _stream()))
 

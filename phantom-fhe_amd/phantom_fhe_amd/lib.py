@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PHA_LIB_OVERRIDE") or os.path.join(_HERE, "libphantom
 u64p = C.POINTER(C.c_uint64)
 vp = C.c_void_p
 sz = C.c_size_t
+u64 = C.c_uint64
 
 # name -> argtypes (restype is int status unless listed in _SPECIAL)
 _SIGS = {
@@ -59,6 +60,21 @@ _SIGS = {
     "pha_fnwt_1d_opt": [vp, vp, vp, vp, sz, sz, sz, vp],
     "pha_inwt_1d": [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp],
     "pha_inwt_1d_opt": [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp],
+    "pha_add_std_cipher": [vp, vp, vp, vp, sz, vp],
+    "pha_add_and_negate_rns_poly": [vp, vp, vp, vp, sz, sz, vp],
+    "pha_add_many_rns_poly": [vp, C.POINTER(vp), sz, vp, sz, sz, vp],
+    "pha_multiply_uniform_scalar_rns_poly": [vp, vp, u64, vp, sz, sz, vp],
+    "pha_multiply_scalar_and_add_rns_poly": [vp, vp, vp, u64, vp, sz, sz, vp],
+    "pha_multiply_scalar_and_sub_rns_poly": [vp, vp, vp, u64, vp, sz, sz, vp],
+    "pha_multiply_and_scale_add_rns_poly": [vp, vp, vp, vp, u64, vp, sz, sz, vp],
+    "pha_multiply_and_add_negate_rns_poly": [vp, vp, vp, vp, vp, sz, sz, vp],
+    "pha_sub_and_scale_rns_poly": [vp, vp, vp, vp, vp, vp, sz, sz, vp],
+    "pha_sub_and_scale_single_mod_poly": [vp, vp, vp, u64, u64, u64, vp, vp],
+    "pha_bfv_add_timesQ_overt": [vp, vp, vp, u64, u64, vp, vp, u64, sz, vp],
+    "pha_bfv_sub_timesQ_overt": [vp, vp, vp, u64, u64, vp, vp, u64, sz, vp],
+    "pha_abs_plain_rns_poly": [vp, vp, u64, vp, vp, sz, vp],
+    "pha_tensor_prod_mxn_rns_poly": [vp, vp, sz, vp, sz, vp, sz, sz, vp],
+    "pha_multiply_and_negated_add_rns_poly": [vp, vp, u64, vp, vp, vp, sz, vp],
     "pha_hoisting": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.c_int, vp],
     "pha_hoisting_weighted": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.POINTER(vp), C.c_int, vp],
     "pha_divide_and_round_q_last_ntt": [vp, sz, vp, sz, vp, vp],

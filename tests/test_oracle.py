@@ -438,3 +438,24 @@ def test_gemm_mod_against_python_ints():
     assert (O.gemm_mod(q, *ones) == 256).all() and (O.gemm_mod(q, *ones, quirk=True) == 256).all()  # the benchmark's input
     big = r.integers(q // 2, q, (2, 256), dtype=np.uint64), r.integers(q // 2, q, (256, 2), dtype=np.uint64)
     assert not np.array_equal(O.gemm_mod(q, *big), O.gemm_mod(q, *big, quirk=True))   # the dropped carries show
+
+
+def test_polymath_ext_restatements_agree_with_the_c_oracle():
+    """oracle/polymath_ext.py (Python integers) against the C restatement where the two overlap."""
+    from oracle import polymath_ext as X
+    name = "hyb12_a2"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc = oracle_ctx(name)
+    L = 4
+    r = rng_for(77)
+    a, b, d = (uniform_poly(r, primes[:L], n) for _ in range(3))
+    assert np.array_equal(X.add_and_negate(a, b, primes[:L]), oc.negate(oc.add(a, b, L), L))
+    assert np.array_equal(X.multiply_and_add_negate(a, b, d, primes[:L]), oc.negate(oc.multiply_and_add(a, b, d, L), L))
+    assert np.array_equal(X.multiply_and_scale_add(a, b, d, 1, primes[:L]), oc.multiply_and_add(a, b, d, L))
+    s = np.array([5] * L, dtype=np.uint64)
+    assert np.array_equal(X.multiply_uniform_scalar(a, 5, primes[:L]), oc.multiply_scalar(a, s, L))
+    assert np.array_equal(X.sub_and_scale(a, b, s, primes[:L]), oc.multiply_scalar(oc.sub(a, b, L), s, L))
+    c1, c2 = np.stack([a, b]), np.stack([b, d])
+    assert np.array_equal(X.tensor_prod_mxn(c1, c2, primes[:L]), oc.tensor_prod_2x2(c1, c2, L))
+    assert np.array_equal(X.add_many([c1, c2, c1], 1, primes[:L]), oc.add(oc.add(b, d, L), b, L))
