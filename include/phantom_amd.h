@@ -222,6 +222,17 @@ int pha_multiply_and_negated_add_rns_poly(pha_context_t ctx, const uint64_t *alp
                                           size_t coeff_mod_size, void *stream);
 
 /* ---- RNS tool at level size_Ql (DRNSTool of context_data(chain) with size_Ql data limbs) ---- */
+/* DBaseConverter (include/rns_bconv.cuh:13-87) between two bases given as rows of the context's prime table
+ * (0 .. size_QP-1 = the Q primes then the P primes; the auxiliary BFV bases follow once a plain modulus is set).
+ * bConv_BEHZ (src/rns_bconv.cu:212-229): dst[j] = sum_i (x_i * qhat_i^-1 mod q_i) * (qhat_i mod p_j) mod p_j, the
+ * approximate conversion of the hot path.  bConv_HPS (:248-372): the exact conversion of the HPS multiply (overflow
+ * count from a double-precision sum, fused multiply-adds as nvcc builds it).  src [ibase][N] -> dst [obase][N]. */
+typedef struct pha_base_converter *pha_base_converter_t;
+int pha_base_converter_create(pha_context_t ctx, const uint32_t *ibase, size_t ibase_size, const uint32_t *obase,
+                              size_t obase_size, pha_base_converter_t *out);
+void pha_base_converter_destroy(pha_base_converter_t conv);
+int pha_bConv_BEHZ(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream);
+int pha_bConv_HPS(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream);
 /* DBaseConverter::bConv_BEHZ for base_P_to_Ql_conv (rns_bconv.cu:212-229): src [P][N] -> dst [Ql][N] */
 int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
 /* DRNSTool::modup (rns_bconv.cu:530-627): cks [Ql][N] -> dst [beta][Ql+P][N] */

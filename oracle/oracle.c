@@ -1071,6 +1071,14 @@ static void hpsconv_apply(const hpsconv_t *h, const u64 *src, u64 *dst, size_t n
     }
     free(y);
 }
+/* DBaseConverter::bConv_HPS for arbitrary bases (rns_bconv.cu:248-372), exported for the converter-object parity test */
+void orc_bconv_hps(const u64 *ibase, size_t isz, const u64 *obase, size_t osz, const u64 *src, u64 *dst, size_t n) {
+    hpsconv_t h;
+    hpsconv_init(&h, ibase, isz, obase, osz);
+    hpsconv_apply(&h, src, dst, n);
+    hpsconv_free(&h);
+}
+
 struct orc_hps {
     const orc_ctx *c;
     size_t n, size_q, size_r;

@@ -102,6 +102,8 @@ void orc_moddown_from_ntt(const orc_tool *t, uint64_t *ct, uint64_t *cx, int sch
 /* keyswitch_inplace eval_key_switch.cu:95-182: ct=[2][size_ql][N] += KS(c2) */
 void orc_keyswitch_inplace(const orc_tool *t, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks, int scheme);
 /* hoisting_inplace evaluate.cu:1670-1866: ct=[2][size_ql][N] <- sum_e rotate_e(ct); glk[e][digit] = key [2][size_QP][N] */
+/* DBaseConverter::bConv_HPS (src/rns_bconv.cu:248-372): exact conversion, overflow count from an fma chain of doubles */
+void orc_bconv_hps(const uint64_t *ibase, size_t isz, const uint64_t *obase, size_t osz, const uint64_t *src, uint64_t *dst, size_t n);
 void orc_hoisting(const orc_tool *t, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                   const uint64_t *const *const *glk, int scheme);
 /* build-defined: sum_e w_e (.) rotate_e(ct), weights over [Q_l || P] in NTT form (BASELINE config 5) */

@@ -81,6 +81,7 @@ def lib(path=None):
     L.orc_key_switch_inner_prod.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p)]
     L.orc_moddown_from_ntt.argtypes = [C.c_void_p, u64p, u64p, C.c_int]
     L.orc_keyswitch_inplace.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p), C.c_int]
+    L.orc_bconv_hps.argtypes = [u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, C.c_size_t]
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_hoisting_weighted.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.POINTER(u64p), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
@@ -284,6 +285,16 @@ def bconv(ibase, obase, src, n):
     dst = np.zeros(len(obase) * n, dtype=np.uint64)
     lib().orc_bconv(_p(ibase), len(ibase), _p(obase), len(obase), _p(src), _p(dst), n)
     return dst.reshape(len(obase), n)
+
+
+def bconv_hps(ibase, obase, src, n):
+    """DBaseConverter::bConv_HPS (src/rns_bconv.cu:248-372) for arbitrary bases."""
+    ib = np.array([int(q) for q in ibase], dtype=np.uint64)
+    ob = np.array([int(q) for q in obase], dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+    dst = np.zeros(len(ob) * n, dtype=np.uint64)
+    lib().orc_bconv_hps(_p(ib), len(ib), _p(ob), len(ob), _p(src), _p(dst), n)
+    return dst.reshape(len(ob), n)
 
 
 class Behz:

@@ -337,3 +337,81 @@ extern "C" int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, con
     }
     PHA_API_END
 }
+
+// ---- DBaseConverter as an object of the ABI (include/rns_bconv.cuh:13-87): a converter between two bases given as
+//      rows of the context's prime table; bConv_BEHZ (rns_bconv.cu:212-229) and bConv_HPS (:248-372) on one polynomial ----
+struct pha_base_converter {
+    pha_context_t ctx;
+    pha::BConv conv;
+    pha::DevBuf<pha::BConvDev> d_conv;
+    pha::DevBuf<double> inv;          // 1 / q_i of the input base (src/host/rns.cu:321-323)
+    pha::DevBuf<pha::u64> alpha_mod;  // [isz + 1][osz] alpha * prod(ibase) mod p_j (:459-466)
+    bool split_ok = true;
+};
+
+extern "C" {
+
+int pha_base_converter_create(pha_context_t ctx, const uint32_t *ibase, size_t ibase_size, const uint32_t *obase,
+                              size_t obase_size, pha_base_converter_t *out) {
+    PHA_API_BEGIN
+    if (!ctx || !ibase || !obase || !out) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (ibase_size == 0 || ibase_size > 64 || obase_size == 0 || obase_size > 256) throw std::invalid_argument("RNSBase is invalid");
+    std::vector<uint32_t> ip(ibase, ibase + ibase_size), op(obase, obase + obase_size);
+    for (size_t i = 0; i < ip.size(); i++) {
+        if (ip[i] >= c.rows) throw std::invalid_argument("modulus index out of range");
+        for (size_t k = 0; k < i; k++)
+            if (ip[k] == ip[i]) throw std::invalid_argument("RNSBase is not coprime");
+    }
+    for (uint32_t row : op)
+        if (row >= c.rows) throw std::invalid_argument("modulus index out of range");
+    PHA_HIP(hipSetDevice(c.device));
+    auto h = std::make_unique<pha_base_converter>();
+    h->ctx = ctx;
+    build_bconv(c, h->conv, ip, op);
+    describe_conv(h->conv, h->d_conv);
+    std::vector<double> inv(ip.size());
+    for (size_t i = 0; i < ip.size(); i++) {
+        inv[i] = 1.0 / (double)c.primes[ip[i]];
+        if (c.primes[ip[i]] >> 60) h->split_ok = false;
+    }
+    std::vector<u64> am((ip.size() + 1) * op.size());
+    for (size_t j = 0; j < op.size(); j++) {
+        const u64 p = c.primes[op[j]];
+        if (p >> 60) h->split_ok = false;
+        u64 prod = 1 % p;
+        for (uint32_t row : ip) prod = (u64)((unsigned __int128)prod * (c.primes[row] % p) % p);
+        for (size_t a = 0; a <= ip.size(); a++) am[a * op.size() + j] = (u64)((unsigned __int128)a * prod % p);
+    }
+    h->inv.upload(inv);
+    h->alpha_mod.upload(am);
+    *out = h.release();
+    PHA_API_END
+}
+
+void pha_base_converter_destroy(pha_base_converter_t conv) {
+    if (!conv) return;
+    (void)hipSetDevice(conv->ctx->c.device);
+    (void)hipDeviceSynchronize();
+    delete conv;
+}
+
+int pha_bConv_BEHZ(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_API_BEGIN
+    if (!conv || !dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = conv->ctx->c;
+    launch_bconv(c, conv->d_conv.p, 0, 1, conv->conv.isz, conv->conv.osz, conv->split_ok, dst, 0, src, 0, nullptr, true,
+                 as_stream(stream));
+    PHA_API_END
+}
+
+int pha_bConv_HPS(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_API_BEGIN
+    if (!conv || !dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = conv->ctx->c;
+    u64 *y = c.scratch(stream, (size_t)conv->conv.isz * c.n);
+    bconv_hps(c, conv->conv, conv->d_conv.p, conv->inv.p, conv->alpha_mod.p, dst, src, y, as_stream(stream));
+    PHA_API_END
+}
+
+}  // extern "C"

@@ -243,7 +243,7 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
     c.rows = size_qp;
 }
 
-static void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
+void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
 
 // Append auxiliary moduli to the context's prime / table arrays: `ntt_primes` get full NTT tables, then one more
 // modulus without tables (m_tilde = 2^32 of BEHZ).  Returns the row of the first one.  Nothing may be in flight.
@@ -290,7 +290,7 @@ uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_l
     return first;
 }
 
-static void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
+void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
     out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.isz, b.osz, 0xffffffffu, 0, 0, 0}});
 }
 
@@ -483,7 +483,7 @@ Behz &Context::behz() {
 }
 
 // q-hat_i^-1 mod q_i and q-hat_i mod p_j for an (ibase -> obase) converter: src/host/rns.cu:282-337,438-457
-static void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op) {
+void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op) {
     b.isz = (uint32_t)ip.size();
     b.osz = (uint32_t)op.size();
     b.iprime = ip;

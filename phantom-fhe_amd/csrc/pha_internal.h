@@ -252,6 +252,9 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                   uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
                   const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0);
+// converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)
+void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
+void describe_conv(const BConv &b, DevBuf<BConvDev> &out);
 void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,
                    hipStream_t s, size_t poly_limbs = 0);
 void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s);

@@ -4,6 +4,6 @@ Host-side mirror of the reference's hot-path interface over libphantom_amd.so (H
 There is no CPU fallback: constructing a PhantomContext without the built library or without a
 HIP device raises.
 """
-from .core import (PhantomContext, PhantomRelinKey, coeff_modulus_create, fnwt_1d, inwt_1d, scheme_type,  # noqa: F401
+from .core import (DBaseConverter, PhantomContext, PhantomRelinKey, coeff_modulus_create, fnwt_1d, inwt_1d, scheme_type,  # noqa: F401
                    set_tuning, to_device, to_host)
 from .lib import EXPORTED, LIB_PATH, load  # noqa: F401

@@ -338,6 +338,30 @@ class PhantomContext:
         return ms.value
 
 
+class DBaseConverter:
+    """DBaseConverter (include/rns_bconv.cuh:13-87) between two bases given as rows of the context's prime table."""
+
+    def __init__(self, ctx, ibase, obase):
+        self._ctx, self._L = ctx, _lib.load()
+        self.ibase, self.obase = [int(i) for i in ibase], [int(o) for o in obase]
+        ib = (C.c_uint32 * len(self.ibase))(*self.ibase)
+        ob = (C.c_uint32 * len(self.obase))(*self.obase)
+        h = C.c_void_p()
+        _lib.check(self._L.pha_base_converter_create(ctx._h, ib, len(self.ibase), ob, len(self.obase), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pha_base_converter_destroy(self._h)
+            self._h = None
+
+    def bConv_BEHZ(self, dst, src):
+        _lib.check(self._L.pha_bConv_BEHZ(self._h, _ptr(dst), _ptr(src), _stream()))
+
+    def bConv_HPS(self, dst, src):
+        _lib.check(self._L.pha_bConv_HPS(self._h, _ptr(dst), _ptr(src), _stream()))
+
+
 class PhantomRelinKey:
     """Device layout of PhantomRelinKey (include/secretkey.h:102-165): dnum public keys, each
     [2][size_QP][N], plus a device array of their pointers."""

@@ -60,6 +60,9 @@ _SIGS = {
     "pha_fnwt_1d_opt": [vp, vp, vp, vp, sz, sz, sz, vp],
     "pha_inwt_1d": [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp],
     "pha_inwt_1d_opt": [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp],
+    "pha_base_converter_create": [vp, C.POINTER(C.c_uint32), sz, C.POINTER(C.c_uint32), sz, C.POINTER(vp)],
+    "pha_bConv_BEHZ": [vp, vp, vp, vp],
+    "pha_bConv_HPS": [vp, vp, vp, vp],
     "pha_add_std_cipher": [vp, vp, vp, vp, sz, vp],
     "pha_add_and_negate_rns_poly": [vp, vp, vp, vp, sz, sz, vp],
     "pha_add_many_rns_poly": [vp, C.POINTER(vp), sz, vp, sz, sz, vp],
@@ -89,6 +92,7 @@ _SIGS = {
 _SPECIAL = {
     "pha_last_error": (C.c_char_p, []),
     "pha_context_destroy": (None, [vp]),
+    "pha_base_converter_destroy": (None, [vp]),
     "pha_context_log_n": (C.c_uint32, [vp]),
     "pha_context_size_qp": (C.c_uint32, [vp]),
     "pha_context_size_p": (C.c_uint32, [vp]),

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from util import oracle_ctx, primes_of, rng_for, uniform_poly
+from util import crt_compose, oracle_ctx, primes_of, rng_for, uniform_poly
 
 pytestmark = pytest.mark.gpu
 
@@ -613,3 +613,52 @@ def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
     ones_a, ones_b = np.ones_like(A), np.ones_like(B)
     ctx.batched_modular_gemm(dC, P.to_device(ones_a, gpu), P.to_device(ones_b, gpu), m, n, k, batch)
     assert (P.to_host(dC) == k).all()
+
+
+@pytest.mark.parametrize("name,ibase,obase", [
+    ("hyb12_a2", [6, 7], [0, 1, 2, 3, 4, 5]),            # P -> Q (2 inputs)
+    ("hyb12_a2", [0, 1, 2, 3, 4, 5], [6, 7]),            # Q -> P
+    ("hyb12_a2", [1], [0, 2, 7]),                        # a single input prime
+    ("hyb13_a3", [3, 4, 5], [0, 1, 2, 6, 7, 8, 9, 10, 11]),
+    ("c4_bfv15", list(range(30)), list(range(30, 45))),  # 30 inputs (register-resident path)
+    ("c3_ckks16", list(range(45)), list(range(45, 60))), # 45 inputs (wide path)
+    ("c3_ckks16", list(range(45, 60)), list(range(45))), # the mod-down conversion at C3
+])
+def test_base_converter_object(name, ibase, obase, gpu):
+    """DBaseConverter (include/rns_bconv.cuh:13-87) for arbitrary bases: bConv_BEHZ (rns_bconv.cu:212-229) and
+    bConv_HPS (:248-372) vs the oracle."""
+    import phantom_fhe_amd as P
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    ctx = _ctx(name, gpu)
+    ip, op = [primes[i] for i in ibase], [primes[j] for j in obase]
+    r = rng_for(1200 + len(ibase))
+    src = uniform_poly(r, ip, n)
+    src[:, :8] = 0
+    src[:, 8:16] = np.array(ip, dtype=np.uint64)[:, None] - 1
+    conv = P.DBaseConverter(ctx, ibase, obase)
+    dst = P.to_device(np.zeros((len(obase), n), dtype=np.uint64), gpu)
+    conv.bConv_BEHZ(dst, P.to_device(src, gpu))
+    assert np.array_equal(P.to_host(dst), O.bconv(ip, op, src, n))
+    conv.bConv_HPS(dst, P.to_device(src, gpu))
+    hps = O.bconv_hps(ip, op, src, n)
+    assert np.array_equal(P.to_host(dst), hps)
+    if len(ibase) <= 3:      # the HPS conversion is exact: x reduced mod p_j, x the centred CRT lift of the residues
+        Q = 1
+        for q in ip:
+            Q *= int(q)
+        for k in range(0, n, 331):
+            x, _ = crt_compose([src[i, k] for i in range(len(ip))], ip)
+            x = x - Q if x > Q // 2 else x
+            assert all(int(hps[j, k]) == x % int(p) for j, p in enumerate(op))
+
+
+def test_base_converter_rejects_bad_bases(gpu):
+    import phantom_fhe_amd as P
+    ctx = _ctx("hyb12_a2", gpu)
+    with pytest.raises(ValueError):
+        P.DBaseConverter(ctx, [0, 0], [1])
+    with pytest.raises(ValueError):
+        P.DBaseConverter(ctx, [0], [99])
+    with pytest.raises(ValueError):
+        P.DBaseConverter(ctx, [], [1])
