@@ -309,6 +309,21 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
 int pha_divide_and_round_q_last(pha_context_t ctx, size_t size_Ql, const uint64_t *src, size_t cipher_size,
                                 uint64_t *dst, void *stream);
 
+/* ---- ciphertext (+|-|*) plaintext (src/evaluate.cu:1105-1340): the device work of add_plain_inplace,
+ *      sub_plain_inplace and multiply_plain_inplace, with DRNSTool's per-level constants (src/rns.cu:292-324) kept by
+ *      the context (pha_context_set_plain_modulus).  CKKS needs nothing beyond pha_add/sub/multiply_rns_poly. ---- */
+/* multiply_add_plain_with_scaling_variant / multiply_sub_plain_with_scaling_variant (src/scalingvariant.cu:10-60):
+ * ct[0] (coefficient form, [Ql][N]) +- round-free (Ql / t) * plain, plain = N coefficients below t */
+int pha_bfv_add_plain(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *plain, int subtract, void *stream);
+/* multiply_plain_normal (src/evaluate.cu:1256-1300): every polynomial of ct [cipher_size][Ql][N] (coefficient form)
+ * times the centred lift of plain, through the NTT */
+int pha_bfv_multiply_plain(pha_context_t ctx, size_t size_Ql, uint64_t *ct, size_t cipher_size, const uint64_t *plain,
+                           void *stream);
+/* BGV: out [Ql][N] = NTT of plain modulo every q_i -- the nwt_2d_radix8_forward_modup_fuse loop of
+ * src/evaluate.cu:1150-1154, 1208-1212, 1319-1323 as one launch; the caller then applies
+ * multiply_scalar_and_add/sub (correction factor) or multiply_rns_poly */
+int pha_bgv_lift_plain(pha_context_t ctx, size_t size_Ql, const uint64_t *plain, uint64_t *out, void *stream);
+
 /* ---- Galois (include/galois.cuh:98-130, src/galois.cu:11-39,67-102) ---- */
 int pha_apply_galois_ntt(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt,
                          size_t coeff_mod_size, void *stream);

@@ -1341,6 +1341,50 @@ void orc_hoisting_weighted(const orc_tool *t, u64 *ct, const uint32_t *elts, siz
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * ciphertext (+|-|*) plaintext (src/evaluate.cu:1105-1340, src/scalingvariant.cu:10-60)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_bfv_add_plain(const orc_ctx *c, size_t size_ql, u64 *ct, const u64 *plain, u64 t, int subtract) {
+    /* bfv_{add,sub}_timesQ_overt_kernel polymath.cu:413-461 with negQl_mod_t = t - (Ql mod t), tInv_mod_q (rns.cu:292-324) */
+    const size_t n = c->n;
+    u64 ql_t = 1 % t;
+    for (size_t i = 0; i < size_ql; i++) ql_t = orc_mulmod(ql_t, c->q[i] % t, t);
+    const u64 neg = t - ql_t;
+    for (size_t i = 0; i < size_ql; i++) {
+        const u64 q = c->q[i];
+        /* t^-1 mod q_i (q_i prime) */
+        const u64 tinv = orc_invmod(t % q, q);
+        for (size_t k = 0; k < n; k++) {
+            const u64 m = orc_mulmod(plain[k], neg, t);
+            const u64 v = orc_mulmod(m, tinv, q);
+            ct[i * n + k] = subtract ? submod(ct[i * n + k], v, q) : addmod(ct[i * n + k], v, q);
+        }
+    }
+}
+void orc_bgv_lift_plain(const orc_ctx *c, size_t size_ql, const u64 *plain, u64 *out) {
+    /* nwt_2d_radix8_forward_modup_fuse per limb (evaluate.cu:1150-1154): NTT of the coefficients modulo every q_i */
+    const size_t n = c->n;
+    for (size_t i = 0; i < size_ql; i++)
+        for (size_t k = 0; k < n; k++) out[i * n + k] = plain[k] % c->q[i];
+    orc_nwt_forward(c, out, size_ql, 0);
+}
+void orc_bfv_multiply_plain(const orc_ctx *c, size_t size_ql, u64 *ct, size_t cipher_size, const u64 *plain, u64 t) {
+    /* multiply_plain_normal evaluate.cu:1256-1300: centred lift (abs_plain_rns_poly polymath.cu:645-664), NTT, product, iNTT */
+    const size_t n = c->n;
+    u64 *tmp = (u64 *)malloc(sizeof(u64) * size_ql * n);
+    const u64 threshold = (t + 1) >> 1;
+    for (size_t i = 0; i < size_ql; i++)
+        for (size_t k = 0; k < n; k++) tmp[i * n + k] = plain[k] >= threshold ? plain[k] + (c->q[i] - t) : plain[k];
+    orc_nwt_forward(c, tmp, size_ql, 0);
+    for (size_t p = 0; p < cipher_size; p++) {
+        u64 *ci = ct + p * size_ql * n;
+        orc_nwt_forward(c, ci, size_ql, 0);
+        orc_multiply_rns_poly(c, ci, tmp, ci, size_ql, 0);
+        orc_nwt_backward(c, ci, size_ql, 0);
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * evaluation-key generation (src/secretkey.cu:232-341, polymath.cu:318-338)
  * evk_i = ( -(a_i*s + e_i) + P*new_key on limbs [i*alpha,(i+1)*alpha) , a_i ), all NTT form, over QP
  * ---------------------------------------------------------------------------------------------- */

@@ -104,6 +104,10 @@ void orc_keyswitch_inplace(const orc_tool *t, uint64_t *ct, const uint64_t *c2, 
 /* hoisting_inplace evaluate.cu:1670-1866: ct=[2][size_ql][N] <- sum_e rotate_e(ct); glk[e][digit] = key [2][size_QP][N] */
 /* DBaseConverter::bConv_HPS (src/rns_bconv.cu:248-372): exact conversion, overflow count from an fma chain of doubles */
 void orc_bconv_hps(const uint64_t *ibase, size_t isz, const uint64_t *obase, size_t osz, const uint64_t *src, uint64_t *dst, size_t n);
+/* ---- ciphertext (+|-|*) plaintext: src/scalingvariant.cu:10-60, src/evaluate.cu:1150-1154, 1256-1300 ---- */
+void orc_bfv_add_plain(const orc_ctx *c, size_t size_ql, uint64_t *ct, const uint64_t *plain, uint64_t t, int subtract);
+void orc_bgv_lift_plain(const orc_ctx *c, size_t size_ql, const uint64_t *plain, uint64_t *out);
+void orc_bfv_multiply_plain(const orc_ctx *c, size_t size_ql, uint64_t *ct, size_t cipher_size, const uint64_t *plain, uint64_t t);
 void orc_hoisting(const orc_tool *t, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                   const uint64_t *const *const *glk, int scheme);
 /* build-defined: sum_e w_e (.) rotate_e(ct), weights over [Q_l || P] in NTT form (BASELINE config 5) */

@@ -82,6 +82,9 @@ def lib(path=None):
     L.orc_moddown_from_ntt.argtypes = [C.c_void_p, u64p, u64p, C.c_int]
     L.orc_keyswitch_inplace.argtypes = [C.c_void_p, u64p, u64p, C.POINTER(u64p), C.c_int]
     L.orc_bconv_hps.argtypes = [u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, C.c_size_t]
+    L.orc_bfv_add_plain.argtypes = [C.c_void_p, C.c_size_t, u64p, u64p, C.c_uint64, C.c_int]
+    L.orc_bgv_lift_plain.argtypes = [C.c_void_p, C.c_size_t, u64p, u64p]
+    L.orc_bfv_multiply_plain.argtypes = [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_uint64]
     L.orc_hoisting.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.c_int]
     L.orc_hoisting_weighted.argtypes = [C.c_void_p, u64p, u32p, C.c_size_t, C.POINTER(C.POINTER(u64p)), C.POINTER(u64p), C.c_int]
     L.orc_rescale_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
@@ -269,6 +272,26 @@ class Ctx:
         r = np.zeros(limbs * self.n, dtype=np.uint64)
         self.L.orc_apply_galois_coeff(self.h, _p(src), _p(r), galois_elt, limbs, start_idx)
         return r.reshape(limbs, self.n)
+
+    def bfv_add_plain(self, ct0, plain, t, subtract=False):
+        """multiply_{add,sub}_plain_with_scaling_variant (src/scalingvariant.cu:10-60) on c0 [Ql][N]."""
+        ct0 = np.array(ct0, dtype=np.uint64, copy=True)
+        ql = ct0.shape[0]
+        flat = ct0.reshape(-1)
+        self.L.orc_bfv_add_plain(self.h, ql, _p(flat), _p(np.ascontiguousarray(plain, dtype=np.uint64).reshape(-1)), int(t), int(subtract))
+        return flat.reshape(ql, self.n)
+
+    def bgv_lift_plain(self, plain, ql):
+        out = np.zeros(ql * self.n, dtype=np.uint64)
+        self.L.orc_bgv_lift_plain(self.h, ql, _p(np.ascontiguousarray(plain, dtype=np.uint64).reshape(-1)), _p(out))
+        return out.reshape(ql, self.n)
+
+    def bfv_multiply_plain(self, ct, plain, t):
+        ct = np.array(ct, dtype=np.uint64, copy=True)
+        size, ql = ct.shape[0], ct.shape[1]
+        flat = ct.reshape(-1)
+        self.L.orc_bfv_multiply_plain(self.h, ql, _p(flat), size, _p(np.ascontiguousarray(plain, dtype=np.uint64).reshape(-1)), int(t))
+        return flat.reshape(size, ql, self.n)
 
     def gen_kswitch_key(self, sk_ntt, new_key_ntt, a_ntt, e_ntt):
         dnum = self.size_q // self.size_p

@@ -648,6 +648,21 @@ Tool &Context::tool(uint32_t size_ql) {
             t->pinv_mod_t = u64x2{ip, h_shoup(ip, pt)};
             t->p_hat_mod_t.upload(hat);
         }
+        {   // BFV enc / add / sub (rns.cu:292-324): -Ql mod t and t^-1 mod q_i; q_i - t for the plain lift
+            u64 ql_t = 1 % pt;
+            std::vector<u64> ti(size_ql), tis(size_ql), inc(size_ql);
+            for (uint32_t i = 0; i < size_ql; i++) {
+                ql_t = h_mulmod(ql_t, primes[i] % pt, pt);
+                ti[i] = h_invmod(pt % primes[i], primes[i]);
+                tis[i] = h_shoup(ti[i], primes[i]);
+                inc[i] = primes[i] - pt;
+            }
+            const u64 neg = pt - ql_t;
+            t->neg_ql_mod_t = u64x2{neg, h_shoup(neg, pt)};
+            t->t_inv_mod_q.upload(ti);
+            t->t_inv_mod_q_shoup.upload(tis);
+            t->plain_upper_half_increment.upload(inc);
+        }
         t->bgv_ready = true;
     }
     Tool &ref = *t;

@@ -124,6 +124,9 @@ struct Tool {
     bool bgv_ready = false;
     DModulus t_mod{};
     u64x2 inv_q_last_mod_t{}, pinv_mod_t{};        // (value, Shoup) modulo t
+    u64x2 neg_ql_mod_t{};                          // t - (Ql mod t) (rns.cu:292-306), BFV add/sub plain
+    DevBuf<u64> t_inv_mod_q, t_inv_mod_q_shoup;    // [Ql] t^-1 mod q_i (rns.cu:308-324)
+    DevBuf<u64> plain_upper_half_increment;        // [Ql] q_i - t (context.cu: plain lift of multiply_plain)
     DevBuf<u64x2> q_last_mod_q2, p_mod_q2;         // [ql-1], [ql]  (value, Shoup) modulo q_i
     DevBuf<u64> p_hat_mod_t;                       // [alpha] row of base_P_to_t_conv
 };

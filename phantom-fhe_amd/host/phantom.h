@@ -22,6 +22,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <istream>
 #include <ostream>
 #include <vector>
@@ -379,6 +380,68 @@ public:
     }
 };
 
+// PhantomPlaintext (include/plaintext.h:8-116): metadata + one device buffer.  BFV / BGV plaintexts hold N coefficients
+// modulo t (coeff_modulus_size 1); CKKS plaintexts hold [limb][coeff] in NTT form at their chain index.  The encoders
+// that fill it are outside the accelerated path; load_from_host stands in for them.
+class PhantomPlaintext {
+    size_t chain_index_ = 0, poly_modulus_degree_ = 0, coeff_modulus_size_ = 0;
+    double scale_ = 1.0;
+    phantom::util::cuda_auto_ptr<uint64_t> data_;
+
+public:
+    void resize(size_t coeff_modulus_size, size_t poly_modulus_degree, const cudaStream_t &stream) {
+        data_ = phantom::util::make_cuda_auto_ptr<uint64_t>(coeff_modulus_size * poly_modulus_degree, stream);
+        coeff_modulus_size_ = coeff_modulus_size;
+        poly_modulus_degree_ = poly_modulus_degree;
+    }
+    void set_chain_index(size_t chain_index) { chain_index_ = chain_index; }
+    void set_scale(double scale) { scale_ = scale; }
+    [[nodiscard]] size_t coeff_count() const noexcept { return poly_modulus_degree_ * coeff_modulus_size_; }
+    [[nodiscard]] size_t chain_index() const noexcept { return chain_index_; }
+    [[nodiscard]] size_t coeff_modulus_size() const noexcept { return coeff_modulus_size_; }
+    [[nodiscard]] size_t poly_modulus_degree() const noexcept { return poly_modulus_degree_; }
+    [[nodiscard]] double scale() const noexcept { return scale_; }
+    [[nodiscard]] uint64_t *data() const noexcept { return data_.get(); }
+    [[nodiscard]] phantom::util::cuda_auto_ptr<uint64_t> &data_ptr() noexcept { return data_; }
+
+    // on-disk format of include/plaintext.h:72-114: four metadata fields, then the words
+    void save(std::ostream &stream) const {
+        stream.write(reinterpret_cast<const char *>(&chain_index_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&poly_modulus_degree_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&coeff_modulus_size_), sizeof(std::size_t));
+        stream.write(reinterpret_cast<const char *>(&scale_), sizeof(double));
+        std::vector<uint64_t> host(coeff_count());
+        if (!host.empty()) store_to_host(host.data());
+        stream.write(reinterpret_cast<const char *>(host.data()), static_cast<std::streamsize>(host.size() * sizeof(uint64_t)));
+    }
+    void load(std::istream &stream) {
+        size_t degree = 0, limbs = 0;
+        stream.read(reinterpret_cast<char *>(&chain_index_), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&degree), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&limbs), sizeof(std::size_t));
+        stream.read(reinterpret_cast<char *>(&scale_), sizeof(double));
+        if (!stream || limbs > 4096 || degree > (size_t(1) << 17)) throw std::invalid_argument("plaintext stream is not valid");
+        std::vector<uint64_t> host(limbs * degree);
+        stream.read(reinterpret_cast<char *>(host.data()), static_cast<std::streamsize>(host.size() * sizeof(uint64_t)));
+        if (!stream) throw std::invalid_argument("plaintext stream is truncated");
+        load_from_host(host.data(), limbs, degree, chain_index_, scale_);
+    }
+    void load_from_host(const uint64_t *host, size_t coeff_modulus_size, size_t poly_modulus_degree, size_t chain_index,
+                        double scale = 1.0, const cudaStream_t &stream = cudaStreamPerThread) {
+        resize(coeff_modulus_size, poly_modulus_degree, stream);
+        chain_index_ = chain_index;
+        scale_ = scale;
+        if (coeff_count()) {
+            phantom::util::check_hip(hipMemcpyAsync(data_.get(), host, coeff_count() * 8, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            phantom::util::check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        }
+    }
+    void store_to_host(uint64_t *host, const cudaStream_t &stream = cudaStreamPerThread) const {
+        phantom::util::check_hip(hipMemcpyAsync(host, data_.get(), coeff_count() * 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+        phantom::util::check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    }
+};
+
 // PhantomRelinKey (include/secretkey.h:102-165): dnum public keys, each a size-2 ciphertext [2][#QP][N] at chain
 // index 0, + the device pointer table the inner product reads
 class PhantomRelinKey {
@@ -517,12 +580,78 @@ inline void negate_inplace(const PhantomContext &context, PhantomCiphertext &enc
     for (size_t i = 0; i < encrypted.size(); i++)
         util::check_pha(pha_negate_rns_poly(context.amd(), encrypted.data() + i * L * n, encrypted.data() + i * L * n, L, 0, s));
 }
+// balance_correction_factors (src/evaluate.cu:20-77): the pair (e1, e2) with e1 * f1 = e2 * f2 (mod t) of smallest
+// |e1| + |e2| (centred) found along the extended Euclidean remainder sequence of (t, f2 / f1); returns (e1 * f1, e1, e2)
+namespace detail {
+inline std::tuple<uint64_t, uint64_t, uint64_t> balance_correction_factors(uint64_t factor1, uint64_t factor2, uint64_t t) {
+    const auto mulmod = [t](uint64_t a, uint64_t b) { return static_cast<uint64_t>(static_cast<unsigned __int128>(a) * b % t); };
+    const auto centred_abs = [t](uint64_t x) { return static_cast<int64_t>(x > t / 2 ? t - x : x); };
+    const auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t r = a % b; a = b; b = r; } return a; };
+    // factor1^-1 mod t
+    __int128 r0 = t, r1 = factor1 % t, s0 = 0, s1 = 1;
+    while (r1 != 0) {
+        const __int128 k = r0 / r1, r2 = r0 - k * r1, s2 = s0 - k * s1;
+        r0 = r1; r1 = r2; s0 = s1; s1 = s2;
+    }
+    if (r0 != 1) throw std::logic_error("invalid correction factor1");
+    const uint64_t inv1 = static_cast<uint64_t>(((s0 % static_cast<__int128>(t)) + t) % t);
+    const uint64_t ratio = mulmod(inv1, factor2 % t);
+    uint64_t e1 = ratio, e2 = 1;
+    int64_t best = centred_abs(e1) + centred_abs(e2);
+    int64_t prev_a = static_cast<int64_t>(t), prev_b = 0, a = static_cast<int64_t>(ratio), b = 1;
+    while (a != 0) {
+        const int64_t q = prev_a / a, rem = prev_a % a;
+        prev_a = a;
+        a = rem;
+        const int64_t nb = prev_b - b * q;
+        prev_b = b;
+        b = nb;
+        const auto to_mod = [t](int64_t v) {
+            const uint64_t m = static_cast<uint64_t>(v < 0 ? -v : v) % t;
+            return (v < 0 && m) ? t - m : m;
+        };
+        const uint64_t a_mod = to_mod(a), b_mod = to_mod(b);
+        if (a_mod != 0 && gcd(a_mod, t) == 1) {
+            const int64_t sum = centred_abs(a_mod) + centred_abs(b_mod);
+            if (sum < best) {
+                best = sum;
+                e1 = a_mod;
+                e2 = b_mod;
+            }
+        }
+    }
+    return {mulmod(e1, factor1 % t), e1, e2};
+}
+// BGV: bring two ciphertexts to a common correction factor before adding / subtracting (src/evaluate.cu:148-168);
+// returns the (possibly scaled) second operand
+inline const PhantomCiphertext &balance(const PhantomContext &context, PhantomCiphertext &encrypted1,
+                                        const PhantomCiphertext &encrypted2, PhantomCiphertext &scratch2) {
+    if (encrypted1.correction_factor() == encrypted2.correction_factor()) return encrypted2;
+    const auto &parms = context.get_context_data(encrypted1.chain_index()).parms();
+    const auto f = balance_correction_factors(encrypted1.correction_factor(), encrypted2.correction_factor(), parms.plain_modulus().value());
+    const auto &s = cudaStreamPerThread;
+    const size_t L = encrypted1.coeff_modulus_size(), n = encrypted1.poly_modulus_degree();
+    scratch2 = encrypted2;
+    for (size_t i = 0; i < encrypted1.size(); i++)
+        util::check_pha(pha_multiply_uniform_scalar_rns_poly(context.amd(), encrypted1.data() + i * L * n, std::get<1>(f),
+                                                             encrypted1.data() + i * L * n, L, 0, s));
+    for (size_t i = 0; i < scratch2.size(); i++)
+        util::check_pha(pha_multiply_uniform_scalar_rns_poly(context.amd(), scratch2.data() + i * L * n, std::get<2>(f),
+                                                             scratch2.data() + i * L * n, L, 0, s));
+    encrypted1.set_correction_factor(std::get<0>(f));
+    scratch2.set_correction_factor(std::get<0>(f));
+    return scratch2;
+}
+}  // namespace detail
+
 inline void add_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2) {
     detail::same_shape(encrypted1, encrypted2);
     const auto &s = cudaStreamPerThread;
     const size_t L = encrypted1.coeff_modulus_size(), n = encrypted1.poly_modulus_degree();
+    PhantomCiphertext scaled;
+    const PhantomCiphertext &rhs = detail::balance(context, encrypted1, encrypted2, scaled);
     for (size_t i = 0; i < encrypted1.size(); i++)
-        util::check_pha(pha_add_rns_poly(context.amd(), encrypted1.data() + i * L * n, encrypted2.data() + i * L * n,
+        util::check_pha(pha_add_rns_poly(context.amd(), encrypted1.data() + i * L * n, rhs.data() + i * L * n,
                                          encrypted1.data() + i * L * n, L, 0, s));
 }
 inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
@@ -530,12 +659,41 @@ inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encryp
     detail::same_shape(encrypted1, encrypted2);
     const auto &s = cudaStreamPerThread;
     const size_t L = encrypted1.coeff_modulus_size(), n = encrypted1.poly_modulus_degree();
+    PhantomCiphertext scaled;
+    const PhantomCiphertext &rhs = detail::balance(context, encrypted1, encrypted2, scaled);
     for (size_t i = 0; i < encrypted1.size(); i++) {
         uint64_t *a = encrypted1.data() + i * L * n;
-        const uint64_t *b = encrypted2.data() + i * L * n;
+        const uint64_t *b = rhs.data() + i * L * n;
         if (negate) util::check_pha(pha_sub_rns_poly(context.amd(), b, a, a, L, 0, s));
         else util::check_pha(pha_sub_rns_poly(context.amd(), a, b, a, L, 0, s));
     }
+}
+
+// add_many (src/evaluate.cu:202-262): BGV folds with add_inplace (correction factors), the others sum in one kernel
+inline void add_many(const PhantomContext &context, const std::vector<PhantomCiphertext> &encrypteds, PhantomCiphertext &destination) {
+    if (encrypteds.empty()) throw std::invalid_argument("encrypteds cannot be empty");
+    for (const auto &e : encrypteds) {
+        if (&e == &destination) throw std::invalid_argument("encrypteds must be different from destination");
+        if (encrypteds[0].chain_index() != e.chain_index()) throw std::invalid_argument("encrypteds parameter mismatch");
+        if (encrypteds[0].is_ntt_form() != e.is_ntt_form()) throw std::invalid_argument("NTT form mismatch");
+        if (encrypteds[0].scale() != e.scale()) throw std::invalid_argument("scale mismatch");
+        if (encrypteds[0].size() != e.size()) throw std::invalid_argument("poly number mismatch");
+    }
+    const auto &parms = context.get_context_data(encrypteds[0].chain_index()).parms();
+    const auto &s = cudaStreamPerThread;
+    if (parms.scheme() == scheme_type::bgv) {
+        destination = encrypteds[0];
+        for (size_t i = 1; i < encrypteds.size(); i++) add_inplace(context, destination, encrypteds[i]);
+        return;
+    }
+    destination.resize(context, encrypteds[0].chain_index(), encrypteds[0].size(), s);
+    destination.set_ntt_form(encrypteds[0].is_ntt_form());
+    destination.set_scale(encrypteds[0].scale());
+    std::vector<const uint64_t *> ptrs;
+    for (const auto &e : encrypteds) ptrs.push_back(e.data());
+    for (size_t i = 0; i < encrypteds[0].size(); i++)
+        util::check_pha(pha_add_many_rns_poly(context.amd(), ptrs.data(), ptrs.size(), destination.data(), i,
+                                              parms.coeff_modulus().size(), s));
 }
 
 // multiply_inplace (src/evaluate.cu:1030-1079 -> bgv_ckks_multiply :345-397)
@@ -676,6 +834,122 @@ inline void mod_switch_to_next_inplace(const PhantomContext &context, PhantomCip
     encrypted = mod_switch_to_next(context, encrypted);
 }
 
+// mod_switch_to (include/evaluate.cuh:153-177)
+inline void mod_switch_to_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, size_t chain_index) {
+    if (encrypted.chain_index() > chain_index) throw std::invalid_argument("cannot switch to higher level modulus");
+    while (encrypted.chain_index() != chain_index) mod_switch_to_next_inplace(context, encrypted);
+}
+[[nodiscard]] inline PhantomCiphertext mod_switch_to(const PhantomContext &context, const PhantomCiphertext &encrypted, size_t chain_index) {
+    PhantomCiphertext destination = encrypted;
+    mod_switch_to_inplace(context, destination, chain_index);
+    return destination;
+}
+// plaintext mod switch (src/evaluate.cu:1474-1503): keeps the leading limbs of the next level
+inline void mod_switch_to_next_inplace(const PhantomContext &context, PhantomPlaintext &plain) {
+    const auto &first = context.get_context_data(context.get_first_index()).parms();
+    if (plain.chain_index() == first.coeff_modulus().size()) throw std::invalid_argument("end of modulus switching chain reached");
+    const size_t next = plain.chain_index() + 1;
+    const auto &next_parms = context.get_context_data(next).parms();
+    const size_t limbs = next_parms.coeff_modulus().size(), n = next_parms.poly_modulus_degree();
+    const auto &s = cudaStreamPerThread;
+    auto old = std::move(plain.data_ptr());
+    const double scale = plain.scale();
+    plain.resize(limbs, n, s);
+    plain.set_scale(scale);
+    util::check_hip(hipMemcpyAsync(plain.data(), old.get(), limbs * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    plain.set_chain_index(next);
+}
+[[nodiscard]] inline PhantomPlaintext mod_switch_to_next(const PhantomContext &context, const PhantomPlaintext &plain) {
+    PhantomPlaintext destination = plain;
+    mod_switch_to_next_inplace(context, destination);
+    return destination;
+}
+inline void mod_switch_to_inplace(const PhantomContext &context, PhantomPlaintext &plain, size_t chain_index) {
+    if (plain.chain_index() > chain_index) throw std::invalid_argument("cannot switch to higher level modulus");
+    while (plain.chain_index() != chain_index) mod_switch_to_next_inplace(context, plain);
+}
+[[nodiscard]] inline PhantomPlaintext mod_switch_to(const PhantomContext &context, const PhantomPlaintext &plain, size_t chain_index) {
+    PhantomPlaintext destination = plain;
+    mod_switch_to_inplace(context, destination, chain_index);
+    return destination;
+}
+
+// add_plain_inplace / sub_plain_inplace (src/evaluate.cu:1105-1226)
+namespace detail {
+inline void add_sub_plain(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain, bool subtract) {
+    const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
+    const auto scheme = parms.scheme();
+    if (scheme == scheme_type::bfv && encrypted.is_ntt_form()) throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+    if (scheme == scheme_type::ckks && !encrypted.is_ntt_form()) throw std::invalid_argument("CKKS encrypted must be in NTT form");
+    if (scheme == scheme_type::bgv && !encrypted.is_ntt_form()) throw std::invalid_argument("BGV encrypted must be in NTT form");
+    if (encrypted.scale() != plain.scale()) throw std::invalid_argument("scale mismatch");
+    const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree();
+    const auto &s = cudaStreamPerThread;
+    switch (scheme) {
+        case scheme_type::bfv:   // multiply_{add,sub}_plain_with_scaling_variant src/scalingvariant.cu:10-60
+            util::check_pha(pha_bfv_add_plain(context.amd(), L, encrypted.data(), plain.data(), subtract ? 1 : 0, s));
+            break;
+        case scheme_type::ckks:  // (c0 +- pt, c1)
+            if (plain.chain_index() != encrypted.chain_index() || plain.coeff_modulus_size() != L)
+                throw std::invalid_argument("encrypted and plain parameter mismatch");
+            if (subtract) util::check_pha(pha_sub_rns_poly(context.amd(), encrypted.data(), plain.data(), encrypted.data(), L, 0, s));
+            else util::check_pha(pha_add_rns_poly(context.amd(), encrypted.data(), plain.data(), encrypted.data(), L, 0, s));
+            break;
+        case scheme_type::bgv: {  // lift t -> {q_i} in NTT form, then c0 +- correction_factor * pt
+            auto lifted = util::make_cuda_auto_ptr<uint64_t>(L * n, s);
+            util::check_pha(pha_bgv_lift_plain(context.amd(), L, plain.data(), lifted.get(), s));
+            if (subtract)
+                util::check_pha(pha_multiply_scalar_and_sub_rns_poly(context.amd(), encrypted.data(), lifted.get(),
+                                                                     encrypted.correction_factor(), encrypted.data(), L, 0, s));
+            else
+                util::check_pha(pha_multiply_scalar_and_add_rns_poly(context.amd(), encrypted.data(), lifted.get(),
+                                                                     encrypted.correction_factor(), encrypted.data(), L, 0, s));
+            break;
+        }
+        default:
+            throw std::invalid_argument("unsupported scheme");
+    }
+}
+}  // namespace detail
+inline void add_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain) {
+    detail::add_sub_plain(context, encrypted, plain, false);
+}
+inline void sub_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain) {
+    detail::add_sub_plain(context, encrypted, plain, true);
+}
+
+// multiply_plain_inplace (src/evaluate.cu:1228-1340)
+inline void multiply_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain) {
+    const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
+    const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree();
+    const auto &s = cudaStreamPerThread;
+    const double new_scale = encrypted.scale() * plain.scale();
+    switch (parms.scheme()) {
+        case scheme_type::bfv:   // multiply_plain_normal :1256-1300
+            util::check_pha(pha_bfv_multiply_plain(context.amd(), L, encrypted.data(), encrypted.size(), plain.data(), s));
+            break;
+        case scheme_type::ckks:  // multiply_plain_ntt :1228-1254
+            if (encrypted.chain_index() != plain.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
+            if (encrypted.poly_modulus_degree() != plain.poly_modulus_degree() || plain.coeff_modulus_size() != L)
+                throw std::invalid_argument("encrypted and plain parameter mismatch");
+            for (size_t i = 0; i < encrypted.size(); i++)
+                util::check_pha(pha_multiply_rns_poly(context.amd(), encrypted.data() + i * L * n, plain.data(),
+                                                      encrypted.data() + i * L * n, L, 0, s));
+            break;
+        case scheme_type::bgv: {
+            auto lifted = util::make_cuda_auto_ptr<uint64_t>(L * n, s);
+            util::check_pha(pha_bgv_lift_plain(context.amd(), L, plain.data(), lifted.get(), s));
+            for (size_t i = 0; i < encrypted.size(); i++)
+                util::check_pha(pha_multiply_rns_poly(context.amd(), encrypted.data() + i * L * n, lifted.get(),
+                                                      encrypted.data() + i * L * n, L, 0, s));
+            break;
+        }
+        default:
+            throw std::invalid_argument("unsupported scheme");
+    }
+    encrypted.set_scale(new_scale);
+}
+
 // apply_galois_inplace (src/evaluate.cu:1567-1630)
 inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, size_t galois_elt,
                                  const PhantomGaloisKey &galois_keys) {
@@ -748,5 +1022,8 @@ inline PhantomCiphertext relinearize(const PhantomContext &c, const PhantomCiphe
 inline PhantomCiphertext multiply_and_relin(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b, const PhantomRelinKey &k) { PhantomCiphertext d = a; multiply_and_relin_inplace(c, d, b, k); return d; }
 inline PhantomCiphertext apply_galois(const PhantomContext &c, const PhantomCiphertext &e, size_t elt, const PhantomGaloisKey &k) { PhantomCiphertext d = e; apply_galois_inplace(c, d, elt, k); return d; }
 inline PhantomCiphertext rotate(const PhantomContext &c, const PhantomCiphertext &e, int step, const PhantomGaloisKey &k) { PhantomCiphertext d = e; rotate_inplace(c, d, step, k); return d; }
+inline PhantomCiphertext add_plain(const PhantomContext &c, const PhantomCiphertext &e, const PhantomPlaintext &p) { PhantomCiphertext d = e; add_plain_inplace(c, d, p); return d; }
+inline PhantomCiphertext sub_plain(const PhantomContext &c, const PhantomCiphertext &e, const PhantomPlaintext &p) { PhantomCiphertext d = e; sub_plain_inplace(c, d, p); return d; }
+inline PhantomCiphertext multiply_plain(const PhantomContext &c, const PhantomCiphertext &e, const PhantomPlaintext &p) { PhantomCiphertext d = e; multiply_plain_inplace(c, d, p); return d; }
 
 }  // namespace phantom

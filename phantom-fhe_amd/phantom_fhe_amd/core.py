@@ -223,6 +223,18 @@ class PhantomContext:
     def multiply_and_negated_add_rns_poly(self, alpha_sk, m_sk, prod_b_mod_q, operand3, r, cms):
         _lib.check(self._L.pha_multiply_and_negated_add_rns_poly(self._h, _ptr(alpha_sk), int(m_sk), _ptr(prod_b_mod_q), _ptr(operand3), _ptr(r), cms, _stream()))
 
+    def bfv_add_plain(self, size_Ql, ct, plain, subtract=False):
+        """multiply_{add,sub}_plain_with_scaling_variant (src/scalingvariant.cu:10-60) on ct[0]."""
+        _lib.check(self._L.pha_bfv_add_plain(self._h, size_Ql, _ptr(ct), _ptr(plain), int(bool(subtract)), _stream()))
+
+    def bfv_multiply_plain(self, size_Ql, ct, cipher_size, plain):
+        """multiply_plain_normal (src/evaluate.cu:1256-1300)."""
+        _lib.check(self._L.pha_bfv_multiply_plain(self._h, size_Ql, _ptr(ct), cipher_size, _ptr(plain), _stream()))
+
+    def bgv_lift_plain(self, size_Ql, plain, out):
+        """NTT of a plaintext modulo every q_i (the modup_fuse loop of src/evaluate.cu:1150-1154)."""
+        _lib.check(self._L.pha_bgv_lift_plain(self._h, size_Ql, _ptr(plain), _ptr(out), _stream()))
+
     def tensor_prod_2x2_rns_poly(self, op1, op2, result, cms):
         _lib.check(self._L.pha_tensor_prod_2x2_rns_poly(self._h, _ptr(op1), _ptr(op2), _ptr(result), cms, _stream()))
 

@@ -63,6 +63,9 @@ _SIGS = {
     "pha_base_converter_create": [vp, C.POINTER(C.c_uint32), sz, C.POINTER(C.c_uint32), sz, C.POINTER(vp)],
     "pha_bConv_BEHZ": [vp, vp, vp, vp],
     "pha_bConv_HPS": [vp, vp, vp, vp],
+    "pha_bfv_add_plain": [vp, sz, vp, vp, C.c_int, vp],
+    "pha_bfv_multiply_plain": [vp, sz, vp, sz, vp, vp],
+    "pha_bgv_lift_plain": [vp, sz, vp, vp, vp],
     "pha_add_std_cipher": [vp, vp, vp, vp, sz, vp],
     "pha_add_and_negate_rns_poly": [vp, vp, vp, vp, sz, sz, vp],
     "pha_add_many_rns_poly": [vp, C.POINTER(vp), sz, vp, sz, sz, vp],

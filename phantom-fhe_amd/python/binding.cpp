@@ -3,8 +3,8 @@
 // Mirrors the names of the reference's python/src/binding.cu:8-166 for everything that is on the
 // accelerated path: enums scheme_type / mul_tech_type, classes modulus, params, context, ciphertext,
 // relin_key, galois_key, and the functions create_coeff_modulus, get_elt_from_step(s), negate, add, sub,
-// multiply, multiply_and_relin, relinearize, rescale_to_next, mod_switch_to_next, apply_galois, rotate,
-// hoisting.  Like the reference, every function returns by value.  Key generation, encryption,
+// add_plain, add_many, sub_plain, multiply, multiply_and_relin, multiply_plain, relinearize, rescale_to_next,
+// mod_switch_to_next / mod_switch_to (ciphertext and plaintext overloads), apply_galois, rotate, hoisting; class plaintext.  Like the reference, every function returns by value.  Key generation, encryption,
 // decryption and the encoders are out of scope, so ciphertexts and keys enter as
 // numpy uint64 arrays (`ciphertext.load`, `relin_key.load`) and leave with `ciphertext.to_numpy()`.
 #include <pybind11/numpy.h>
@@ -61,6 +61,8 @@ PYBIND11_MODULE(pyPhantom, m) {
         .def("chain_index", &PhantomCiphertext::chain_index)
         .def("coeff_modulus_size", &PhantomCiphertext::coeff_modulus_size)
         .def("set_ntt_form", &PhantomCiphertext::set_ntt_form)
+        .def("set_correction_factor", &PhantomCiphertext::set_correction_factor)
+        .def("correction_factor", &PhantomCiphertext::correction_factor)
         .def("is_ntt_form", &PhantomCiphertext::is_ntt_form)
         .def("load", [](PhantomCiphertext &ct, const PhantomContext &c, size_t chain_index, u64_array data) {
             if (data.ndim() != 3) throw std::invalid_argument("expected [poly][limb][coeff]");
@@ -82,6 +84,23 @@ PYBIND11_MODULE(pyPhantom, m) {
             std::ifstream f(path, std::ios::binary);
             if (!f) throw std::runtime_error("cannot open " + path);
             ct.load(f);
+        });
+
+    py::class_<PhantomPlaintext>(m, "plaintext")
+        .def(py::init<>())
+        .def("chain_index", [](const PhantomPlaintext &p) { return p.chain_index(); })
+        .def("scale", [](const PhantomPlaintext &p) { return p.scale(); })
+        .def("set_scale", &PhantomPlaintext::set_scale)
+        .def("coeff_modulus_size", [](const PhantomPlaintext &p) { return p.coeff_modulus_size(); })
+        // the encoders are out of scope: a BFV / BGV plaintext is [1][N] coefficients modulo t, a CKKS one [limb][N] in NTT form
+        .def("load", [](PhantomPlaintext &p, u64_array data, size_t chain_index, double scale) {
+            if (data.ndim() != 2) throw std::invalid_argument("expected [limb][coeff]");
+            p.load_from_host(data.data(), static_cast<size_t>(data.shape(0)), static_cast<size_t>(data.shape(1)), chain_index, scale);
+        }, py::arg("data"), py::arg("chain_index") = 0, py::arg("scale") = 1.0)
+        .def("to_numpy", [](const PhantomPlaintext &p) {
+            u64_array out({p.coeff_modulus_size(), p.poly_modulus_degree()});
+            p.store_to_host(out.mutable_data());
+            return out;
         });
 
     py::class_<PhantomRelinKey>(m, "relin_key")
@@ -131,12 +150,23 @@ PYBIND11_MODULE(pyPhantom, m) {
 
     m.def("negate", &negate);
     m.def("add", &add);
+    m.def("add_plain", &add_plain);
+    m.def("sub_plain", &sub_plain);
+    m.def("multiply_plain", &multiply_plain);
+    m.def("add_many", [](const PhantomContext &c, const std::vector<PhantomCiphertext> &cts) {
+        PhantomCiphertext dest;
+        add_many(c, cts, dest);
+        return dest;
+    });
+    m.def("mod_switch_to", py::overload_cast<const PhantomContext &, const PhantomCiphertext &, size_t>(&mod_switch_to));
+    m.def("mod_switch_to", py::overload_cast<const PhantomContext &, const PhantomPlaintext &, size_t>(&mod_switch_to));
+    m.def("mod_switch_to_next", py::overload_cast<const PhantomContext &, const PhantomPlaintext &>(&mod_switch_to_next));
     m.def("sub", &sub, py::arg(), py::arg(), py::arg(), py::arg("negate") = false);
     m.def("multiply", &multiply);
     m.def("multiply_and_relin", &multiply_and_relin);
     m.def("relinearize", &relinearize);
     m.def("rescale_to_next", &rescale_to_next);
-    m.def("mod_switch_to_next", &mod_switch_to_next);
+    m.def("mod_switch_to_next", py::overload_cast<const PhantomContext &, const PhantomCiphertext &>(&mod_switch_to_next));
     m.def("apply_galois", &apply_galois);
     m.def("rotate", &rotate);
     m.def("hoisting", &hoisting);

@@ -97,6 +97,59 @@ int main() {
         REQUIRE(got == ref);
     }
 
+    // add_plain / sub_plain / multiply_plain (CKKS: residue-wise on NTT-form plaintexts), add_many, mod_switch_to
+    {
+        auto hp = uniform(g, q, n);
+        PhantomPlaintext pt;
+        pt.load_from_host(hp.data(), size_q, n, 1, std::pow(2.0, 40));
+        std::vector<uint64_t> got(2 * ln), ref = h1;
+        auto s1 = add_plain(context, ct1, pt);
+        orc_add_rns_poly(oc, h1.data(), hp.data(), ref.data(), size_q, 0);
+        s1.store_to_host(got.data());
+        REQUIRE(got == ref);
+        auto s2 = sub_plain(context, ct1, pt);
+        orc_sub_rns_poly(oc, h1.data(), hp.data(), ref.data(), size_q, 0);
+        s2.store_to_host(got.data());
+        REQUIRE(got == ref);
+        auto s3 = multiply_plain(context, ct1, pt);
+        for (int p = 0; p < 2; p++) orc_multiply_rns_poly(oc, h1.data() + p * ln, hp.data(), ref.data() + p * ln, size_q, 0);
+        s3.store_to_host(got.data());
+        REQUIRE(got == ref && s3.scale() == std::pow(2.0, 80));
+        PhantomPlaintext wrong = pt;
+        wrong.set_scale(2.0);
+        REQUIRE(throws_invalid([&] { PhantomCiphertext c = ct1; add_plain_inplace(context, c, wrong); }));
+        // plaintext file round trip and level switch (keeps the leading limbs)
+        std::stringstream io;
+        pt.save(io);
+        PhantomPlaintext back;
+        back.load(io);
+        REQUIRE(back.chain_index() == 1 && back.coeff_modulus_size() == size_q && back.scale() == pt.scale());
+        PhantomPlaintext lower = mod_switch_to(context, back, 3);
+        REQUIRE(lower.chain_index() == 3 && lower.coeff_modulus_size() == size_q - 2);
+        std::vector<uint64_t> low((size_q - 2) * n);
+        lower.store_to_host(low.data());
+        REQUIRE(std::equal(low.begin(), low.end(), hp.begin()));
+        REQUIRE(throws_invalid([&] { PhantomPlaintext x = lower; mod_switch_to_inplace(context, x, 1); }));
+        // add_many: one kernel over the operand table
+        std::vector<PhantomCiphertext> many{ct1, ct2, ct1};
+        PhantomCiphertext total;
+        add_many(context, many, total);
+        for (int p = 0; p < 2; p++) {
+            orc_add_rns_poly(oc, h1.data() + p * ln, h2.data() + p * ln, ref.data() + p * ln, size_q, 0);
+            orc_add_rns_poly(oc, ref.data() + p * ln, h1.data() + p * ln, ref.data() + p * ln, size_q, 0);
+        }
+        total.store_to_host(got.data());
+        REQUIRE(got == ref && total.chain_index() == 1);
+        REQUIRE(throws_invalid([&] { std::vector<PhantomCiphertext> none; add_many(context, none, total); }));
+        // ciphertext mod_switch_to: CKKS drops limbs
+        PhantomCiphertext dropped = mod_switch_to(context, ct1, 3);
+        REQUIRE(dropped.chain_index() == 3 && dropped.coeff_modulus_size() == size_q - 2);
+        std::vector<uint64_t> dd(2 * (size_q - 2) * n);
+        dropped.store_to_host(dd.data());
+        for (int p = 0; p < 2; p++) REQUIRE(std::equal(dd.begin() + p * (size_q - 2) * n, dd.begin() + (p + 1) * (size_q - 2) * n, h1.begin() + p * ln));
+        REQUIRE(throws_invalid([&] { PhantomCiphertext x = dropped; mod_switch_to_inplace(context, x, 1); }));
+    }
+
     // multiply -> relinearize -> rescale (examples/3_ckks.cu:496-498)
     std::vector<uint64_t> ref3(3 * ln);
     orc_tensor_prod_2x2(oc, h1.data(), h2.data(), ref3.data(), size_q);
@@ -303,6 +356,58 @@ int main() {
         REQUIRE(out == ref);
         const uint64_t inv = orc_invmod(q.back() % 65537, 65537);   // 65537 is prime
         REQUIRE(bnext.correction_factor() == 15 * inv % 65537);
+        // balance_correction_factors (src/evaluate.cu:20-77): known answers from an independent restatement
+        const uint64_t kat[][6] = {{3ULL, 5ULL, 65537ULL, 15ULL, 5ULL, 3ULL}, {1ULL, 65536ULL, 65537ULL, 65536ULL, 65536ULL, 1ULL},
+                                   {12345ULL, 54321ULL, 65537ULL, 44864ULL, 285ULL, 65533ULL}, {7ULL, 7ULL, 786433ULL, 7ULL, 1ULL, 1ULL},
+                                   {2ULL, 1032192ULL, 1032193ULL, 2ULL, 1ULL, 1032191ULL}, {40000ULL, 3ULL, 65537ULL, 429ULL, 136ULL, 143ULL}};
+        for (auto &k : kat) {
+            const auto f = detail::balance_correction_factors(k[0], k[1], k[2]);
+            REQUIRE(std::get<0>(f) == k[3] && std::get<1>(f) == k[4] && std::get<2>(f) == k[5]);
+        }
+        // add / sub of ciphertexts with different correction factors (3 and 5 -> 15: scalars 5 and 3)
+        {
+            PhantomCiphertext a = b1, d = b1;
+            add_inplace(bctx, a, b2);
+            sub_inplace(bctx, d, b2);
+            REQUIRE(a.correction_factor() == 15 && d.correction_factor() == 15);
+            std::vector<uint64_t> s5(size_q, 5), s3(size_q, 3), x(2 * ln), y(2 * ln), ref(2 * ln), got(2 * ln);
+            for (int p = 0; p < 2; p++) {
+                orc_multiply_scalar_rns_poly(oc, h1.data() + p * ln, s5.data(), x.data() + p * ln, size_q, 0);
+                orc_multiply_scalar_rns_poly(oc, h2.data() + p * ln, s3.data(), y.data() + p * ln, size_q, 0);
+                orc_add_rns_poly(oc, x.data() + p * ln, y.data() + p * ln, ref.data() + p * ln, size_q, 0);
+            }
+            a.store_to_host(got.data());
+            REQUIRE(got == ref);
+            for (int p = 0; p < 2; p++) orc_sub_rns_poly(oc, x.data() + p * ln, y.data() + p * ln, ref.data() + p * ln, size_q, 0);
+            d.store_to_host(got.data());
+            REQUIRE(got == ref);
+            std::vector<PhantomCiphertext> many{b1, b2};
+            PhantomCiphertext total;
+            add_many(bctx, many, total);      // BGV folds with add_inplace
+            REQUIRE(total.correction_factor() == 15);
+        }
+        // add_plain / sub_plain / multiply_plain: lift t -> {q_i}, then c0 +- correction_factor * pt
+        {
+            std::vector<uint64_t> m(n);
+            for (auto &v : m) v = g() % 65537;
+            PhantomPlaintext pt;
+            pt.load_from_host(m.data(), 1, n, 0);
+            std::vector<uint64_t> lifted(ln), scaled(ln), cf(size_q, 3), ref = h1, got(2 * ln);
+            orc_bgv_lift_plain(oc, size_q, m.data(), lifted.data());
+            orc_multiply_scalar_rns_poly(oc, lifted.data(), cf.data(), scaled.data(), size_q, 0);
+            auto s1 = add_plain(bctx, b1, pt);
+            orc_add_rns_poly(oc, h1.data(), scaled.data(), ref.data(), size_q, 0);
+            s1.store_to_host(got.data());
+            REQUIRE(got == ref);
+            auto s2 = sub_plain(bctx, b1, pt);
+            orc_sub_rns_poly(oc, h1.data(), scaled.data(), ref.data(), size_q, 0);
+            s2.store_to_host(got.data());
+            REQUIRE(got == ref);
+            auto s3 = multiply_plain(bctx, b1, pt);
+            for (int p = 0; p < 2; p++) orc_multiply_rns_poly(oc, h1.data() + p * ln, lifted.data(), ref.data() + p * ln, size_q, 0);
+            s3.store_to_host(got.data());
+            REQUIRE(got == ref);
+        }
         orc_tool_destroy(bt);
     }
     // BFV: multiply (BEHZ, evaluate.cu:447-548) -> relinearize, coefficient-form ciphertexts (examples/1_bfv.cu flow)
@@ -344,6 +449,32 @@ int main() {
         fsq.store_to_host(got3.data());
         REQUIRE(got3 == r3);
         REQUIRE(throws_invalid([&] { PhantomCiphertext c = f1; c.set_ntt_form(true); multiply_inplace(fctx, c, f2); }));
+        // add_plain / sub_plain (scaling variant) and multiply_plain (centred lift through the NTT)
+        {
+            std::vector<uint64_t> m(n);
+            for (auto &v : m) v = g() % 65537;
+            PhantomPlaintext pt;
+            pt.load_from_host(m.data(), 1, n, 0);
+            std::vector<uint64_t> ref = h1, got(2 * ln);
+            auto s1 = add_plain(fctx, f1, pt);
+            orc_bfv_add_plain(oc, size_q, ref.data(), m.data(), 65537, 0);
+            s1.store_to_host(got.data());
+            REQUIRE(got == ref);
+            auto s2 = sub_plain(fctx, f1, pt);
+            ref = h1;
+            orc_bfv_add_plain(oc, size_q, ref.data(), m.data(), 65537, 1);
+            s2.store_to_host(got.data());
+            REQUIRE(got == ref);
+            auto s3 = multiply_plain(fctx, f1, pt);
+            ref = h1;
+            orc_bfv_multiply_plain(oc, size_q, ref.data(), 2, m.data(), 65537);
+            s3.store_to_host(got.data());
+            REQUIRE(got == ref && !s3.is_ntt_form());
+            REQUIRE(throws_invalid([&] { PhantomCiphertext c = f1; c.set_ntt_form(true); add_plain_inplace(fctx, c, pt); }));
+            // BFV mod_switch_to: divide-and-round chain
+            PhantomCiphertext two = mod_switch_to(fctx, f1, 3);
+            REQUIRE(two.chain_index() == 3 && two.coeff_modulus_size() == size_q - 2);
+        }
         orc_behz_destroy(ob);
         // the reference's default mul_tech (hps) on a second context
         EncryptionParameters hp = fp;

@@ -127,3 +127,34 @@ def test_tensor_prod_mxn(env, m, k):
     if (m, k) == (8, 8):
         with pytest.raises(ValueError):
             ctx.tensor_prod_mxn_rns_poly(P.to_device(op1, gpu), 9, P.to_device(op2, gpu), k, out, L)
+
+
+@pytest.mark.parametrize("name,ql,t", [("hyb12_a2", 6, 65537), ("hyb12_a2", 3, 1 << 20), ("c4_bfv15", 30, 1032193)])
+def test_plaintext_ops(name, ql, t, gpu):
+    """pha_bfv_add_plain / pha_bfv_multiply_plain / pha_bgv_lift_plain (src/scalingvariant.cu:10-60,
+    src/evaluate.cu:1256-1300, 1150-1154) vs the C oracle."""
+    import phantom_fhe_amd as P
+    from util import oracle_ctx
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    oc = oracle_ctx(name)
+    ctx = P.PhantomContext(log_n, list(primes), size_p, device=gpu)
+    r = rng_for(330 + ql)
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    m = r.integers(0, t, n, dtype=np.uint64)
+    m[:3] = [0, 1, t - 1]
+    d_m = P.to_device(m, gpu)
+    with pytest.raises(ValueError):
+        ctx.bfv_add_plain(ql, P.to_device(ct[0], gpu), d_m)          # no plain modulus yet
+    ctx.set_plain_modulus(t)
+    for sub in (False, True):
+        d = P.to_device(ct[0], gpu)
+        ctx.bfv_add_plain(ql, d, d_m, subtract=sub)
+        assert np.array_equal(P.to_host(d), oc.bfv_add_plain(ct[0], m, t, subtract=sub))
+    out = P.to_device(np.zeros((ql, n), dtype=np.uint64), gpu)
+    ctx.bgv_lift_plain(ql, d_m, out)
+    assert np.array_equal(P.to_host(out), oc.bgv_lift_plain(m, ql))
+    assert np.array_equal(P.to_host(d_m), m)
+    d = P.to_device(ct, gpu)
+    ctx.bfv_multiply_plain(ql, d, 2, d_m)
+    assert np.array_equal(P.to_host(d), oc.bfv_multiply_plain(ct, m, t))

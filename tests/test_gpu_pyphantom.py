@@ -13,7 +13,8 @@ def test_module_surface():
     for name in ("scheme_type", "mul_tech_type", "modulus", "params", "context", "ciphertext", "relin_key",
                  "galois_key", "create_coeff_modulus", "get_elt_from_step", "get_elts_from_steps", "negate", "add",
                  "sub", "multiply", "multiply_and_relin", "relinearize", "rescale_to_next", "mod_switch_to_next",
-                 "apply_galois", "rotate", "hoisting"):
+                 "apply_galois", "rotate", "hoisting", "plaintext", "add_plain", "sub_plain", "multiply_plain", "add_many",
+                 "mod_switch_to"):
         assert hasattr(ph, name), name
     assert ph.get_elt_from_step(1, 4096) == 5 and ph.get_elt_from_step(0, 4096) == 8191
     mods = ph.create_coeff_modulus(1 << 14, [60] + [40] * 6 + [60])
@@ -111,3 +112,63 @@ def test_keygen_and_files(gpu, tmp_path):
     ct2 = ph.ciphertext()
     ct2.load_file(cpath)
     assert np.array_equal(ct2.to_numpy(), h) and ct2.scale() == 2.0 ** 40 and ct2.chain_index() == 1
+
+
+@pytest.mark.gpu
+def test_plaintext_flows(gpu):
+    """add_plain / sub_plain / multiply_plain / add_many / mod_switch_to through the reference's Python names
+    (python/examples/bfv.py, bgv.py, ckks.py use them), BGV and BFV with coefficient plaintexts modulo t."""
+    from phantom_fhe_amd import pyPhantom as ph
+    name = "hyb12_a2"
+    log_n, primes, size_p = primes_of(name)
+    n, size_q = 1 << log_n, len(primes) - size_p
+    oc = oracle_ctx(name)
+    r = rng_for(91)
+    t = 65537
+    h1 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    m = r.integers(0, t, (1, n), dtype=np.uint64)
+
+    def make(scheme):
+        parms = ph.params(scheme)
+        parms.set_poly_modulus_degree(n)
+        parms.set_special_modulus_size(size_p)
+        parms.set_coeff_modulus(ph.create_coeff_modulus(n, [60, 40, 40, 40, 40, 40, 60, 60]))
+        if scheme != ph.scheme_type.ckks:
+            parms.set_plain_modulus(ph.modulus(t))
+        return ph.context(parms)
+
+    # BGV
+    ctx = make(ph.scheme_type.bgv)
+    a = ph.ciphertext(); a.load(ctx, 1, h1); a.set_correction_factor(7)
+    pt = ph.plaintext(); pt.load(m)
+    lifted = oc.bgv_lift_plain(m[0], size_q)
+    scaled = oc.multiply_scalar(lifted, np.array([7] * size_q, dtype=np.uint64), size_q)
+    got = ph.add_plain(ctx, a, pt).to_numpy()
+    assert np.array_equal(got[0], oc.add(h1[0], scaled, size_q)) and np.array_equal(got[1], h1[1])
+    got = ph.sub_plain(ctx, a, pt).to_numpy()
+    assert np.array_equal(got[0], oc.sub(h1[0], scaled, size_q))
+    got = ph.multiply_plain(ctx, a, pt).to_numpy()
+    assert np.array_equal(got, np.stack([oc.multiply(h1[p], lifted, size_q) for p in range(2)]))
+    # BFV
+    ctx = make(ph.scheme_type.bfv)
+    a = ph.ciphertext(); a.load(ctx, 1, h1); a.set_ntt_form(False)
+    got = ph.add_plain(ctx, a, pt).to_numpy()
+    assert np.array_equal(got[0], oc.bfv_add_plain(h1[0], m[0], t)) and np.array_equal(got[1], h1[1])
+    got = ph.multiply_plain(ctx, a, pt).to_numpy()
+    assert np.array_equal(got, oc.bfv_multiply_plain(h1, m[0], t))
+    lower = ph.mod_switch_to(ctx, a, 3)
+    assert lower.chain_index() == 3 and lower.coeff_modulus_size() == size_q - 2
+    # CKKS
+    ctx = make(ph.scheme_type.ckks)
+    a = ph.ciphertext(); a.load(ctx, 1, h1); a.set_scale(2.0 ** 40)
+    hp = uniform_poly(r, primes[:size_q], n)
+    pt = ph.plaintext(); pt.load(hp, 1, 2.0 ** 40)
+    got = ph.add_plain(ctx, a, pt).to_numpy()
+    assert np.array_equal(got[0], oc.add(h1[0], hp, size_q))
+    prod = ph.multiply_plain(ctx, a, pt)
+    assert prod.scale() == 2.0 ** 80
+    assert np.array_equal(prod.to_numpy(), np.stack([oc.multiply(h1[p], hp, size_q) for p in range(2)]))
+    total = ph.add_many(ctx, [a, a, a])
+    assert np.array_equal(total.to_numpy()[0], oc.add(oc.add(h1[0], h1[0], size_q), h1[0], size_q))
+    low = ph.mod_switch_to(ctx, pt, 2)
+    assert low.chain_index() == 2 and np.array_equal(low.to_numpy(), hp[: size_q - 1])

@@ -459,3 +459,41 @@ def test_polymath_ext_restatements_agree_with_the_c_oracle():
     c1, c2 = np.stack([a, b]), np.stack([b, d])
     assert np.array_equal(X.tensor_prod_mxn(c1, c2, primes[:L]), oc.tensor_prod_2x2(c1, c2, L))
     assert np.array_equal(X.add_many([c1, c2, c1], 1, primes[:L]), oc.add(oc.add(b, d, L), b, L))
+
+
+@pytest.mark.parametrize("t", [65537, 1 << 20, 786433])
+def test_plaintext_ops_of_the_oracle(t):
+    """BFV add_plain adds exactly ceil(Q m / t) (the scaling variant of src/scalingvariant.cu:10-60); the C restatements
+    agree with the Python-integer formulas of oracle/polymath_ext.py; multiply_plain is the negacyclic product with the
+    centred plaintext."""
+    from oracle import polymath_ext as X
+    name = "hyb12_a2"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    oc = oracle_ctx(name)
+    ql = 3
+    r = rng_for(88)
+    ct0 = uniform_poly(r, primes[:ql], n)
+    m = r.integers(0, t, n, dtype=np.uint64)
+    m[:3] = [0, 1, t - 1]
+    Q = 1
+    for q in primes[:ql]:
+        Q *= int(q)
+    neg = t - Q % t
+    t_inv = [pow(t, -1, int(q)) for q in primes[:ql]]
+    for sub in (False, True):
+        got = oc.bfv_add_plain(ct0, m, t, subtract=sub)
+        assert np.array_equal(got, X.bfv_timesQ_overt(ct0, m, neg, t_inv, t, primes[:ql], sub=sub))
+    delta = oc.sub(oc.bfv_add_plain(ct0, m, t), ct0, ql)
+    for k in (0, 1, 2, 5, 77, n - 1):
+        v, _ = crt_compose([delta[l, k] for l in range(ql)], primes[:ql])
+        assert v == (-(-Q * int(m[k]) // t)) % Q          # ceil(Q m / t)
+    lifted = oc.bgv_lift_plain(m, ql)
+    assert np.array_equal(lifted, oc.nwt_forward(np.stack([m % np.uint64(q) for q in primes[:ql]]), ql, 0))
+    if t < min(primes[:ql]):
+        ct = np.stack([ct0, uniform_poly(r, primes[:ql], n)])
+        prod = oc.bfv_multiply_plain(ct, m, t)
+        centred = X.abs_plain(m, (t + 1) >> 1, [int(q) - t for q in primes[:ql]])
+        for p in range(2):
+            want = oc.nwt_backward(oc.multiply(oc.nwt_forward(ct[p], ql, 0), oc.nwt_forward(centred, ql, 0), ql), ql, 0)
+            assert np.array_equal(prod[p], want)
