@@ -292,6 +292,11 @@ int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, const uint64_t
  * below the smallest q_i, src/rns.cu:687-693) and its tables are built on first use.  The double-precision
  * sums are fused multiply-add chains, as nvcc builds the reference's kernels by default. */
 int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst, void *stream);
+/* bfv_multiply_hps with mul_tech_type::hps_overq, no levels dropped (src/evaluate.cu:674-818, overq branches :745-751,
+ * :790-792; bConv_BEHZ_var1 src/rns_bconv.cu:231-246; scaleAndRound_HPS_QlRl_Ql src/rns.cu:1748-1796).  Same shapes as
+ * pha_bfv_multiply_hps.  ct1 == ct2 (the same pointer) takes the reference's squaring shortcut, whose result is Q / Rl
+ * times the product of two separate objects -- kept as the reference has it.  hps_overq_leveled is not built. */
+int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst, void *stream);
 /* Batched modular GEMM (benchmark/matmul_bench.cu:215-541): for z in [0, batch): C[z] = A[z] * B[z] mod q, q = the
  * context prime mod_start_idx + z; row-major A [batch][m][lda], B [batch][k][ldb], C [batch][m][ldc], inputs
  * canonical.  Exact (the reference's benchmark kernels lose the carries of the low product word, :231-232). */

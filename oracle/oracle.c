@@ -1189,6 +1189,136 @@ void orc_bfv_multiply_hps(const orc_hps *h, const u64 *ct1, const u64 *ct2, u64 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * BFV multiply, HPS-over-Q variant (mul_tech_type::hps_overq, no levels dropped; src/evaluate.cu:674-818 with the
+ * hps_overq branches :745-751 and :790-792; bConv_BEHZ_var1 src/rns_bconv.cu:231-246 with the constants of
+ * src/host/rns.cu:469-496; scaleAndRound_HPS_QlRl_Ql src/rns.cu:1748-1796; constants src/rns.cu:792-885).
+ * Base Rl has as many primes as Q (the first |Q| primes below the smallest q_i).  The first operand is lifted
+ * exactly (bConv_HPS); the second goes Q -> Rl through the quotient-style conversion var1 and comes back Rl -> Q
+ * exactly; the product is scaled by t / Rl and rounded straight into base Q.
+ * ---------------------------------------------------------------------------------------------- */
+struct orc_hpsq {
+    const orc_ctx *c;
+    size_t n, size_q, size_r;
+    int log_n;
+    u64 *r, *qr;
+    u64 (*qr_mu)[2];
+    u64 *tw, *tws, *itw, *itws, *n_inv, *n_inv_s;
+    hpsconv_t q_to_r, r_to_q;
+    bconv_t q_to_r_var1;         /* hat_inv := -Rl * qhat_i^-1 mod q_i, mat[j][i] := q_i^-1 mod r_j */
+    double *frac;                /* [R]  tQlSlHatInvModsDivsFrac */
+    u64 *div_mod_q;              /* [Q][R + 1] tQlSlHatInvModsDivsModq */
+};
+size_t orc_hpsq_r_size(const orc_hpsq *h) { return h->size_r; }
+void orc_hpsq_base(const orc_hpsq *h, u64 *out) { memcpy(out, h->r, sizeof(u64) * h->size_r); }
+orc_hpsq *orc_hpsq_create(const orc_ctx *c, u64 plain_t) {
+    orc_hpsq *h = (orc_hpsq *)calloc(1, sizeof(*h));
+    const size_t sq = c->size_q, sr = sq, sqr = sq + sr, n = c->n;
+    h->c = c; h->n = n; h->log_n = c->log_n; h->size_q = sq; h->size_r = sr;
+    u64 minq = c->q[0];
+    for (size_t i = 1; i < sq; i++) if (c->q[i] < minq) minq = c->q[i];
+    h->r = (u64 *)malloc(sizeof(u64) * sr);
+    {
+        const u64 factor = 2 * (u64)n, lower = (u64)1 << (63 - __builtin_clzll(minq));
+        size_t found = 0;
+        for (u64 v = minq - factor; found < sr && v > lower; v -= factor)
+            if (orc_is_prime(v)) h->r[found++] = v;
+        if (found < sr) { free(h->r); free(h); return NULL; }
+    }
+    h->qr = (u64 *)malloc(sizeof(u64) * sqr);
+    memcpy(h->qr, c->q, sizeof(u64) * sq);
+    memcpy(h->qr + sq, h->r, sizeof(u64) * sr);
+    h->qr_mu = malloc(sizeof(u64[2]) * sqr);
+    h->tw = (u64 *)malloc(sizeof(u64) * sqr * n); h->tws = (u64 *)malloc(sizeof(u64) * sqr * n);
+    h->itw = (u64 *)malloc(sizeof(u64) * sqr * n); h->itws = (u64 *)malloc(sizeof(u64) * sqr * n);
+    h->n_inv = (u64 *)malloc(sizeof(u64) * sqr); h->n_inv_s = (u64 *)malloc(sizeof(u64) * sqr);
+    for (size_t i = 0; i < sqr; i++) {
+        orc_const_ratio(h->qr[i], h->qr_mu[i]);
+        orc_ntt_tables(c->log_n, h->qr[i], h->tw + i * n, h->tws + i * n, h->itw + i * n, h->itws + i * n, &h->n_inv[i], &h->n_inv_s[i]);
+    }
+    hpsconv_init(&h->q_to_r, c->q, sq, h->r, sr);
+    hpsconv_init(&h->r_to_q, h->r, sr, c->q, sq);
+    /* bConv_BEHZ_var1 constants (src/host/rns.cu:469-496): negPQHatInvModq_i = q_i - (P mod q_i) * qhat_i^-1, QInvModp[j][i] = q_i^-1 mod p_j */
+    bconv_init(&h->q_to_r_var1, c->q, sq, h->r, sr);
+    for (size_t i = 0; i < sq; i++) {
+        const u64 qi = c->q[i];
+        const u64 pm = prod_mod(h->r, sr, qi);
+        const u64 v = qi - orc_mulmod(pm, h->q_to_r_var1.hat_inv[i], qi);
+        h->q_to_r_var1.hat_inv[i] = v;
+        h->q_to_r_var1.hat_inv_s[i] = orc_compute_shoup(v, qi);
+    }
+    for (size_t j = 0; j < sr; j++)
+        for (size_t i = 0; i < sq; i++) h->q_to_r_var1.mat[j * sq + i] = orc_invmod(c->q[i] % h->r[j], h->r[j]);
+    /* t/Rl scale-and-round tables (rns.cu:836-885): S = Q || Rl, x_i = t * Q * (S/s_i)^-1 mod s_i as big integers */
+    h->frac = (double *)malloc(sizeof(double) * sr);
+    h->div_mod_q = (u64 *)malloc(sizeof(u64) * sq * (sr + 1));
+    for (size_t i = 0; i < sqr; i++) {
+        u64 hat = 1;
+        for (size_t k = 0; k < sqr; k++) if (k != i) hat = orc_mulmod(hat, h->qr[k] % h->qr[i], h->qr[i]);
+        const u64 shat_inv = orc_invmod(hat, h->qr[i]);
+        big_t x = big_one(sq + 4);
+        for (size_t k = 0; k < sq; k++) big_mul_small(&x, c->q[k]);
+        big_mul_small(&x, plain_t);
+        big_mul_small(&x, shat_inv);
+        if (i >= sq) h->frac[i - sq] = (double)big_mod_small(&x, h->qr[i]) / (double)h->qr[i];
+        big_div_small(&x, h->qr[i]);
+        if (i >= sq) {
+            for (size_t l = 0; l < sq; l++) h->div_mod_q[l * (sr + 1) + (i - sq)] = big_mod_small(&x, c->q[l]);
+        } else {
+            h->div_mod_q[i * (sr + 1) + sr] = big_mod_small(&x, c->q[i]);
+        }
+        free(x.w);
+    }
+    return h;
+}
+void orc_hpsq_destroy(orc_hpsq *h) {
+    if (!h) return;
+    free(h->r); free(h->qr); free(h->qr_mu); free(h->tw); free(h->tws); free(h->itw); free(h->itws); free(h->n_inv); free(h->n_inv_s);
+    hpsconv_free(&h->q_to_r); hpsconv_free(&h->r_to_q); bconv_free(&h->q_to_r_var1); free(h->frac); free(h->div_mod_q); free(h);
+}
+/* ct2 == ct1 (the same pointer) takes the reference's squaring path: one exact lift, tensor_square (evaluate.cu:720-731).
+ * That path still scales by t / Rl, so its result is (Q / Rl) times the wanted one (it does not decrypt to the square);
+ * restated as is. */
+void orc_bfv_multiply_hps_overq(const orc_hpsq *h, const u64 *ct1, const u64 *ct2, u64 *dst) {
+    const size_t n = h->n, sq = h->size_q, sr = h->size_r, sqr = sq + sr;
+    const int square = ct1 == ct2;
+    u64 *x1 = (u64 *)calloc(3 * sqr * n, 8), *x2 = (u64 *)calloc(2 * sqr * n, 8), *y = (u64 *)malloc(sizeof(u64) * sq * n);
+    for (int p = 0; p < 2; p++) {
+        u64 *a = x1 + p * sqr * n, *b = x2 + p * sqr * n;
+        memcpy(a, ct1 + p * sq * n, sizeof(u64) * sq * n);
+        hpsconv_apply(&h->q_to_r, a, a + sq * n, n);                           /* evaluate.cu:716 */
+        for (size_t i = 0; i < sqr; i++) orc_ntt_forward(a + i * n, h->log_n, h->qr[i], h->tw + i * n, h->tws + i * n);
+        if (square) { memcpy(b, a, sizeof(u64) * sqr * n); continue; }
+        bconv_mult(&h->q_to_r_var1, ct2 + p * sq * n, y, n);                   /* bConv_BEHZ_var1 :747-748 */
+        bconv_matmul(&h->q_to_r_var1, y, b + sq * n, n, (size_t)-1, 0);
+        hpsconv_apply(&h->r_to_q, b + sq * n, b, n);                           /* :750 */
+        for (size_t i = 0; i < sqr; i++) orc_ntt_forward(b + i * n, h->log_n, h->qr[i], h->tw + i * n, h->tws + i * n);
+    }
+    tensor_generic(x1, x2, x1, h->qr, h->qr_mu, sqr, n);
+    for (int p = 0; p < 3; p++) {
+        u64 *x = x1 + p * sqr * n, *out = dst + p * sq * n;
+        for (size_t i = 0; i < sqr; i++)
+            orc_ntt_inverse(x + i * n, h->log_n, h->qr[i], h->itw + i * n, h->itws + i * n, h->n_inv[i], h->n_inv_s[i]);
+        /* scaleAndRound_HPS_QlRl_Ql_kernel rns.cu:1749-1786 */
+        for (size_t k = 0; k < n; k++) {
+            double nu = 0.5;
+            for (size_t j = 0; j < sr; j++) nu = fma((double)x[(sq + j) * n + k], h->frac[j], nu);
+            u64 alpha = (u64)nu;
+            for (size_t i = 0; i < sq; i++) {
+                const u64 qi = h->qr[i];
+                const u64 *tab = h->div_mod_q + i * (sr + 1);
+                u128 cur = 0;
+                for (size_t j = 0; j < sr; j++) cur += (u128)x[(sq + j) * n + k] * tab[j];
+                cur += (u128)x[i * n + k] * tab[sr];
+                const u64 v = barrett128(cur, qi, h->qr_mu[i]);
+                alpha = barrett64(alpha, qi, h->qr_mu[i][1]);                   /* reduced in place, :1783 */
+                out[i * n + k] = addmod(v, alpha, qi);
+            }
+        }
+    }
+    free(x1); free(x2); free(y);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * batched modular GEMM (benchmark/matmul_bench.cu:215-541), exact: C = A * B mod q, row-major.
  * (The reference's kernels add low and high product words separately and lose the low word's carries, :231-232;
  * orc_gemm_mod_ref_quirk restates that arithmetic so that the difference can be shown on data.)

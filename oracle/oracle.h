@@ -108,6 +108,14 @@ void orc_bconv_hps(const uint64_t *ibase, size_t isz, const uint64_t *obase, siz
 void orc_bfv_add_plain(const orc_ctx *c, size_t size_ql, uint64_t *ct, const uint64_t *plain, uint64_t t, int subtract);
 void orc_bgv_lift_plain(const orc_ctx *c, size_t size_ql, const uint64_t *plain, uint64_t *out);
 void orc_bfv_multiply_plain(const orc_ctx *c, size_t size_ql, uint64_t *ct, size_t cipher_size, const uint64_t *plain, uint64_t t);
+/* ---- BFV multiply, hps_overq (src/evaluate.cu:674-818 overq branches; rns.cu:792-885, 1748-1796; rns_bconv.cu:231-246) ---- */
+typedef struct orc_hpsq orc_hpsq;
+orc_hpsq *orc_hpsq_create(const orc_ctx *c, uint64_t plain_t);
+void orc_hpsq_destroy(orc_hpsq *h);
+size_t orc_hpsq_r_size(const orc_hpsq *h);
+void orc_hpsq_base(const orc_hpsq *h, uint64_t *out);
+/* ct2 == ct1 (same pointer) selects the squaring path, as in the reference */
+void orc_bfv_multiply_hps_overq(const orc_hpsq *h, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst);
 void orc_hoisting(const orc_tool *t, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                   const uint64_t *const *const *glk, int scheme);
 /* build-defined: sum_e w_e (.) rotate_e(ct), weights over [Q_l || P] in NTT form (BASELINE config 5) */

@@ -98,6 +98,13 @@ def lib(path=None):
     L.orc_hps_r_size.argtypes = [C.c_void_p]
     L.orc_hps_base.argtypes = [C.c_void_p, u64p]
     L.orc_bfv_multiply_hps.argtypes = [C.c_void_p, u64p, u64p, u64p]
+    L.orc_hpsq_create.restype = C.c_void_p
+    L.orc_hpsq_create.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_hpsq_destroy.argtypes = [C.c_void_p]
+    L.orc_hpsq_r_size.restype = C.c_size_t
+    L.orc_hpsq_r_size.argtypes = [C.c_void_p]
+    L.orc_hpsq_base.argtypes = [C.c_void_p, u64p]
+    L.orc_bfv_multiply_hps_overq.argtypes = [C.c_void_p, u64p, u64p, u64p]
     L.orc_behz_create.restype = C.c_void_p
     L.orc_behz_create.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_behz_destroy.argtypes = [C.c_void_p]
@@ -383,6 +390,34 @@ class Hps:
         b = np.ascontiguousarray(ct2, dtype=np.uint64).reshape(-1)
         out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
         self.L.orc_bfv_multiply_hps(self.h, _p(a), _p(b), _p(out))
+        return out.reshape(3, c.size_q, c.n)
+
+
+class HpsOverQ:
+    """BFV multiply, hps_overq variant (mul_tech_type::hps_overq, no levels dropped; src/evaluate.cu:674-818)."""
+
+    def __init__(self, ctx, plain_t):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = self.L.orc_hpsq_create(ctx.h, int(plain_t))
+        if not self.h:
+            raise ValueError("cannot set up the HPS bases")
+        self.size_r = self.L.orc_hpsq_r_size(self.h)
+        r = np.zeros(self.size_r, dtype=np.uint64)
+        self.L.orc_hpsq_base(self.h, _p(r))
+        self.r = [int(v) for v in r]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_hpsq_destroy(self.h)
+            self.h = None
+
+    def multiply(self, ct1, ct2):
+        """`ct2 is ct1` selects the reference's squaring path (evaluate.cu:720-731)."""
+        c = self.ctx
+        a = np.ascontiguousarray(ct1, dtype=np.uint64).reshape(-1)
+        b = a if ct2 is ct1 else np.ascontiguousarray(ct2, dtype=np.uint64).reshape(-1)
+        out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
+        self.L.orc_bfv_multiply_hps_overq(self.h, _p(a), _p(b), _p(out))
         return out.reshape(3, c.size_q, c.n)
 
 

@@ -197,6 +197,53 @@ __global__ __launch_bounds__(256) void hps_scale_round_wide_kernel(const ScaleRo
     }
 }
 
+// scaleAndRound_HPS_QlRl_Ql (src/rns.cu:1748-1796): [Q || Rl] coefficient form -> base Q, scaled by t / Rl and rounded;
+// the carry alpha is reduced in place across the Q limbs exactly as :1783 does.
+struct ScaleRoundQArgs {
+    u64 *dst;                // [Q][N]
+    const u64 *src;          // [Q + Rl][N]
+    const double *frac;      // [Rl]
+    const u64 *tab;          // [Q][Rl + 1]
+    const DModulus *mod;
+    uint32_t size_q, size_r, n;
+};
+template <int RPAD>   // RPAD >= size_r: the Rl residues of the coefficient stay in registers across the Q limbs (0 = re-read)
+__global__ __launch_bounds__(256) void hps_scale_round_q_kernel(const ScaleRoundQArgs k) {
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    const u64 *src_r = k.src + (size_t)k.size_q * k.n + coeff;
+    u64 x[RPAD ? RPAD : 1];
+    double nu = 0.5;
+    if (RPAD) {
+#pragma unroll
+        for (int j = 0; j < RPAD; j++) {
+            x[j] = 0;
+            if (j < (int)k.size_r) {
+                x[j] = src_r[(size_t)j * k.n];
+                nu = __builtin_fma((double)x[j], k.frac[j], nu);
+            }
+        }
+    } else {
+        for (uint32_t j = 0; j < k.size_r; j++) nu = __builtin_fma((double)src_r[(size_t)j * k.n], k.frac[j], nu);
+    }
+    u64 alpha = (u64)nu;
+    for (uint32_t i = 0; i < k.size_q; i++) {
+        const DModulus m = k.mod[i];
+        const u64 *tab = k.tab + (size_t)i * (k.size_r + 1);
+        u64 lo = 0, hi = 0;
+        if (RPAD) {
+#pragma unroll
+            for (int j = 0; j < RPAD; j++)
+                if (j < (int)k.size_r) mac128(x[j], tab[j], lo, hi);
+        } else {
+            for (uint32_t j = 0; j < k.size_r; j++) mac128(src_r[(size_t)j * k.n], tab[j], lo, hi);
+        }
+        mac128(k.src[(size_t)i * k.n + coeff], tab[k.size_r], lo, hi);
+        const u64 v = barrett128(lo, hi, m);
+        alpha = barrett64(alpha, m.value, m.ratio1);
+        k.dst[(size_t)i * k.n + coeff] = add_mod(v, alpha, m.value);
+    }
+}
+
 void launch_bconv_phase1(Context &c, const BConv &conv, u64 *dst, const u64 *src, hipStream_t s);
 
 // DBaseConverter::bConv_HPS on one polynomial: dst [osz][N] <- src [isz][N]
@@ -284,6 +331,55 @@ extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, cons
         else hipLaunchKernelGGL(hps_scale_round_wide_kernel, dim3(n / 256), dim3(256), 0, s, ka);
         check_launch();
         bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, dst + p * qn, tmp, y, s);
+    }
+    PHA_API_END
+}
+
+// bfv_multiply_hps with mul_tech hps_overq and no levels dropped (src/evaluate.cu:674-818: the overq branches :745-751,
+// :790-792).  ct1 == ct2 (the same pointer) is the reference's squaring shortcut (:720-731), kept as it is.
+extern "C" int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
+                                          void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    HpsQ &h = c.hps_overq();
+    hipStream_t s = as_stream(stream);
+    const uint32_t n = (uint32_t)c.n, sq = h.size_q, sr = h.size_r, sqr = sq + sr;
+    const size_t qn = (size_t)sq * n, rn = (size_t)sr * n, qrn = (size_t)sqr * n;
+    const bool square = ct1 == ct2;
+    // scratch: x1 [3][Q+Rl] | x2 [2][Q+Rl] | y [max(Q, Rl)]
+    u64 *base = c.scratch(stream, 5 * qrn + std::max(qn, rn));
+    u64 *x1 = base, *x2 = x1 + 3 * qrn, *y = x2 + 2 * qrn;
+    for (uint32_t p = 0; p < 2; p++) {   // first operand: exact lift Q -> Q || Rl (:702-716)
+        PHA_HIP(hipMemcpyAsync(x1 + p * qrn, ct1 + p * qn, qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x1 + p * qrn + qn, ct1 + p * qn, y, s);
+    }
+    if (!square) {
+        for (uint32_t p = 0; p < 2; p++) {   // second operand: Q -> Rl by bConv_BEHZ_var1, then Rl -> Q exactly (:745-751)
+            u64 *xr = x2 + p * qrn + qn;
+            launch_bconv(c, h.d_q_to_r_var1.p, 0, 1, sq, sr, false, xr, 0, ct2 + p * qn, 0, nullptr, true, s);
+            bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, x2 + p * qrn, xr, y, s);
+        }
+    }
+    NttExtra xf;
+    xf.batch = 2;
+    xf.poly_stride = qrn;
+    ntt_forward(c, x1, x1, x1, qr_sel(sq, sr, h.aux0), EPI_FWD_CANON, xf, s);
+    if (!square) ntt_forward(c, x2, x2, x2, qr_sel(sq, sr, h.aux0), EPI_FWD_CANON, xf, s);
+    const u64 *rhs = square ? x1 : x2;
+    launch_tensor(c, x1, rhs, x1, sq, 0, square, s, sqr);
+    launch_tensor(c, x1 + qn, rhs + qn, x1 + qn, sr, h.aux0, square, s, sqr);
+    NttExtra xi;
+    xi.batch = 3;
+    xi.poly_stride = qrn;
+    ntt_inverse(c, x1, x1, x1, qr_sel(sq, sr, h.aux0), EPI_INV_CANON, xi, s);
+    for (uint32_t p = 0; p < 3; p++) {   // scale by t / Rl and round straight into base Q (:790-792)
+        ScaleRoundQArgs ka{dst + p * qn, x1 + p * qrn, h.frac.p, h.div_mod_q.p, c.d_mod.p, sq, sr, n};
+        if (sr <= 8) hipLaunchKernelGGL(hps_scale_round_q_kernel<8>, dim3(n / 256), dim3(256), 0, s, ka);
+        else if (sr <= 16) hipLaunchKernelGGL(hps_scale_round_q_kernel<16>, dim3(n / 256), dim3(256), 0, s, ka);
+        else if (sr <= 32) hipLaunchKernelGGL(hps_scale_round_q_kernel<32>, dim3(n / 256), dim3(256), 0, s, ka);
+        else hipLaunchKernelGGL(hps_scale_round_q_kernel<0>, dim3(n / 256), dim3(256), 0, s, ka);
+        check_launch();
     }
     PHA_API_END
 }

@@ -387,6 +387,96 @@ Hps &Context::hps() {
     return *hps_tool;
 }
 
+// DRNSTool constructor, hps_overq part (src/rns.cu:792-885) at the top data level.
+HpsQ &Context::hps_overq() {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (hpsq_tool) return *hpsq_tool;
+    }
+    Hps &base = hps();                       // its base R starts with the |Q| primes of Rl (same get_primes_below walk)
+    std::lock_guard<std::mutex> lk(mu);
+    if (hpsq_tool) return *hpsq_tool;
+    auto h = std::make_unique<HpsQ>();
+    const uint32_t sq = size_q, sr = size_q;
+    h->size_q = sq;
+    h->size_r = sr;
+    h->aux0 = base.aux0;
+    std::vector<uint32_t> iq, ir;
+    std::vector<u64> r(sr);
+    for (uint32_t i = 0; i < sq; i++) iq.push_back(i);
+    for (uint32_t j = 0; j < sr; j++) { ir.push_back(h->aux0 + j); r[j] = primes[h->aux0 + j]; }
+    build_bconv(*this, h->q_to_r, iq, ir);
+    build_bconv(*this, h->r_to_q, ir, iq);
+    build_bconv_var1(*this, h->q_to_r_var1, iq, ir);
+    describe_conv(h->q_to_r, h->d_q_to_r);
+    describe_conv(h->r_to_q, h->d_r_to_q);
+    describe_conv(h->q_to_r_var1, h->d_q_to_r_var1);
+    auto prod_mod = [&](const std::vector<uint32_t> &rows_, u64 m) {
+        u64 p = 1 % m;
+        for (uint32_t row : rows_) p = h_mulmod(p, primes[row] % m, m);
+        return p;
+    };
+    {
+        std::vector<double> qi(sq), ri(sr);
+        for (uint32_t i = 0; i < sq; i++) qi[i] = 1.0 / (double)primes[i];
+        for (uint32_t j = 0; j < sr; j++) ri[j] = 1.0 / (double)r[j];
+        h->q_inv.upload(qi);
+        h->r_inv.upload(ri);
+        std::vector<u64> aq((size_t)(sq + 1) * sr), ar((size_t)(sr + 1) * sq);
+        for (uint32_t j = 0; j < sr; j++) {
+            const u64 qm = prod_mod(iq, r[j]);
+            for (uint32_t a = 0; a <= sq; a++) aq[(size_t)a * sr + j] = h_mulmod(a, qm, r[j]);
+        }
+        for (uint32_t i = 0; i < sq; i++) {
+            const u64 rm = prod_mod(ir, primes[i]);
+            for (uint32_t a = 0; a <= sr; a++) ar[(size_t)a * sq + i] = h_mulmod(a, rm, primes[i]);
+        }
+        h->alpha_q_mod_r.upload(aq);
+        h->alpha_r_mod_q.upload(ar);
+    }
+    {   // t/Rl scale-and-round tables (rns.cu:836-885): x_i = t * Q * (S / s_i)^-1 mod s_i as big integers, S = Q || Rl
+        std::vector<u64> s_all(primes.begin(), primes.begin() + sq);
+        s_all.insert(s_all.end(), r.begin(), r.end());
+        std::vector<double> frac(sr);
+        std::vector<u64> tab((size_t)sq * (sr + 1));
+        auto mul_small = [](std::vector<u64> &b, u64 m) {
+            u64 carry = 0;
+            for (auto &w : b) { const u128 t = (u128)w * m + carry; w = (u64)t; carry = (u64)(t >> 64); }
+            if (carry) b.push_back(carry);
+        };
+        auto mod_small = [](const std::vector<u64> &b, u64 m) {
+            u128 rem = 0;
+            for (size_t i = b.size(); i-- > 0;) rem = ((rem << 64) | b[i]) % m;
+            return (u64)rem;
+        };
+        auto div_small = [](std::vector<u64> &b, u64 m) {
+            u128 rem = 0;
+            for (size_t i = b.size(); i-- > 0;) { const u128 cur = (rem << 64) | b[i]; b[i] = (u64)(cur / m); rem = cur % m; }
+        };
+        for (uint32_t i = 0; i < sq + sr; i++) {
+            u64 hat = 1;
+            for (uint32_t k = 0; k < sq + sr; k++)
+                if (k != i) hat = h_mulmod(hat, s_all[k] % s_all[i], s_all[i]);
+            const u64 shat_inv = h_invmod(hat, s_all[i]);
+            std::vector<u64> x{1};
+            for (uint32_t k = 0; k < sq; k++) mul_small(x, primes[k]);
+            mul_small(x, plain_t);
+            mul_small(x, shat_inv);
+            if (i >= sq) frac[i - sq] = (double)mod_small(x, s_all[i]) / (double)s_all[i];
+            div_small(x, s_all[i]);
+            if (i >= sq) {
+                for (uint32_t l = 0; l < sq; l++) tab[(size_t)l * (sr + 1) + (i - sq)] = mod_small(x, primes[l]);
+            } else {
+                tab[(size_t)i * (sr + 1) + sr] = mod_small(x, primes[i]);
+            }
+        }
+        h->frac.upload(frac);
+        h->div_mod_q.upload(tab);
+    }
+    hpsq_tool = std::move(h);
+    return *hpsq_tool;
+}
+
 // DRNSTool constructor, BEHZ part (src/rns.cu:392-560).  Needs the plain modulus; top data level only.
 Behz &Context::behz() {
     std::lock_guard<std::mutex> lk(mu);
@@ -483,30 +573,13 @@ Behz &Context::behz() {
 }
 
 // q-hat_i^-1 mod q_i and q-hat_i mod p_j for an (ibase -> obase) converter: src/host/rns.cu:282-337,438-457
-void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op) {
+// upload converter constants: hat_inv [isz] (value, Shoup), mat [osz][isz]
+static void upload_bconv(BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
+                         const std::vector<u64x2> &hat_inv, const std::vector<u64> &mat) {
     b.isz = (uint32_t)ip.size();
     b.osz = (uint32_t)op.size();
     b.iprime = ip;
     b.oprime = op;
-    std::vector<u64x2> hat_inv(b.isz);
-    for (uint32_t i = 0; i < b.isz; i++) {
-        const u64 qi = c.primes[ip[i]];
-        u64 h = 1;
-        for (uint32_t k = 0; k < b.isz; k++)
-            if (k != i) h = h_mulmod(h, c.primes[ip[k]] % qi, qi);
-        const u64 inv = h_invmod(h, qi);
-        hat_inv[i] = u64x2{inv, h_shoup(inv, qi)};
-    }
-    std::vector<u64> mat((size_t)b.osz * b.isz);
-    for (uint32_t j = 0; j < b.osz; j++) {
-        const u64 pj = c.primes[op[j]];
-        for (uint32_t i = 0; i < b.isz; i++) {
-            u64 h = 1;
-            for (uint32_t k = 0; k < b.isz; k++)
-                if (k != i) h = h_mulmod(h, c.primes[ip[k]] % pj, pj);
-            mat[(size_t)j * b.isz + i] = h;
-        }
-    }
     std::vector<uint32_t> mat30((size_t)b.osz * kBcRowPad * 2, 0u);
     if (b.isz <= (uint32_t)kBcRowPad)
         for (uint32_t j = 0; j < b.osz; j++)
@@ -520,6 +593,52 @@ void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const st
     b.mat30.upload(mat30);
     b.d_iprime.upload(ip);
     b.d_oprime.upload(op);
+}
+
+void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op) {
+    const uint32_t isz = (uint32_t)ip.size(), osz = (uint32_t)op.size();
+    std::vector<u64x2> hat_inv(isz);
+    for (uint32_t i = 0; i < isz; i++) {
+        const u64 qi = c.primes[ip[i]];
+        u64 h = 1;
+        for (uint32_t k = 0; k < isz; k++)
+            if (k != i) h = h_mulmod(h, c.primes[ip[k]] % qi, qi);
+        const u64 inv = h_invmod(h, qi);
+        hat_inv[i] = u64x2{inv, h_shoup(inv, qi)};
+    }
+    std::vector<u64> mat((size_t)osz * isz);
+    for (uint32_t j = 0; j < osz; j++) {
+        const u64 pj = c.primes[op[j]];
+        for (uint32_t i = 0; i < isz; i++) {
+            u64 h = 1;
+            for (uint32_t k = 0; k < isz; k++)
+                if (k != i) h = h_mulmod(h, c.primes[ip[k]] % pj, pj);
+            mat[(size_t)j * isz + i] = h;
+        }
+    }
+    upload_bconv(b, ip, op, hat_inv, mat);
+}
+
+// bConv_BEHZ_var1 (src/rns_bconv.cu:231-246, constants src/host/rns.cu:469-496): the quotient-style conversion
+// x -> about P * x / Q in base P: phase 1 multiplies by -P * qhat_i^-1 mod q_i, the matrix is q_i^-1 mod p_j.
+void build_bconv_var1(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op) {
+    const uint32_t isz = (uint32_t)ip.size(), osz = (uint32_t)op.size();
+    std::vector<u64x2> hat_inv(isz);
+    for (uint32_t i = 0; i < isz; i++) {
+        const u64 qi = c.primes[ip[i]];
+        u64 h = 1, pm = 1;
+        for (uint32_t k = 0; k < isz; k++)
+            if (k != i) h = h_mulmod(h, c.primes[ip[k]] % qi, qi);
+        for (uint32_t j = 0; j < osz; j++) pm = h_mulmod(pm, c.primes[op[j]] % qi, qi);
+        const u64 v = qi - h_mulmod(pm, h_invmod(h, qi), qi);
+        hat_inv[i] = u64x2{v, h_shoup(v, qi)};
+    }
+    std::vector<u64> mat((size_t)osz * isz);
+    for (uint32_t j = 0; j < osz; j++) {
+        const u64 pj = c.primes[op[j]];
+        for (uint32_t i = 0; i < isz; i++) mat[(size_t)j * isz + i] = h_invmod(c.primes[ip[i]] % pj, pj);
+    }
+    upload_bconv(b, ip, op, hat_inv, mat);
 }
 
 Tool &Context::tool(uint32_t size_ql) {
@@ -769,6 +888,7 @@ int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus) {
         c.tools.clear();
         c.behz_tool.reset();   // (their auxiliary table rows stay; a later tool appends fresh ones)
         c.hps_tool.reset();
+        c.hpsq_tool.reset();
         c.plain_t = plain_modulus;
     }
     PHA_API_END

@@ -159,6 +159,18 @@ struct Hps {
     DevBuf<u64> div_mod_r;                       // [R][Q + 1] tRSHatInvModsDivsModr
 };
 
+// ---- BFV HPS-over-Q multiply (mul_tech hps_overq, no levels dropped; src/rns.cu:792-885): base Rl = the first |Q|
+//      primes below the smallest q_i = the first |Q| rows of the HPS base R
+struct HpsQ {
+    uint32_t size_q = 0, size_r = 0, aux0 = 0;
+    BConv q_to_r, r_to_q, q_to_r_var1;           // exact Q -> Rl, exact Rl -> Q, quotient-style Q -> Rl (bConv_BEHZ_var1)
+    DevBuf<BConvDev> d_q_to_r, d_r_to_q, d_q_to_r_var1;
+    DevBuf<double> q_inv, r_inv;
+    DevBuf<u64> alpha_q_mod_r, alpha_r_mod_q;
+    DevBuf<double> frac;                         // [Rl]        tQlSlHatInvModsDivsFrac
+    DevBuf<u64> div_mod_q;                       // [Q][Rl + 1] tQlSlHatInvModsDivsModq
+};
+
 // ---- scratch arena: one per (context, stream), grown on demand, never freed until destroy ----
 struct Arena {
     DevBuf<u64> buf;
@@ -192,6 +204,7 @@ struct Context {
     std::map<uint32_t, std::unique_ptr<Tool>> tools;
     std::unique_ptr<Behz> behz_tool;
     std::unique_ptr<Hps> hps_tool;
+    std::unique_ptr<HpsQ> hpsq_tool;
     uint32_t rows = 0;  // table rows = size_qp + auxiliary moduli
     std::map<void *, std::unique_ptr<Arena>> arenas;
     std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
@@ -199,6 +212,7 @@ struct Context {
     Tool &tool(uint32_t size_ql);
     Behz &behz();                                             // built on first use; needs the plain modulus
     Hps &hps();
+    HpsQ &hps_overq();
     uint32_t add_aux_moduli(const std::vector<u64> &ntt_primes, u64 plain_modulus_like);
     u64 *scratch(void *stream, size_t words);
     const uint32_t *galois_table(uint32_t elt);
@@ -257,6 +271,7 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
                   const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0);
 // converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)
 void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
+void build_bconv_var1(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
 void describe_conv(const BConv &b, DevBuf<BConvDev> &out);
 void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,
                    hipStream_t s, size_t poly_limbs = 0);

@@ -700,11 +700,11 @@ inline void add_many(const PhantomContext &context, const std::vector<PhantomCip
 inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2) {
     const auto &parms = context.get_context_data(encrypted1.chain_index()).parms();
     if (parms.scheme() == scheme_type::bfv) {
-        // bfv_multiply (src/evaluate.cu:962-982) -> bfv_multiply_behz (:447-548) or bfv_multiply_hps with mul_tech hps
-        // (:674-818); the hps_overq variants are not built
+        // bfv_multiply (src/evaluate.cu:962-982) -> bfv_multiply_behz (:447-548) or bfv_multiply_hps with mul_tech hps /
+        // hps_overq (:674-818); hps_overq_leveled (levels dropped inside the multiply) is not built
         const auto mul_tech = parms.mul_tech();
-        if (mul_tech != mul_tech_type::behz && mul_tech != mul_tech_type::hps)
-            throw std::invalid_argument("only the BEHZ and HPS variants of BFV multiply are on the accelerated path");
+        if (mul_tech != mul_tech_type::behz && mul_tech != mul_tech_type::hps && mul_tech != mul_tech_type::hps_overq)
+            throw std::invalid_argument("only the BEHZ, HPS and HPS-over-Q variants of BFV multiply are on the accelerated path");
         if (encrypted1.is_ntt_form() || encrypted2.is_ntt_form())
             throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
         if (encrypted1.chain_index() != encrypted2.chain_index())
@@ -718,6 +718,8 @@ inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &e
         auto out = util::make_cuda_auto_ptr<uint64_t>(3 * L * n, s);
         if (mul_tech == mul_tech_type::behz)
             util::check_pha(pha_bfv_multiply_behz(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
+        else if (mul_tech == mul_tech_type::hps_overq)
+            util::check_pha(pha_bfv_multiply_hps_overq(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
         else
             util::check_pha(pha_bfv_multiply_hps(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
         encrypted1.resize(context, encrypted1.chain_index(), 3, s);

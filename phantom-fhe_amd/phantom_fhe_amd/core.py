@@ -280,6 +280,11 @@ class PhantomContext:
         """bfv_multiply_hps, mul_tech hps (src/evaluate.cu:674-818): same shapes as bfv_multiply_behz."""
         _lib.check(self._L.pha_bfv_multiply_hps(self._h, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
 
+    def bfv_multiply_hps_overq(self, ct1, ct2, dst):
+        """bfv_multiply_hps, mul_tech hps_overq without dropped levels (src/evaluate.cu:674-818); passing the same
+        tensor twice takes the reference's squaring shortcut."""
+        _lib.check(self._L.pha_bfv_multiply_hps_overq(self._h, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
+
     def batched_modular_gemm(self, C, A, B, m, n, k, batch, mod_start=0):
         """C[z] = A[z] @ B[z] mod q_{mod_start + z}, row-major [batch][m][k] x [batch][k][n] (benchmark/matmul_bench.cu)."""
         _lib.check(self._L.pha_batched_modular_gemm(self._h, _ptr(C), n, _ptr(A), k, _ptr(B), n, m, n, k, batch, mod_start,

@@ -492,6 +492,29 @@ int main() {
         hprod.store_to_host(got3.data());
         REQUIRE(got3 == r3);
         orc_hps_destroy(oh);
+        // mul_tech hps_overq on a third context
+        EncryptionParameters qp_ = fp;
+        qp_.set_mul_tech(mul_tech_type::hps_overq);
+        PhantomContext qctx(qp_);
+        orc_hpsq *oq = orc_hpsq_create(oc, 65537);
+        REQUIRE(oq != nullptr);
+        PhantomCiphertext k1, k2;
+        k1.load_from_host(qctx, 1, 2, h1.data());
+        k2.load_from_host(qctx, 1, 2, h2.data());
+        k1.set_ntt_form(false);
+        k2.set_ntt_form(false);
+        PhantomCiphertext qprod = multiply(qctx, k1, k2);
+        orc_bfv_multiply_hps_overq(oq, h1.data(), h2.data(), r3.data());
+        qprod.store_to_host(got3.data());
+        REQUIRE(got3 == r3);
+        orc_hpsq_destroy(oq);
+        EncryptionParameters lp = fp;
+        lp.set_mul_tech(mul_tech_type::hps_overq_leveled);
+        PhantomContext lctx(lp);
+        PhantomCiphertext l1;
+        l1.load_from_host(lctx, 1, 2, h1.data());
+        l1.set_ntt_form(false);
+        REQUIRE(throws_invalid([&] { PhantomCiphertext c = l1; multiply_inplace(lctx, c, l1); }));
     }
     phantom::util::check_hip(hipDeviceSynchronize(), "sync");
     orc_tool_destroy(tool);

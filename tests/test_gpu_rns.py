@@ -593,6 +593,35 @@ def test_bfv_multiply_hps(name, plain_t, gpu):
     assert np.array_equal(P.to_host(dst), hps.multiply(ct1, ct2))
 
 
+@pytest.mark.parametrize("name,plain_t", [("c1_bfv4096", 65537), ("bfv13_50", 65537), ("hyb12_a2", 1032193), ("c4_bfv15", 1032193)])
+def test_bfv_multiply_hps_overq(name, plain_t, gpu):
+    """bfv_multiply_hps with mul_tech hps_overq (src/evaluate.cu:674-818, overq branches), incl. the reference's
+    squaring shortcut (same buffer on both sides), vs the oracle; then hps on the same context (shared base R rows)."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    ctx.set_plain_modulus(plain_t)
+    hq = O.HpsOverQ(oc, plain_t)
+    r = rng_for(141)
+    ct1 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct2 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct2[:, :, :32] = np.array(primes[:size_q], dtype=np.uint64)[None, :, None] - 1       # extreme residues
+    ct2[:, :, 32:64] = 0
+    dst = P.to_device(np.zeros((3, size_q, n), dtype=np.uint64), gpu)
+    d1, d2 = P.to_device(ct1, gpu), P.to_device(ct2, gpu)
+    ctx.bfv_multiply_hps_overq(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), hq.multiply(ct1, ct2))
+    ctx.bfv_multiply_hps_overq(d2, d1, dst)
+    assert np.array_equal(P.to_host(dst), hq.multiply(ct2, ct1))          # not symmetric: only the second operand is switched
+    ctx.bfv_multiply_hps_overq(d2, d2, dst)
+    assert np.array_equal(P.to_host(dst), hq.multiply(ct2, ct2))          # squaring shortcut
+    ctx.bfv_multiply_hps(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), O.Hps(oc, plain_t).multiply(ct1, ct2))
+    assert np.array_equal(P.to_host(d1), ct1) and np.array_equal(P.to_host(d2), ct2)
+
+
 @pytest.mark.parametrize("bits,m,n,k,batch", [(50, 256, 256, 256, 3), (50, 96, 40, 72, 2), (60, 128, 64, 100, 2), (36, 64, 32, 16, 1)])
 def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
     """matmul_bench shape (256^3 per 50-bit modulus) and ragged shapes, wide (60-bit) and narrow paths, vs the oracle;

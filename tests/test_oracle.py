@@ -427,6 +427,62 @@ def test_bfv_hps_multiply_decrypts_to_the_product(name, plain_t):
         assert got == w % plain_t, k
 
 
+@pytest.mark.parametrize("name,plain_t", [("c1_bfv4096", 65537), ("bfv13_50", 65537), ("bfv13_50", 1032193)])
+def test_bfv_hps_overq_multiply_decrypts_to_the_product(name, plain_t):
+    """BFV hps_overq multiply (src/evaluate.cu:674-818, overq branches) pinned by its meaning: the product decrypts to
+    m1 * m2 mod t; base Rl has |Q| primes."""
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    q = [int(p) for p in primes[:size_q]]
+    oc = oracle_ctx(name)
+    hq = O.HpsOverQ(oc, plain_t)
+    assert hq.size_r == size_q and hq.r == O.Hps(oc, plain_t).r[:size_q]
+    r = rng_for(79)
+    Q = 1
+    for p in q:
+        Q *= p
+    delta = Q // plain_t
+    s_small = r.integers(-1, 2, n)
+    sk_ntt = oc.nwt_forward(np.stack([(s_small % p).astype(np.uint64) for p in q]), size_q, 0)
+    s2 = oc.multiply(sk_ntt, sk_ntt, size_q)
+
+    def encrypt(m):
+        a = uniform_poly(r, q, n)
+        e = r.integers(-3, 4, n)
+        dm = np.stack([np.array([(delta * int(v) + int(ev)) % p for v, ev in zip(m, e)], dtype=np.uint64) for p in q])
+        a_s = oc.nwt_backward(oc.multiply(oc.nwt_forward(a, size_q, 0), sk_ntt, size_q), size_q)
+        return np.stack([oc.sub(dm, a_s, size_q), a])
+
+    big = int(O.get_primes(n, 60, 1)[0])
+    bc = O.Ctx(log_n, [big], 0)
+
+    def check(d, ma, mb):
+        d_ntt = [oc.nwt_forward(d[i], size_q, 0) for i in range(3)]
+        phase = oc.add(oc.add(d_ntt[0], oc.multiply(d_ntt[1], sk_ntt, size_q), size_q), oc.multiply(d_ntt[2], s2, size_q), size_q)
+        phase = oc.nwt_backward(phase, size_q)
+        pm = bc.nwt_backward(bc.multiply(bc.nwt_forward(ma.astype(np.uint64).reshape(1, n), 1, 0),
+                                         bc.nwt_forward(mb.astype(np.uint64).reshape(1, n), 1, 0), 1), 1)[0]
+        for k in range(0, n, 61):
+            v, _ = crt_compose([phase[l, k] for l in range(size_q)], q)
+            got = ((v * plain_t + Q // 2) // Q) % plain_t
+            w = int(pm[k])
+            w = w - big if w > big // 2 else w
+            assert got == w % plain_t, k
+
+    m1, m2 = r.integers(0, plain_t, n), r.integers(0, plain_t, n)
+    c1, c2 = encrypt(m1), encrypt(m2)
+    check(hq.multiply(c1, c2), m1, m2)
+    check(hq.multiply(c1, c1.copy()), m1, m1)
+    # The reference's squaring shortcut (same object on both sides, evaluate.cu:720-731) lifts BOTH factors exactly and
+    # still scales by t / Rl (scaleAndRound_HPS_QlRl_Ql), i.e. it returns (Q / Rl) times the wanted t / Q * c1^2: a
+    # different ciphertext, which does not decrypt to m1^2.  Restated as is; callers that square pass two objects.
+    sq = hq.multiply(c1, c1)
+    assert not np.array_equal(sq, hq.multiply(c1, c1.copy()))
+    with pytest.raises(AssertionError):
+        check(sq, m1, m1)
+
+
 def test_gemm_mod_against_python_ints():
     q = int(O.get_primes(4096, 50, 1)[0])
     r = rng_for(200)
