@@ -295,8 +295,21 @@ int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, const uint64_t 
 /* bfv_multiply_hps with mul_tech_type::hps_overq, no levels dropped (src/evaluate.cu:674-818, overq branches :745-751,
  * :790-792; bConv_BEHZ_var1 src/rns_bconv.cu:231-246; scaleAndRound_HPS_QlRl_Ql src/rns.cu:1748-1796).  Same shapes as
  * pha_bfv_multiply_hps.  ct1 == ct2 (the same pointer) takes the reference's squaring shortcut, whose result is Q / Rl
- * times the product of two separate objects -- kept as the reference has it.  hps_overq_leveled is not built. */
+ * times the product of two separate objects -- kept as the reference has it. */
 int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst, void *stream);
+/* hps_overq_leveled with size_Q - size_Ql levels dropped (mul_tech_type::hps_overq_leveled; constants src/rns.cu:897-975).
+ * How many levels to drop is host arithmetic (FindLevelsToDrop, src/evaluate.cu:551-647; phantom::detail in the host
+ * mirror).  All ciphertext buffers stay over the FULL base Q ([.][Q][N]); size_Ql = size_Q is plain hps_overq.
+ *   pha_bfv_multiply_hps_overq_leveled -- bfv_multiply_hps, leveled branches src/evaluate.cu:709-711, :747-748, :794-795
+ *   pha_scaleAndRound_HPS_Q_Ql         -- DRNSTool::scaleAndRound_HPS_Q_Ql src/rns.cu:1798-1808: [Q][N] -> [Ql][N]
+ *   pha_ExpandCRTBasis_Ql_Q            -- DRNSTool::ExpandCRTBasis_Ql_Q src/rns.cu:1810-1836: [Ql][N] -> [Q][N] (in place allowed)
+ *   pha_keyswitch_inplace_bfv_leveled  -- keyswitch_inplace, leveled branches src/eval_key_switch.cu:142-147, :170-175 */
+int pha_bfv_multiply_hps_overq_leveled(pha_context_t ctx, size_t size_Ql, const uint64_t *ct1, const uint64_t *ct2,
+                                       uint64_t *dst, void *stream);
+int pha_scaleAndRound_HPS_Q_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
+int pha_ExpandCRTBasis_Ql_Q(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
+int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
+                                      const uint64_t *const *rlk, void *stream);
 /* Batched modular GEMM (benchmark/matmul_bench.cu:215-541): for z in [0, batch): C[z] = A[z] * B[z] mod q, q = the
  * context prime mod_start_idx + z; row-major A [batch][m][lda], B [batch][k][ldb], C [batch][m][ldc], inputs
  * canonical.  Exact (the reference's benchmark kernels lose the carries of the low product word, :231-232). */

@@ -1204,18 +1204,24 @@ struct orc_hpsq {
     u64 (*qr_mu)[2];
     u64 *tw, *tws, *itw, *itws, *n_inv, *n_inv_s;
     hpsconv_t q_to_r, r_to_q;
-    bconv_t q_to_r_var1;         /* hat_inv := -Rl * qhat_i^-1 mod q_i, mat[j][i] := q_i^-1 mod r_j */
+    bconv_t q_to_r_var1;         /* hat_inv := -Rl * qhat_i^-1 mod q_i, mat[j][i] := q_i^-1 mod r_j; from the FULL base Q when levels are dropped */
     double *frac;                /* [R]  tQlSlHatInvModsDivsFrac */
     u64 *div_mod_q;              /* [Q][R + 1] tQlSlHatInvModsDivsModq */
+    /* hps_overq_leveled with levels dropped (rns.cu:897-975): size_q above is |Ql|, the chain has size_q_full primes */
+    size_t size_q_full, drop;
+    double *frac_drop;           /* [drop]          QlQHatInvModqDivqFrac */
+    u64 *div_mod_q_drop;         /* [Ql][drop + 1]  QlQHatInvModqDivqModq */
+    u64 *drop_mod_q;             /* [Ql]            prod(dropped primes) mod q_i (base_Ql_to_QlDrop_conv.PModq) */
 };
 size_t orc_hpsq_r_size(const orc_hpsq *h) { return h->size_r; }
 void orc_hpsq_base(const orc_hpsq *h, u64 *out) { memcpy(out, h->r, sizeof(u64) * h->size_r); }
-orc_hpsq *orc_hpsq_create(const orc_ctx *c, u64 plain_t) {
+orc_hpsq *orc_hpsq_create_level(const orc_ctx *c, u64 plain_t, size_t size_ql) {
+    if (size_ql < 1 || size_ql > c->size_q) return NULL;
     orc_hpsq *h = (orc_hpsq *)calloc(1, sizeof(*h));
-    const size_t sq = c->size_q, sr = sq, sqr = sq + sr, n = c->n;
-    h->c = c; h->n = n; h->log_n = c->log_n; h->size_q = sq; h->size_r = sr;
-    u64 minq = c->q[0];
-    for (size_t i = 1; i < sq; i++) if (c->q[i] < minq) minq = c->q[i];
+    const size_t sq = size_ql, sr = sq, sqr = sq + sr, n = c->n, sq_full = c->size_q;
+    h->c = c; h->n = n; h->log_n = c->log_n; h->size_q = sq; h->size_r = sr; h->size_q_full = sq_full; h->drop = sq_full - sq;
+    u64 minq = c->q[0];                                  /* over the FULL chain (rns.cu:581, :800) */
+    for (size_t i = 1; i < sq_full; i++) if (c->q[i] < minq) minq = c->q[i];
     h->r = (u64 *)malloc(sizeof(u64) * sr);
     {
         const u64 factor = 2 * (u64)n, lower = (u64)1 << (63 - __builtin_clzll(minq));
@@ -1237,18 +1243,22 @@ orc_hpsq *orc_hpsq_create(const orc_ctx *c, u64 plain_t) {
     }
     hpsconv_init(&h->q_to_r, c->q, sq, h->r, sr);
     hpsconv_init(&h->r_to_q, h->r, sr, c->q, sq);
-    /* bConv_BEHZ_var1 constants (src/host/rns.cu:469-496): negPQHatInvModq_i = q_i - (P mod q_i) * qhat_i^-1, QInvModp[j][i] = q_i^-1 mod p_j */
-    bconv_init(&h->q_to_r_var1, c->q, sq, h->r, sr);
-    for (size_t i = 0; i < sq; i++) {
-        const u64 qi = c->q[i];
-        const u64 pm = prod_mod(h->r, sr, qi);
-        const u64 v = qi - orc_mulmod(pm, h->q_to_r_var1.hat_inv[i], qi);
-        h->q_to_r_var1.hat_inv[i] = v;
-        h->q_to_r_var1.hat_inv_s[i] = orc_compute_shoup(v, qi);
+    /* bConv_BEHZ_var1 constants (src/host/rns.cu:469-496): negPQHatInvModq_i = q_i - (P mod q_i) * qhat_i^-1, QInvModp[j][i] =
+     * q_i^-1 mod p_j.  With levels dropped the second operand is converted from the FULL base Q (base_Q_to_Rl_conv, rns.cu:911) */
+    {
+        const size_t isz = h->drop ? sq_full : sq;
+        bconv_init(&h->q_to_r_var1, c->q, isz, h->r, sr);
+        for (size_t i = 0; i < isz; i++) {
+            const u64 qi = c->q[i];
+            const u64 pm = prod_mod(h->r, sr, qi);
+            const u64 v = qi - orc_mulmod(pm, h->q_to_r_var1.hat_inv[i], qi);
+            h->q_to_r_var1.hat_inv[i] = v;
+            h->q_to_r_var1.hat_inv_s[i] = orc_compute_shoup(v, qi);
+        }
+        for (size_t j = 0; j < sr; j++)
+            for (size_t i = 0; i < isz; i++) h->q_to_r_var1.mat[j * isz + i] = orc_invmod(c->q[i] % h->r[j], h->r[j]);
     }
-    for (size_t j = 0; j < sr; j++)
-        for (size_t i = 0; i < sq; i++) h->q_to_r_var1.mat[j * sq + i] = orc_invmod(c->q[i] % h->r[j], h->r[j]);
-    /* t/Rl scale-and-round tables (rns.cu:836-885): S = Q || Rl, x_i = t * Q * (S/s_i)^-1 mod s_i as big integers */
+    /* t/Rl scale-and-round tables (rns.cu:836-885): S = Ql || Rl, x_i = t * Ql * (S/s_i)^-1 mod s_i as big integers */
     h->frac = (double *)malloc(sizeof(double) * sr);
     h->div_mod_q = (u64 *)malloc(sizeof(u64) * sq * (sr + 1));
     for (size_t i = 0; i < sqr; i++) {
@@ -1268,54 +1278,122 @@ orc_hpsq *orc_hpsq_create(const orc_ctx *c, u64 plain_t) {
         }
         free(x.w);
     }
+    if (h->drop) {
+        /* Ql/Q scale-and-round tables (rns.cu:918-972): x_i = Ql * (Q/q_i)^-1 mod q_i as big integers, i over the full chain */
+        const size_t dr = h->drop;
+        h->frac_drop = (double *)malloc(sizeof(double) * dr);
+        h->div_mod_q_drop = (u64 *)malloc(sizeof(u64) * sq * (dr + 1));
+        h->drop_mod_q = (u64 *)malloc(sizeof(u64) * sq);
+        for (size_t i = 0; i < sq_full; i++) {
+            u64 hat = 1;
+            for (size_t k = 0; k < sq_full; k++) if (k != i) hat = orc_mulmod(hat, c->q[k] % c->q[i], c->q[i]);
+            const u64 qhat_inv = orc_invmod(hat, c->q[i]);
+            big_t x = big_one(sq + 4);
+            for (size_t k = 0; k < sq; k++) big_mul_small(&x, c->q[k]);
+            big_mul_small(&x, qhat_inv);
+            if (i >= sq) h->frac_drop[i - sq] = (double)big_mod_small(&x, c->q[i]) / (double)c->q[i];
+            big_div_small(&x, c->q[i]);
+            if (i >= sq) {
+                for (size_t l = 0; l < sq; l++) h->div_mod_q_drop[l * (dr + 1) + (i - sq)] = big_mod_small(&x, c->q[l]);
+            } else {
+                h->div_mod_q_drop[i * (dr + 1) + dr] = big_mod_small(&x, c->q[i]);
+            }
+            free(x.w);
+        }
+        for (size_t i = 0; i < sq; i++) h->drop_mod_q[i] = prod_mod(c->q + sq, dr, c->q[i]);
+    }
     return h;
 }
+orc_hpsq *orc_hpsq_create(const orc_ctx *c, u64 plain_t) { return orc_hpsq_create_level(c, plain_t, c->size_q); }
 void orc_hpsq_destroy(orc_hpsq *h) {
     if (!h) return;
     free(h->r); free(h->qr); free(h->qr_mu); free(h->tw); free(h->tws); free(h->itw); free(h->itws); free(h->n_inv); free(h->n_inv_s);
-    hpsconv_free(&h->q_to_r); hpsconv_free(&h->r_to_q); bconv_free(&h->q_to_r_var1); free(h->frac); free(h->div_mod_q); free(h);
+    hpsconv_free(&h->q_to_r); hpsconv_free(&h->r_to_q); bconv_free(&h->q_to_r_var1); free(h->frac); free(h->div_mod_q);
+    free(h->frac_drop); free(h->div_mod_q_drop); free(h->drop_mod_q); free(h);
 }
 /* ct2 == ct1 (the same pointer) takes the reference's squaring path: one exact lift, tensor_square (evaluate.cu:720-731).
  * That path still scales by t / Rl, so its result is (Q / Rl) times the wanted one (it does not decrypt to the square);
  * restated as is. */
+/* the scale-and-round kernel shared by scaleAndRound_HPS_QlRl_Ql and scaleAndRound_HPS_Q_Ql (rns.cu:1749-1808):
+ * src = [Ql limbs || extra limbs], dst = [Ql limbs]; alpha is reduced in place across the Ql limbs (:1783) */
+static void hps_scale_round_to_ql(const orc_hpsq *h, const u64 *src, u64 *dst, const double *frac, const u64 *tab, size_t extra) {
+    const size_t n = h->n, sq = h->size_q;
+    for (size_t k = 0; k < n; k++) {
+        double nu = 0.5;
+        for (size_t j = 0; j < extra; j++) nu = fma((double)src[(sq + j) * n + k], frac[j], nu);
+        u64 alpha = (u64)nu;
+        for (size_t i = 0; i < sq; i++) {
+            const u64 qi = h->qr[i];
+            const u64 *row = tab + i * (extra + 1);
+            u128 cur = 0;
+            for (size_t j = 0; j < extra; j++) cur += (u128)src[(sq + j) * n + k] * row[j];
+            cur += (u128)src[i * n + k] * row[extra];
+            const u64 v = barrett128(cur, qi, h->qr_mu[i]);
+            alpha = barrett64(alpha, qi, h->qr_mu[i][1]);
+            dst[i * n + k] = addmod(v, alpha, qi);
+        }
+    }
+}
+/* scaleAndRound_HPS_Q_Ql (rns.cu:1798-1808): [Q][N] -> [Ql][N], scaled by Ql / Q and rounded */
+void orc_hps_scale_q_ql(const orc_hpsq *h, const u64 *src, u64 *dst) {
+    hps_scale_round_to_ql(h, src, dst, h->frac_drop, h->div_mod_q_drop, h->drop);
+}
+/* ExpandCRTBasis_Ql_Q (rns.cu:1810-1836): [Ql][N] -> [Q][N]: times the product of the dropped primes on the Ql limbs,
+ * zero on the dropped limbs; works in place when dst == src (the limb stride is N either way) */
+void orc_hps_expand_ql_q(const orc_hpsq *h, const u64 *src, u64 *dst) {
+    const size_t n = h->n, sq = h->size_q;
+    for (size_t i = 0; i < sq; i++)
+        for (size_t k = 0; k < n; k++) dst[i * n + k] = orc_mulmod(src[i * n + k], h->drop_mod_q[i], h->qr[i]);
+    memset(dst + sq * n, 0, sizeof(u64) * h->drop * n);
+}
+/* bfv_multiply_hps with mul_tech hps_overq (h built at the top level) or hps_overq_leveled with levels dropped (h built at a
+ * lower level: evaluate.cu:709-711, :747-748, :794-795).  Operands and result are over the FULL base Q: [.][Q][N]. */
 void orc_bfv_multiply_hps_overq(const orc_hpsq *h, const u64 *ct1, const u64 *ct2, u64 *dst) {
-    const size_t n = h->n, sq = h->size_q, sr = h->size_r, sqr = sq + sr;
+    const size_t n = h->n, sq = h->size_q, sr = h->size_r, sqr = sq + sr, sqf = h->size_q_full;
     const int square = ct1 == ct2;
-    u64 *x1 = (u64 *)calloc(3 * sqr * n, 8), *x2 = (u64 *)calloc(2 * sqr * n, 8), *y = (u64 *)malloc(sizeof(u64) * sq * n);
+    u64 *x1 = (u64 *)calloc(3 * sqr * n, 8), *x2 = (u64 *)calloc(2 * sqr * n, 8), *y = (u64 *)malloc(sizeof(u64) * sqf * n);
     for (int p = 0; p < 2; p++) {
         u64 *a = x1 + p * sqr * n, *b = x2 + p * sqr * n;
-        memcpy(a, ct1 + p * sq * n, sizeof(u64) * sq * n);
-        hpsconv_apply(&h->q_to_r, a, a + sq * n, n);                           /* evaluate.cu:716 */
+        if (h->drop) orc_hps_scale_q_ql(h, ct1 + p * sqf * n, a);             /* evaluate.cu:709-710 */
+        else memcpy(a, ct1 + p * sq * n, sizeof(u64) * sq * n);
+        hpsconv_apply(&h->q_to_r, a, a + sq * n, n);                           /* :716 */
         for (size_t i = 0; i < sqr; i++) orc_ntt_forward(a + i * n, h->log_n, h->qr[i], h->tw + i * n, h->tws + i * n);
         if (square) { memcpy(b, a, sizeof(u64) * sqr * n); continue; }
-        bconv_mult(&h->q_to_r_var1, ct2 + p * sq * n, y, n);                   /* bConv_BEHZ_var1 :747-748 */
+        bconv_mult(&h->q_to_r_var1, ct2 + p * sqf * n, y, n);                  /* bConv_BEHZ_var1 :745-749 (from the full Q when leveled) */
         bconv_matmul(&h->q_to_r_var1, y, b + sq * n, n, (size_t)-1, 0);
         hpsconv_apply(&h->r_to_q, b + sq * n, b, n);                           /* :750 */
         for (size_t i = 0; i < sqr; i++) orc_ntt_forward(b + i * n, h->log_n, h->qr[i], h->tw + i * n, h->tws + i * n);
     }
     tensor_generic(x1, x2, x1, h->qr, h->qr_mu, sqr, n);
     for (int p = 0; p < 3; p++) {
-        u64 *x = x1 + p * sqr * n, *out = dst + p * sq * n;
+        u64 *x = x1 + p * sqr * n, *out = dst + p * sqf * n;
         for (size_t i = 0; i < sqr; i++)
             orc_ntt_inverse(x + i * n, h->log_n, h->qr[i], h->itw + i * n, h->itws + i * n, h->n_inv[i], h->n_inv_s[i]);
-        /* scaleAndRound_HPS_QlRl_Ql_kernel rns.cu:1749-1786 */
-        for (size_t k = 0; k < n; k++) {
-            double nu = 0.5;
-            for (size_t j = 0; j < sr; j++) nu = fma((double)x[(sq + j) * n + k], h->frac[j], nu);
-            u64 alpha = (u64)nu;
-            for (size_t i = 0; i < sq; i++) {
-                const u64 qi = h->qr[i];
-                const u64 *tab = h->div_mod_q + i * (sr + 1);
-                u128 cur = 0;
-                for (size_t j = 0; j < sr; j++) cur += (u128)x[(sq + j) * n + k] * tab[j];
-                cur += (u128)x[i * n + k] * tab[sr];
-                const u64 v = barrett128(cur, qi, h->qr_mu[i]);
-                alpha = barrett64(alpha, qi, h->qr_mu[i][1]);                   /* reduced in place, :1783 */
-                out[i * n + k] = addmod(v, alpha, qi);
-            }
-        }
+        hps_scale_round_to_ql(h, x, out, h->frac, h->div_mod_q, sr);           /* scaleAndRound_HPS_QlRl_Ql :790-792 */
+        if (h->drop) orc_hps_expand_ql_q(h, out, out);                         /* :794-795 */
     }
     free(x1); free(x2); free(y);
+}
+/* keyswitch_inplace for BFV under hps_overq_leveled with levels dropped (eval_key_switch.cu:142-147, :170-175): c2 is
+ * scaled from Q down to Ql, switched at that level, and both results are expanded back to Q before they are added.
+ * t is the tool of the level (size_ql = h->size_q); ct [2][Q][N] and c2 [Q][N] are over the full base. */
+void orc_keyswitch_bfv_leveled(const orc_tool *t, const orc_hpsq *h, u64 *ct, const u64 *c2, const u64 *const *evks) {
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp, sqf = h->size_q_full;
+    u64 *c2l = (u64 *)malloc(sizeof(u64) * ql * n);
+    u64 *mu = (u64 *)malloc(sizeof(u64) * t->beta * qlp * n);
+    u64 *cx = (u64 *)malloc(sizeof(u64) * 2 * qlp * n);
+    u64 *full = (u64 *)malloc(sizeof(u64) * sqf * n);
+    orc_hps_scale_q_ql(h, c2, c2l);
+    orc_modup(t, mu, c2l, ORC_BFV);
+    orc_key_switch_inner_prod(t, cx, mu, evks);
+    for (int i = 0; i < 2; i++) {
+        u64 *cxi = cx + (size_t)i * qlp * n;
+        orc_moddown_from_ntt(t, cxi, cxi, ORC_BFV);
+        orc_hps_expand_ql_q(h, cxi, full);
+        orc_add_rns_poly(c, ct + (size_t)i * sqf * n, full, ct + (size_t)i * sqf * n, sqf, 0);
+    }
+    free(c2l); free(mu); free(cx); free(full);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -111,6 +111,12 @@ void orc_bfv_multiply_plain(const orc_ctx *c, size_t size_ql, uint64_t *ct, size
 /* ---- BFV multiply, hps_overq (src/evaluate.cu:674-818 overq branches; rns.cu:792-885, 1748-1796; rns_bconv.cu:231-246) ---- */
 typedef struct orc_hpsq orc_hpsq;
 orc_hpsq *orc_hpsq_create(const orc_ctx *c, uint64_t plain_t);
+/* hps_overq_leveled with size_Q - size_ql levels dropped (src/rns.cu:897-975); size_ql = size_Q is orc_hpsq_create */
+orc_hpsq *orc_hpsq_create_level(const orc_ctx *c, uint64_t plain_t, size_t size_ql);
+void orc_hps_scale_q_ql(const orc_hpsq *h, const uint64_t *src, uint64_t *dst);   /* scaleAndRound_HPS_Q_Ql rns.cu:1798-1808 */
+void orc_hps_expand_ql_q(const orc_hpsq *h, const uint64_t *src, uint64_t *dst);  /* ExpandCRTBasis_Ql_Q rns.cu:1810-1836 */
+/* BFV key switch with levels dropped (eval_key_switch.cu:142-147,170-175); t = orc_tool of that level */
+void orc_keyswitch_bfv_leveled(const orc_tool *t, const orc_hpsq *h, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks);
 void orc_hpsq_destroy(orc_hpsq *h);
 size_t orc_hpsq_r_size(const orc_hpsq *h);
 void orc_hpsq_base(const orc_hpsq *h, uint64_t *out);

@@ -101,6 +101,11 @@ def lib(path=None):
     L.orc_hpsq_create.restype = C.c_void_p
     L.orc_hpsq_create.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_hpsq_destroy.argtypes = [C.c_void_p]
+    L.orc_hpsq_create_level.restype = C.c_void_p
+    L.orc_hpsq_create_level.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t]
+    L.orc_hps_scale_q_ql.argtypes = [C.c_void_p, u64p, u64p]
+    L.orc_hps_expand_ql_q.argtypes = [C.c_void_p, u64p, u64p]
+    L.orc_keyswitch_bfv_leveled.argtypes = [C.c_void_p, C.c_void_p, u64p, u64p, C.POINTER(u64p)]
     L.orc_hpsq_r_size.restype = C.c_size_t
     L.orc_hpsq_r_size.argtypes = [C.c_void_p]
     L.orc_hpsq_base.argtypes = [C.c_void_p, u64p]
@@ -394,11 +399,13 @@ class Hps:
 
 
 class HpsOverQ:
-    """BFV multiply, hps_overq variant (mul_tech_type::hps_overq, no levels dropped; src/evaluate.cu:674-818)."""
+    """BFV multiply, hps_overq variant (mul_tech_type::hps_overq; src/evaluate.cu:674-818), and with size_ql < size_Q
+    the hps_overq_leveled form with size_Q - size_ql levels dropped (src/rns.cu:897-975)."""
 
-    def __init__(self, ctx, plain_t):
+    def __init__(self, ctx, plain_t, size_ql=None):
         self.ctx, self.L = ctx, ctx.L
-        self.h = self.L.orc_hpsq_create(ctx.h, int(plain_t))
+        self.size_ql = ctx.size_q if size_ql is None else int(size_ql)
+        self.h = self.L.orc_hpsq_create_level(ctx.h, int(plain_t), self.size_ql)
         if not self.h:
             raise ValueError("cannot set up the HPS bases")
         self.size_r = self.L.orc_hpsq_r_size(self.h)
@@ -412,13 +419,35 @@ class HpsOverQ:
             self.h = None
 
     def multiply(self, ct1, ct2):
-        """`ct2 is ct1` selects the reference's squaring path (evaluate.cu:720-731)."""
+        """Operands and result over the full base Q; `ct2 is ct1` selects the reference's squaring path."""
         c = self.ctx
         a = np.ascontiguousarray(ct1, dtype=np.uint64).reshape(-1)
         b = a if ct2 is ct1 else np.ascontiguousarray(ct2, dtype=np.uint64).reshape(-1)
         out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
         self.L.orc_bfv_multiply_hps_overq(self.h, _p(a), _p(b), _p(out))
         return out.reshape(3, c.size_q, c.n)
+
+    def scale_q_ql(self, src):
+        """scaleAndRound_HPS_Q_Ql (src/rns.cu:1798-1808): [Q][N] -> [Ql][N]."""
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(self.size_ql * self.ctx.n, dtype=np.uint64)
+        self.L.orc_hps_scale_q_ql(self.h, _p(src), _p(dst))
+        return dst.reshape(self.size_ql, self.ctx.n)
+
+    def expand_ql_q(self, src):
+        """ExpandCRTBasis_Ql_Q (src/rns.cu:1810-1836): [Ql][N] -> [Q][N]."""
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(self.ctx.size_q * self.ctx.n, dtype=np.uint64)
+        self.L.orc_hps_expand_ql_q(self.h, _p(src), _p(dst))
+        return dst.reshape(self.ctx.size_q, self.ctx.n)
+
+    def keyswitch_leveled(self, tool, ct, c2, evks):
+        """BFV key switch with levels dropped (src/eval_key_switch.cu:142-147, 170-175); tool = Tool(ctx, size_ql)."""
+        ct = np.array(ct, dtype=np.uint64, copy=True).reshape(-1)
+        c2 = np.ascontiguousarray(c2, dtype=np.uint64).reshape(-1)
+        arr, keep = tool._evk_ptrs(evks)
+        self.L.orc_keyswitch_bfv_leveled(tool.h, self.h, _p(ct), _p(c2), arr)
+        return ct.reshape(2, self.ctx.size_q, self.ctx.n)
 
 
 class Tool:

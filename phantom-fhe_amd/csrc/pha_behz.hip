@@ -335,29 +335,56 @@ extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, cons
     PHA_API_END
 }
 
-// bfv_multiply_hps with mul_tech hps_overq and no levels dropped (src/evaluate.cu:674-818: the overq branches :745-751,
-// :790-792).  ct1 == ct2 (the same pointer) is the reference's squaring shortcut (:720-731), kept as it is.
-extern "C" int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
-                                          void *stream) {
-    PHA_API_BEGIN
-    if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
-    Context &c = ctx->c;
-    HpsQ &h = c.hps_overq();
+// ExpandCRTBasis_Ql_Q (src/rns.cu:1810-1836): the Ql limbs times the product of the dropped primes, the dropped limbs zero.
+// blockIdx.y over the |Q| limbs of dst; src has |Ql| limbs with the same limb pitch, so dst == src works in place.
+struct ExpandArgs {
+    u64 *dst;
+    const u64 *src;
+    const u64 *c, *c_shoup;
+    const DModulus *mod;
+    uint32_t size_ql, n;
+};
+__global__ __launch_bounds__(256) void hps_expand_kernel(const ExpandArgs k) {
+    const uint32_t i = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = (size_t)i * k.n + coeff;
+    k.dst[id] = i < k.size_ql ? shoup(k.src[id], u64x2{k.c[i], k.c_shoup[i]}, k.mod[i].value) : 0;
+}
+static void launch_scale_round_q(Context &c, u64 *dst, const u64 *src, const double *frac, const u64 *tab, uint32_t size_ql,
+                                 uint32_t extra, hipStream_t s) {
+    const uint32_t n = (uint32_t)c.n;
+    ScaleRoundQArgs ka{dst, src, frac, tab, c.d_mod.p, size_ql, extra, n};
+    if (extra <= 8) hipLaunchKernelGGL(hps_scale_round_q_kernel<8>, dim3(n / 256), dim3(256), 0, s, ka);
+    else if (extra <= 16) hipLaunchKernelGGL(hps_scale_round_q_kernel<16>, dim3(n / 256), dim3(256), 0, s, ka);
+    else if (extra <= 32) hipLaunchKernelGGL(hps_scale_round_q_kernel<32>, dim3(n / 256), dim3(256), 0, s, ka);
+    else hipLaunchKernelGGL(hps_scale_round_q_kernel<0>, dim3(n / 256), dim3(256), 0, s, ka);
+    check_launch();
+}
+static void launch_expand(Context &c, HpsQ &h, u64 *dst, const u64 *src, hipStream_t s) {
+    ExpandArgs ka{dst, src, h.drop_mod_q.p, h.drop_mod_q_shoup.p, c.d_mod.p, h.size_q, (uint32_t)c.n};
+    hipLaunchKernelGGL(hps_expand_kernel, dim3((unsigned)(c.n / 256), h.size_q_full), dim3(256), 0, s, ka);
+    check_launch();
+}
+
+// bfv_multiply_hps with mul_tech hps_overq (h of the top level) or hps_overq_leveled with levels dropped (h of a lower level):
+// src/evaluate.cu:674-818, the overq branches :709-711, :745-751, :790-795.  Operands and result are over the full base Q.
+// ct1 == ct2 (the same pointer) is the reference's squaring shortcut (:720-731), kept as it is.
+static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *ct2, u64 *dst, void *stream) {
     hipStream_t s = as_stream(stream);
-    const uint32_t n = (uint32_t)c.n, sq = h.size_q, sr = h.size_r, sqr = sq + sr;
-    const size_t qn = (size_t)sq * n, rn = (size_t)sr * n, qrn = (size_t)sqr * n;
+    const uint32_t n = (uint32_t)c.n, sq = h.size_q, sr = h.size_r, sqr = sq + sr, sqf = h.size_q_full;
+    const size_t qn = (size_t)sq * n, rn = (size_t)sr * n, qrn = (size_t)sqr * n, qfn = (size_t)sqf * n;
     const bool square = ct1 == ct2;
-    // scratch: x1 [3][Q+Rl] | x2 [2][Q+Rl] | y [max(Q, Rl)]
-    u64 *base = c.scratch(stream, 5 * qrn + std::max(qn, rn));
+    // scratch: x1 [3][Ql+Rl] | x2 [2][Ql+Rl] | y [max(Q, Rl)]
+    u64 *base = c.scratch(stream, 5 * qrn + std::max(qfn, rn));
     u64 *x1 = base, *x2 = x1 + 3 * qrn, *y = x2 + 2 * qrn;
-    for (uint32_t p = 0; p < 2; p++) {   // first operand: exact lift Q -> Q || Rl (:702-716)
-        PHA_HIP(hipMemcpyAsync(x1 + p * qrn, ct1 + p * qn, qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
-        bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x1 + p * qrn + qn, ct1 + p * qn, y, s);
+    for (uint32_t p = 0; p < 2; p++) {   // first operand: (scaled down to Ql when levels are dropped, :709-710) exact lift to Ql || Rl
+        if (h.drop) launch_scale_round_q(c, x1 + p * qrn, ct1 + p * qfn, h.frac_drop.p, h.div_mod_q_drop.p, sq, h.drop, s);
+        else PHA_HIP(hipMemcpyAsync(x1 + p * qrn, ct1 + p * qfn, qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x1 + p * qrn + qn, x1 + p * qrn, y, s);
     }
     if (!square) {
-        for (uint32_t p = 0; p < 2; p++) {   // second operand: Q -> Rl by bConv_BEHZ_var1, then Rl -> Q exactly (:745-751)
+        for (uint32_t p = 0; p < 2; p++) {   // second operand: Q -> Rl by bConv_BEHZ_var1, then Rl -> Ql exactly (:745-751)
             u64 *xr = x2 + p * qrn + qn;
-            launch_bconv(c, h.d_q_to_r_var1.p, 0, 1, sq, sr, false, xr, 0, ct2 + p * qn, 0, nullptr, true, s);
+            launch_bconv(c, h.d_q_to_r_var1.p, 0, 1, h.q_to_r_var1.isz, sr, false, xr, 0, ct2 + p * qfn, 0, nullptr, true, s);
             bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, x2 + p * qrn, xr, y, s);
         }
     }
@@ -373,14 +400,71 @@ extern "C" int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1
     xi.batch = 3;
     xi.poly_stride = qrn;
     ntt_inverse(c, x1, x1, x1, qr_sel(sq, sr, h.aux0), EPI_INV_CANON, xi, s);
-    for (uint32_t p = 0; p < 3; p++) {   // scale by t / Rl and round straight into base Q (:790-792)
-        ScaleRoundQArgs ka{dst + p * qn, x1 + p * qrn, h.frac.p, h.div_mod_q.p, c.d_mod.p, sq, sr, n};
-        if (sr <= 8) hipLaunchKernelGGL(hps_scale_round_q_kernel<8>, dim3(n / 256), dim3(256), 0, s, ka);
-        else if (sr <= 16) hipLaunchKernelGGL(hps_scale_round_q_kernel<16>, dim3(n / 256), dim3(256), 0, s, ka);
-        else if (sr <= 32) hipLaunchKernelGGL(hps_scale_round_q_kernel<32>, dim3(n / 256), dim3(256), 0, s, ka);
-        else hipLaunchKernelGGL(hps_scale_round_q_kernel<0>, dim3(n / 256), dim3(256), 0, s, ka);
-        check_launch();
+    for (uint32_t p = 0; p < 3; p++) {   // scale by t / Rl and round straight into base Ql (:790-792), expand to Q (:794-795)
+        launch_scale_round_q(c, dst + p * qfn, x1 + p * qrn, h.frac.p, h.div_mod_q.p, sq, sr, s);
+        if (h.drop) launch_expand(c, h, dst + p * qfn, dst + p * qfn, s);
     }
+}
+
+extern "C" int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
+                                          void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
+    hps_overq_multiply(ctx->c, ctx->c.hps_overq(), ct1, ct2, dst, stream);
+    PHA_API_END
+}
+
+extern "C" int pha_bfv_multiply_hps_overq_leveled(pha_context_t ctx, size_t size_Ql, const uint64_t *ct1, const uint64_t *ct2,
+                                                  uint64_t *dst, void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
+    if (size_Ql < 1 || size_Ql > ctx->c.size_q) throw std::invalid_argument("RNSBase is invalid");
+    hps_overq_multiply(ctx->c, ctx->c.hps_overq((uint32_t)size_Ql), ct1, ct2, dst, stream);
+    PHA_API_END
+}
+
+extern "C" int pha_scaleAndRound_HPS_Q_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
+    HpsQ &h = c.hps_overq((uint32_t)size_Ql);
+    launch_scale_round_q(c, dst, src, h.frac_drop.p, h.div_mod_q_drop.p, h.size_q, h.drop, as_stream(stream));
+    PHA_API_END
+}
+
+extern "C" int pha_ExpandCRTBasis_Ql_Q(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
+    launch_expand(c, c.hps_overq((uint32_t)size_Ql), dst, src, as_stream(stream));
+    PHA_API_END
+}
+
+// keyswitch_inplace for BFV under hps_overq_leveled with levels dropped (src/eval_key_switch.cu:142-147, :170-175): c2 [Q][N] is
+// scaled down to Ql, switched with the level's DRNSTool, and both halves are expanded to Q before they are added to ct [2][Q][N]
+extern "C" int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
+                                                 const uint64_t *const *rlk, void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !ct || !c2 || !rlk) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
+    HpsQ &h = c.hps_overq((uint32_t)size_Ql);
+    hipStream_t s = as_stream(stream);
+    const size_t n = c.n, qln = size_Ql * n, qfn = (size_t)c.size_q * n;
+    // device buffers of this call: c2 at level l, the level's key-switch result (c0, c1), one expanded polynomial
+    DevBuf<u64> tmp(3 * qln + qfn);
+    u64 *c2l = tmp.p, *res = c2l + qln, *full = res + 2 * qln;
+    launch_scale_round_q(c, c2l, c2, h.frac_drop.p, h.div_mod_q_drop.p, h.size_q, h.drop, s);
+    PHA_HIP(hipMemsetAsync(res, 0, 2 * qln * sizeof(u64), s));
+    const int rc = pha_keyswitch_inplace(ctx, size_Ql, res, c2l, rlk, /*scheme bfv*/ 1, stream);
+    if (rc != 0) throw std::runtime_error(pha_last_error());
+    for (int p = 0; p < 2; p++) {
+        launch_expand(c, h, full, res + (size_t)p * qln, s);
+        launch_add(c, ct + (size_t)p * qfn, full, ct + (size_t)p * qfn, c.size_q, 0, s);
+    }
+    PHA_HIP(hipStreamSynchronize(s));   // tmp is released on return
     PHA_API_END
 }
 

@@ -387,27 +387,37 @@ Hps &Context::hps() {
     return *hps_tool;
 }
 
-// DRNSTool constructor, hps_overq part (src/rns.cu:792-885) at the top data level.
-HpsQ &Context::hps_overq() {
+// DRNSTool constructor, hps_overq part (src/rns.cu:792-885), and for size_ql < |Q| the hps_overq_leveled part with
+// |Q| - size_ql levels dropped (:897-975).
+HpsQ &Context::hps_overq(uint32_t size_ql) {
+    if (size_ql == 0) size_ql = size_q;
+    if (size_ql < 1 || size_ql > size_q) throw std::invalid_argument("RNSBase is invalid");
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (hpsq_tool) return *hpsq_tool;
+        auto it = hpsq_tools.find(size_ql);
+        if (it != hpsq_tools.end()) return *it->second;
     }
-    Hps &base = hps();                       // its base R starts with the |Q| primes of Rl (same get_primes_below walk)
+    Hps &base = hps();                       // its base R starts with the primes of every Rl (same get_primes_below walk)
     std::lock_guard<std::mutex> lk(mu);
-    if (hpsq_tool) return *hpsq_tool;
+    {
+        auto it = hpsq_tools.find(size_ql);
+        if (it != hpsq_tools.end()) return *it->second;
+    }
     auto h = std::make_unique<HpsQ>();
-    const uint32_t sq = size_q, sr = size_q;
+    const uint32_t sq = size_ql, sr = size_ql, drop = size_q - size_ql;
     h->size_q = sq;
     h->size_r = sr;
+    h->size_q_full = size_q;
+    h->drop = drop;
     h->aux0 = base.aux0;
-    std::vector<uint32_t> iq, ir;
+    std::vector<uint32_t> iq, ir, iq_full;
     std::vector<u64> r(sr);
     for (uint32_t i = 0; i < sq; i++) iq.push_back(i);
+    for (uint32_t i = 0; i < size_q; i++) iq_full.push_back(i);
     for (uint32_t j = 0; j < sr; j++) { ir.push_back(h->aux0 + j); r[j] = primes[h->aux0 + j]; }
     build_bconv(*this, h->q_to_r, iq, ir);
     build_bconv(*this, h->r_to_q, ir, iq);
-    build_bconv_var1(*this, h->q_to_r_var1, iq, ir);
+    build_bconv_var1(*this, h->q_to_r_var1, drop ? iq_full : iq, ir);
     describe_conv(h->q_to_r, h->d_q_to_r);
     describe_conv(h->r_to_q, h->d_r_to_q);
     describe_conv(h->q_to_r_var1, h->d_q_to_r_var1);
@@ -434,47 +444,73 @@ HpsQ &Context::hps_overq() {
         h->alpha_q_mod_r.upload(aq);
         h->alpha_r_mod_q.upload(ar);
     }
-    {   // t/Rl scale-and-round tables (rns.cu:836-885): x_i = t * Q * (S / s_i)^-1 mod s_i as big integers, S = Q || Rl
+    auto mul_small = [](std::vector<u64> &b, u64 m) {
+        u64 carry = 0;
+        for (auto &w : b) { const u128 t = (u128)w * m + carry; w = (u64)t; carry = (u64)(t >> 64); }
+        if (carry) b.push_back(carry);
+    };
+    auto mod_small = [](const std::vector<u64> &b, u64 m) {
+        u128 rem = 0;
+        for (size_t i = b.size(); i-- > 0;) rem = ((rem << 64) | b[i]) % m;
+        return (u64)rem;
+    };
+    auto div_small = [](std::vector<u64> &b, u64 m) {
+        u128 rem = 0;
+        for (size_t i = b.size(); i-- > 0;) { const u128 cur = (rem << 64) | b[i]; b[i] = (u64)(cur / m); rem = cur % m; }
+    };
+    // scale-and-round tables of the shape [Ql][extra + 1] + fractions [extra]: x_i = factor * prod(Ql) * (S / s_i)^-1 mod
+    // s_i as big integers over S = Ql || extra primes
+    auto scale_tables = [&](const std::vector<u64> &extra, u64 factor, std::vector<double> &frac, std::vector<u64> &tab) {
+        const uint32_t ne = (uint32_t)extra.size();
         std::vector<u64> s_all(primes.begin(), primes.begin() + sq);
-        s_all.insert(s_all.end(), r.begin(), r.end());
-        std::vector<double> frac(sr);
-        std::vector<u64> tab((size_t)sq * (sr + 1));
-        auto mul_small = [](std::vector<u64> &b, u64 m) {
-            u64 carry = 0;
-            for (auto &w : b) { const u128 t = (u128)w * m + carry; w = (u64)t; carry = (u64)(t >> 64); }
-            if (carry) b.push_back(carry);
-        };
-        auto mod_small = [](const std::vector<u64> &b, u64 m) {
-            u128 rem = 0;
-            for (size_t i = b.size(); i-- > 0;) rem = ((rem << 64) | b[i]) % m;
-            return (u64)rem;
-        };
-        auto div_small = [](std::vector<u64> &b, u64 m) {
-            u128 rem = 0;
-            for (size_t i = b.size(); i-- > 0;) { const u128 cur = (rem << 64) | b[i]; b[i] = (u64)(cur / m); rem = cur % m; }
-        };
-        for (uint32_t i = 0; i < sq + sr; i++) {
+        s_all.insert(s_all.end(), extra.begin(), extra.end());
+        frac.assign(ne, 0.0);
+        tab.assign((size_t)sq * (ne + 1), 0);
+        for (uint32_t i = 0; i < sq + ne; i++) {
             u64 hat = 1;
-            for (uint32_t k = 0; k < sq + sr; k++)
+            for (uint32_t k = 0; k < sq + ne; k++)
                 if (k != i) hat = h_mulmod(hat, s_all[k] % s_all[i], s_all[i]);
             const u64 shat_inv = h_invmod(hat, s_all[i]);
             std::vector<u64> x{1};
             for (uint32_t k = 0; k < sq; k++) mul_small(x, primes[k]);
-            mul_small(x, plain_t);
+            if (factor != 1) mul_small(x, factor);
             mul_small(x, shat_inv);
             if (i >= sq) frac[i - sq] = (double)mod_small(x, s_all[i]) / (double)s_all[i];
             div_small(x, s_all[i]);
             if (i >= sq) {
-                for (uint32_t l = 0; l < sq; l++) tab[(size_t)l * (sr + 1) + (i - sq)] = mod_small(x, primes[l]);
+                for (uint32_t l = 0; l < sq; l++) tab[(size_t)l * (ne + 1) + (i - sq)] = mod_small(x, primes[l]);
             } else {
-                tab[(size_t)i * (sr + 1) + sr] = mod_small(x, primes[i]);
+                tab[(size_t)i * (ne + 1) + ne] = mod_small(x, primes[i]);
             }
         }
+    };
+    {   // t/Rl scale-and-round (rns.cu:836-885)
+        std::vector<double> frac;
+        std::vector<u64> tab;
+        scale_tables(r, plain_t, frac, tab);
         h->frac.upload(frac);
         h->div_mod_q.upload(tab);
     }
-    hpsq_tool = std::move(h);
-    return *hpsq_tool;
+    if (drop) {   // Ql/Q scale-and-round (rns.cu:918-972) and the expansion constants (base_Ql_to_QlDrop_conv.PModq)
+        std::vector<u64> dropped(primes.begin() + sq, primes.begin() + size_q);
+        std::vector<double> frac;
+        std::vector<u64> tab;
+        scale_tables(dropped, 1, frac, tab);
+        h->frac_drop.upload(frac);
+        h->div_mod_q_drop.upload(tab);
+        std::vector<u64> dm(sq), dms(sq);
+        for (uint32_t i = 0; i < sq; i++) {
+            u64 p = 1;
+            for (u64 d : dropped) p = h_mulmod(p, d % primes[i], primes[i]);
+            dm[i] = p;
+            dms[i] = h_shoup(p, primes[i]);
+        }
+        h->drop_mod_q.upload(dm);
+        h->drop_mod_q_shoup.upload(dms);
+    }
+    HpsQ &ref = *h;
+    hpsq_tools[size_ql] = std::move(h);
+    return ref;
 }
 
 // DRNSTool constructor, BEHZ part (src/rns.cu:392-560).  Needs the plain modulus; top data level only.
@@ -888,7 +924,7 @@ int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus) {
         c.tools.clear();
         c.behz_tool.reset();   // (their auxiliary table rows stay; a later tool appends fresh ones)
         c.hps_tool.reset();
-        c.hpsq_tool.reset();
+        c.hpsq_tools.clear();
         c.plain_t = plain_modulus;
     }
     PHA_API_END

@@ -169,6 +169,12 @@ struct HpsQ {
     DevBuf<u64> alpha_q_mod_r, alpha_r_mod_q;
     DevBuf<double> frac;                         // [Rl]        tQlSlHatInvModsDivsFrac
     DevBuf<u64> div_mod_q;                       // [Q][Rl + 1] tQlSlHatInvModsDivsModq
+    // hps_overq_leveled with levels dropped (src/rns.cu:897-975): size_q above is |Ql|; q_to_r_var1 then converts from the
+    // FULL base Q (base_Q_to_Rl_conv)
+    uint32_t size_q_full = 0, drop = 0;
+    DevBuf<double> frac_drop;                    // [drop]          QlQHatInvModqDivqFrac
+    DevBuf<u64> div_mod_q_drop;                  // [Ql][drop + 1]  QlQHatInvModqDivqModq
+    DevBuf<u64> drop_mod_q, drop_mod_q_shoup;    // [Ql]            product of the dropped primes mod q_i
 };
 
 // ---- scratch arena: one per (context, stream), grown on demand, never freed until destroy ----
@@ -204,7 +210,7 @@ struct Context {
     std::map<uint32_t, std::unique_ptr<Tool>> tools;
     std::unique_ptr<Behz> behz_tool;
     std::unique_ptr<Hps> hps_tool;
-    std::unique_ptr<HpsQ> hpsq_tool;
+    std::map<uint32_t, std::unique_ptr<HpsQ>> hpsq_tools;   // by |Ql| (|Q| = plain hps_overq)
     uint32_t rows = 0;  // table rows = size_qp + auxiliary moduli
     std::map<void *, std::unique_ptr<Arena>> arenas;
     std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
@@ -212,7 +218,7 @@ struct Context {
     Tool &tool(uint32_t size_ql);
     Behz &behz();                                             // built on first use; needs the plain modulus
     Hps &hps();
-    HpsQ &hps_overq();
+    HpsQ &hps_overq(uint32_t size_ql = 0);
     uint32_t add_aux_moduli(const std::vector<u64> &ntt_primes, u64 plain_modulus_like);
     u64 *scratch(void *stream, size_t words);
     const uint32_t *galois_table(uint32_t elt);

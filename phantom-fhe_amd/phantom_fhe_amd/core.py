@@ -285,6 +285,20 @@ class PhantomContext:
         tensor twice takes the reference's squaring shortcut."""
         _lib.check(self._L.pha_bfv_multiply_hps_overq(self._h, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
 
+    def bfv_multiply_hps_overq_leveled(self, size_Ql, ct1, ct2, dst):
+        """bfv_multiply_hps under hps_overq_leveled with size_Q - size_Ql levels dropped; buffers over the full base Q."""
+        _lib.check(self._L.pha_bfv_multiply_hps_overq_leveled(self._h, size_Ql, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
+
+    def scaleAndRound_HPS_Q_Ql(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_scaleAndRound_HPS_Q_Ql(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
+
+    def ExpandCRTBasis_Ql_Q(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_ExpandCRTBasis_Ql_Q(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
+
+    def keyswitch_inplace_bfv_leveled(self, size_Ql, ct, c2, rlk_ptrs):
+        """keyswitch_inplace for BFV with levels dropped (src/eval_key_switch.cu:142-147, 170-175); ct [2][Q][N], c2 [Q][N]."""
+        _lib.check(self._L.pha_keyswitch_inplace_bfv_leveled(self._h, size_Ql, _ptr(ct), _ptr(c2), _ptr(rlk_ptrs), _stream()))
+
     def batched_modular_gemm(self, C, A, B, m, n, k, batch, mod_start=0):
         """C[z] = A[z] @ B[z] mod q_{mod_start + z}, row-major [batch][m][k] x [batch][k][n] (benchmark/matmul_bench.cu)."""
         _lib.check(self._L.pha_batched_modular_gemm(self._h, _ptr(C), n, _ptr(A), k, _ptr(B), n, m, n, k, batch, mod_start,

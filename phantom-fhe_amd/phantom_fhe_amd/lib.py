@@ -53,6 +53,10 @@ _SIGS = {
     "pha_bfv_multiply_behz": [vp, vp, vp, vp, vp],
     "pha_bfv_multiply_hps": [vp, vp, vp, vp, vp],
     "pha_bfv_multiply_hps_overq": [vp, vp, vp, vp, vp],
+    "pha_bfv_multiply_hps_overq_leveled": [vp, sz, vp, vp, vp, vp],
+    "pha_scaleAndRound_HPS_Q_Ql": [vp, sz, vp, vp, vp],
+    "pha_ExpandCRTBasis_Ql_Q": [vp, sz, vp, vp, vp],
+    "pha_keyswitch_inplace_bfv_leveled": [vp, sz, vp, vp, vp, vp],
     "pha_batched_modular_gemm": [vp, vp, sz, vp, sz, vp, sz, sz, sz, sz, sz, sz, vp],
     "pha_nwt_2d_radix8_forward_inplace_include_temp_mod": [vp, vp, sz, sz, sz, vp],
     "pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale": [vp, vp, sz, sz, sz, vp, vp, vp],

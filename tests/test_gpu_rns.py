@@ -622,6 +622,51 @@ def test_bfv_multiply_hps_overq(name, plain_t, gpu):
     assert np.array_equal(P.to_host(d1), ct1) and np.array_equal(P.to_host(d2), ct2)
 
 
+@pytest.mark.parametrize("name,plain_t,ql", [("bfv13_50", 65537, 3), ("bfv13_50", 65537, 2), ("hyb12_a2", 1032193, 4),
+                                             ("c4_bfv15", 1032193, 29), ("c4_bfv15", 1032193, 15)])
+def test_bfv_hps_overq_leveled(name, plain_t, ql, gpu):
+    """hps_overq_leveled with levels dropped: scaleAndRound_HPS_Q_Ql, ExpandCRTBasis_Ql_Q (src/rns.cu:1798-1836), the
+    leveled multiply (src/evaluate.cu:709-711,747-748,794-795) and the leveled BFV key switch
+    (src/eval_key_switch.cu:142-147,170-175) vs the oracle."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    ctx.set_plain_modulus(plain_t)
+    hq = O.HpsOverQ(oc, plain_t, ql)
+    r = rng_for(150 + ql)
+    ct1 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct2 = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    ct2[:, :, :32] = np.array(primes[:size_q], dtype=np.uint64)[None, :, None] - 1
+    d1, d2 = P.to_device(ct1, gpu), P.to_device(ct2, gpu)
+    low = P.to_device(np.zeros((ql, n), dtype=np.uint64), gpu)
+    ctx.scaleAndRound_HPS_Q_Ql(ql, low, d2[0])
+    y = hq.scale_q_ql(ct2[0])
+    assert np.array_equal(P.to_host(low), y)
+    full = P.to_device(np.full((size_q, n), 5, dtype=np.uint64), gpu)
+    ctx.ExpandCRTBasis_Ql_Q(ql, full, low)
+    assert np.array_equal(P.to_host(full), hq.expand_ql_q(y))
+    dst = P.to_device(np.zeros((3, size_q, n), dtype=np.uint64), gpu)
+    ctx.bfv_multiply_hps_overq_leveled(ql, d1, d2, dst)
+    ref = hq.multiply(ct1, ct2)
+    assert np.array_equal(P.to_host(dst), ref)
+    ctx.bfv_multiply_hps_overq_leveled(ql, d2, d2, dst)
+    assert np.array_equal(P.to_host(dst), hq.multiply(ct2, ct2))
+    # leveled relinearisation of the product
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    tool = O.Tool(oc, ql)
+    d_ct = P.to_device(ref[:2], gpu)
+    ctx.keyswitch_inplace_bfv_leveled(ql, d_ct, P.to_device(ref[2], gpu), rlk.public_keys_ptr)
+    assert np.array_equal(P.to_host(d_ct), hq.keyswitch_leveled(tool, ref[:2], ref[2], [evk[i] for i in range(tool.beta)]))
+    with pytest.raises(ValueError):
+        ctx.scaleAndRound_HPS_Q_Ql(size_q, low, d2[0])          # nothing dropped
+    # the top level through the leveled entry is plain hps_overq
+    ctx.bfv_multiply_hps_overq_leveled(size_q, d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), O.HpsOverQ(oc, plain_t).multiply(ct1, ct2))
+
+
 @pytest.mark.parametrize("bits,m,n,k,batch", [(50, 256, 256, 256, 3), (50, 96, 40, 72, 2), (60, 128, 64, 100, 2), (36, 64, 32, 16, 1)])
 def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
     """matmul_bench shape (256^3 per 50-bit modulus) and ragged shapes, wide (60-bit) and narrow paths, vs the oracle;

@@ -483,6 +483,84 @@ def test_bfv_hps_overq_multiply_decrypts_to_the_product(name, plain_t):
         check(sq, m1, m1)
 
 
+@pytest.mark.parametrize("drop", [1, 2])
+def test_bfv_hps_overq_leveled_primitives_and_multiply(drop):
+    """hps_overq_leveled with levels dropped (src/rns.cu:897-975, src/evaluate.cu:709-711,747-748,794-795): the scale
+    Q -> Ql is round(Ql x / Q) (within the floating-point carry), the expansion is times the dropped primes, the
+    leveled multiply decrypts to the product, and the leveled key switch relinearises."""
+    name, plain_t = "bfv13_50", 65537
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    ql = size_q - drop
+    q = [int(p) for p in primes[:size_q]]
+    oc = oracle_ctx(name)
+    hq = O.HpsOverQ(oc, plain_t, ql)
+    assert hq.size_r == ql
+    Q, Ql, D = 1, 1, 1
+    for i, p in enumerate(q):
+        Q *= p
+        if i < ql:
+            Ql *= p
+        else:
+            D *= p
+    r = rng_for(83)
+    x = uniform_poly(r, q, n)
+    y = hq.scale_q_ql(x)
+    z = hq.expand_ql_q(y)
+    for k in range(0, n, 501):
+        X, _ = crt_compose([x[l, k] for l in range(size_q)], q)
+        Y, _ = crt_compose([y[l, k] for l in range(ql)], q[:ql])
+        Xc = X - Q if X > Q // 2 else X                       # the conversion reads residues as the centred value
+        want = (Xc * Ql * 2 + Q) // (2 * Q)                   # round(Ql * x / Q)
+        dd = (Y - want) % Ql
+        dd = dd - Ql if dd > Ql // 2 else dd
+        assert abs(dd) <= 1
+        Z, _ = crt_compose([z[l, k] for l in range(size_q)], q)
+        assert Z == Y * D % Q
+    # leveled multiply of genuine encryptions
+    delta = Q // plain_t
+    s_small = r.integers(-1, 2, n)
+    sk_ntt = oc.nwt_forward(np.stack([(s_small % p).astype(np.uint64) for p in q]), size_q, 0)
+    s2 = oc.multiply(sk_ntt, sk_ntt, size_q)
+
+    def encrypt(m):
+        a = uniform_poly(r, q, n)
+        e = r.integers(-3, 4, n)
+        dm = np.stack([np.array([(delta * int(v) + int(ev)) % p for v, ev in zip(m, e)], dtype=np.uint64) for p in q])
+        a_s = oc.nwt_backward(oc.multiply(oc.nwt_forward(a, size_q, 0), sk_ntt, size_q), size_q)
+        return np.stack([oc.sub(dm, a_s, size_q), a])
+
+    big = int(O.get_primes(n, 60, 1)[0])
+    bc = O.Ctx(log_n, [big], 0)
+    m1, m2 = r.integers(0, plain_t, n), r.integers(0, plain_t, n)
+    pm = bc.nwt_backward(bc.multiply(bc.nwt_forward(m1.astype(np.uint64).reshape(1, n), 1, 0),
+                                     bc.nwt_forward(m2.astype(np.uint64).reshape(1, n), 1, 0), 1), 1)[0]
+
+    def check(parts):
+        d_ntt = [oc.nwt_forward(p, size_q, 0) for p in parts]
+        phase = oc.add(d_ntt[0], oc.multiply(d_ntt[1], sk_ntt, size_q), size_q)
+        if len(parts) == 3:
+            phase = oc.add(phase, oc.multiply(d_ntt[2], s2, size_q), size_q)
+        phase = oc.nwt_backward(phase, size_q)
+        for k in range(0, n, 61):
+            v, _ = crt_compose([phase[l, k] for l in range(size_q)], q)
+            got = ((v * plain_t + Q // 2) // Q) % plain_t
+            w = int(pm[k])
+            w = w - big if w > big // 2 else w
+            assert got == w % plain_t, k
+
+    d = hq.multiply(encrypt(m1), encrypt(m2))
+    assert not d[:, ql:].any()                                # expanded: multiples of the dropped primes
+    check([d[0], d[1], d[2]])
+    # leveled relinearisation with genuine keys for s^2
+    evk = _small_keys(oc, primes, n, size_q, size_p, r, s2, oc.nwt_forward(
+        np.stack([(s_small % int(p)).astype(np.uint64) for p in primes]), len(primes), 0))
+    tool = O.Tool(oc, ql)
+    relin = hq.keyswitch_leveled(tool, d[:2], d[2], [evk[i] for i in range(tool.beta)])
+    check([relin[0], relin[1]])
+
+
 def test_gemm_mod_against_python_ints():
     q = int(O.get_primes(4096, 50, 1)[0])
     r = rng_for(200)
