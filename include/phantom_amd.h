@@ -306,6 +306,10 @@ int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uin
  *   pha_keyswitch_inplace_bfv_leveled  -- keyswitch_inplace, leveled branches src/eval_key_switch.cu:142-147, :170-175 */
 int pha_bfv_multiply_hps_overq_leveled(pha_context_t ctx, size_t size_Ql, const uint64_t *ct1, const uint64_t *ct2,
                                        uint64_t *dst, void *stream);
+/* bfv_mul_relin_hps with levels dropped (src/evaluate.cu:822-1027): multiply + relinearize in one call; the product's c2
+ * never leaves level l, so the result differs (in its noise) from multiply followed by the leveled key switch. dst [2][Q][N] */
+int pha_bfv_mul_relin_hps_overq_leveled(pha_context_t ctx, size_t size_Ql, const uint64_t *ct1, const uint64_t *ct2,
+                                        const uint64_t *const *rlk, uint64_t *dst, void *stream);
 int pha_scaleAndRound_HPS_Q_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
 int pha_ExpandCRTBasis_Ql_Q(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
 int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,

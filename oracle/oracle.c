@@ -1348,7 +1348,7 @@ void orc_hps_expand_ql_q(const orc_hpsq *h, const u64 *src, u64 *dst) {
 }
 /* bfv_multiply_hps with mul_tech hps_overq (h built at the top level) or hps_overq_leveled with levels dropped (h built at a
  * lower level: evaluate.cu:709-711, :747-748, :794-795).  Operands and result are over the FULL base Q: [.][Q][N]. */
-void orc_bfv_multiply_hps_overq(const orc_hpsq *h, const u64 *ct1, const u64 *ct2, u64 *dst) {
+static void hpsq_multiply(const orc_hpsq *h, const u64 *ct1, const u64 *ct2, u64 *dst, int keep_c2_low) {
     const size_t n = h->n, sq = h->size_q, sr = h->size_r, sqr = sq + sr, sqf = h->size_q_full;
     const int square = ct1 == ct2;
     u64 *x1 = (u64 *)calloc(3 * sqr * n, 8), *x2 = (u64 *)calloc(2 * sqr * n, 8), *y = (u64 *)malloc(sizeof(u64) * sqf * n);
@@ -1370,9 +1370,33 @@ void orc_bfv_multiply_hps_overq(const orc_hpsq *h, const u64 *ct1, const u64 *ct
         for (size_t i = 0; i < sqr; i++)
             orc_ntt_inverse(x + i * n, h->log_n, h->qr[i], h->itw + i * n, h->itws + i * n, h->n_inv[i], h->n_inv_s[i]);
         hps_scale_round_to_ql(h, x, out, h->frac, h->div_mod_q, sr);           /* scaleAndRound_HPS_QlRl_Ql :790-792 */
-        if (h->drop) orc_hps_expand_ql_q(h, out, out);                         /* :794-795 */
+        if (h->drop && !(keep_c2_low && p == 2)) orc_hps_expand_ql_q(h, out, out);   /* :794-795 (:957-958 leaves c2 at level l) */
     }
     free(x1); free(x2); free(y);
+}
+void orc_bfv_multiply_hps_overq(const orc_hpsq *h, const u64 *ct1, const u64 *ct2, u64 *dst) { hpsq_multiply(h, ct1, ct2, dst, 0); }
+/* bfv_mul_relin_hps with levels dropped (evaluate.cu:822-1027): the product's c2 stays at level l (:957-958), is switched
+ * there, and the two results are expanded onto the Ql limbs of (c0, c1) (ExpandCRTBasis_Ql_Q_add_to_ct :1014-1016).
+ * dst [2][Q][N]; t = the tool of level l. */
+void orc_bfv_mul_relin_hps_overq_leveled(const orc_tool *t, const orc_hpsq *h, const u64 *ct1, const u64 *ct2,
+                                         const u64 *const *evks, u64 *dst) {
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp, sqf = h->size_q_full;
+    u64 *d3 = (u64 *)malloc(sizeof(u64) * 3 * sqf * n);
+    u64 *mu = (u64 *)malloc(sizeof(u64) * t->beta * qlp * n);
+    u64 *cx = (u64 *)malloc(sizeof(u64) * 2 * qlp * n);
+    hpsq_multiply(h, ct1, ct2, d3, 1);
+    orc_modup(t, mu, d3 + 2 * sqf * n, ORC_BFV);
+    orc_key_switch_inner_prod(t, cx, mu, evks);
+    memcpy(dst, d3, sizeof(u64) * 2 * sqf * n);
+    for (int i = 0; i < 2; i++) {
+        u64 *cxi = cx + (size_t)i * qlp * n, *ct = dst + (size_t)i * sqf * n;
+        orc_moddown_from_ntt(t, cxi, cxi, ORC_BFV);
+        for (size_t l = 0; l < ql; l++)
+            for (size_t k = 0; k < n; k++)
+                ct[l * n + k] = addmod(ct[l * n + k], orc_mulmod(cxi[l * n + k], h->drop_mod_q[l], c->q[l]), c->q[l]);
+    }
+    free(d3); free(mu); free(cx);
 }
 /* keyswitch_inplace for BFV under hps_overq_leveled with levels dropped (eval_key_switch.cu:142-147, :170-175): c2 is
  * scaled from Q down to Ql, switched at that level, and both results are expanded back to Q before they are added.

@@ -115,6 +115,9 @@ orc_hpsq *orc_hpsq_create(const orc_ctx *c, uint64_t plain_t);
 orc_hpsq *orc_hpsq_create_level(const orc_ctx *c, uint64_t plain_t, size_t size_ql);
 void orc_hps_scale_q_ql(const orc_hpsq *h, const uint64_t *src, uint64_t *dst);   /* scaleAndRound_HPS_Q_Ql rns.cu:1798-1808 */
 void orc_hps_expand_ql_q(const orc_hpsq *h, const uint64_t *src, uint64_t *dst);  /* ExpandCRTBasis_Ql_Q rns.cu:1810-1836 */
+/* bfv_mul_relin_hps with levels dropped (evaluate.cu:822-1027): c2 never leaves level l; dst [2][Q][N] */
+void orc_bfv_mul_relin_hps_overq_leveled(const orc_tool *t, const orc_hpsq *h, const uint64_t *ct1, const uint64_t *ct2,
+                                         const uint64_t *const *evks, uint64_t *dst);
 /* BFV key switch with levels dropped (eval_key_switch.cu:142-147,170-175); t = orc_tool of that level */
 void orc_keyswitch_bfv_leveled(const orc_tool *t, const orc_hpsq *h, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks);
 void orc_hpsq_destroy(orc_hpsq *h);

@@ -105,6 +105,7 @@ def lib(path=None):
     L.orc_hpsq_create_level.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t]
     L.orc_hps_scale_q_ql.argtypes = [C.c_void_p, u64p, u64p]
     L.orc_hps_expand_ql_q.argtypes = [C.c_void_p, u64p, u64p]
+    L.orc_bfv_mul_relin_hps_overq_leveled.argtypes = [C.c_void_p, C.c_void_p, u64p, u64p, C.POINTER(u64p), u64p]
     L.orc_keyswitch_bfv_leveled.argtypes = [C.c_void_p, C.c_void_p, u64p, u64p, C.POINTER(u64p)]
     L.orc_hpsq_r_size.restype = C.c_size_t
     L.orc_hpsq_r_size.argtypes = [C.c_void_p]
@@ -440,6 +441,16 @@ class HpsOverQ:
         dst = np.zeros(self.ctx.size_q * self.ctx.n, dtype=np.uint64)
         self.L.orc_hps_expand_ql_q(self.h, _p(src), _p(dst))
         return dst.reshape(self.ctx.size_q, self.ctx.n)
+
+    def mul_relin_leveled(self, tool, ct1, ct2, evks):
+        """bfv_mul_relin_hps with levels dropped (src/evaluate.cu:822-1027); `ct2 is ct1` is the squaring path."""
+        c = self.ctx
+        a = np.ascontiguousarray(ct1, dtype=np.uint64).reshape(-1)
+        b = a if ct2 is ct1 else np.ascontiguousarray(ct2, dtype=np.uint64).reshape(-1)
+        out = np.zeros(2 * c.size_q * c.n, dtype=np.uint64)
+        arr, keep = tool._evk_ptrs(evks)
+        self.L.orc_bfv_mul_relin_hps_overq_leveled(tool.h, self.h, _p(a), _p(b), arr, _p(out))
+        return out.reshape(2, c.size_q, c.n)
 
     def keyswitch_leveled(self, tool, ct, c2, evks):
         """BFV key switch with levels dropped (src/eval_key_switch.cu:142-147, 170-175); tool = Tool(ctx, size_ql)."""

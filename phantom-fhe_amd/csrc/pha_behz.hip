@@ -368,7 +368,8 @@ static void launch_expand(Context &c, HpsQ &h, u64 *dst, const u64 *src, hipStre
 // bfv_multiply_hps with mul_tech hps_overq (h of the top level) or hps_overq_leveled with levels dropped (h of a lower level):
 // src/evaluate.cu:674-818, the overq branches :709-711, :745-751, :790-795.  Operands and result are over the full base Q.
 // ct1 == ct2 (the same pointer) is the reference's squaring shortcut (:720-731), kept as it is.
-static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *ct2, u64 *dst, void *stream) {
+static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *ct2, u64 *dst, void *stream,
+                               bool keep_c2_low = false) {
     hipStream_t s = as_stream(stream);
     const uint32_t n = (uint32_t)c.n, sq = h.size_q, sr = h.size_r, sqr = sq + sr, sqf = h.size_q_full;
     const size_t qn = (size_t)sq * n, rn = (size_t)sr * n, qrn = (size_t)sqr * n, qfn = (size_t)sqf * n;
@@ -402,7 +403,7 @@ static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *c
     ntt_inverse(c, x1, x1, x1, qr_sel(sq, sr, h.aux0), EPI_INV_CANON, xi, s);
     for (uint32_t p = 0; p < 3; p++) {   // scale by t / Rl and round straight into base Ql (:790-792), expand to Q (:794-795)
         launch_scale_round_q(c, dst + p * qfn, x1 + p * qrn, h.frac.p, h.div_mod_q.p, sq, sr, s);
-        if (h.drop) launch_expand(c, h, dst + p * qfn, dst + p * qfn, s);
+        if (h.drop && !(keep_c2_low && p == 2)) launch_expand(c, h, dst + p * qfn, dst + p * qfn, s);   // (:957-958: c2 stays at level l)
     }
 }
 
@@ -439,6 +440,41 @@ extern "C" int pha_ExpandCRTBasis_Ql_Q(pha_context_t ctx, size_t size_Ql, uint64
     Context &c = ctx->c;
     if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
     launch_expand(c, c.hps_overq((uint32_t)size_Ql), dst, src, as_stream(stream));
+    PHA_API_END
+}
+
+// dst[i] += src[i] * prod(dropped primes) on the Ql limbs only (ExpandCRTBasis_Ql_Q_add_to_ct, src/rns.cu:1838-1858)
+__global__ __launch_bounds__(256) void hps_expand_add_kernel(const ExpandArgs k) {
+    const uint32_t i = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = (size_t)i * k.n + coeff;
+    const u64 q = k.mod[i].value;
+    k.dst[id] = add_mod(shoup(k.src[id], u64x2{k.c[i], k.c_shoup[i]}, q), k.dst[id], q);
+}
+
+// bfv_mul_relin_hps under hps_overq_leveled with levels dropped (src/evaluate.cu:822-1027): the product's c2 is left at
+// level l, key-switched there, and the results go onto the Ql limbs of (c0, c1).  dst [2][Q][N].
+extern "C" int pha_bfv_mul_relin_hps_overq_leveled(pha_context_t ctx, size_t size_Ql, const uint64_t *ct1, const uint64_t *ct2,
+                                                   const uint64_t *const *rlk, uint64_t *dst, void *stream) {
+    PHA_API_BEGIN
+    if (!ctx || !ct1 || !ct2 || !rlk || !dst) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
+    HpsQ &h = c.hps_overq((uint32_t)size_Ql);
+    hipStream_t s = as_stream(stream);
+    const size_t n = c.n, qln = size_Ql * n, qfn = (size_t)c.size_q * n;
+    DevBuf<u64> tmp(3 * qfn + 2 * qln);
+    u64 *d3 = tmp.p, *res = d3 + 3 * qfn;
+    hps_overq_multiply(c, h, ct1, ct2, d3, stream, true);
+    PHA_HIP(hipMemsetAsync(res, 0, 2 * qln * sizeof(u64), s));
+    const int rc = pha_keyswitch_inplace(ctx, size_Ql, res, d3 + 2 * qfn, rlk, /*scheme bfv*/ 1, stream);
+    if (rc != 0) throw std::runtime_error(pha_last_error());
+    PHA_HIP(hipMemcpyAsync(dst, d3, 2 * qfn * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    for (int p = 0; p < 2; p++) {
+        ExpandArgs ka{dst + (size_t)p * qfn, res + (size_t)p * qln, h.drop_mod_q.p, h.drop_mod_q_shoup.p, c.d_mod.p, h.size_q, (uint32_t)n};
+        hipLaunchKernelGGL(hps_expand_add_kernel, dim3((unsigned)(n / 256), h.size_q), dim3(256), 0, s, ka);
+        check_launch();
+    }
+    PHA_HIP(hipStreamSynchronize(s));   // tmp is released on return
     PHA_API_END
 }
 

@@ -563,12 +563,75 @@ inline void same_shape(const PhantomCiphertext &a, const PhantomCiphertext &b) {
 }
 }  // namespace detail
 
+// FindLevelsToDrop (src/evaluate.cu:551-647): how many primes of Q a BFV operation may ignore under hps_overq_leveled,
+// from the noise estimate of a ciphertext of the given multiplicative depth (host arithmetic in double precision).
+namespace detail {
+inline size_t find_levels_to_drop(const PhantomContext &context, size_t multiplicativeDepth, double dcrtBits, bool isKeySwitch,
+                                  bool isAsymmetric) {
+    const auto &parms = context.get_context_data(0).parms();
+    if (parms.mul_tech() != mul_tech_type::hps_overq_leveled)
+        throw std::invalid_argument("FindLevelsToDrop is only used in HPS over Q Leveled");
+    const auto n = static_cast<uint32_t>(parms.poly_modulus_degree());
+    const double sigma = static_cast<double>(3.2f), alpha = 36.0;   // distributionParameter, assuranceMeasure (hestdparms.h:152-153)
+    const double p = static_cast<double>(parms.plain_modulus().value());
+    const size_t size_P = context.using_keyswitching() ? parms.special_modulus_size() : 0;
+    const size_t size_Q = parms.coeff_modulus().size() - size_P;
+    const auto k = static_cast<uint32_t>(size_P);
+    const auto numPartQ = static_cast<uint32_t>(size_P ? (size_Q + size_P - 1) / size_P : 0);
+    const double Bkey = 1.0;
+    const double Berr = sigma * std::sqrt(alpha);
+    const auto delta = [](uint32_t m) { return 2. * std::sqrt(static_cast<double>(m)); };
+    const auto Vnorm = [&](uint32_t m) {
+        if (isAsymmetric) return (1. + delta(m) * Bkey) / 2.;
+        return Berr * (1. + 2. * delta(m) * Bkey);
+    };
+    const auto noiseKS = [&](uint32_t m) { return k * (numPartQ * delta(m) * Berr + delta(m) * Bkey + 1.0) / 2; };
+    const auto C1 = [&](uint32_t m) { return delta(m) * delta(m) * p * Bkey; };
+    const auto C2 = [&](uint32_t m) { return delta(m) * delta(m) * Bkey * Bkey / 2.0 + noiseKS(m); };
+    const auto logqBFV = [&](uint32_t m) {
+        if (multiplicativeDepth > 0)
+            return std::log(4 * p) + (static_cast<double>(multiplicativeDepth) - 1) * std::log(C1(m)) +
+                   std::log(C1(m) * Vnorm(m) + static_cast<double>(multiplicativeDepth) * C2(m));
+        return std::log(p * (4 * Vnorm(m)));
+    };
+    double logqPrev = 6. * std::log(10.);
+    double logq = logqBFV(n);
+    while (std::fabs(logq - logqPrev) > std::log(1.001)) {
+        logqPrev = logq;
+        logq = logqBFV(n);
+    }
+    const double loge = logq / std::log(2.) - 2 - std::log2(p);
+    const double logExtra = isKeySwitch ? std::log2(noiseKS(n)) : std::log2(delta(n));
+    auto levels = static_cast<int32_t>(std::floor((loge - 2 * static_cast<double>(multiplicativeDepth) - 16 - logExtra) / dcrtBits));
+    const auto sizeQ = static_cast<int32_t>(size_Q);
+    if (levels < 0) levels = 0;
+    else if (levels > sizeQ - 1) levels = sizeQ - 1;
+    return static_cast<size_t>(levels);
+}
+// qMSB of the top level's DRNSTool (src/rns.cu:587): bit count of the largest prime of Q
+inline double dcrt_bits(const PhantomContext &context) {
+    const auto &parms = context.get_context_data(context.get_first_index()).parms();
+    int bits = 0;
+    for (const auto &m : parms.coeff_modulus()) bits = std::max(bits, m.bit_count());
+    return static_cast<double>(bits);
+}
+}  // namespace detail
+
 // phantom::keyswitch_inplace (include/evaluate.cuh:29-32, src/eval_key_switch.cu:95-182)
 inline void keyswitch_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, uint64_t *c2,
-                              const PhantomRelinKey &relin_keys, bool /*is_relin*/, const cudaStream_t &stream) {
+                              const PhantomRelinKey &relin_keys, bool is_relin, const cudaStream_t &stream) {
     const auto &key_parms = context.get_context_data(0).parms();
-    if (key_parms.mul_tech() == mul_tech_type::hps_overq_leveled && key_parms.scheme() == scheme_type::bfv)
-        throw std::invalid_argument("hps_overq_leveled key switching is not on the accelerated path");
+    if (key_parms.scheme() == scheme_type::bfv && key_parms.mul_tech() == mul_tech_type::hps_overq_leveled) {
+        // levels to ignore from the ciphertext's depth (:113-123); the key switch then runs at the lower level (:142-175)
+        const size_t levelsDropped = detail::find_levels_to_drop(context, encrypted.GetNoiseScaleDeg() - 1, detail::dcrt_bits(context),
+                                                                 !is_relin, encrypted.is_asymmetric());
+        if (levelsDropped) {
+            const size_t size_Q = context.get_context_data(1).parms().coeff_modulus().size();
+            util::check_pha(pha_keyswitch_inplace_bfv_leveled(context.amd(), size_Q - levelsDropped, encrypted.data(), c2,
+                                                              relin_keys.public_keys_ptr(), stream));
+            return;
+        }
+    }
     util::check_pha(pha_keyswitch_inplace(context.amd(), detail::level_size_Ql(context, encrypted), encrypted.data(), c2,
                                           relin_keys.public_keys_ptr(), static_cast<int>(key_parms.scheme()), stream));
 }
@@ -701,10 +764,9 @@ inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &e
     const auto &parms = context.get_context_data(encrypted1.chain_index()).parms();
     if (parms.scheme() == scheme_type::bfv) {
         // bfv_multiply (src/evaluate.cu:962-982) -> bfv_multiply_behz (:447-548) or bfv_multiply_hps with mul_tech hps /
-        // hps_overq (:674-818); hps_overq_leveled (levels dropped inside the multiply) is not built
+        // hps_overq / hps_overq_leveled (:674-818)
         const auto mul_tech = parms.mul_tech();
-        if (mul_tech != mul_tech_type::behz && mul_tech != mul_tech_type::hps && mul_tech != mul_tech_type::hps_overq)
-            throw std::invalid_argument("only the BEHZ, HPS and HPS-over-Q variants of BFV multiply are on the accelerated path");
+        if (mul_tech == mul_tech_type::none) throw std::invalid_argument("mul_tech not supported for bfv_multiply");
         if (encrypted1.is_ntt_form() || encrypted2.is_ntt_form())
             throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
         if (encrypted1.chain_index() != encrypted2.chain_index())
@@ -720,7 +782,12 @@ inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &e
             util::check_pha(pha_bfv_multiply_behz(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
         else if (mul_tech == mul_tech_type::hps_overq)
             util::check_pha(pha_bfv_multiply_hps_overq(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
-        else
+        else if (mul_tech == mul_tech_type::hps_overq_leveled) {   // levels from the operands' depth (:680-691)
+            const size_t levels = std::max(encrypted1.GetNoiseScaleDeg(), encrypted2.GetNoiseScaleDeg()) - 1;
+            const size_t dropped = detail::find_levels_to_drop(context, levels, detail::dcrt_bits(context), false, encrypted1.is_asymmetric());
+            util::check_pha(pha_bfv_multiply_hps_overq_leveled(context.amd(), L - dropped, encrypted1.data(), encrypted2.data(), out.get(), s));
+            encrypted1.SetNoiseScaleDeg(std::max(encrypted1.GetNoiseScaleDeg(), encrypted2.GetNoiseScaleDeg()) + 1);   // :798-800
+        } else
             util::check_pha(pha_bfv_multiply_hps(context.amd(), encrypted1.data(), encrypted2.data(), out.get(), s));
         encrypted1.resize(context, encrypted1.chain_index(), 3, s);
         util::check_hip(hipMemcpyAsync(encrypted1.data(), out.get(), 3 * L * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
@@ -760,8 +827,36 @@ inline void relinearize_inplace(const PhantomContext &context, PhantomCiphertext
     keyswitch_inplace(context, encrypted, c2, relin_keys, true, s);
     encrypted.resize(2, decomp_modulus_size, n, s);
 }
+// multiply_and_relin_inplace (src/evaluate.cu:1064-1103): for the HPS variants of BFV the reference fuses the two
+// (bfv_mul_relin_hps :822-1027).  Without dropped levels that is multiply followed by the ordinary key switch; with dropped
+// levels c2 never leaves level l and the key switch reuses the multiply's level count (not a second estimate).
 inline void multiply_and_relin_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1,
                                        const PhantomCiphertext &encrypted2, const PhantomRelinKey &relin_keys) {
+    const auto &parms = context.get_context_data(encrypted1.chain_index()).parms();
+    if (parms.scheme() == scheme_type::bfv && parms.mul_tech() == mul_tech_type::hps_overq_leveled) {
+        if (encrypted1.is_ntt_form() || encrypted2.is_ntt_form()) throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
+        if (encrypted1.size() != 2 || encrypted2.size() != 2) throw std::logic_error("dest_size must be 3 when computing BFV multiplication using HPS");
+        if (encrypted1.chain_index() != context.get_first_index() || encrypted2.chain_index() != encrypted1.chain_index())
+            throw std::invalid_argument("BFV multiply runs at the top data level");
+        const auto &s = cudaStreamPerThread;
+        const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree();
+        const size_t depth = std::max(encrypted1.GetNoiseScaleDeg(), encrypted2.GetNoiseScaleDeg());
+        const size_t dropped = detail::find_levels_to_drop(context, depth - 1, detail::dcrt_bits(context), false, encrypted1.is_asymmetric());
+        if (dropped) {
+            auto out = util::make_cuda_auto_ptr<uint64_t>(2 * L * n, s);
+            util::check_pha(pha_bfv_mul_relin_hps_overq_leveled(context.amd(), L - dropped, encrypted1.data(), encrypted2.data(),
+                                                                relin_keys.public_keys_ptr(), out.get(), s));
+            util::check_hip(hipMemcpyAsync(encrypted1.data(), out.get(), 2 * L * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        } else {
+            auto out = util::make_cuda_auto_ptr<uint64_t>(3 * L * n, s);
+            util::check_pha(pha_bfv_multiply_hps_overq_leveled(context.amd(), L, encrypted1.data(), encrypted2.data(), out.get(), s));
+            util::check_pha(pha_keyswitch_inplace(context.amd(), L, out.get(), out.get() + 2 * L * n, relin_keys.public_keys_ptr(),
+                                                  static_cast<int>(scheme_type::bfv), s));
+            util::check_hip(hipMemcpyAsync(encrypted1.data(), out.get(), 2 * L * n * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        }
+        encrypted1.SetNoiseScaleDeg(depth + 1);
+        return;
+    }
     multiply_inplace(context, encrypted1, encrypted2);
     relinearize_inplace(context, encrypted1, relin_keys);
 }
@@ -1010,6 +1105,9 @@ inline void hoisting_inplace(const PhantomContext &context, PhantomCiphertext &c
         if (it == have.end()) throw std::logic_error("Galois key not present in hoisting");
         tables.push_back(glk.get_relin_keys(static_cast<size_t>(it - have.begin())).public_keys_ptr());
     }
+    if (key_parms.scheme() == scheme_type::bfv && key_parms.mul_tech() == mul_tech_type::hps_overq_leveled &&
+        detail::find_levels_to_drop(context, ct.GetNoiseScaleDeg() - 1, detail::dcrt_bits(context), true, ct.is_asymmetric()))
+        throw std::invalid_argument("hoisting with dropped levels (hps_overq_leveled) is not on the accelerated path");
     util::check_pha(pha_hoisting(context.amd(), detail::level_size_Ql(context, ct), ct.data(), elts.data(), elts.size(),
                                  tables.data(), static_cast<int>(key_parms.scheme()), cudaStreamPerThread));
 }

@@ -289,6 +289,10 @@ class PhantomContext:
         """bfv_multiply_hps under hps_overq_leveled with size_Q - size_Ql levels dropped; buffers over the full base Q."""
         _lib.check(self._L.pha_bfv_multiply_hps_overq_leveled(self._h, size_Ql, _ptr(ct1), _ptr(ct2), _ptr(dst), _stream()))
 
+    def bfv_mul_relin_hps_overq_leveled(self, size_Ql, ct1, ct2, rlk_ptrs, dst):
+        """bfv_mul_relin_hps with levels dropped (src/evaluate.cu:822-1027); dst [2][Q][N]."""
+        _lib.check(self._L.pha_bfv_mul_relin_hps_overq_leveled(self._h, size_Ql, _ptr(ct1), _ptr(ct2), _ptr(rlk_ptrs), _ptr(dst), _stream()))
+
     def scaleAndRound_HPS_Q_Ql(self, size_Ql, dst, src):
         _lib.check(self._L.pha_scaleAndRound_HPS_Q_Ql(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
 

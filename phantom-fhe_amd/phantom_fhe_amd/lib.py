@@ -54,6 +54,7 @@ _SIGS = {
     "pha_bfv_multiply_hps": [vp, vp, vp, vp, vp],
     "pha_bfv_multiply_hps_overq": [vp, vp, vp, vp, vp],
     "pha_bfv_multiply_hps_overq_leveled": [vp, sz, vp, vp, vp, vp],
+    "pha_bfv_mul_relin_hps_overq_leveled": [vp, sz, vp, vp, vp, vp, vp],
     "pha_scaleAndRound_HPS_Q_Ql": [vp, sz, vp, vp, vp],
     "pha_ExpandCRTBasis_Ql_Q": [vp, sz, vp, vp, vp],
     "pha_keyswitch_inplace_bfv_leveled": [vp, sz, vp, vp, vp, vp],

@@ -508,13 +508,63 @@ int main() {
         qprod.store_to_host(got3.data());
         REQUIRE(got3 == r3);
         orc_hpsq_destroy(oq);
+        // mul_tech hps_overq_leveled: levels from the ciphertext's depth (FindLevelsToDrop), multiply / relinearize /
+        // multiply_and_relin with and without dropped levels
         EncryptionParameters lp = fp;
         lp.set_mul_tech(mul_tech_type::hps_overq_leveled);
         PhantomContext lctx(lp);
-        PhantomCiphertext l1;
+        {
+            // known answers from an independent restatement of src/evaluate.cu:551-647 (n 4096, t 65537, |P| 2, 3 digits, 60-bit primes)
+            const size_t mult[9] = {0, 0, 0, 1, 1, 2, 2, 3, 3}, ks[9] = {0, 0, 0, 1, 1, 2, 2, 2, 3};
+            for (size_t d = 0; d < 9; d++) {
+                REQUIRE(detail::find_levels_to_drop(lctx, d, 60.0, false, false) == mult[d]);
+                REQUIRE(detail::find_levels_to_drop(lctx, d, 60.0, true, false) == ks[d]);
+                REQUIRE(detail::find_levels_to_drop(lctx, d, 60.0, false, true) == ks[d]);
+            }
+            REQUIRE(detail::dcrt_bits(lctx) == 60.0);
+            REQUIRE(throws_invalid([&] { (void)detail::find_levels_to_drop(fctx, 1, 60.0, false, false); }));
+        }
+        PhantomRelinKey lrlk;
+        {
+            std::vector<uint64_t> flat;
+            for (auto &k : rlk_host) flat.insert(flat.end(), k.begin(), k.end());
+            lrlk.load_from_host(lctx, flat.data(), dnum);
+        }
+        PhantomCiphertext l1, l2;
         l1.load_from_host(lctx, 1, 2, h1.data());
+        l2.load_from_host(lctx, 1, 2, h2.data());
         l1.set_ntt_form(false);
-        REQUIRE(throws_invalid([&] { PhantomCiphertext c = l1; multiply_inplace(lctx, c, l1); }));
+        l2.set_ntt_form(false);
+        {   // fresh ciphertexts: nothing dropped, the result is plain hps_overq
+            orc_hpsq *top = orc_hpsq_create(oc, 65537);
+            PhantomCiphertext lprod = multiply(lctx, l1, l2);
+            orc_bfv_multiply_hps_overq(top, h1.data(), h2.data(), r3.data());
+            lprod.store_to_host(got3.data());
+            REQUIRE(got3 == r3 && lprod.GetNoiseScaleDeg() == 2);
+            orc_hpsq_destroy(top);
+        }
+        {   // depth 3 (noise scale degree 4): one level dropped in the multiply, in the key switch and in the fused form
+            orc_hpsq *lev = orc_hpsq_create_level(oc, 65537, size_q - 1);
+            orc_tool *lt = orc_tool_create(oc, size_q - 1);
+            PhantomCiphertext d1 = l1, d2 = l2;
+            d1.SetNoiseScaleDeg(4);
+            d2.SetNoiseScaleDeg(2);
+            PhantomCiphertext lprod = multiply(lctx, d1, d2);
+            orc_bfv_multiply_hps_overq(lev, h1.data(), h2.data(), r3.data());
+            lprod.store_to_host(got3.data());
+            REQUIRE(got3 == r3 && lprod.GetNoiseScaleDeg() == 5);
+            relinearize_inplace(lctx, lprod, lrlk);           // degree 5 -> depth 4 -> one level
+            std::vector<uint64_t> r2(r3.begin(), r3.begin() + 2 * ln), got2(2 * ln);
+            orc_keyswitch_bfv_leveled(lt, lev, r2.data(), r3.data() + 2 * ln, rlk_ptrs.data());
+            lprod.store_to_host(got2.data());
+            REQUIRE(got2 == r2 && lprod.size() == 2);
+            PhantomCiphertext fused = multiply_and_relin(lctx, d1, d2, lrlk);
+            orc_bfv_mul_relin_hps_overq_leveled(lt, lev, h1.data(), h2.data(), rlk_ptrs.data(), r2.data());
+            fused.store_to_host(got2.data());
+            REQUIRE(got2 == r2 && fused.size() == 2 && fused.GetNoiseScaleDeg() == 5);
+            orc_tool_destroy(lt);
+            orc_hpsq_destroy(lev);
+        }
     }
     phantom::util::check_hip(hipDeviceSynchronize(), "sync");
     orc_tool_destroy(tool);

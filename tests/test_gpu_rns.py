@@ -660,6 +660,9 @@ def test_bfv_hps_overq_leveled(name, plain_t, ql, gpu):
     d_ct = P.to_device(ref[:2], gpu)
     ctx.keyswitch_inplace_bfv_leveled(ql, d_ct, P.to_device(ref[2], gpu), rlk.public_keys_ptr)
     assert np.array_equal(P.to_host(d_ct), hq.keyswitch_leveled(tool, ref[:2], ref[2], [evk[i] for i in range(tool.beta)]))
+    fused = P.to_device(np.zeros((2, size_q, n), dtype=np.uint64), gpu)
+    ctx.bfv_mul_relin_hps_overq_leveled(ql, d1, d2, rlk.public_keys_ptr, fused)
+    assert np.array_equal(P.to_host(fused), hq.mul_relin_leveled(tool, ct1, ct2, [evk[i] for i in range(tool.beta)]))
     with pytest.raises(ValueError):
         ctx.scaleAndRound_HPS_Q_Ql(size_q, low, d2[0])          # nothing dropped
     # the top level through the leveled entry is plain hps_overq

@@ -559,6 +559,9 @@ def test_bfv_hps_overq_leveled_primitives_and_multiply(drop):
     tool = O.Tool(oc, ql)
     relin = hq.keyswitch_leveled(tool, d[:2], d[2], [evk[i] for i in range(tool.beta)])
     check([relin[0], relin[1]])
+    # the fused multiply + relinearise keeps c2 at level l: a different ciphertext with the same plaintext
+    fused = hq.mul_relin_leveled(tool, encrypt(m1), encrypt(m2), [evk[i] for i in range(tool.beta)])
+    check([fused[0], fused[1]])
 
 
 def test_gemm_mod_against_python_ints():
