@@ -1105,9 +1105,24 @@ inline void hoisting_inplace(const PhantomContext &context, PhantomCiphertext &c
         if (it == have.end()) throw std::logic_error("Galois key not present in hoisting");
         tables.push_back(glk.get_relin_keys(static_cast<size_t>(it - have.begin())).public_keys_ptr());
     }
-    if (key_parms.scheme() == scheme_type::bfv && key_parms.mul_tech() == mul_tech_type::hps_overq_leveled &&
-        detail::find_levels_to_drop(context, ct.GetNoiseScaleDeg() - 1, detail::dcrt_bits(context), true, ct.is_asymmetric()))
-        throw std::invalid_argument("hoisting with dropped levels (hps_overq_leveled) is not on the accelerated path");
+    if (key_parms.scheme() == scheme_type::bfv && key_parms.mul_tech() == mul_tech_type::hps_overq_leveled) {
+        // levels from the depth (:1689-1700); with dropped levels both polynomials are scaled down to Ql, rotated and summed
+        // at that level, and expanded back to Q (:1732-1738, :1757-1763, :1845-1862)
+        const size_t dropped = detail::find_levels_to_drop(context, ct.GetNoiseScaleDeg() - 1, detail::dcrt_bits(context), true, ct.is_asymmetric());
+        if (dropped) {
+            const auto &s = cudaStreamPerThread;
+            const size_t size_Q = context.get_context_data(1).parms().coeff_modulus().size(), ql = size_Q - dropped;
+            const size_t n = key_parms.poly_modulus_degree();
+            auto low = util::make_cuda_auto_ptr<uint64_t>(2 * ql * n, s);
+            for (size_t p = 0; p < 2; p++)
+                util::check_pha(pha_scaleAndRound_HPS_Q_Ql(context.amd(), ql, low.get() + p * ql * n, ct.data() + p * size_Q * n, s));
+            util::check_pha(pha_hoisting(context.amd(), ql, low.get(), elts.data(), elts.size(), tables.data(),
+                                         static_cast<int>(scheme_type::bfv), s));
+            for (size_t p = 0; p < 2; p++)
+                util::check_pha(pha_ExpandCRTBasis_Ql_Q(context.amd(), ql, ct.data() + p * size_Q * n, low.get() + p * ql * n, s));
+            return;
+        }
+    }
     util::check_pha(pha_hoisting(context.amd(), detail::level_size_Ql(context, ct), ct.data(), elts.data(), elts.size(),
                                  tables.data(), static_cast<int>(key_parms.scheme()), cudaStreamPerThread));
 }

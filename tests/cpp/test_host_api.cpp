@@ -562,6 +562,25 @@ int main() {
             orc_bfv_mul_relin_hps_overq_leveled(lt, lev, h1.data(), h2.data(), rlk_ptrs.data(), r2.data());
             fused.store_to_host(got2.data());
             REQUIRE(got2 == r2 && fused.size() == 2 && fused.GetNoiseScaleDeg() == 5);
+            // hoisted rotation with a dropped level: scale to Ql, hoist there, expand (evaluate.cu:1732-1862)
+            PhantomGaloisKey lglk;
+            {
+                PhantomRelinKey k1;
+                std::vector<uint64_t> flat;
+                for (auto &k : glk_host) flat.insert(flat.end(), k.begin(), k.end());
+                k1.load_from_host(lctx, flat.data(), dnum);
+                lglk.add(elt1, std::move(k1));
+            }
+            PhantomCiphertext rot = d1;      // degree 4 -> depth 3 -> one level for a key switch too
+            hoisting_inplace(lctx, rot, lglk, {1});
+            const size_t lq = size_q - 1;
+            std::vector<uint64_t> lowv(2 * lq * n), want(2 * ln), gotr(2 * ln);
+            for (int p = 0; p < 2; p++) orc_hps_scale_q_ql(lev, h1.data() + p * ln, lowv.data() + p * lq * n);
+            const uint64_t *const *gl[1] = {glk_ptrs.data()};
+            orc_hoisting(lt, lowv.data(), &elt1, 1, gl, ORC_BFV);
+            for (int p = 0; p < 2; p++) orc_hps_expand_ql_q(lev, lowv.data() + p * lq * n, want.data() + p * ln);
+            rot.store_to_host(gotr.data());
+            REQUIRE(gotr == want);
             orc_tool_destroy(lt);
             orc_hpsq_destroy(lev);
         }
