@@ -739,3 +739,52 @@ def test_base_converter_rejects_bad_bases(gpu):
         P.DBaseConverter(ctx, [0], [99])
     with pytest.raises(ValueError):
         P.DBaseConverter(ctx, [], [1])
+
+
+def test_concurrent_host_threads_on_their_own_streams(gpu):
+    """The context is immutable after construction and its scratch arenas are per stream, so several host threads may
+    evaluate on their own streams at once (the reference is built --default-stream per-thread for the same use)."""
+    import threading
+    import torch
+    import phantom_fhe_amd as P
+    name = "hyb13_a3"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(160)
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    jobs = []
+    for i, ql in enumerate((9, 7, 4, 9)):       # different levels: the per-level tools are built concurrently too
+        ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+        c2 = uniform_poly(r, primes[:ql], n)
+        tool = O.Tool(oc, ql)
+        want = tool.keyswitch_inplace(ct, c2, [evk[k] for k in range(tool.beta)], O.CKKS)
+        want = tool.rescale_ntt(want, 2) if ql > 1 else want
+        jobs.append((ql, ct, c2, want))
+    results, errors = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            ql, ct, c2, _ = jobs[i]
+            stream = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(stream):
+                for _ in range(5):                                   # repeat: reuse of the stream's arena
+                    d_ct, d_c2 = P.to_device(ct, gpu), P.to_device(c2, gpu)
+                    ctx.keyswitch_inplace(ql, d_ct, d_c2, rlk.public_keys_ptr, O.CKKS)
+                    dst = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+                    ctx.divide_and_round_q_last_ntt(ql, d_ct, 2, dst)
+                stream.synchronize()
+                results[i] = P.to_host(dst)
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (_, _, _, want) in enumerate(jobs):
+        assert np.array_equal(results[i], want)
