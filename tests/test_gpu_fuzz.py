@@ -1,6 +1,8 @@
 """Seeded random parameter sets through the whole key-switch path on the GPU vs the oracle: mixed prime sizes
 (30..60 bits: FP64 light / FP64 / integer NTT paths side by side), alpha 1..4, dnum 1..4, every level including
 short last digits, all three schemes, plus rescale / modulus switch and hoisted rotations."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,7 +19,8 @@ def _chain(rng, n, count):
     return [pools[b].pop(0) for b in sizes]
 
 
-@pytest.mark.parametrize("case", range(27))
+# PHA_FUZZ_EXTRA=k adds k more seeded cases (a longer hunt, not part of the default run)
+@pytest.mark.parametrize("case", list(range(27)) + [100 + i for i in range(int(os.environ.get("PHA_FUZZ_EXTRA", "0")))])
 def test_random_parameter_sets(case, gpu):
     import phantom_fhe_amd as P
     rng = rng_for(5000 + case)

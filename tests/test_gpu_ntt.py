@@ -195,7 +195,7 @@ def test_empty_and_full_size_properties(gpu):
     assert not P.to_host(dz).any()
 
 
-@pytest.mark.parametrize("log_n", [12, 13, 17])
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
 def test_large_residues_fp_thresholds(log_n, gpu, ntt_variant):
     """Residues just below q everywhere (busy low bits): the unreduced FP64 sums of the light butterflies reach
     their worst case, right at the prime sizes where the light / deferred variants switch."""
