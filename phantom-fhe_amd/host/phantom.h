@@ -50,6 +50,18 @@ inline void check_pha(int status) {  // C-ABI status -> the reference's exceptio
     throw std::runtime_error(pha_last_error());
 }
 
+// cuda_stream_wrapper (include/cuda_wrapper.cuh:47-63): an owned non-blocking stream
+class cuda_stream_wrapper {
+    cudaStream_t stream_{};
+
+public:
+    cuda_stream_wrapper() { check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreateWithFlags"); }
+    ~cuda_stream_wrapper() { (void)hipStreamDestroy(stream_); }
+    cuda_stream_wrapper(const cuda_stream_wrapper &) = delete;
+    cuda_stream_wrapper &operator=(const cuda_stream_wrapper &) = delete;
+    [[nodiscard]] const cudaStream_t &get_stream() const { return stream_; }
+};
+
 // cuda_auto_ptr<T> (include/cuda_wrapper.cuh:65-189): stream-ordered RAII buffer; move steals, copy is a
 // deep device copy on the source's stream.
 template <class T>
@@ -165,6 +177,16 @@ struct CoeffModulus {
         return out;
     }
 };
+
+// PlainModulus::Batching (include/host/modulus.h:301-320): a prime = 1 mod 2N of the given size
+struct PlainModulus {
+    [[nodiscard]] static Modulus Batching(size_t poly_modulus_degree, int bit_size) {
+        return CoeffModulus::Create(poly_modulus_degree, {bit_size})[0];
+    }
+};
+
+// sec_level_type (include/host/modulus.h:217-232)
+enum class sec_level_type : int { none = 0, tc128 = 128, tc192 = 192, tc256 = 256 };
 
 }  // namespace arith
 

@@ -32,7 +32,12 @@ PYBIND11_MODULE(pyPhantom, m) {
         .value("hps_overq", mul_tech_type::hps_overq).value("hps_overq_leveled", mul_tech_type::hps_overq_leveled);
 
     py::class_<Modulus>(m, "modulus").def(py::init<uint64_t>()).def("value", &Modulus::value).def("bit_count", &Modulus::bit_count);
+    py::enum_<sec_level_type>(m, "sec_level_type")
+        .value("none", sec_level_type::none).value("tc128", sec_level_type::tc128)
+        .value("tc192", sec_level_type::tc192).value("tc256", sec_level_type::tc256);
     m.def("create_coeff_modulus", &CoeffModulus::Create);
+    m.def("create_plain_modulus", &PlainModulus::Batching);
+    py::class_<util::cuda_stream_wrapper>(m, "cuda_stream").def(py::init<>());
     m.def("get_elt_from_step", &util::get_elt_from_step);
     m.def("get_elts_from_steps", &util::get_elts_from_steps);
 

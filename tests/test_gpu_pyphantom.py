@@ -14,9 +14,11 @@ def test_module_surface():
                  "galois_key", "create_coeff_modulus", "get_elt_from_step", "get_elts_from_steps", "negate", "add",
                  "sub", "multiply", "multiply_and_relin", "relinearize", "rescale_to_next", "mod_switch_to_next",
                  "apply_galois", "rotate", "hoisting", "plaintext", "add_plain", "sub_plain", "multiply_plain", "add_many",
-                 "mod_switch_to"):
+                 "mod_switch_to", "create_plain_modulus", "sec_level_type"):
         assert hasattr(ph, name), name
     assert ph.get_elt_from_step(1, 4096) == 5 and ph.get_elt_from_step(0, 4096) == 8191
+    t = ph.create_plain_modulus(4096, 20).value()          # PlainModulus::Batching(4096, 20), examples/1_bfv.cu
+    assert t % 8192 == 1 and t.bit_length() == 20
     mods = ph.create_coeff_modulus(1 << 14, [60] + [40] * 6 + [60])
     assert mods[0].value() == 1152921504606683137          # SURVEY.md 8(c) known answer
 
