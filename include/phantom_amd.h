@@ -355,7 +355,9 @@ int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint
 /* ---- tuning knob for A/B measurements: key 0 = NTT thread geometry (0: 16 coefficients per thread,
  *      256-thread workgroups; bit 0: 8 per thread, 512-thread workgroups; bit 3: integer butterflies for every
  *      prime (FP64 path off); bit 4: on-the-fly twiddles in the contiguous pass; bit 5: bit 4 automatically for
- *      launches of >= 1024 tiles (default 1|32)); key 1 = base-conversion MAC (1: carry-free split
+ *      launches of >= 1024 tiles; bit 6: one wavefront per workgroup in the contiguous pass; bit 7: N = 4096 / 8192
+ *      through the two-pass plans instead of the one-launch ones; bit 8: the one-launch plan at N = 8192 for every
+ *      launch size (default: from 64 limb-polynomials); default 1|32|64); key 1 = base-conversion MAC (1: carry-free split
  *      accumulators, 0: 128-bit carry chain).  Results are identical for every setting. ---- */
 int pha_set_tuning(int key, int value);
 

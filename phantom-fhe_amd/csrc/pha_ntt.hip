@@ -139,11 +139,15 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
     PHA_STAMP(2);
     Prog::template run<1>(a, lds, tid, reg, twreg);
     PHA_STAMP(3);
-    if constexpr (Prog::NSEG == 3) {
+    if constexpr (Prog::NSEG >= 3) {
         tile_sync<C>();
         PHA_STAMP(4);
         Prog::template run<2>(a, lds, tid, reg, twreg);
         PHA_STAMP(5);
+    }
+    if constexpr (Prog::NSEG == 4) {
+        tile_sync<C>();
+        Prog::template run<3>(a, lds, tid, reg, twreg);
     }
 #if defined(PHA_EXP_STAMPS)
     __builtin_amdgcn_s_waitcnt(0);
@@ -165,25 +169,32 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     //  DESIGN.md section 7)
     dim3 grid(tiles_per_limb, k.sel.count, k.batch);
     (void)total;
+    if (lds_bytes > 64 * 1024) {   // beyond the default dynamic LDS limit: raise it once per kernel
+        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<C, FWD, EPI, FOLD, 0>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        PHA_HIP(raised);
+    }
     hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, k);
     check_launch();
 }
 
-// N = 4096 as ONE pass (the transform fits a tile): T1 = 1, T2 = N
-static void forward_whole12(NttKArgs k, int epi, hipStream_t s) {
+// N = 4096 / 8192 as ONE pass (the transform fits a tile): T1 = 1, T2 = N
+template <class W>
+static void forward_whole(NttKArgs k, int epi, hipStream_t s) {
     k.t1 = 1;
-    k.t2 = WholePlan12::T;
+    k.t2 = W::T;
     k.mid = k.out;
-    if (epi == EPI_FWD_MODDOWN) launch_pass<WholePlan12, true, EPI_FWD_MODDOWN, false>(k, s);
-    else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<WholePlan12, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
-    else launch_pass<WholePlan12, true, EPI_FWD_CANON, false>(k, s);
+    if (epi == EPI_FWD_MODDOWN) launch_pass<W, true, EPI_FWD_MODDOWN, false>(k, s);
+    else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<W, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
+    else launch_pass<W, true, EPI_FWD_CANON, false>(k, s);
 }
-static void inverse_whole12(NttKArgs k, int epi, hipStream_t s) {
+template <class W>
+static void inverse_whole(NttKArgs k, int epi, hipStream_t s) {
     k.t1 = 1;
-    k.t2 = WholePlan12::T;
+    k.t2 = W::T;
     k.mid = k.out;
-    if (epi == EPI_INV_SCALE) launch_pass<WholePlan12, false, EPI_INV_SCALE, true>(k, s);
-    else launch_pass<WholePlan12, false, EPI_INV_CANON, true>(k, s);
+    if (epi == EPI_INV_SCALE) launch_pass<W, false, EPI_INV_SCALE, true>(k, s);
+    else launch_pass<W, false, EPI_INV_CANON, true>(k, s);
 }
 
 template <int LOGN, int VARIANT>
@@ -284,7 +295,14 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
     if (c.log_n == 12 && !(vv & 128)) {  // bit 7 clear (default): N = 4096 in one launch
-        forward_whole12(k, epi, s);
+        forward_whole<WholePlan12>(k, epi, s);
+        return;
+    }
+    // N = 8192 in one launch pays from about 64 limb-polynomials per launch (one 512-thread workgroup per limb: 1 / 10 /
+    // 60 / 240 / 1020 limbs 10.4 / 10.8 / 11.5 / 13.7 / 53.8 us against 8.7 / 9.4 / 12.0 / 26.2 / 58.2 in two passes);
+    // bit 8 forces it for every size (tests)
+    if (c.log_n == 13 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= 64)) {
+        forward_whole<WholePlan13>(k, epi, s);
         return;
     }
     switch (c.log_n) {
@@ -310,7 +328,11 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
     if (c.log_n == 12 && !(vv & 128)) {
-        inverse_whole12(k, epi, s);
+        inverse_whole<WholePlan12>(k, epi, s);
+        return;
+    }
+    if (c.log_n == 13 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= 64)) {
+        inverse_whole<WholePlan13>(k, epi, s);
         return;
     }
     switch (c.log_n) {
@@ -517,7 +539,7 @@ int pha_exp_read_wg_times(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 255 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 511 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

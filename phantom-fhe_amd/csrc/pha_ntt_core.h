@@ -53,38 +53,42 @@ enum Epilogue {
 // (Splitting the STRIDED pass by columns between the wavefronts makes it barrier-free too; measured r01g:
 // 16-byte runs per row cost more than the barriers, 45 limbs 29.1 -> 34.1 us, so that form was dropped.)
 // WHOLE_: the pass is the whole transform (N = 4096 fits one tile): it is both the first and the last pass.
+// R3_: a fourth round (whole-transform plans beyond 12 stages).
 template <int LOGT_, bool STRIDED_, int R0_, int R1_, int R2_ = 0, int EPT_ = 16, bool OT_ = false, int LOGTILE_ = 12,
-          bool WHOLE_ = false>
+          bool WHOLE_ = false, int R3_ = 0>
 struct PassCfg {
     static constexpr int EPT = EPT_;
     static constexpr bool OT = OT_ && !STRIDED_;
     static constexpr int LOGTILE = LOGTILE_;
     static constexpr int TILE = 1 << LOGTILE_;
     static constexpr int THREADS = TILE / EPT_;
-    static_assert(LOGTILE_ >= LOGT_ && LOGTILE_ <= 12, "a tile holds whole transforms and fits the LDS budget");
+    static_assert(LOGTILE_ >= LOGT_ && LOGTILE_ <= 13, "a tile holds whole transforms and fits the LDS budget");
     // one wavefront per workgroup: every exchange between rounds stays inside it, no workgroup barrier
     static constexpr bool WAVE_LOCAL = TILE / EPT_ == 64;
     static constexpr bool WHOLE = WHOLE_ && !STRIDED_;
-    static_assert((1 << R0_) <= EPT_ && (1 << R1_) <= EPT_ && (1 << R2_) <= EPT_, "radix exceeds registers");
+    static_assert((1 << R0_) <= EPT_ && (1 << R1_) <= EPT_ && (1 << R2_) <= EPT_ && (1 << R3_) <= EPT_, "radix exceeds registers");
+    static_assert(!R3_ || R2_, "rounds are filled in order");
     static constexpr int LOGT = LOGT_;
     static constexpr int T = 1 << LOGT_;
     static constexpr int LOGV = LOGTILE_ - LOGT_;
     static constexpr int V = 1 << LOGV;
     static constexpr bool STRIDED = STRIDED_;
-    static constexpr int NR = R2_ ? 3 : 2;
-    static_assert(R0_ + R1_ + R2_ == LOGT_, "round schedule must cover all stages");
-    static_assert(LOGT_ >= 4 && LOGT_ <= 12, "tile transform length out of range");
+    static constexpr int NR = R3_ ? 4 : R2_ ? 3 : 2;
+    static_assert(R0_ + R1_ + R2_ + R3_ == LOGT_, "round schedule must cover all stages");
+    static_assert(LOGT_ >= 4 && LOGT_ <= 13, "tile transform length out of range");
     static_assert(THREADS >= 64, "a workgroup is at least one wavefront");
-    static constexpr int r(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : R2_; }
+    static constexpr int r(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : i == 2 ? R2_ : R3_; }
     // twiddle registers per thread: round i holds G_i groups x (2^r_i - 1) pairs
     static constexpr bool ot_round(int i) { return OT && i == NR - 1; }
     // on-the-fly round: (2^r - 1) shared factors + r per-row factors for each of the G groups
     static constexpr int tw_count(int i) {
         return !r(i) ? 0 : ot_round(i) ? ((1 << r(i)) - 1) + (EPT_ >> r(i)) * r(i) : (EPT_ >> r(i)) * ((1 << r(i)) - 1);
     }
-    static constexpr int tw_off(int i) { return i == 0 ? 0 : i == 1 ? tw_count(0) : tw_count(0) + tw_count(1); }
-    static constexpr int TW_TOTAL = tw_count(0) + tw_count(1) + tw_count(2);
-    static constexpr int s0(int i) { return i == 0 ? 0 : i == 1 ? R0_ : R0_ + R1_; }
+    static constexpr int tw_off(int i) {
+        return i == 0 ? 0 : i == 1 ? tw_count(0) : i == 2 ? tw_count(0) + tw_count(1) : tw_count(0) + tw_count(1) + tw_count(2);
+    }
+    static constexpr int TW_TOTAL = tw_count(0) + tw_count(1) + tw_count(2) + tw_count(3);
+    static constexpr int s0(int i) { return i == 0 ? 0 : i == 1 ? R0_ : i == 2 ? R0_ + R1_ : R0_ + R1_ + R2_; }
     // LDS layouts (u64 units).  contiguous pass: [v][e] with 2 words of padding per 16 so that a
     // thread's 16-coefficient run starts on a distinct 16-byte bank slot (ds_read_b128, 16-lane
     // groups).  strided pass: [e][v] with one 128-byte skew per 16 rows (ds_read_b64).
@@ -449,9 +453,9 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
                 // stages of this pass already done (inverse order: rounds NR-1 .. 0), and whether it began canonical
                 constexpr int stage0 = C::LOGT - C::s0(RI) - r;
                 constexpr bool canon_in = !C::STRIDED;  // the inverse's first pass is the contiguous one
-                // unreduced sums double every stage: a 12-stage pass (N = 4096 in one launch) reaches 2^12 q, so it
-                // only runs light below 2^40 (2^52 worst case; all-(q-1) inputs do reach it)
-                const bool light = a.fpm.gs_light && (C::LOGT <= 9 || a.fpm.q < 0x1p40);
+                // unreduced sums double every stage: a LOGT-stage pass reaches 2^LOGT q, so the whole-transform plans
+                // (12 / 13 stages) only run light while that stays within 2^52 (inputs just below q do reach it)
+                const bool light = a.fpm.gs_light && (C::LOGT <= 9 || a.fpm.q < (double)(1ull << (52 - C::LOGT)));
                 if (light) fp_gs_round<r, FOLD, true>(rg, t, a.fpm, a.ninv, a.w1ninv);
                 else fp_gs_round<r, FOLD, false, stage0, canon_in>(rg, t, a.fpm, a.ninv, a.w1ninv);
             }
@@ -559,7 +563,8 @@ struct PassProgram {
         if (HOIST == 1) {
             round_load_tw<C, 0>(a, tid, twreg);
             round_load_tw<C, 1>(a, tid, twreg);
-            if (C::NR == 3) round_load_tw<C, 2>(a, tid, twreg);
+            if (C::NR >= 3) round_load_tw<C, 2>(a, tid, twreg);
+            if (C::NR == 4) round_load_tw<C, 3>(a, tid, twreg);
         } else if (HOIST == 2) {
             round_load_tw<C, round_of(0)>(a, tid, twreg);
         }
@@ -645,5 +650,7 @@ template <> struct NttPlan<16, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  us
 template <> struct NttPlan<17, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, true, 9>; };
 // N = 4096: the whole transform in one 4096-coefficient tile (three radix-16 rounds, one launch, no intermediate)
 using WholePlan12 = PassCfg<12, false, 4, 4, 4, 16, false, 12, true>;
+// N = 8192: the same with a fourth (radix-2) round: one 8192-coefficient tile, 512 threads, 72 KiB of LDS
+using WholePlan13 = PassCfg<13, false, 4, 4, 4, 16, false, 13, true, 1>;
 
 }  // namespace pha

@@ -87,7 +87,7 @@ static int check_wave_local() {
     if (!C::WAVE_LOCAL) return 0;
     std::vector<int> owner(C::LDS_WORDS, -1);
     int bad = check_round_owner<C, 0>(owner) + check_round_owner<C, 1>(owner);
-    if constexpr (C::NR == 3) bad += check_round_owner<C, 2>(owner);
+    if constexpr (C::NR >= 3) bad += check_round_owner<C, 2>(owner);
     int used = 0;
     for (int o : owner) used += o >= 0;
     if (used != C::TILE) bad += 1000000;   // every coefficient of the tile has exactly one slot
@@ -107,20 +107,20 @@ extern "C" int emu_plan_is_wave_local(int log_n, int variant) {   // bit 0: pass
     switch (log_n) { WLC(12) WLC(13) WLC(14) WLC(15) WLC(16) WLC(17) default: return -1; }
 }
 
-// N = 4096 as one pass (variant 6)
-static void emu_whole12(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *tw, u64x2 ninv, u64x2 w1ninv,
-                        u64x2 scale, const u64 *aux, bool fp) {
-    using P = WholePlan12;
+// N = 4096 / 8192 as one pass (variant 6)
+template <class P>
+static void emu_whole(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *tw, u64x2 ninv, u64x2 w1ninv,
+                      u64x2 scale, const u64 *aux, bool fp) {
     PassArgs a{};
     a.tw = tw; a.twd = reinterpret_cast<const u64 *>(tw); a.q = q; a.rho0 = 1; a.stride = P::T; a.ninv = ninv; a.w1ninv = w1ninv;
     a.scale = scale; a.aux = aux; a.fp = fp; a.fpm = make_fpmod(q);
     a.in = in; a.out = out;
     if (fwd) {
-        if (epi == EPI_FWD_MODDOWN) run_pass<P, true, EPI_FWD_MODDOWN, false>(a, 4096);
-        else run_pass<P, true, EPI_FWD_CANON, false>(a, 4096);
+        if (epi == EPI_FWD_MODDOWN) run_pass<P, true, EPI_FWD_MODDOWN, false>(a, P::T);
+        else run_pass<P, true, EPI_FWD_CANON, false>(a, P::T);
     } else {
-        if (epi == EPI_INV_SCALE) run_pass<P, false, EPI_INV_SCALE, true>(a, 4096);
-        else run_pass<P, false, EPI_INV_CANON, true>(a, 4096);
+        if (epi == EPI_INV_SCALE) run_pass<P, false, EPI_INV_SCALE, true>(a, P::T);
+        else run_pass<P, false, EPI_INV_CANON, true>(a, P::T);
     }
 }
 
@@ -137,8 +137,9 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
     const int log_n = log_n_and_variant & 0xff, variant = (log_n_and_variant >> 8) & 0xff;
     const bool fp = (log_n_and_variant >> 16) & 1;
     if (variant == 6) {
-        if (log_n != 12) return -2;
-        emu_whole12(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        if (log_n == 12) emu_whole<WholePlan12>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else if (log_n == 13) emu_whole<WholePlan13>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else return -2;
         return 0;
     }
 #define EMU_CASE(N) case N: if (variant == 4) emu<N, 4>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 3) emu<N, 3>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 2) emu<N, 2>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;

@@ -36,8 +36,8 @@ def pair(v, q):
 @pytest.mark.parametrize("bits", [40, 42, 43, 47, 48, 50, 60, 61])   # 42 / 47: just under the light-butterfly thresholds
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
 def test_thread_program_matches_oracle(emu, log_n, bits, variant):
-    if variant == 6 and log_n != 12:
-        pytest.skip("the one-launch plan exists for N = 4096 only")
+    if variant == 6 and log_n not in (12, 13):
+        pytest.skip("the one-launch plans exist for N = 4096 and 8192 only")
     n = 1 << log_n
     code = log_n | (variant << 8)   # variant 1 = 8 coefficients per thread (512-thread workgroups); 2 = 1 + on-the-fly twiddles
     q = int(O.get_primes(n, bits, 1)[0])

@@ -39,7 +39,7 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
     assert np.array_equal(P.to_host(d2), oc.nwt_backward(x, L, 0))
 
 
-@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave", "two-pass-4096"])
+@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave", "two-pass-4096", "one-launch-8192", "one-launch-8192-int"])
 def ntt_variant(request):
     """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
     import phantom_fhe_amd as P
@@ -317,3 +317,21 @@ def test_single_workgroup_transforms(log_n, gpu):
     assert np.array_equal(got[:, : n // 2], oc.multiply_scalar(x, nvec, L, 0)[:, : n // 2])
     with pytest.raises(ValueError):
         P.fnwt_1d(dev(np.zeros((1, 4096), dtype=np.uint64)), d_tw, d_tws, d_mod, 4096, 1, 0)
+
+
+def test_one_launch_8192_takes_over_for_large_launches(gpu):
+    """N = 8192: launches of 64 or more limb-polynomials take the one-launch plan by default (smaller ones keep the two
+    passes); both must agree with the oracle, also with the special-prime remap and a skipped digit range."""
+    import phantom_fhe_amd as P
+    name = "hyb13_a3"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L, batch = len(primes), 8                                     # 12 x 8 = 96 limb-polynomials
+    x = np.stack([uniform_poly(rng_for(50 + b), primes, n) for b in range(batch)])
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_batched(d, L, 0, batch, L * n)
+    want = np.stack([oc.nwt_forward(x[b], L, 0) for b in range(batch)])
+    assert np.array_equal(P.to_host(d), want)
+    ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
+    assert np.array_equal(P.to_host(d), x)
