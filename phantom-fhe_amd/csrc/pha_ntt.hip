@@ -169,10 +169,16 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     //  DESIGN.md section 7)
     dim3 grid(tiles_per_limb, k.sel.count, k.batch);
     (void)total;
-    if (lds_bytes > 64 * 1024) {   // beyond the default dynamic LDS limit: raise it once per kernel
-        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<C, FWD, EPI, FOLD, 0>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        PHA_HIP(raised);
+    if (lds_bytes > 64 * 1024) {   // beyond the default dynamic LDS limit: raise it once per kernel and device
+        static std::atomic<uint64_t> raised{0};
+        int dev = 0;
+        PHA_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(raised.load(std::memory_order_acquire) & bit)) {
+            PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<C, FWD, EPI, FOLD, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            raised.fetch_or(bit, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, k);
     check_launch();
