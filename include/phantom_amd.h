@@ -351,6 +351,10 @@ int pha_apply_galois_ntt(pha_context_t ctx, const uint64_t *src, uint64_t *dst, 
                          size_t coeff_mod_size, void *stream);
 int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt,
                      size_t coeff_mod_size, size_t mod_start_idx, void *stream);
+/* the same permutation on `polys` polynomials [polys][coeff_mod_size][N] in one launch (ntt_form != 0: the NTT-domain
+ * table permutation, else the coefficient-domain one with its sign) */
+int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt,
+                             size_t coeff_mod_size, size_t polys, int ntt_form, void *stream);
 
 /* ---- tuning knob for A/B measurements: key 0 = NTT thread geometry (0: 16 coefficients per thread,
  *      256-thread workgroups; bit 0: 8 per thread, 512-thread workgroups; bit 3: integer butterflies for every

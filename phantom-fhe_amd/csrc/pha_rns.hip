@@ -547,10 +547,11 @@ __global__ __launch_bounds__(256) void galois_ntt_kernel(u64 *dst, const u64 *sr
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
     dst[(size_t)limb * n + coeff] = src[(size_t)limb * n + table[coeff]];
 }
+// blockIdx.z = polynomial of a batch (stride = gridDim.y limbs)
 __global__ __launch_bounds__(256) void galois_coeff_kernel(u64 *dst, const u64 *src, const DModulus *mod,
                                                            uint32_t mod_start, uint32_t elt, uint32_t n) {
-    const uint32_t limb = blockIdx.y;
-    const u64 q = mod[mod_start + limb].value;
+    const uint32_t limb = blockIdx.z * gridDim.y + blockIdx.y;
+    const u64 q = mod[mod_start + blockIdx.y].value;
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
     // index_raw = coeff * galois_elt mod 2n (include/galois.cuh:115-130)
     const uint32_t raw = (uint32_t)(((u64)coeff * elt) & (2 * (u64)n - 1));
@@ -1069,6 +1070,31 @@ int pha_apply_galois_ntt(pha_context_t ctx, const uint64_t *src, uint64_t *dst, 
     const uint32_t *tab = c.galois_table(galois_elt);
     hipLaunchKernelGGL(galois_ntt_kernel, dim3((unsigned)(c.n / 256), (unsigned)cms), dim3(256), 0,
                        as_stream(stream), dst, src, tab, (uint32_t)c.n);
+    check_launch();
+    PHA_API_END
+}
+
+int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt, size_t cms,
+                             size_t polys, int ntt_form, void *stream) {
+    PHA_API_BEGIN
+    need(src); need(dst);
+    if (src == dst) throw std::invalid_argument("apply_galois cannot run in place");
+    Context &c = ctx->c;
+    if (!(galois_elt & 1) || galois_elt >= 2 * c.n) throw std::invalid_argument("Galois element is not valid");
+    if (cms > c.size_qp) throw std::invalid_argument("modulus index out of range");
+    if (polys == 0 || cms == 0) return 0;
+    if (polys > 65535) throw std::invalid_argument("batch out of range");
+    if (ntt_form) {   // the NTT-domain permutation does not depend on the modulus: the polynomials are just more limbs
+        const uint32_t *tab = c.galois_table(galois_elt);
+        for (size_t p0 = 0; p0 < polys * cms; p0 += 65535) {
+            const size_t cnt = std::min<size_t>(65535, polys * cms - p0);
+            hipLaunchKernelGGL(galois_ntt_kernel, dim3((unsigned)(c.n / 256), (unsigned)cnt), dim3(256), 0, as_stream(stream),
+                               dst + p0 * c.n, src + p0 * c.n, tab, (uint32_t)c.n);
+        }
+    } else {
+        hipLaunchKernelGGL(galois_coeff_kernel, dim3((unsigned)(c.n / 256), (unsigned)cms, (unsigned)polys), dim3(256), 0,
+                           as_stream(stream), dst, src, c.d_mod.p, 0u, galois_elt, (uint32_t)c.n);
+    }
     check_launch();
     PHA_API_END
 }

@@ -366,6 +366,9 @@ class PhantomContext:
         _lib.check(self._L.pha_nwt_2d_radix8_forward_modup_fuse(self._h, _ptr(out), _ptr(inp), modulus_index, cms, start,
                                                                 _stream()))
 
+    def apply_galois_batched(self, src, dst, galois_elt, cms, polys, ntt_form):
+        _lib.check(self._L.pha_apply_galois_batched(self._h, _ptr(src), _ptr(dst), galois_elt, cms, polys, int(bool(ntt_form)), _stream()))
+
     # -- measurement ------------------------------------------------------------------------------
     def time_forward_ntt(self, inout, cms, iters):
         ms = C.c_float()

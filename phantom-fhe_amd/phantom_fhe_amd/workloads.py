@@ -35,12 +35,7 @@ def _relinearize_rotate_chunk(ctx, size_Ql, ct3, relin_key, galois_key, galois_e
     ct = ct3[:, :2].clone(memory_format=torch.contiguous_format)   # never a view: the key switch works in place
     ctx.keyswitch_inplace_batched(size_Ql, ct, ct3[:, 2].contiguous(), B, relin_key.public_keys_ptr, scheme)
     g = torch.empty_like(ct)
-    for b in range(B):
-        for p in range(2):
-            if int(scheme) == int(scheme_type.bfv):
-                ctx.apply_galois(ct[b, p], g[b, p], galois_elt, size_Ql)
-            else:
-                ctx.apply_galois_ntt(ct[b, p], g[b, p], galois_elt, size_Ql)
+    ctx.apply_galois_batched(ct, g, galois_elt, size_Ql, 2 * B, int(scheme) != int(scheme_type.bfv))
     rot = torch.zeros_like(ct)
     rot[:, 0] = g[:, 0]
     ctx.keyswitch_inplace_batched(size_Ql, rot, g[:, 1].contiguous(), B, galois_key.public_keys_ptr, scheme)

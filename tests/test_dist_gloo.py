@@ -90,6 +90,9 @@ class _StubCtx:
 
     apply_galois_ntt = apply_galois
 
+    def apply_galois_batched(self, src, dst, elt, ql, polys, ntt_form):
+        dst.copy_(src.flip(-1) + elt)
+
     def hoisting_weighted(self, ql, ct, elts, keys, weights, scheme):
         acc = sum(w[:ql] * int(e) for w, e in zip(weights, elts))
         ct *= acc[None]

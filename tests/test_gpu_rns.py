@@ -831,3 +831,25 @@ def test_key_switch_and_rescale_replay_from_a_hip_graph(gpu):
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(P.to_host(out), want)
+
+
+@pytest.mark.parametrize("ntt_form", [False, True])
+def test_apply_galois_batched(ntt_form, gpu):
+    """One launch for the permutation of several polynomials == the per-polynomial calls (src/galois.cu:11-39)."""
+    import phantom_fhe_amd as P
+    name = "hyb12_a2"
+    log_n, primes, _ = primes_of(name)
+    n = 1 << log_n
+    ctx = _ctx(name, gpu)
+    ql, polys, elt = 5, 6, 2 * n - 1
+    x = np.stack([uniform_poly(rng_for(180 + p), primes[:ql], n) for p in range(polys)])
+    d_x = P.to_device(x, gpu)
+    ref = P.to_device(np.zeros_like(x), gpu)
+    for p in range(polys):
+        if ntt_form:
+            ctx.apply_galois_ntt(d_x[p], ref[p], elt, ql)
+        else:
+            ctx.apply_galois(d_x[p], ref[p], elt, ql)
+    out = P.to_device(np.zeros_like(x), gpu)
+    ctx.apply_galois_batched(d_x, out, elt, ql, polys, ntt_form)
+    assert np.array_equal(P.to_host(out), P.to_host(ref))
