@@ -72,3 +72,44 @@ def test_random_parameter_sets(case, gpu):
     d_h = P.to_device(ct, gpu)
     ctx.hoisting(ql, d_h, elts, [P.PhantomRelinKey.from_numpy(k, gpu) for k in glk], scheme)
     assert np.array_equal(P.to_host(d_h), tool.hoisting(ct, elts, [[k[i] for i in range(tool.beta)] for k in glk], scheme))
+
+
+@pytest.mark.parametrize("case", list(range(6)) + [100 + i for i in range(int(os.environ.get("PHA_FUZZ_EXTRA", "0")) // 4)])
+def test_random_bfv_multiply_parameter_sets(case, gpu):
+    """Seeded random chains (uniform prime size per chain as the HPS variants need, 36..60 bits, 2..6 data primes, random
+    plain modulus) through the four BFV multiply variants, the leveled primitives and the plaintext operations."""
+    import phantom_fhe_amd as P
+    rng = rng_for(7000 + case)
+    log_n = int(rng.choice([12, 13]))
+    n = 1 << log_n
+    bits = int(rng.choice([36, 40, 45, 50, 55, 60]))
+    size_q = int(rng.integers(2, 7))
+    alpha = int(rng.choice([a for a in (1, 2, 3) if size_q % a == 0]))
+    primes = [int(p) for p in O.coeff_modulus_create(n, [bits] * size_q + [60] * alpha)]
+    t = int(rng.choice([65537, 786433, 1032193, 1 << 16, 1 << 20]))
+    if t >= min(primes):
+        t = 65537
+    oc = O.Ctx(log_n, primes, alpha)
+    ctx = P.PhantomContext(log_n, primes, alpha, device=gpu)
+    ctx.set_plain_modulus(t)
+    ct1 = np.stack([uniform_poly(rng, primes[:size_q], n) for _ in range(2)])
+    ct2 = np.stack([uniform_poly(rng, primes[:size_q], n) for _ in range(2)])
+    d1, d2 = P.to_device(ct1, gpu), P.to_device(ct2, gpu)
+    dst = P.to_device(np.zeros((3, size_q, n), dtype=np.uint64), gpu)
+    ctx.bfv_multiply_behz(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), O.Behz(oc, t).multiply(ct1, ct2)), f"behz {primes} t={t}"
+    ctx.bfv_multiply_hps(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), O.Hps(oc, t).multiply(ct1, ct2)), f"hps {primes} t={t}"
+    ctx.bfv_multiply_hps_overq(d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), O.HpsOverQ(oc, t).multiply(ct1, ct2)), f"overq {primes} t={t}"
+    ql = int(rng.integers(1, size_q))
+    hq = O.HpsOverQ(oc, t, ql)
+    ctx.bfv_multiply_hps_overq_leveled(ql, d1, d2, dst)
+    assert np.array_equal(P.to_host(dst), hq.multiply(ct1, ct2)), f"leveled {primes} t={t} ql={ql}"
+    m = rng.integers(0, t, n, dtype=np.uint64)
+    d = P.to_device(ct1[0], gpu)
+    ctx.bfv_add_plain(size_q, d, P.to_device(m, gpu))
+    assert np.array_equal(P.to_host(d), oc.bfv_add_plain(ct1[0], m, t))
+    d = P.to_device(ct1, gpu)
+    ctx.bfv_multiply_plain(size_q, d, 2, P.to_device(m, gpu))
+    assert np.array_equal(P.to_host(d), oc.bfv_multiply_plain(ct1, m, t))
