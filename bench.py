@@ -45,9 +45,10 @@ def uniform_residues(primes, n, device, gen):
     return out
 
 
-def cpu_baseline(primes, n, seconds=12.0):
+def cpu_baseline(primes, n, seconds=12.0, gpu_forward=None):
     """Time the oracle's forward NTT (C port of the reference semantics) on the host: one core (the reported
-    baseline) and, informational, OpenMP over the 45 limbs on every core of the box."""
+    baseline) and, informational, OpenMP over the 45 limbs on every core of the box.  Before the timing is
+    accepted the same input goes through the GPU path (gpu_forward) and the two outputs are compared bit for bit."""
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # idle OpenMP threads must not spin on a shared box
     from oracle import oracle as O
     path = O.build(native=True)
@@ -56,6 +57,16 @@ def cpu_baseline(primes, n, seconds=12.0):
     x = np.stack([rng.integers(0, int(q), n, dtype=np.uint64) for q in primes[:45]]).reshape(-1)
     import ctypes as C
     ptr = x.ctypes.data_as(C.POINTER(C.c_uint64))
+
+    checked = None
+    if gpu_forward is not None:
+        want = x.copy()
+        oc.L.orc_set_threads(1)
+        oc.L.orc_nwt_forward(oc.h, want.ctypes.data_as(C.POINTER(C.c_uint64)), 45, 0)
+        got = gpu_forward(x.reshape(45, n))
+        if not np.array_equal(got.reshape(-1), want):
+            raise SystemExit("bench: the GPU forward NTT differs from the CPU restatement -- timing rejected")
+        checked = "GPU forward NTT of the baseline's 45-limb input == CPU restatement, bit for bit"
 
     def run(threads, budget):
         oc.L.orc_set_threads(threads)
@@ -83,7 +94,7 @@ def cpu_baseline(primes, n, seconds=12.0):
     oc.L.orc_set_threads(1)
     return {"value": 45 * reps / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
             "sample": f"{reps} forward NTTs of 45 limbs at N=2^16 ({dt:.1f} s, oracle/oracle.c -O3 -march=native, 1 thread)",
-            "host_cpus": cores,
+            "host_cpus": cores, "checked": checked,
             "all_cores": {"value": 45 * reps_all / dt_all, "unit": "NTT/s", "cores": threads,
                           "sample": f"{reps_all} x 45 limbs, OpenMP over limbs ({threads} threads, one limb each), "
                                     f"{dt_all:.1f} s; cores = min(affinity, cgroup quota, 45)"}}
@@ -328,7 +339,11 @@ def main():
                                              "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_inplace_batched + rescale of the batch"},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(primes, n)
+            def gpu_forward(host_poly):   # the product path on the baseline's own input
+                d = P.to_device(host_poly, dev)
+                ctx.nwt_2d_radix8_forward_inplace(d, 45, 0)
+                return P.to_host(d)
+            line["cpu_baseline"] = cpu_baseline(primes, n, gpu_forward=gpu_forward)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
