@@ -462,8 +462,7 @@ extern "C" int pha_bfv_mul_relin_hps_overq_leveled(pha_context_t ctx, size_t siz
     HpsQ &h = c.hps_overq((uint32_t)size_Ql);
     hipStream_t s = as_stream(stream);
     const size_t n = c.n, qln = size_Ql * n, qfn = (size_t)c.size_q * n;
-    DevBuf<u64> tmp(3 * qfn + 2 * qln);
-    u64 *d3 = tmp.p, *res = d3 + 3 * qfn;
+    u64 *d3 = c.scratch_outer(stream, 3 * qfn + 2 * qln), *res = d3 + 3 * qfn;   // the inner calls use the stream's own arena
     hps_overq_multiply(c, h, ct1, ct2, d3, stream, true);
     PHA_HIP(hipMemsetAsync(res, 0, 2 * qln * sizeof(u64), s));
     const int rc = pha_keyswitch_inplace(ctx, size_Ql, res, d3 + 2 * qfn, rlk, /*scheme bfv*/ 1, stream);
@@ -474,7 +473,6 @@ extern "C" int pha_bfv_mul_relin_hps_overq_leveled(pha_context_t ctx, size_t siz
         hipLaunchKernelGGL(hps_expand_add_kernel, dim3((unsigned)(n / 256), h.size_q), dim3(256), 0, s, ka);
         check_launch();
     }
-    PHA_HIP(hipStreamSynchronize(s));   // tmp is released on return
     PHA_API_END
 }
 
@@ -489,9 +487,9 @@ extern "C" int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_
     HpsQ &h = c.hps_overq((uint32_t)size_Ql);
     hipStream_t s = as_stream(stream);
     const size_t n = c.n, qln = size_Ql * n, qfn = (size_t)c.size_q * n;
-    // device buffers of this call: c2 at level l, the level's key-switch result (c0, c1), one expanded polynomial
-    DevBuf<u64> tmp(3 * qln + qfn);
-    u64 *c2l = tmp.p, *res = c2l + qln, *full = res + 2 * qln;
+    // buffers of this call (second arena: the inner key switch uses the stream's own): c2 at level l, the level's
+    // key-switch result (c0, c1), one expanded polynomial
+    u64 *c2l = c.scratch_outer(stream, 3 * qln + qfn), *res = c2l + qln, *full = res + 2 * qln;
     launch_scale_round_q(c, c2l, c2, h.frac_drop.p, h.div_mod_q_drop.p, h.size_q, h.drop, s);
     PHA_HIP(hipMemsetAsync(res, 0, 2 * qln * sizeof(u64), s));
     const int rc = pha_keyswitch_inplace(ctx, size_Ql, res, c2l, rlk, /*scheme bfv*/ 1, stream);
@@ -500,7 +498,6 @@ extern "C" int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_
         launch_expand(c, h, full, res + (size_t)p * qln, s);
         launch_add(c, ct + (size_t)p * qfn, full, ct + (size_t)p * qfn, c.size_q, 0, s);
     }
-    PHA_HIP(hipStreamSynchronize(s));   // tmp is released on return
     PHA_API_END
 }
 

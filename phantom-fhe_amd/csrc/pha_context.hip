@@ -837,6 +837,17 @@ u64 *Context::scratch(void *stream, size_t words) {
     return a->buf.p;
 }
 
+u64 *Context::scratch_outer(void *stream, size_t words) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto &a = outer_arenas[stream];
+    if (!a) a = std::make_unique<Arena>();
+    if (a->buf.count < words) {
+        PHA_HIP(hipStreamSynchronize(as_stream(stream)));
+        a->buf.alloc(words);
+    }
+    return a->buf.p;
+}
+
 const uint32_t *Context::galois_table(uint32_t elt) {
     // NTT-domain permutation table, include/galois.cuh:98-113
     std::lock_guard<std::mutex> lk(mu);

@@ -213,6 +213,8 @@ struct Context {
     std::map<uint32_t, std::unique_ptr<HpsQ>> hpsq_tools;   // by |Ql| (|Q| = plain hps_overq)
     uint32_t rows = 0;  // table rows = size_qp + auxiliary moduli
     std::map<void *, std::unique_ptr<Arena>> arenas;
+    std::map<void *, std::unique_ptr<Arena>> outer_arenas;   // for entry points that call other entry points (which use `arenas`)
+    u64 *scratch_outer(void *stream, size_t words);
     std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
 
     Tool &tool(uint32_t size_ql);
