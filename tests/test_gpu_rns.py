@@ -853,3 +853,26 @@ def test_apply_galois_batched(ntt_form, gpu):
     out = P.to_device(np.zeros_like(x), gpu)
     ctx.apply_galois_batched(d_x, out, elt, ql, polys, ntt_form)
     assert np.array_equal(P.to_host(out), P.to_host(ref))
+
+
+def test_empty_batches_and_zero_sizes_are_no_ops(gpu):
+    """Zero-sized work (no ciphertexts in a batch, no polynomials, no limbs) returns without touching the buffers."""
+    import phantom_fhe_amd as P
+    name = "hyb12_a2"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(190)
+    rlk = P.PhantomRelinKey.from_numpy(_keys(oc, r, primes, n, size_q, size_p), gpu)
+    x = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    d = P.to_device(x, gpu)
+    ctx.keyswitch_inplace_batched(size_q, d, d[0], 0, rlk.public_keys_ptr, O.CKKS)
+    ctx.tensor_prod_2x2_batched(d, d, d, d[0], size_q, 0)
+    ctx.apply_galois_batched(d, d[1:], 3, size_q, 0, True)
+    ctx.divide_and_round_q_last_ntt(size_q, d, 0, d)
+    ctx.add_rns_poly(d, d, d, 0)
+    ctx.nwt_2d_radix8_forward_inplace_batched(d, 0, 0, 2, size_q * n)
+    assert np.array_equal(P.to_host(d), x)
+    with pytest.raises(ValueError):
+        ctx.keyswitch_inplace_batched(size_q, d, d[0], 2000, rlk.public_keys_ptr, O.CKKS)     # beyond the batch limit
