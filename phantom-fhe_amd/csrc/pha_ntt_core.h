@@ -99,6 +99,9 @@ struct PassCfg {
     }
 };
 
+#ifndef PHA_FPSEL
+#define PHA_FPSEL(a) ((a).fp)   // experiment hook: -D'PHA_FPSEL(a)=true' builds FP64-only kernels (timing only)
+#endif
 // Per-workgroup arguments (all uniform across the workgroup -> SGPRs).
 struct PassArgs {
     const u64 *in;     // limb base to read (first round only)
@@ -150,14 +153,14 @@ PHA_HD void decode_group(int g, int &v, int &hi, int &lo) {
 
 // Twiddles of one radix-2^R group, preloaded in heap order: stage j, sub-group kk -> t[(1 << j) - 1 + kk],
 // taken from tw[(base0 << j) + kk] (base0 = rho * 2^s0 + hi, see round_compute).
-// One table entry: the integer path reads the (W, W') pair, the FP64 path the double W (a.fp is uniform).
+// One table entry: the integer path reads the (W, W') pair, the FP64 path the double W (PHA_FPSEL(a) is uniform).
 PHA_HD u64x2 tw_entry(const PassArgs &a, u32 idx) {
-    if (a.fp) return u64x2{a.twd[idx], 0};
+    if (PHA_FPSEL(a)) return u64x2{a.twd[idx], 0};
     return a.tw[idx];
 }
 template <int R>
 PHA_HD void load_group_twiddles(u64x2 *t, const PassArgs &a, u32 base0) {
-    if (a.fp) {
+    if (PHA_FPSEL(a)) {
 #pragma unroll
         for (int j = 0; j < R; j++)
 #pragma unroll
@@ -332,14 +335,14 @@ PHA_HD void gs_round(u64 *v, const u64x2 *t, u64 q4, u64 nq, u64x2 ninv, u64x2 w
 template <int EPI>
 PHA_HD u64 apply_epilogue_v(u64 x, const PassArgs &a, u64 aux, u64 acc) {
     const u64 q = a.q;
-    // the FP64 path hands over canonical residues already (fp_to_canon); a.fp is uniform per workgroup
-    if (EPI == EPI_FWD_CANON) return a.fp ? x : csub(csub(csub(x, q << 2), q << 1), q);
+    // the FP64 path hands over canonical residues already (fp_to_canon); PHA_FPSEL(a) is uniform per workgroup
+    if (EPI == EPI_FWD_CANON) return PHA_FPSEL(a) ? x : csub(csub(csub(x, q << 2), q << 1), q);
     if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) {
-        const u64 t = a.fp ? x : csub(csub(csub(x, q << 2), q << 1), q);
+        const u64 t = PHA_FPSEL(a) ? x : csub(csub(csub(x, q << 2), q << 1), q);
         const u64 r = shoup(sub_mod(aux, t, q), a.scale, q);
         return EPI == EPI_FWD_MODDOWN_ADD ? add_mod(acc, r, q) : r;
     }
-    if (EPI == EPI_INV_CANON) return a.fp ? x : csub(csub(x, q << 1), q);
+    if (EPI == EPI_INV_CANON) return PHA_FPSEL(a) ? x : csub(csub(x, q << 1), q);
     if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);
     return x;
 }
@@ -432,7 +435,7 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
         for (int gi = 0; gi < G; gi++) {
             u64 *rg = reg + gi * K;
             const u64x2 *tr = tc + (K - 1) + gi * r;
-            if (a.fp) {
+            if (PHA_FPSEL(a)) {
                 if (FWD ? a.fpm.ct_light : a.fpm.gs_light) ot_round_fp<r, FWD, true>(rg, tc, tr, a.fpm);
                 else ot_round_fp<r, FWD, false>(rg, tc, tr, a.fpm);
             } else {
@@ -441,7 +444,7 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
         }
         return;
     }
-    if (a.fp) {  // uniform per workgroup
+    if (PHA_FPSEL(a)) {  // uniform per workgroup
 #pragma unroll
         for (int gi = 0; gi < G; gi++) {
             u64 *rg = reg + gi * K;
@@ -543,14 +546,14 @@ struct PassProgram {
     // FP64 path: what just came from global memory becomes a small double.  First pass: canonical
     // integers -> doubles; second pass: the lazy doubles of the first pass are centred again.
     PHA_HD static void fp_after_global_load(const PassArgs &a, u64 *reg) {
-        if (!a.fp) return;
+        if (!PHA_FPSEL(a)) return;
 #pragma unroll
         for (int i = 0; i < C::EPT; i++)
             reg[i] = as_u64(FIRST_PASS ? fp_from_canon(reg[i]) : fp_reduce(as_f64(reg[i]), a.fpm));
     }
     // FP64 path, last pass: doubles -> canonical integers (the integer epilogue then sees [0,q))
     PHA_HD static void fp_before_global_store(const PassArgs &a, u64 *reg) {
-        if (!a.fp || !LAST_PASS) return;
+        if (!PHA_FPSEL(a) || !LAST_PASS) return;
 #pragma unroll
         for (int i = 0; i < C::EPT; i++) reg[i] = fp_to_canon(as_f64(reg[i]), a.fpm);
     }
