@@ -317,7 +317,7 @@ def main():
                        "launch": "hipGraph replay of the K steps" if graph is not None else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM, "traffic": NTT_TRAFFIC_BYTES,
-                         "traffic_source": "profiles/r01l_pmc_fetch.csv + r01l_pmc_write.csv (same figures as r01j) (rocprofv3 PMC, per launch pair)",
+                         "traffic_source": "profiles/r01m_pmc_fetch.csv + r01m_pmc_write.csv (same figures as r01j / r01l) (rocprofv3 PMC, per launch pair)",
                          "kernel": "ntt_pass_kernel pair (strided pass + contiguous pass)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
                          "calibrated_copy_GBps": copy_gbps,
