@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native RNS core (BASELINE.json metric).
 
-A "step" is one forward negacyclic NTT over one ciphertext polynomial of the CKKS set
-N = 2^16, 45 RNS limbs (examples/3_ckks.cu:729-739) -- exactly the reference call
-nwt_2d_radix8_forward_inplace(data, tables, 45, 0) (src/ntt/fntt_2d.cu:620-653) -- on synthetic
-uniform residues already resident in HBM.  `value` is limb-transforms per second over all ranks.
-The same line also carries HomMul+relinearize+rescale/s for the same parameter set,
-the roofline object for the forward NTT, and the CPU baseline (the oracle, timed on host cores).
+A "step" is one forward negacyclic NTT over one batch of ciphertext polynomials of the CKKS set
+N = 2^16, 45 RNS limbs (examples/3_ckks.cu:729-739): NTT_BATCH = 16 polynomials x 45 limbs = 720
+limb-transforms, 360 MiB, i.e. larger than the 256 MiB MALL, so every step streams from and to HBM.  It is the
+reference call nwt_2d_radix8_forward_inplace(data, tables, 45, 0) (src/ntt/fntt_2d.cu:620-653) applied to every
+polynomial of the batch in one launch pair (pha_nwt_2d_radix8_forward_inplace_batched; the reference's own
+ntt_bench sweeps the limbs per launch the same way, benchmark/ntt_bench.cu:104-117).  `value` is
+limb-transforms per second over all ranks.  The same line also carries
+  * single_polynomial: the r01 protocol (one 45-limb polynomial per launch pair), in place (MALL-resident) and
+    rotating over the 16 buffers (HBM-resident),
+  * HomMul + relinearize + rescale per second for the same parameter set, alone and batched,
+  * keyswitch_c4: BASELINE config 4 -- BFV relinearize + Galois rotate at N = 2^15, 30 + 15 limbs, a batch of 64
+    ciphertexts split over the ranks (strong scaling), with a checksum that is the same for every world size,
+  * the roofline object of the forward NTT and the CPU baseline (the oracle, timed on host cores).
 
-Multi-GPU: independent ciphertexts shard across ranks (weak scaling, no data-path collective); the
-evaluation key is generated on rank 0 and broadcast once over RCCL (setup, not timed).
+Multi-GPU: independent ciphertexts shard across ranks (no data-path collective); evaluation / Galois keys are
+generated on rank 0 and broadcast once over RCCL (setup, not timed).  `python bench.py --gpus N` without a
+launcher starts the N ranks itself; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one rank.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,23 +34,40 @@ for p in (ROOT, os.path.join(ROOT, "phantom-fhe_amd"), os.path.join(ROOT, "tests
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 LOG_N = 16
 BITS = [60] + [50] * 44 + [60] * 15   # 45 data primes + 15 special primes
 SIZE_P = 15
+NTT_BATCH = 16                        # polynomials per step: 16 x 22.5 MiB = 360 MiB > 256 MiB MALL
 PEAK_HBM = 8.0e12                     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
-# HBM-side bytes of one 45-limb forward NTT from the PMC passes of profiles/r01j_pmc_{fetch,write}.csv
-# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction of
-# MI355X_MICROARCH.md): strided pass 2*12023 + 23040 KiB, contiguous pass 2*24142 + 23040 KiB (it streams the
-# twiddle table: 8-byte entries for the 44 FP64 limbs, 16-byte pairs for the 60-bit limb).  Not measurable inside this process, hence a recorded constant.
-NTT_TRAFFIC_BYTES = (2 * (12023 + 24142) + 23040 + 23040) * 1024
+C4_LOG_N = 15
+C4_BITS = [60] + [50] * 29 + [60] * 15  # benchmark/keyswitch_bench.cu:25-34
+C4_BATCH = 64
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes (tools/traffic_from_pmc.py)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher: start N ranks of this script (one per GPU, RCCL rendezvous on
+    127.0.0.1), pass rank 0's stdout through, return the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def uniform_residues(primes, n, device, gen):
     """[len(primes)][n] int64 tensor, limb i uniform in [0, primes[i]) (bits = uint64 residues)."""
+    import torch
     out = torch.empty((len(primes), n), dtype=torch.int64, device=device)
     for i, q in enumerate(primes):
         out[i] = torch.randint(0, int(q), (n,), dtype=torch.int64, device=device, generator=gen)
@@ -49,6 +78,7 @@ def cpu_baseline(primes, n, seconds=12.0, gpu_forward=None):
     """Time the oracle's forward NTT (C port of the reference semantics) on the host: one core (the reported
     baseline) and, informational, OpenMP over the 45 limbs on every core of the box.  Before the timing is
     accepted the same input goes through the GPU path (gpu_forward) and the two outputs are compared bit for bit."""
+    import numpy as np
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # idle OpenMP threads must not spin on a shared box
     from oracle import oracle as O
     path = O.build(native=True)
@@ -100,30 +130,59 @@ def cpu_baseline(primes, n, seconds=12.0, gpu_forward=None):
                                     f"{dt_all:.1f} s; cores = min(affinity, cgroup quota, 45)"}}
 
 
+def load_traffic():
+    """PMC-derived HBM bytes per launch (rocprofv3 counters cannot be read inside this process): the committed
+    summary of the last profile run, with the sha of the file so that staleness is visible in the bench line."""
+    try:
+        raw = open(TRAFFIC_FILE, "rb").read()
+        t = json.loads(raw)
+        t["file"] = os.path.relpath(TRAFFIC_FILE, ROOT)
+        t["file_sha16"] = hashlib.sha256(raw).hexdigest()[:16]
+        t["file_mtime"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(TRAFFIC_FILE)))
+        return t
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay")
+    ap.add_argument("--only-ntt", action="store_true", help="skip the HomMul and config-4 legs (profiling runs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}")
     # test hook (1-GPU boxes): PHA_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, to exercise the
     # multi-rank code path where RCCL cannot be used (it refuses two ranks on one device)
     share = os.environ.get("PHA_BENCH_SHARE_GPU") == "1"
+    if world > 1 and not share and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench: --gpus {world} but only {torch.cuda.device_count()} HIP device(s) visible "
+                         "(PHA_BENCH_SHARE_GPU=1 puts all ranks on cuda:0 over gloo: a functional test, not a measurement)")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://")   # "nccl" is RCCL on ROCm
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    small = os.environ.get("PHA_BENCH_SMALL") == "1"    # functional test of the multi-rank path: smaller batches
 
     import phantom_fhe_amd as P
+    from phantom_fhe_amd import dist as pdist
+    from phantom_fhe_amd import workloads as W
     if os.environ.get("PHA_NTT_VARIANT"):   # A/B experiments only (pha_set_tuning key 0); results never change
         P.set_tuning(0, int(os.environ["PHA_NTT_VARIANT"]))
     n = 1 << LOG_N
@@ -132,31 +191,57 @@ def main():
     ctx = P.PhantomContext(LOG_N, primes, SIZE_P, device=dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x5EED0000 + 3 + rank)
+    red_dev = None if share else dev
 
-    # ---- evaluation key: generated on rank 0, broadcast once over RCCL/xGMI --------
-    dnum = size_q // SIZE_P
-    evk = [torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum)]
-    if rank == 0:
-        for k in evk:
-            k[0] = uniform_residues(primes, n, dev, gen)
-            k[1] = uniform_residues(primes, n, dev, gen)
-    from phantom_fhe_amd import dist as pdist
-    if share and world > 1:               # gloo moves host tensors
-        host = [k.cpu() for k in evk]
-        pdist.broadcast_keys(host, src=0)
-        for k, h in zip(evk, host):
-            k.copy_(h)
-    else:
-        pdist.broadcast_keys(evk, src=0)  # one-time RCCL broadcast; no collective on the data path
-    rlk = P.PhantomRelinKey(evk)
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
-    # ---- forward NTT: the timed headline ---------------------------------------------------------------
-    poly = uniform_residues(primes[:size_q], n, dev, gen)
+    def broadcast(keys):
+        if share and world > 1:               # gloo moves host tensors
+            host = [k.cpu() for k in keys]
+            pdist.broadcast_keys(host, src=0)
+            for k, h in zip(keys, host):
+                k.copy_(h)
+        else:
+            pdist.broadcast_keys(keys, src=0)  # one-time RCCL broadcast over xGMI; no collective on the data path
+
+    def timed(fn, steps):
+        """K calls between barrier + synchronize on both sides; whole-job time = the slowest rank's."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        return pdist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+
+    def per_step_events(fn, steps):
+        """GPU-side duration of each of `steps` calls, from event pairs on the launch stream (torch's current stream,
+        which is the stream every pha_* call is enqueued on)."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in evs]
+        return {"mean_ms": statistics.fmean(ms), "median_ms": statistics.median(ms), "min_ms": min(ms), "steps": steps}
+
+    # ---- forward NTT: the timed headline (HBM-resident batch) --------------------------------------------------
+    nb = 4 if small else NTT_BATCH
+    polys = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(nb)])
+    poly_stride = size_q * n
+
+    def ntt_step():
+        ctx.nwt_2d_radix8_forward_inplace_batched(polys, size_q, 0, nb, poly_stride)
+
     for _ in range(args.warmup):
-        ctx.nwt_2d_radix8_forward_inplace(poly, size_q, 0)
+        ntt_step()
     torch.cuda.synchronize()
-    # The K timed steps are captured once into a hipGraph (the launch-bound inner loop: 2 kernels of
-    # ~14 us each per step) and replayed inside the timed region; eager launches are the fallback.
+    # The K timed steps are captured once into a hipGraph and replayed inside the timed region; eager launches are
+    # the fallback (and --no-graph).
     graph = None
     if not args.no_graph:
         try:
@@ -166,7 +251,7 @@ def main():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
                     for _ in range(args.steps):
-                        ctx.nwt_2d_radix8_forward_inplace(poly, size_q, 0)
+                        ntt_step()
             torch.cuda.current_stream().wait_stream(side)
             g.replay()                   # one untimed replay (warm instantiation)
             torch.cuda.synchronize()
@@ -174,8 +259,7 @@ def main():
         except Exception as exc:         # pragma: no cover - depends on the runtime
             print(f"[bench] hipGraph capture unavailable ({exc}); timing eager launches", file=sys.stderr)
             graph = None
-    if world > 1:
-        dist.barrier()
+    barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()                       # same stream the launches go to (torch's current stream)
@@ -183,109 +267,31 @@ def main():
         graph.replay()
     else:
         for _ in range(args.steps):
-            ctx.nwt_2d_radix8_forward_inplace(poly, size_q, 0)
+            ntt_step()
     e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / args.steps      # average duration of one forward NTT (2 kernels)
-    elapsed = pdist.max_over_ranks(elapsed, device=None if share else dev)
-    ntt_per_s = world * args.steps * size_q / elapsed
+    barrier()
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+    kernel_ms = e0.elapsed_time(e1) / args.steps      # average duration of one launch pair inside the timed region
+    ntt_per_s = world * args.steps * nb * size_q / elapsed
+    step_stats = per_step_events(ntt_step, max(100, args.steps) if not small else 10)
 
-    # ---- informational: the same transform over a batch of 4 polynomials in one launch (extension API) ----
-    batch = 4
-    polys = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(batch)])
+    # ---- informational: one 45-limb polynomial per launch pair (the r01 headline protocol) ------------------
+    def single_inplace():
+        ctx.nwt_2d_radix8_forward_inplace(polys[0], size_q, 0)
+
+    rot = [0]
+
+    def single_rotating():
+        ctx.nwt_2d_radix8_forward_inplace(polys[rot[0] % nb], size_q, 0)
+        rot[0] += 1
+
+    single_steps = 20 if small else max(100, args.steps)
     for _ in range(5):
-        ctx.nwt_2d_radix8_forward_inplace_batched(polys, size_q, 0, batch, size_q * n)
-    torch.cuda.synchronize()
-    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    b_steps = max(10, args.steps // 4)
-    b0.record()
-    for _ in range(b_steps):
-        ctx.nwt_2d_radix8_forward_inplace_batched(polys, size_q, 0, batch, size_q * n)
-    b1.record()
-    torch.cuda.synchronize()
-    batched_ms = b0.elapsed_time(b1) / b_steps
-    del polys
-
-    # ---- HomMul + relinearize + rescale (secondary figure, same parameter set) -------------------------
-    ct1 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
-    ct2 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
-    buf = torch.zeros((3, size_q, n), dtype=torch.int64, device=dev)
-    out = torch.zeros((2, size_q - 1, n), dtype=torch.int64, device=dev)
-
-    def hommul():
-        buf[:2].copy_(ct1)
-        ctx.tensor_prod_2x2_rns_poly(buf, ct2, buf, size_q)                              # multiply_inplace
-        ctx.keyswitch_inplace(size_q, buf, buf[2], rlk.public_keys_ptr, P.scheme_type.ckks)  # relinearize
-        ctx.divide_and_round_q_last_ntt(size_q, buf, 2, out)                             # rescale_to_next
-
-    hm_steps = max(5, args.steps // 10)
-    for _ in range(3):
-        hommul()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(hm_steps):
-        hommul()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    hm_elapsed = time.perf_counter() - t0
-    hm_elapsed = pdist.max_over_ranks(hm_elapsed, device=None if share else dev)
-
-    # the same operation on S independent ciphertext pairs, one HIP stream each (per-stream scratch arenas):
-    # the latency-bound kernels of different ciphertexts overlap on the chip.  Informational (this rank).
-    S = 4
-    lanes = []
-    for i in range(S):
-        a = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
-        lanes.append((torch.cuda.Stream(device=dev), a, torch.zeros((3, size_q, n), dtype=torch.int64, device=dev),
-                      torch.zeros((2, size_q - 1, n), dtype=torch.int64, device=dev)))
-
-    def hommul_lanes():
-        for st, a, b3, o in lanes:
-            with torch.cuda.stream(st):
-                b3[:2].copy_(a)
-                ctx.tensor_prod_2x2_rns_poly(b3, ct2, b3, size_q)
-                ctx.keyswitch_inplace(size_q, b3, b3[2], rlk.public_keys_ptr, P.scheme_type.ckks)
-                ctx.divide_and_round_q_last_ntt(size_q, b3, 2, o)
-
-    torch.cuda.synchronize()
-    for _ in range(2):
-        hommul_lanes()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(hm_steps):
-        hommul_lanes()
-    torch.cuda.synchronize()
-    hm_lanes_elapsed = time.perf_counter() - t0
-
-    # the same operation on a batch of B ciphertext pairs through the batched entry points (one set of launches:
-    # key limbs read once, NTT / base-conversion launches B times larger).  Informational (this rank).
-    del lanes
-    B = int(os.environ.get("PHA_BENCH_BATCH", "8"))
-    bt1 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
-    bt2 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
-    b01 = torch.zeros_like(bt1)
-    b2 = torch.zeros((B, size_q, n), dtype=torch.int64, device=dev)
-    bout = torch.zeros((B, 2, size_q - 1, n), dtype=torch.int64, device=dev)
-
-    def hommul_batched():
-        ctx.tensor_prod_2x2_batched(bt1, bt2, b01, b2, size_q, B)
-        ctx.keyswitch_inplace_batched(size_q, b01, b2, B, rlk.public_keys_ptr, P.scheme_type.ckks)
-        ctx.divide_and_round_q_last_ntt(size_q, b01, 2 * B, bout)
-
-    for _ in range(2):
-        hommul_batched()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(hm_steps):
-        hommul_batched()
-    torch.cuda.synchronize()
-    hm_batched_elapsed = time.perf_counter() - t0
+        single_inplace()
+    mall_stats = per_step_events(single_inplace, single_steps)
+    for _ in range(nb):
+        single_rotating()
+    rot_stats = per_step_events(single_rotating, single_steps)
 
     # device-to-device copy of 512 MiB (read + write), the calibrated counterpart of the nominal 8 TB/s
     cal_a = torch.empty(64 << 20, dtype=torch.int64, device=dev)
@@ -298,52 +304,162 @@ def main():
         cal_b.copy_(cal_a)
     ev1.record()
     torch.cuda.synchronize()
-    copy_gbps = 10 * 2 * cal_a.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    copy_bps = 10 * 2 * cal_a.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3)
     del cal_a, cal_b
-    # minimal per-stage traffic of one HomMul + relinearize + rescale at C3: 929 MiB
-    hm_alg_bytes = 929.0 * (1 << 20)
+    del polys
+
+    hm = None
+    c4 = None
+    if not args.only_ntt:
+        # ---- evaluation key: generated on rank 0, broadcast once over RCCL/xGMI --------
+        dnum = size_q // SIZE_P
+        evk = [torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum)]
+        if rank == 0:
+            for k in evk:
+                k[0] = uniform_residues(primes, n, dev, gen)
+                k[1] = uniform_residues(primes, n, dev, gen)
+        broadcast(evk)
+        rlk = P.PhantomRelinKey(evk)
+
+        # ---- HomMul + relinearize + rescale (secondary figure, same parameter set) -------------------------
+        ct1 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
+        ct2 = torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)])
+        buf = torch.zeros((3, size_q, n), dtype=torch.int64, device=dev)
+        out = torch.zeros((2, size_q - 1, n), dtype=torch.int64, device=dev)
+
+        def hommul():
+            buf[:2].copy_(ct1)
+            ctx.tensor_prod_2x2_rns_poly(buf, ct2, buf, size_q)                              # multiply_inplace
+            ctx.keyswitch_inplace(size_q, buf, buf[2], rlk.public_keys_ptr, P.scheme_type.ckks)  # relinearize
+            ctx.divide_and_round_q_last_ntt(size_q, buf, 2, out)                             # rescale_to_next
+
+        hm_steps = 3 if small else max(20, args.steps // 2)
+        for _ in range(3):
+            hommul()
+        hm_elapsed = timed(hommul, hm_steps)
+        hm_stats = per_step_events(hommul, hm_steps)
+
+        # the same operation on a batch of B ciphertext pairs through the batched entry points (one set of launches:
+        # key limbs read once, NTT / base-conversion launches B times larger).
+        B = 2 if small else int(os.environ.get("PHA_BENCH_BATCH", "8"))
+        bt1 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
+        bt2 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
+        b01 = torch.zeros_like(bt1)
+        b2 = torch.zeros((B, size_q, n), dtype=torch.int64, device=dev)
+        bout = torch.zeros((B, 2, size_q - 1, n), dtype=torch.int64, device=dev)
+
+        def hommul_batched():
+            ctx.tensor_prod_2x2_batched(bt1, bt2, b01, b2, size_q, B)
+            ctx.keyswitch_inplace_batched(size_q, b01, b2, B, rlk.public_keys_ptr, P.scheme_type.ckks)
+            ctx.divide_and_round_q_last_ntt(size_q, b01, 2 * B, bout)
+
+        hb_steps = 2 if small else max(5, args.steps // 10)
+        for _ in range(2):
+            hommul_batched()
+        hm_batched_elapsed = timed(hommul_batched, hb_steps)
+        # minimal per-stage traffic of one HomMul + relinearize + rescale at C3: 929 MiB
+        hm_alg_bytes = 929.0 * (1 << 20)
+        hm = {"value": world * hm_steps / hm_elapsed, "unit": "ops/s", "ms_per_op": 1e3 * hm_elapsed / hm_steps,
+              "steps": hm_steps, "gpu_ms_per_op": hm_stats, "algorithmic_bytes_per_op": hm_alg_bytes,
+              "frac_of_peak": hm_alg_bytes / (hm_elapsed / hm_steps) / PEAK_HBM,
+              "batched": {"value": world * B * hb_steps / hm_batched_elapsed, "unit": "ops/s",
+                          "ms_per_op": 1e3 * hm_batched_elapsed / (B * hb_steps), "batch": B,
+                          "frac_of_peak": hm_alg_bytes / (hm_batched_elapsed / (B * hb_steps)) / PEAK_HBM,
+                          "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_inplace_batched + rescale of the batch"}}
+        del ct1, ct2, buf, out, bt1, bt2, b01, b2, bout, rlk, evk
+
+        # ---- BASELINE config 4: BFV relinearize + Galois rotate, N = 2^15, 30 + 15 limbs, batch 64 over the ranks ----
+        n4 = 1 << C4_LOG_N
+        primes4 = [int(p) for p in P.coeff_modulus_create(n4, C4_BITS)]
+        q4 = len(primes4) - SIZE_P
+        ctx4 = P.PhantomContext(C4_LOG_N, primes4, SIZE_P, device=dev)
+        batch4 = 6 if small else C4_BATCH
+        kgen = torch.Generator(device=dev)
+        kgen.manual_seed(0x5EED0000 + 4)
+        keys4 = [torch.empty((2, len(primes4), n4), dtype=torch.int64, device=dev) for _ in range(2 * (q4 // SIZE_P))]
+        if rank == 0:
+            for k in keys4:
+                k[0] = uniform_residues(primes4, n4, dev, kgen)
+                k[1] = uniform_residues(primes4, n4, dev, kgen)
+        broadcast(keys4)                                    # relin key + one Galois key, RCCL broadcast from rank 0
+        rlk4 = P.PhantomRelinKey(keys4[: q4 // SIZE_P])
+        glk4 = P.PhantomRelinKey(keys4[q4 // SIZE_P:])
+        mine = pdist.shard_range(batch4, rank, world)
+        # ciphertext b is generated from its own seed, so the inputs (and the checksum) do not depend on the world size
+        ct3 = torch.empty((len(mine), 3, q4, n4), dtype=torch.int64, device=dev)
+        for i, b in enumerate(mine):
+            kgen.manual_seed(0x5EED4000 + b)
+            for p_ in range(3):
+                ct3[i, p_] = uniform_residues(primes4[:q4], n4, dev, kgen)
+        elt = 3
+        res = [None]
+
+        def c4_step():
+            if len(mine):
+                res[0] = W.relinearize_rotate_batch(ctx4, q4, ct3, rlk4, glk4, elt, P.scheme_type.bfv)
+
+        c4_step()
+        c4_steps = 1 if small else 3
+        c4_elapsed = timed(c4_step, c4_steps)
+        local_sum = int(res[0].sum().item()) & ((1 << 64) - 1) if len(mine) else 0
+        sums = pdist.gather_checksums(local_sum - (1 << 64) if local_sum >= (1 << 63) else local_sum, device=red_dev)
+        c4 = {"value": batch4 * c4_steps / c4_elapsed, "unit": "relinearize+rotate ciphertexts/s (whole job)",
+              "batch": batch4, "scaling": "strong", "ms_per_ciphertext": 1e3 * c4_elapsed / (batch4 * c4_steps),
+              "per_rank_ciphertexts": [len(pdist.shard_range(batch4, r, world)) for r in range(world)],
+              "checksum": f"{sum(sums) & ((1 << 64) - 1):016x}",
+              "checksum_note": "sum mod 2^64 of all output words of the 64 ciphertexts; identical for every --gpus",
+              "config": "BFV N=2^15, 30 data + 15 special limbs (keyswitch_bench.cu:25-34), keys broadcast from rank 0"}
 
     if rank == 0:
-        alg_bytes = 16.0 * n * size_q                  # 8 B read + 8 B write per coefficient
+        alg_bytes = 16.0 * n * size_q * nb             # 8 B read + 8 B write per coefficient
         achieved = alg_bytes / (kernel_ms * 1e-3)
+        one = 16.0 * n * size_q
+        traffic = load_traffic()
+        ceiling = copy_bps / 2.0 / PEAK_HBM            # two passes: every coefficient crosses the fabric twice each way
         line = {
             "metric": "forward NTT limb-transforms/s at N=2^16, 45 RNS moduli",
             "value": ntt_per_s, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "CKKS N=2^16, 45 data limbs (+15 special), forward NTT of one ciphertext "
-                                   "polynomial per step (configs[2] parameter set)",
-                       "N": n, "limbs": size_q, "special_limbs": SIZE_P, "parallelism": f"ciphertext-batch x{world}",
+            "config": {"workload": f"CKKS N=2^16, 45 data limbs (+15 special), forward NTT of a batch of {nb} ciphertext "
+                                   f"polynomials per step ({nb * size_q} limb-transforms, {nb * size_q * n * 8 >> 20} MiB, "
+                                   "HBM-resident; configs[2] parameter set)",
+                       "N": n, "limbs": size_q, "special_limbs": SIZE_P, "polynomials_per_step": nb,
+                       "parallelism": f"ciphertext-batch x{world}",
                        "launch": "hipGraph replay of the K steps" if graph is not None else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM, "traffic": NTT_TRAFFIC_BYTES,
-                         "traffic_source": "profiles/r01m_pmc_fetch.csv + r01m_pmc_write.csv (same figures as r01j / r01l) (rocprofv3 PMC, per launch pair)",
+                         "frac": achieved / PEAK_HBM,
+                         "traffic": (traffic or {}).get("ntt_batched_bytes_per_launch"),
+                         "traffic_source": traffic,
                          "kernel": "ntt_pass_kernel pair (strided pass + contiguous pass)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
-                         "calibrated_copy_GBps": copy_gbps,
-                         "calibrated_note": "512 MiB device-to-device copy, read + write bytes / time, this run"},
-            "batched_ntt": {"polynomials_per_launch": batch, "ms_per_launch": batched_ms,
-                            "value": batch * size_q / (batched_ms * 1e-3), "unit": "NTT/s (this rank)",
-                            "frac_of_peak": batch * alg_bytes / (batched_ms * 1e-3) / PEAK_HBM,
-                            "note": "pha_nwt_2d_radix8_forward_inplace_batched: 4 x 45 limbs per launch pair"},
-            "hommul_relin_rescale": {"value": world * hm_steps / hm_elapsed, "unit": "ops/s",
-                                     "ms_per_op": 1e3 * hm_elapsed / hm_steps, "steps": hm_steps,
-                                     "algorithmic_bytes_per_op": hm_alg_bytes,
-                                     "frac_of_peak": hm_alg_bytes / (hm_elapsed / hm_steps) / PEAK_HBM},
-            "hommul_relin_rescale_4_streams": {"value": S * hm_steps / hm_lanes_elapsed, "unit": "ops/s (this rank)",
-                                               "ms_per_op": 1e3 * hm_lanes_elapsed / (S * hm_steps),
-                                               "note": "4 independent ciphertext pairs, one HIP stream each"},
-            "hommul_relin_rescale_batched": {"value": B * hm_steps / hm_batched_elapsed, "unit": "ops/s (this rank)",
-                                             "ms_per_op": 1e3 * hm_batched_elapsed / (B * hm_steps), "batch": B,
-                                             "frac_of_peak": hm_alg_bytes / (hm_batched_elapsed / (B * hm_steps)) / PEAK_HBM,
-                                             "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_inplace_batched + rescale of the batch"},
+                         "per_step_events": step_stats,
+                         "calibrated_copy_GBps": copy_bps / 1e9,
+                         "calibrated_note": "512 MiB device-to-device copy, read + write bytes / time, this run",
+                         "ceiling_two_pass": ceiling, "frac_of_ceiling": achieved / PEAK_HBM / ceiling,
+                         "ceiling_note": "a two-pass transform moves every coefficient through the fabric twice in each "
+                                         "direction: algorithmic rate <= measured copy rate / 2; N = 2^16 (512 KiB per limb) "
+                                         "does not fit one CU's 160 KiB LDS, so no single-pass plan exists for it (DESIGN 4.1)"},
+            "single_polynomial": {
+                "mall_resident": dict(mall_stats, value=size_q / (mall_stats["mean_ms"] * 1e-3), unit="NTT/s (this rank)",
+                                      frac_of_peak=one / (mall_stats["mean_ms"] * 1e-3) / PEAK_HBM,
+                                      note="one 45-limb polynomial transformed in place again and again (22.5 MiB: "
+                                           "stays in the 256 MiB MALL); the r01 headline protocol"),
+                "hbm_resident": dict(rot_stats, value=size_q / (rot_stats["mean_ms"] * 1e-3), unit="NTT/s (this rank)",
+                                     frac_of_peak=one / (rot_stats["mean_ms"] * 1e-3) / PEAK_HBM,
+                                     note=f"one 45-limb polynomial per launch pair, rotating over {nb} buffers")},
+            "hommul_relin_rescale": hm,
+            "keyswitch_c4": c4,
         }
+        if hm is not None and traffic and traffic.get("hommul_bytes_per_op"):
+            hm["traffic"] = traffic["hommul_bytes_per_op"]
+            hm["traffic_ratio"] = traffic["hommul_bytes_per_op"] / hm["algorithmic_bytes_per_op"]
         if not args.no_cpu_baseline and world == 1:
             def gpu_forward(host_poly):   # the product path on the baseline's own input
                 d = P.to_device(host_poly, dev)
                 ctx.nwt_2d_radix8_forward_inplace(d, 45, 0)
                 return P.to_host(d)
-            line["cpu_baseline"] = cpu_baseline(primes, n, gpu_forward=gpu_forward)
+            line["cpu_baseline"] = cpu_baseline(primes, n, seconds=2.0 if small else 12.0, gpu_forward=gpu_forward)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

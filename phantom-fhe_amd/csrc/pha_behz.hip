@@ -290,7 +290,7 @@ using namespace pha;
 
 extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
                                     void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     Hps &h = c.hps();
@@ -409,7 +409,7 @@ static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *c
 
 extern "C" int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
                                           void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
     hps_overq_multiply(ctx->c, ctx->c.hps_overq(), ct1, ct2, dst, stream);
     PHA_API_END
@@ -417,7 +417,7 @@ extern "C" int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1
 
 extern "C" int pha_bfv_multiply_hps_overq_leveled(pha_context_t ctx, size_t size_Ql, const uint64_t *ct1, const uint64_t *ct2,
                                                   uint64_t *dst, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
     if (size_Ql < 1 || size_Ql > ctx->c.size_q) throw std::invalid_argument("RNSBase is invalid");
     hps_overq_multiply(ctx->c, ctx->c.hps_overq((uint32_t)size_Ql), ct1, ct2, dst, stream);
@@ -425,7 +425,7 @@ extern "C" int pha_bfv_multiply_hps_overq_leveled(pha_context_t ctx, size_t size
 }
 
 extern "C" int pha_scaleAndRound_HPS_Q_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !dst || !src) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
@@ -435,7 +435,7 @@ extern "C" int pha_scaleAndRound_HPS_Q_Ql(pha_context_t ctx, size_t size_Ql, uin
 }
 
 extern "C" int pha_ExpandCRTBasis_Ql_Q(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !dst || !src) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void hps_expand_add_kernel(const ExpandArgs k)
 // level l, key-switched there, and the results go onto the Ql limbs of (c0, c1).  dst [2][Q][N].
 extern "C" int pha_bfv_mul_relin_hps_overq_leveled(pha_context_t ctx, size_t size_Ql, const uint64_t *ct1, const uint64_t *ct2,
                                                    const uint64_t *const *rlk, uint64_t *dst, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !ct1 || !ct2 || !rlk || !dst) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
@@ -480,7 +480,7 @@ extern "C" int pha_bfv_mul_relin_hps_overq_leveled(pha_context_t ctx, size_t siz
 // scaled down to Ql, switched with the level's DRNSTool, and both halves are expanded to Q before they are added to ct [2][Q][N]
 extern "C" int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
                                                  const uint64_t *const *rlk, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !ct || !c2 || !rlk) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
@@ -503,7 +503,7 @@ extern "C" int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_
 
 extern "C" int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,
                                      void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !ct1 || !ct2 || !dst) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     Behz &b = c.behz();
@@ -566,7 +566,7 @@ extern "C" {
 
 int pha_base_converter_create(pha_context_t ctx, const uint32_t *ibase, size_t ibase_size, const uint32_t *obase,
                               size_t obase_size, pha_base_converter_t *out) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !ibase || !obase || !out) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     if (ibase_size == 0 || ibase_size > 64 || obase_size == 0 || obase_size > 256) throw std::invalid_argument("RNSBase is invalid");

@@ -186,7 +186,7 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
     if (log_n < 12 || log_n > 17) throw std::invalid_argument("poly_modulus_degree is invalid (2^12..2^17 supported)");
     if (size_qp < 1 || size_qp > 64 || size_p >= size_qp) throw std::invalid_argument("RNSBase is invalid");
     c.device = device;
-    PHA_HIP(hipSetDevice(device));
+    DeviceGuard on_device(device);   // the caller's current device is restored when the context has been built
     {
         hipDeviceProp_t prop;
         PHA_HIP(hipGetDeviceProperties(&prop, device));
@@ -825,9 +825,14 @@ Tool &Context::tool(uint32_t size_ql) {
     return ref;
 }
 
+Context::ArenaKey Context::arena_key(void *stream) {
+    const bool sentinel = stream == nullptr || as_stream(stream) == hipStreamPerThread;
+    return ArenaKey{stream, sentinel ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0};
+}
+
 u64 *Context::scratch(void *stream, size_t words) {
     std::lock_guard<std::mutex> lk(mu);
-    auto &a = arenas[stream];
+    auto &a = arenas[arena_key(stream)];
     if (!a) a = std::make_unique<Arena>();
     if (a->buf.count < words) {
         // growing invalidates earlier pointers: make sure nothing in flight still uses the old block
@@ -839,7 +844,7 @@ u64 *Context::scratch(void *stream, size_t words) {
 
 u64 *Context::scratch_outer(void *stream, size_t words) {
     std::lock_guard<std::mutex> lk(mu);
-    auto &a = outer_arenas[stream];
+    auto &a = outer_arenas[arena_key(stream)];
     if (!a) a = std::make_unique<Arena>();
     if (a->buf.count < words) {
         PHA_HIP(hipStreamSynchronize(as_stream(stream)));
@@ -918,7 +923,7 @@ uint32_t pha_context_size_qp(pha_context_t ctx) { return ctx->c.size_qp; }
 uint32_t pha_context_size_p(pha_context_t ctx) { return ctx->c.size_p; }
 
 int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx) throw std::invalid_argument("null context");
     Context &c = ctx->c;
     if (plain_modulus == 1 || (plain_modulus >> 60)) throw std::invalid_argument("plain_modulus is not valid");
@@ -943,7 +948,7 @@ int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus) {
 
 int pha_context_prime_info(pha_context_t ctx, uint32_t i, uint64_t *value, uint64_t ratio[2], uint64_t *root,
                            uint64_t *n_inv) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     Context &c = ctx->c;
     if (i >= c.size_qp) throw std::invalid_argument("prime index out of range");
     if (value) *value = c.primes[i];
@@ -954,7 +959,7 @@ int pha_context_prime_info(pha_context_t ctx, uint32_t i, uint64_t *value, uint6
 }
 
 int pha_context_download_twiddle(pha_context_t ctx, uint32_t i, int which, uint64_t *host_out) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     Context &c = ctx->c;
     if (i >= c.size_qp || which < 0 || which > 3) throw std::invalid_argument("bad twiddle selector");
     PHA_HIP(hipSetDevice(c.device));
@@ -971,7 +976,7 @@ int pha_context_download_twiddle(pha_context_t ctx, uint32_t i, int which, uint6
 }
 
 int pha_tool_beta(pha_context_t ctx, uint32_t size_ql, uint32_t *beta) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     *beta = ctx->c.tool(size_ql).beta;
     PHA_API_END
 }

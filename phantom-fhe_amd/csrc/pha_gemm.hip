@@ -11,7 +11,8 @@
 // into plain 64-bit partial sums (the trick of the base converter).  SB = 25 for moduli below 2^50 (partial
 // products below 2^50: the sums never overflow for k <= 16384, one recombination at the very end); SB = 30 for
 // moduli up to 2^60 (partial products below 2^60: sixteen terms per partial sum, so the partial sums are folded
-// into 128-bit totals after every 16-deep tile).
+// into 128-bit totals after every 16-deep tile, and the totals are Barrett-reduced to one word every 8 tiles so that
+// they cannot overflow for any k).
 #include "../../include/phantom_amd.h"
 #include "pha_internal.h"
 
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_mod_kernel(const GemmArgs g
             tot_lo[i][j] = tot_hi[i][j] = 0;
         }
 
+    uint32_t tiles_since_reduce = 0;
     for (uint32_t k0 = 0; k0 < g.k; k0 += kGemmBK) {
         // stage A (64 rows x 16: four coefficients per thread) and B (16 x 32: two per thread), cut into halves on the way
         {
@@ -113,6 +115,18 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_mod_kernel(const GemmArgs g
                     fold<SB>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], tot_lo[i][j], tot_hi[i][j]);
                     acc[i][j][0] = acc[i][j][1] = acc[i][j][2] = acc[i][j][3] = 0;
                 }
+            // products of two 60-bit residues are below 2^120: the 128-bit totals hold 128 of them plus one reduced
+            // word, so they go back to a single word every 8 tiles (k = 128); without this k > 256 would overflow
+            if (++tiles_since_reduce == 8) {
+                tiles_since_reduce = 0;
+#pragma unroll
+                for (int i = 0; i < kGemmTM; i++)
+#pragma unroll
+                    for (int j = 0; j < kGemmTN; j++) {
+                        tot_lo[i][j] = barrett128(tot_lo[i][j], tot_hi[i][j], mo);
+                        tot_hi[i][j] = 0;
+                    }
+            }
         }
     }
 #pragma unroll
@@ -134,7 +148,7 @@ using namespace pha;
 extern "C" int pha_batched_modular_gemm(pha_context_t ctx, uint64_t *C, size_t ldc, const uint64_t *A, size_t lda,
                                         const uint64_t *B, size_t ldb, size_t m, size_t n, size_t k, size_t batch,
                                         size_t mod_start_idx, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     if (!ctx || !C || !A || !B) throw std::invalid_argument("null pointer");
     Context &c = ctx->c;
     if (batch == 0 || m == 0 || n == 0) return 0;

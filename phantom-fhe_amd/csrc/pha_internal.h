@@ -7,6 +7,8 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "pha_arith.h"
@@ -26,12 +28,34 @@ int translate_exception();  // call inside catch(...)
     } while (0)
 
 #define PHA_API_BEGIN try {
+// entry points that take a context run on the context's device whatever the calling thread's current device is, and
+// leave that current device as they found it
+#define PHA_CTX_BEGIN(ctx) \
+    try {                  \
+        if (!(ctx)) throw std::invalid_argument("null context"); \
+        pha::DeviceGuard device_guard__((ctx)->c.device);
 #define PHA_API_END                  \
     return 0;                        \
     }                                \
     catch (...) {                    \
         return pha::translate_exception(); \
     }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            PHA_HIP(hipSetDevice(dev));
+            changed = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 // ---- device buffer (RAII) --------------------------------------------------------------------
 template <class T>
@@ -212,8 +236,12 @@ struct Context {
     std::unique_ptr<Hps> hps_tool;
     std::map<uint32_t, std::unique_ptr<HpsQ>> hpsq_tools;   // by |Ql| (|Q| = plain hps_overq)
     uint32_t rows = 0;  // table rows = size_qp + auxiliary moduli
-    std::map<void *, std::unique_ptr<Arena>> arenas;
-    std::map<void *, std::unique_ptr<Arena>> outer_arenas;   // for entry points that call other entry points (which use `arenas`)
+    // keyed by (stream handle, host thread): hipStreamPerThread and the null stream are sentinels that name a different
+    // real stream (or none) in every host thread, so those two handles get one arena per calling thread
+    typedef std::pair<void *, size_t> ArenaKey;
+    static ArenaKey arena_key(void *stream);
+    std::map<ArenaKey, std::unique_ptr<Arena>> arenas;
+    std::map<ArenaKey, std::unique_ptr<Arena>> outer_arenas;   // for entry points that call other entry points (which use `arenas`)
     u64 *scratch_outer(void *stream, size_t words);
     std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
 

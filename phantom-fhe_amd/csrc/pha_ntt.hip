@@ -19,7 +19,6 @@ std::atomic<int> g_ntt_variant{1 | 32 | 64};  // default: 8 coefficients per thr
 __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_wg_times[2048];
 #endif
-int g_num_cus = 256;
 extern std::atomic<int> g_bconv_split;  // pha_rns.hip
 
 struct NttKArgs {
@@ -292,7 +291,6 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
         if (excl && (lo != sel.excl_start || hi != sel.excl_end)) excl = 0xffffffffu;  // partial overlap: not pipelined
     }
     k.active = excl == 0xffffffffu ? 0 : sel.count - excl;
-    g_num_cus = c.num_cus;
     return k;
 }
 
@@ -377,7 +375,7 @@ static void need(const void *p) {
 extern "C" {
 
 int pha_nwt_2d_radix8_forward_inplace(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     ntt_forward(ctx->c, inout, inout, inout, plain_sel(start, cms), EPI_FWD_CANON, NttExtra{}, as_stream(stream));
     PHA_API_END
@@ -386,7 +384,7 @@ int pha_nwt_2d_radix8_forward_inplace(pha_context_t ctx, uint64_t *inout, size_t
 int pha_nwt_2d_radix8_forward_inplace_include_special_mod(pha_context_t ctx, uint64_t *inout, size_t cms,
                                                           size_t start, size_t size_QP, size_t size_P,
                                                           void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     if (size_P > cms) throw std::invalid_argument("size_P exceeds coeff_modulus_size");
     ntt_forward(ctx->c, inout, inout, inout, special_sel(start, cms, size_QP, size_P), EPI_FWD_CANON, NttExtra{},
@@ -398,7 +396,7 @@ int pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(pha_cont
                                                                         size_t cms, size_t start, size_t size_QP,
                                                                         size_t size_P, size_t ex_start,
                                                                         size_t ex_end, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     if (size_P > cms) throw std::invalid_argument("size_P exceeds coeff_modulus_size");
     LimbSel sel = special_sel(start, cms, size_QP, size_P);
@@ -411,7 +409,7 @@ int pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(pha_cont
 int pha_nwt_2d_radix8_forward_inplace_fuse_moddown(pha_context_t ctx, uint64_t *ct, const uint64_t *cx,
                                                    const uint64_t *pinv, const uint64_t *pinv_shoup,
                                                    uint64_t *delta, size_t cms, size_t start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(ct); need(cx); need(pinv); need(pinv_shoup); need(delta);
     NttExtra x;
     x.scale = pinv;
@@ -424,7 +422,7 @@ int pha_nwt_2d_radix8_forward_inplace_fuse_moddown(pha_context_t ctx, uint64_t *
 }
 
 int pha_nwt_2d_radix8_backward_inplace(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     ntt_inverse(ctx->c, inout, inout, inout, plain_sel(start, cms), EPI_INV_CANON, NttExtra{}, as_stream(stream));
     PHA_API_END
@@ -432,7 +430,7 @@ int pha_nwt_2d_radix8_backward_inplace(pha_context_t ctx, uint64_t *inout, size_
 
 int pha_nwt_2d_radix8_backward(pha_context_t ctx, uint64_t *out, const uint64_t *in, size_t cms, size_t start,
                                void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(out); need(in);
     ntt_inverse(ctx->c, in, out, out, plain_sel(start, cms), EPI_INV_CANON, NttExtra{}, as_stream(stream));
     PHA_API_END
@@ -441,7 +439,7 @@ int pha_nwt_2d_radix8_backward(pha_context_t ctx, uint64_t *out, const uint64_t 
 int pha_nwt_2d_radix8_backward_scale(pha_context_t ctx, uint64_t *out, const uint64_t *in, size_t cms,
                                      size_t start, const uint64_t *scale, const uint64_t *scale_shoup,
                                      void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(out); need(in); need(scale); need(scale_shoup);
     NttExtra x;
     x.scale = scale;
@@ -458,7 +456,7 @@ int pha_nwt_2d_radix8_backward_inplace_scale(pha_context_t ctx, uint64_t *inout,
 int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context_t ctx, uint64_t *inout, size_t cms,
                                                            size_t start, size_t size_QP, size_t size_P,
                                                            void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     if (size_P > cms) throw std::invalid_argument("size_P exceeds coeff_modulus_size");
     ntt_inverse(ctx->c, inout, inout, inout, special_sel(start, cms, size_QP, size_P), EPI_INV_CANON, NttExtra{},
@@ -481,7 +479,7 @@ static LimbSel temp_mod_sel(Context &c, size_t cms, size_t start, size_t total) 
 
 int pha_nwt_2d_radix8_forward_inplace_include_temp_mod(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start,
                                                        size_t total_modulus_size, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     ntt_forward(ctx->c, inout, inout, inout, temp_mod_sel(ctx->c, cms, start, total_modulus_size), EPI_FWD_CANON, NttExtra{},
                 as_stream(stream));
@@ -492,7 +490,7 @@ int pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale(pha_context_t ctx,
                                                               size_t start, size_t total_modulus_size,
                                                               const uint64_t *scale, const uint64_t *scale_shoup,
                                                               void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout); need(scale); need(scale_shoup);
     NttExtra x;
     x.scale = scale;
@@ -508,7 +506,7 @@ int pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale(pha_context_t ctx,
 // that reduction commented out, :47-49: same results for its inputs below q).
 int pha_nwt_2d_radix8_forward_modup_fuse(pha_context_t ctx, uint64_t *out, const uint64_t *in, size_t modulus_index,
                                          size_t cms, size_t start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(out); need(in);
     Context &c = ctx->c;
     if (modulus_index >= c.size_qp) throw std::invalid_argument("modulus_index out of range");
@@ -525,7 +523,7 @@ int pha_nwt_2d_radix8_forward_modup_fuse(pha_context_t ctx, uint64_t *out, const
 
 int pha_nwt_2d_radix8_forward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start,
                                               size_t batch, size_t poly_stride, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     if (batch == 0 || batch > 65535) throw std::invalid_argument("batch out of range");
     NttExtra x;
@@ -537,7 +535,7 @@ int pha_nwt_2d_radix8_forward_inplace_batched(pha_context_t ctx, uint64_t *inout
 
 int pha_nwt_2d_radix8_backward_inplace_batched(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start,
                                                size_t batch, size_t poly_stride, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     if (batch == 0 || batch > 65535) throw std::invalid_argument("batch out of range");
     NttExtra x;
@@ -570,7 +568,7 @@ int pha_set_tuning(int key, int value) {
 }
 
 int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t cms, int iters, void *stream, float *ms_out) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(inout);
     hipStream_t s = as_stream(stream);
     hipEvent_t e0, e1;

@@ -27,7 +27,7 @@ static Tool &plain_tool(Context &c, size_t size_Ql) {
 extern "C" {
 
 int pha_bfv_add_plain(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *plain, int subtract, void *stream) {
-    PHA_API_BEGIN   // multiply_add_plain_with_scaling_variant / multiply_sub_plain_with_scaling_variant
+    PHA_CTX_BEGIN(ctx)   // multiply_add_plain_with_scaling_variant / multiply_sub_plain_with_scaling_variant
     need(ct); need(plain);
     Context &c = ctx->c;
     Tool &t = plain_tool(c, size_Ql);
@@ -42,7 +42,7 @@ int pha_bfv_add_plain(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uin
 
 int pha_bfv_multiply_plain(pha_context_t ctx, size_t size_Ql, uint64_t *ct, size_t cipher_size, const uint64_t *plain,
                            void *stream) {
-    PHA_API_BEGIN   // multiply_plain_normal evaluate.cu:1256-1300
+    PHA_CTX_BEGIN(ctx)   // multiply_plain_normal evaluate.cu:1256-1300
     need(ct); need(plain);
     Context &c = ctx->c;
     Tool &t = plain_tool(c, size_Ql);
@@ -63,7 +63,7 @@ int pha_bfv_multiply_plain(pha_context_t ctx, size_t size_Ql, uint64_t *ct, size
 }
 
 int pha_bgv_lift_plain(pha_context_t ctx, size_t size_Ql, const uint64_t *plain, uint64_t *out, void *stream) {
-    PHA_API_BEGIN   // the modup_fuse loop of evaluate.cu:1150-1154 / 1208-1212 / 1319-1323, every limb in one launch
+    PHA_CTX_BEGIN(ctx)   // the modup_fuse loop of evaluate.cu:1150-1154 / 1208-1212 / 1319-1323, every limb in one launch
     need(plain); need(out);
     Context &c = ctx->c;
     if (size_Ql < 1 || size_Ql > c.size_q) throw std::invalid_argument("RNSBase is invalid");

@@ -137,14 +137,14 @@ extern "C" {
 
 int pha_add_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t cms,
                      size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
     launch_add(ctx->c, a, b, r, cms, mod_start, as_stream(stream));
     PHA_API_END
 }
 int pha_sub_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t cms,
                      size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
     EwArgs k{};
     k.a = a; k.b = b; k.r = r;
@@ -153,7 +153,7 @@ int pha_sub_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, ui
 }
 int pha_negate_rns_poly(pha_context_t ctx, const uint64_t *a, uint64_t *r, size_t cms, size_t mod_start,
                         void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(r);
     EwArgs k{};
     k.a = a; k.r = r;
@@ -162,7 +162,7 @@ int pha_negate_rns_poly(pha_context_t ctx, const uint64_t *a, uint64_t *r, size_
 }
 int pha_multiply_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t cms,
                           size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
     EwArgs k{};
     k.a = a; k.b = b; k.r = r;
@@ -171,7 +171,7 @@ int pha_multiply_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *
 }
 int pha_multiply_and_add_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, const uint64_t *d,
                                   uint64_t *r, size_t cms, size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(d); need(r);
     EwArgs k{};
     k.a = a; k.b = b; k.d = d; k.r = r;
@@ -181,7 +181,7 @@ int pha_multiply_and_add_rns_poly(pha_context_t ctx, const uint64_t *a, const ui
 int pha_multiply_scalar_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *scalar,
                                  const uint64_t *scalar_shoup, uint64_t *r, size_t cms, size_t mod_start,
                                  void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(scalar); need(scalar_shoup); need(r);
     EwArgs k{};
     k.a = a; k.s0 = scalar; k.s1 = scalar_shoup; k.r = r;
@@ -190,7 +190,7 @@ int pha_multiply_scalar_rns_poly(pha_context_t ctx, const uint64_t *a, const uin
 }
 int pha_tensor_prod_2x2_rns_poly(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *res,
                                  size_t cms, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(op1); need(op2); need(res);
     EwArgs k{};
     k.a = op1; k.b = op2; k.r = res;
@@ -199,7 +199,7 @@ int pha_tensor_prod_2x2_rns_poly(pha_context_t ctx, const uint64_t *op1, const u
 }
 int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *res01,
                                 uint64_t *res2, size_t cms, size_t batch, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(op1); need(op2); need(res01); need(res2);
     const size_t ln = cms * ctx->c.n;
     for (size_t b = 0; b < batch; b++) {  // HBM-streaming kernel: one launch per ciphertext loses nothing
@@ -211,7 +211,7 @@ int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *op1, const ui
 }
 int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *op, uint64_t *res, size_t cms,
                                    void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(op); need(res);
     EwArgs k{};
     k.a = op; k.r = res;
@@ -219,7 +219,7 @@ int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *op, uint64
     PHA_API_END
 }
 int pha_add_to_ct(pha_context_t ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(ct); need(cx);
     launch_add(ctx->c, ct, cx, ct, size_Ql, 0, as_stream(stream));  // add_to_ct_kernel rns_bconv.cu:763-769
     PHA_API_END

@@ -112,7 +112,7 @@ extern "C" {
 
 int pha_add_std_cipher(pha_context_t ctx, const uint64_t *cipher1, const uint64_t *cipher2, uint64_t *result, size_t cms,
                        void *stream) {
-    PHA_API_BEGIN   // add_std_cipher polymath.cu:56-73: both polynomials of a size-2 ciphertext
+    PHA_CTX_BEGIN(ctx)   // add_std_cipher polymath.cu:56-73: both polynomials of a size-2 ciphertext
     need(cipher1); need(cipher2); need(result);
     const size_t ln = cms * ctx->c.n;
     launch_add(ctx->c, cipher1, cipher2, result, cms, 0, as_stream(stream));
@@ -122,7 +122,7 @@ int pha_add_std_cipher(pha_context_t ctx, const uint64_t *cipher1, const uint64_
 
 int pha_add_and_negate_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t *r, size_t cms,
                                 size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
     XArgs k{};
     k.a = a; k.b = b; k.r = r;
@@ -132,7 +132,7 @@ int pha_add_and_negate_rns_poly(pha_context_t ctx, const uint64_t *a, const uint
 
 int pha_add_many_rns_poly(pha_context_t ctx, const uint64_t *const *operands, size_t add_size, uint64_t *result,
                           size_t poly_index, size_t cms, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(operands); need(result);
     if (add_size == 0 || add_size > 65535) throw std::invalid_argument("add_size out of range");
     for (size_t e = 0; e < add_size; e++) need(operands[e]);
@@ -149,7 +149,7 @@ int pha_add_many_rns_poly(pha_context_t ctx, const uint64_t *const *operands, si
 
 int pha_multiply_uniform_scalar_rns_poly(pha_context_t ctx, const uint64_t *a, uint64_t scale, uint64_t *r, size_t cms,
                                          size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(r);
     XArgs k{};
     k.a = a; k.r = r; k.c0 = scale;
@@ -159,7 +159,7 @@ int pha_multiply_uniform_scalar_rns_poly(pha_context_t ctx, const uint64_t *a, u
 
 int pha_multiply_scalar_and_add_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t scalar,
                                          uint64_t *r, size_t cms, size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
     XArgs k{};
     k.a = a; k.b = b; k.r = r; k.c0 = scalar;
@@ -169,7 +169,7 @@ int pha_multiply_scalar_and_add_rns_poly(pha_context_t ctx, const uint64_t *a, c
 
 int pha_multiply_scalar_and_sub_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t scalar,
                                          uint64_t *r, size_t cms, size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
     XArgs k{};
     k.a = a; k.b = b; k.r = r; k.c0 = scalar;
@@ -179,7 +179,7 @@ int pha_multiply_scalar_and_sub_rns_poly(pha_context_t ctx, const uint64_t *a, c
 
 int pha_multiply_and_scale_add_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, const uint64_t *d,
                                         uint64_t scale, uint64_t *r, size_t cms, size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(d); need(r);
     XArgs k{};
     k.a = a; k.b = b; k.d = d; k.r = r; k.c0 = scale;
@@ -189,7 +189,7 @@ int pha_multiply_and_scale_add_rns_poly(pha_context_t ctx, const uint64_t *a, co
 
 int pha_multiply_and_add_negate_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, const uint64_t *d,
                                          uint64_t *r, size_t cms, size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(d); need(r);
     XArgs k{};
     k.a = a; k.b = b; k.d = d; k.r = r;
@@ -199,7 +199,7 @@ int pha_multiply_and_add_negate_rns_poly(pha_context_t ctx, const uint64_t *a, c
 
 int pha_sub_and_scale_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, const uint64_t *scale,
                                const uint64_t *scale_shoup, uint64_t *r, size_t cms, size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(scale); need(scale_shoup); need(r);
     XArgs k{};
     k.a = a; k.b = b; k.s0 = scale; k.s1 = scale_shoup; k.r = r;
@@ -209,7 +209,7 @@ int pha_sub_and_scale_rns_poly(pha_context_t ctx, const uint64_t *a, const uint6
 
 int pha_sub_and_scale_single_mod_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, uint64_t scale,
                                       uint64_t scale_shoup, uint64_t modulus, uint64_t *r, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
     if (modulus < 2 || modulus >> 62) throw std::invalid_argument("modulus out of range");
     XArgs k{};
@@ -232,7 +232,7 @@ static void bfv_times_q_over_t(pha_context_t ctx, bool add, uint64_t *ct, const 
 int pha_bfv_add_timesQ_overt(pha_context_t ctx, uint64_t *ct, const uint64_t *pt, uint64_t neg_ql_mod_t,
                              uint64_t neg_ql_mod_t_shoup, const uint64_t *t_inv_mod_q, const uint64_t *t_inv_mod_q_shoup,
                              uint64_t t, size_t size_Ql, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     bfv_times_q_over_t(ctx, true, ct, pt, neg_ql_mod_t, neg_ql_mod_t_shoup, t_inv_mod_q, t_inv_mod_q_shoup, t, size_Ql, stream);
     PHA_API_END
 }
@@ -240,14 +240,14 @@ int pha_bfv_add_timesQ_overt(pha_context_t ctx, uint64_t *ct, const uint64_t *pt
 int pha_bfv_sub_timesQ_overt(pha_context_t ctx, uint64_t *ct, const uint64_t *pt, uint64_t neg_ql_mod_t,
                              uint64_t neg_ql_mod_t_shoup, const uint64_t *t_inv_mod_q, const uint64_t *t_inv_mod_q_shoup,
                              uint64_t t, size_t size_Ql, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     bfv_times_q_over_t(ctx, false, ct, pt, neg_ql_mod_t, neg_ql_mod_t_shoup, t_inv_mod_q, t_inv_mod_q_shoup, t, size_Ql, stream);
     PHA_API_END
 }
 
 int pha_abs_plain_rns_poly(pha_context_t ctx, const uint64_t *operand, uint64_t plain_upper_half_threshold,
                            const uint64_t *plain_upper_half_increment, uint64_t *result, size_t cms, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(operand); need(plain_upper_half_increment); need(result);
     XArgs k{};
     k.a = operand; k.r = result; k.c0 = plain_upper_half_threshold; k.s0 = plain_upper_half_increment;
@@ -257,7 +257,7 @@ int pha_abs_plain_rns_poly(pha_context_t ctx, const uint64_t *operand, uint64_t 
 
 int pha_tensor_prod_mxn_rns_poly(pha_context_t ctx, const uint64_t *op1, size_t op1_size, const uint64_t *op2,
                                  size_t op2_size, uint64_t *result, size_t res_size, size_t cms, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(op1); need(op2); need(result);
     if (op1_size == 0 || op2_size == 0 || op1_size > kMaxCipher || op2_size > kMaxCipher)
         throw std::invalid_argument("ciphertext size out of range (1..8 polynomials)");
@@ -273,7 +273,7 @@ int pha_tensor_prod_mxn_rns_poly(pha_context_t ctx, const uint64_t *op1, size_t 
 int pha_multiply_and_negated_add_rns_poly(pha_context_t ctx, const uint64_t *alpha_sk, uint64_t m_sk,
                                           const uint64_t *prod_B_mod_q, const uint64_t *operand3, uint64_t *result,
                                           size_t cms, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(alpha_sk); need(prod_B_mod_q); need(operand3); need(result);
     XArgs k{};
     k.a = alpha_sk; k.c0 = m_sk; k.s0 = prod_B_mod_q; k.d = operand3; k.r = result;

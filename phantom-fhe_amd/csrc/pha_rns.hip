@@ -741,7 +741,7 @@ static void need(const void *p) {
 extern "C" {
 
 int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(dst); need(src);
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
@@ -753,7 +753,7 @@ int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const ui
 }
 
 int pha_modup(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *cks, int scheme, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(dst); need(cks);
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
@@ -765,7 +765,7 @@ int pha_modup(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *
 
 int pha_key_switch_inner_prod(pha_context_t ctx, size_t size_Ql, uint64_t *p_cx, const uint64_t *p_t_mod_up,
                               const uint64_t *const *rlk, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(p_cx); need(p_t_mod_up); need(rlk);
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
@@ -775,7 +775,7 @@ int pha_key_switch_inner_prod(pha_context_t ctx, size_t size_Ql, uint64_t *p_cx,
 
 int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint64_t *cx_i, int scheme,
                          void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(ct_i); need(cx_i);
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
@@ -787,7 +787,7 @@ int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint
 
 int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
                           const uint64_t *const *rlk, int scheme, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(ct); need(c2); need(rlk);
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
@@ -806,7 +806,7 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
 
 int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2, size_t batch,
                                   const uint64_t *const *rlk, int scheme, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(ct); need(c2); need(rlk);
     if (batch == 0) return 0;
     if (batch > 1024) throw std::invalid_argument("batch out of range");
@@ -829,7 +829,7 @@ int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *c
 
 int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                  const uint64_t *const *const *glk, int scheme, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(ct); need(galois_elts); need(glk);
     if (n_elts == 0) throw std::invalid_argument("steps must not be empty");
     Context &c = ctx->c;
@@ -857,8 +857,14 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
     PHA_HIP(hipMemcpyAsync(c0, ct, ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));
     // one mod-up of c1 shared by every rotation (evaluate.cu:1758-1760)
     modup(c, t, t_mod_up, ct + ql_n, scheme, tmp, s);
-    // all rotations' inner products in one kernel (128-bit headroom: at most 255 terms per call)
-    const size_t per_call = std::max<size_t>(1, 255 / t.beta);
+    // all rotations' inner products in one kernel; the unreduced 128-bit accumulators hold floor(2^128 / q_max^2) - 1
+    // products (255 for primes up to 60 bits, 63 for the 61-bit primes the context also accepts)
+    u64 qmax = 0;
+    for (uint32_t i = 0; i < c.size_qp; i++) qmax = std::max(qmax, c.primes[i]);
+    int qbits = 0;
+    while (qbits < 64 && (qmax >> qbits)) qbits++;
+    const size_t max_terms = qbits >= 64 ? 1 : ((size_t)1 << std::min(20, 128 - 2 * qbits)) - 1;
+    const size_t per_call = std::max<size_t>(1, max_terms / t.beta);
     for (size_t e0 = 0; e0 < n_elts; e0 += per_call) {
         HoistArgs k{};
         k.cx = acc_cx; k.t_mod_up = t_mod_up; k.keys = d_keys + e0; k.tables = d_tabs + e0; k.mod = c.d_mod.p;
@@ -889,7 +895,7 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
 
 int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                           const uint64_t *const *const *glk, const uint64_t *const *weights, int scheme, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(ct); need(galois_elts); need(glk); need(weights);
     if (n_elts == 0) throw std::invalid_argument("steps must not be empty");
     if (!ntt_domain_scheme(scheme)) throw std::invalid_argument("weighted hoisting takes NTT-form ciphertexts (ckks / bgv)");
@@ -953,7 +959,7 @@ int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
 
 int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,
                                     uint64_t *dst, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(src); need(dst);
     Context &c = ctx->c;
     check_level(c, size_Ql, false);
@@ -987,7 +993,7 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
 
 int pha_generate_one_kswitch_key(pha_context_t ctx, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,
                                  const uint64_t *a, uint64_t *e, uint64_t *const *evk, int scheme, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(sk_ntt); need(new_key_ntt); need(a); need(e); need(evk);
     Context &c = ctx->c;
     if (c.size_p == 0) throw std::invalid_argument("context has no special modulus");
@@ -1015,7 +1021,7 @@ int pha_generate_one_kswitch_key(pha_context_t ctx, const uint64_t *sk_ntt, cons
 
 int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t *src, size_t cipher_size,
                                     uint64_t *dst, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(src); need(dst);
     Context &c = ctx->c;
     check_level(c, size_Ql, false);
@@ -1044,7 +1050,7 @@ int pha_mod_t_and_divide_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
 
 int pha_divide_and_round_q_last(pha_context_t ctx, size_t size_Ql, const uint64_t *src, size_t cipher_size,
                                 uint64_t *dst, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(src); need(dst);
     Context &c = ctx->c;
     check_level(c, size_Ql, false);
@@ -1063,7 +1069,7 @@ int pha_divide_and_round_q_last(pha_context_t ctx, size_t size_Ql, const uint64_
 
 int pha_apply_galois_ntt(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt, size_t cms,
                          void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(src); need(dst);
     if (src == dst) throw std::invalid_argument("apply_galois_ntt cannot run in place");
     Context &c = ctx->c;
@@ -1076,7 +1082,7 @@ int pha_apply_galois_ntt(pha_context_t ctx, const uint64_t *src, uint64_t *dst, 
 
 int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt, size_t cms,
                              size_t polys, int ntt_form, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(src); need(dst);
     if (src == dst) throw std::invalid_argument("apply_galois cannot run in place");
     Context &c = ctx->c;
@@ -1101,7 +1107,7 @@ int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *d
 
 int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt, size_t cms,
                      size_t mod_start, void *stream) {
-    PHA_API_BEGIN
+    PHA_CTX_BEGIN(ctx)
     need(src); need(dst);
     if (src == dst) throw std::invalid_argument("apply_galois cannot run in place");
     Context &c = ctx->c;

@@ -670,7 +670,8 @@ def test_bfv_hps_overq_leveled(name, plain_t, ql, gpu):
     assert np.array_equal(P.to_host(dst), O.HpsOverQ(oc, plain_t).multiply(ct1, ct2))
 
 
-@pytest.mark.parametrize("bits,m,n,k,batch", [(50, 256, 256, 256, 3), (50, 96, 40, 72, 2), (60, 128, 64, 100, 2), (36, 64, 32, 16, 1)])
+@pytest.mark.parametrize("bits,m,n,k,batch", [(50, 256, 256, 256, 3), (50, 96, 40, 72, 2), (60, 128, 64, 100, 2), (36, 64, 32, 16, 1),
+                                                 (60, 64, 32, 1200, 2)])
 def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
     """matmul_bench shape (256^3 per 50-bit modulus) and ragged shapes, wide (60-bit) and narrow paths, vs the oracle;
     the benchmark's all-ones input gives k everywhere."""
@@ -682,6 +683,9 @@ def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
     B = np.stack([r.integers(0, q, (k, n), dtype=np.uint64) for q in primes])
     A[:, 0, :] = np.array(primes, dtype=np.uint64)[:, None] - 1       # a row and a column of q - 1
     B[:, :, 0] = np.array(primes, dtype=np.uint64)[:, None] - 1
+    if k > 256:   # 60-bit residues just below q everywhere: k q^2 exceeds 2^128 unless the totals are reduced on the way
+        A = (np.array(primes, dtype=np.uint64)[:, None, None] - 1 - r.integers(0, 4, A.shape, dtype=np.uint64))
+        B = (np.array(primes, dtype=np.uint64)[:, None, None] - 1 - r.integers(0, 4, B.shape, dtype=np.uint64))
     dC = P.to_device(np.zeros((batch, m, n), dtype=np.uint64), gpu)
     ctx.batched_modular_gemm(dC, P.to_device(A, gpu), P.to_device(B, gpu), m, n, k, batch)
     got = P.to_host(dC)
