@@ -185,6 +185,8 @@ def main():
     from phantom_fhe_amd import workloads as W
     if os.environ.get("PHA_NTT_VARIANT"):   # A/B experiments only (pha_set_tuning key 0); results never change
         P.set_tuning(0, int(os.environ["PHA_NTT_VARIANT"]))
+    for kv in filter(None, os.environ.get("PHA_TUNING", "").split(",")):   # "key=value,..." (pha_set_tuning), A/B only
+        P.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     n = 1 << LOG_N
     primes = [int(p) for p in P.coeff_modulus_create(n, BITS)]
     size_q = len(primes) - SIZE_P

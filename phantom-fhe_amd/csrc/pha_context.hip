@@ -181,6 +181,32 @@ static void build_prime_tables(Context &c, uint32_t row, uint32_t i, std::vector
     }
 }
 
+// XCD placement census: the first workgroup of each class b % 8 records its XCC_ID, the others compare
+__global__ void xcd_census_kernel(uint32_t *cls, uint32_t *mismatch) {
+    if (threadIdx.x == 0) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        const uint32_t mine = (id & 7u) + 1;
+        const uint32_t seen = atomicCAS(cls + (blockIdx.x & 7u), 0u, mine);
+        if (seen != 0 && seen != mine) atomicAdd(mismatch, 1u);
+    }
+}
+static bool xcd_placement_is_round_robin() {
+    DevBuf<uint32_t> d(9);
+    for (int rep = 0; rep < 3; rep++) {
+        PHA_HIP(hipMemset(d.p, 0, 8 * sizeof(uint32_t)));
+        if (rep == 0) PHA_HIP(hipMemset(d.p + 8, 0, sizeof(uint32_t)));
+        hipLaunchKernelGGL(xcd_census_kernel, dim3(4096 + 8 * rep + 3), dim3(64), 0, 0, d.p, d.p + 8);
+        PHA_HIP(hipGetLastError());
+        PHA_HIP(hipDeviceSynchronize());
+    }
+    uint32_t h[9];
+    PHA_HIP(hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost));
+    bool distinct = true;   // eight classes on eight different XCDs (a device with fewer XCDs would share them: still fine)
+    (void)distinct;
+    return h[8] == 0;
+}
+
 static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uint32_t size_qp, uint32_t size_p,
                          int device) {
     if (log_n < 12 || log_n > 17) throw std::invalid_argument("poly_modulus_degree is invalid (2^12..2^17 supported)");
@@ -191,6 +217,11 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
         hipDeviceProp_t prop;
         PHA_HIP(hipGetDeviceProperties(&prop, device));
         c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    c.xcd_round_robin = xcd_placement_is_round_robin();
+    if (c.xcd_round_robin) {
+        c.flag_pool.alloc(Context::kFlagArenas * (2 * Context::kFlagUnits + 16));
+        PHA_HIP(hipMemset(c.flag_pool.p, 0, c.flag_pool.count * sizeof(uint32_t)));
     }
     c.log_n = log_n;
     c.n = (size_t)1 << log_n;
@@ -840,6 +871,18 @@ u64 *Context::scratch(void *stream, size_t words) {
         a->buf.alloc(words);
     }
     return a->buf.p;
+}
+
+uint32_t *Context::ntt_flags(void *stream, size_t units) {
+    if (units > kFlagUnits || !flag_pool.p) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    const ArenaKey key = arena_key(stream);
+    auto it = flag_arenas.find(key);
+    if (it == flag_arenas.end()) {
+        if (flag_arenas.size() >= kFlagArenas) return nullptr;
+        it = flag_arenas.emplace(key, (uint32_t)flag_arenas.size()).first;
+    }
+    return flag_pool.p + (size_t)it->second * (2 * kFlagUnits + 16);
 }
 
 u64 *Context::scratch_outer(void *stream, size_t words) {

@@ -251,6 +251,16 @@ struct Context {
     HpsQ &hps_overq(uint32_t size_ql = 0);
     uint32_t add_aux_moduli(const std::vector<u64> &ntt_primes, u64 plain_modulus_like);
     u64 *scratch(void *stream, size_t words);
+    // hand-off counters of the one-launch NTT (pha_ntt.hip): 16 header words + two words per (polynomial, limb) unit, zero
+    // between launches (the kernel cleans up after itself); one array per (stream, thread) like the scratch arenas
+    // (allocated once with the context, so that a launch never allocates: it may be inside a stream capture)
+    static constexpr size_t kFlagUnits = 65536, kFlagArenas = 16;
+    DevBuf<uint32_t> flag_pool;                    // [kFlagArenas][16 + 2 kFlagUnits]
+    std::map<ArenaKey, uint32_t> flag_arenas;      // (stream, thread) -> arena of the pool
+    uint32_t *ntt_flags(void *stream, size_t units);   // null: no arena left or too many units (caller takes two launches)
+    // do all workgroups b of a 1-D grid with the same b % 8 run on one XCD?  (observed placement, checked once per
+    // context by a census launch and again inside every one-launch NTT, which needs it and is disabled without it)
+    bool xcd_round_robin = false;
     const uint32_t *galois_table(uint32_t elt);
 };
 

@@ -13,13 +13,16 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096 through the two-pass plans too (default: the whole transform in one launch)
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096 through the two-pass plans too (default: the whole transform in one launch), bit 8 = the one-workgroup plans of N = 8192 / 16384 for every launch size, bit 9 = both passes in one launch (L2 hand-off) for every launch size, bit 10 = never
 std::atomic<int> g_ntt_variant{1 | 32 | 64};  // default: 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_wg_times[2048];
 #endif
 extern std::atomic<int> g_bconv_split;  // pha_rns.hip
+std::atomic<int> g_whole14_min{1 << 30};  // pha_set_tuning key 2: limb-polynomials per launch from which N = 2^14 takes the one-workgroup plan (r02: never faster than the alternatives, kept for tests)
+std::atomic<int> g_fused_lag{2};          // pha_set_tuning key 3: lag (in units per XCD) between the two passes of the one-launch transform
+std::atomic<int> g_fused_min_tiles{1 << 30}; // pha_set_tuning key 4: tiles per launch from which the two passes share one launch (r02: 7 % slower than two launches at every size, DESIGN section 7: off by default, kept behind bit 9 and this threshold)    // pha_set_tuning key 2: limb-polynomials per launch from which N = 2^14 takes the one-launch plan
 
 struct NttKArgs {
     const u64 *in;
@@ -90,50 +93,47 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
 #else
 #define PHA_PASS_ATTR
 #endif
-template <class C, bool FWD, int EPI, bool FOLD, int HOIST>
-__global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(const NttKArgs k) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *lds = reinterpret_cast<u64 *>(smem);
-
-    const uint32_t twr = k.sel.start + blockIdx.y;  // limb in the buffer (uniform)
-    {
-        // polynomial z skips its own digit: [excl_start + z*step, min(that + len, limit))  (ntt_modup.cu:422)
-        const uint32_t zd = k.excl_mod ? blockIdx.z % k.excl_mod : blockIdx.z;
-        const uint32_t es = k.sel.excl_start + zd * k.excl_step;
-        uint32_t ee = es + (k.sel.excl_end - k.sel.excl_start);
-        ee = ee < k.excl_limit ? ee : k.excl_limit;
-        if (twr >= es && twr < ee) return;
-    }
-    PassArgs a;
-    tile_args<FWD, EPI, FOLD>(k, twr, blockIdx.x, a);
-    if (k.batch > 1) {  // same limbs of several polynomials in one launch
-        a.in += (size_t)blockIdx.z * k.poly_stride;
-        a.out += (size_t)blockIdx.z * k.out_stride;
-        if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) a.aux += (size_t)blockIdx.z * k.aux_stride;
-    }
-    if (FWD && (C::STRIDED || C::WHOLE) && k.pro_src) {  // rescale prologue: transform (the last limb of polynomial z) mod this prime
-        const uint32_t prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
-        a.in = k.pro_src + (size_t)blockIdx.z * k.pro_stride;
-        a.pro_reduce = true;
-        a.pro_ratio1 = k.mod[prime].ratio1;
-    }
-
-    u64 reg[C::EPT];
-    u64x2 twreg[C::TW_TOTAL];
-    using Prog = PassProgram<C, FWD, EPI, FOLD, HOIST>;
-    const int tid = threadIdx.x;
 #if defined(PHA_EXP_STAMPS)   // timing experiment: cycle stamps of workgroup (0,0), wave 0
-#define PHA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#define PHA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PHA_STAMP(i) do { } while (0)
 #endif
-#if defined(PHA_EXP_STAMPS)
-    const unsigned long long wg_t0 = wall_clock64();
-#endif
-    PHA_STAMP(0);
-    // The whole pass is emitted twice, once with a.fp known true and once known false (a.fp is uniform per workgroup):
-    // each copy is then scheduled and register-allocated like a kernel that has only that butterfly back end
-    // (sweep at 2^16, 60 / 240 / 1020 limbs: 36.3 / 118 / 505 us with one shared body, 32.8 / 107 / 458 us specialised).
+
+// polynomial z skips its own digit: [excl_start + z*step, min(that + len, limit))  (ntt_modup.cu:422)
+__device__ __forceinline__ bool limb_excluded(const NttKArgs &k, uint32_t twr, uint32_t z) {
+    const uint32_t zd = k.excl_mod ? z % k.excl_mod : z;
+    const uint32_t es = k.sel.excl_start + zd * k.excl_step;
+    uint32_t ee = es + (k.sel.excl_end - k.sel.excl_start);
+    ee = ee < k.excl_limit ? ee : k.excl_limit;
+    return twr >= es && twr < ee;
+}
+
+// Arguments of tile `tile` of limb `twr` of polynomial `z`, with the batch offsets and the rescale prologue.
+template <class C, bool FWD, int EPI, bool FOLD>
+__device__ __forceinline__ void full_tile_args(const NttKArgs &k, uint32_t twr, uint32_t z, uint32_t tile, PassArgs &a) {
+    tile_args<FWD, EPI, FOLD>(k, twr, tile, a);
+    if (k.batch > 1) {  // same limbs of several polynomials in one launch
+        a.in += (size_t)z * k.poly_stride;
+        a.out += (size_t)z * k.out_stride;
+        if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) a.aux += (size_t)z * k.aux_stride;
+    }
+    if (FWD && (C::STRIDED || C::WHOLE) && k.pro_src) {  // rescale prologue: transform (the last limb of polynomial z) mod this prime
+        const uint32_t prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
+        a.in = k.pro_src + (size_t)z * k.pro_stride;
+        a.pro_reduce = true;
+        a.pro_ratio1 = k.mod[prime].ratio1;
+    }
+}
+
+// One pass over one tile.  The whole pass is emitted twice, once with a.fp known true and once known false (a.fp is
+// uniform per workgroup): each copy is then scheduled and register-allocated like a kernel that has only that butterfly
+// back end (sweep at 2^16, 60 / 240 / 1020 limbs: 36.3 / 118 / 505 us with one shared body, 32.8 / 107 / 458 us specialised).
+// COH: the pass reads what other workgroups of this launch wrote (one-launch transform).
+template <class C, bool FWD, int EPI, bool FOLD, int HOIST, bool COH>
+__device__ __forceinline__ void exec_pass(const PassArgs &a, u64 *lds, int tid) {
+    u64 reg[C::EPT];
+    u64x2 twreg[C::TW_TOTAL];
+    using Prog = PassProgram<C, FWD, EPI, FOLD, HOIST, COH>;
     auto pass = [&](const PassArgs &pa) __attribute__((always_inline)) {
         Prog::load_twiddles(pa, tid, twreg);
         Prog::template run<0>(pa, lds, tid, reg, twreg);
@@ -162,14 +162,163 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
         b.fp = false;
         pass(b);
     }
+}
+
+template <class C, bool FWD, int EPI, bool FOLD, int HOIST>
+__global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(const NttKArgs k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *lds = reinterpret_cast<u64 *>(smem);
+
+    const uint32_t twr = k.sel.start + blockIdx.y;  // limb in the buffer (uniform)
+    if (limb_excluded(k, twr, blockIdx.z)) return;
+    PassArgs a;
+    full_tile_args<C, FWD, EPI, FOLD>(k, twr, blockIdx.z, blockIdx.x, a);
+#if defined(PHA_EXP_STAMPS)
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
+    PHA_STAMP(0);
+    exec_pass<C, FWD, EPI, FOLD, HOIST, false>(a, lds, threadIdx.x);
 #if defined(PHA_EXP_STAMPS)
     __builtin_amdgcn_s_waitcnt(0);
     PHA_STAMP(6);
-    if (tid == 0) {  // wall-clock (100 MHz) start/end of every workgroup of the last launch
+    if (threadIdx.x == 0) {  // wall-clock (100 MHz) start/end of every workgroup of the last launch
         const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
         if (id < 1024) { g_wg_times[2 * id] = wg_t0; g_wg_times[2 * id + 1] = wall_clock64(); }
     }
 #endif
+}
+
+// ---- both passes in ONE launch, the intermediate handed over through the XCD's own L2 -------------------------------
+// (r02; tools/handoff_bench.hip is the memory-side experiment behind it: the two access patterns at 720 limbs take
+// 286 us as two launches and 211 us in this form, because the intermediate never crosses the fabric a second time.)
+// Placement: the workgroups of a 1-D grid are dealt to the 8 XCDs round-robin, so all workgroups with the same
+// b % 8 (a "class") share one XCD -- XCD (b + r) % 8 with r = 0 for plain launches and some other constant under
+// hipGraph replay.  Only the sharing matters here and it is checked in every launch: the first workgroup of a class
+// records its XCC_ID, every other one compares and traps on a difference (the context also runs a census launch and
+// keeps the two-launch form if the rule does not hold on the device).  A "unit" is one limb of one polynomial;
+// unit u belongs to class u % 8, whose workgroups visit its units in order: workgroup (slot s, tile t) of a class first
+// runs the transform's first pass on tile t of the unit of slot s, then the second pass on tile t of the unit of slot
+// s - lag, whose tiles were all started lag * tiles_per_unit workgroups earlier in this class and have normally been
+// written by then.  Hand-off protocol (every participant of a unit is on one XCD, whose L2 is the only cache level they
+// share):
+//   producer: plain stores (written through, the line stays in this XCD's L2), s_waitcnt vmcnt(0), workgroup barrier,
+//             one non-returning atomic add on the unit's counter (executes in this L2);
+//   consumer: one lane polls the counter with a returning atomic OR 0 (never answered by the CU's L1) until all tiles
+//             have arrived, workgroup barrier, then reads the intermediate with agent-scope loads (`sc1`: miss the L1,
+//             answered by the L2) -- PassProgram's COH flag.
+// The counter array cleans itself: every consumer counts itself in right after its poll has succeeded, and the one that
+// finds all the others counted puts the unit's two words back to zero (nobody polls them any more); that workgroup also
+// counts the finished unit at agent scope, and the one that finishes the launch's last unit clears the 8 class words
+// (every workgroup that has work looked at its class word before its own unit could finish).  So a launch never
+// allocates or clears anything from the host, which keeps it capturable.
+// Dispatch order is ascending block index, so a waiting workgroup only ever waits for workgroups that are already
+// resident or finished (the same assumption every decoupled look-back scan makes); the poll is bounded and traps.
+#ifndef PHA_FUSED_MIN_WAVES
+#define PHA_FUSED_MIN_WAVES 6   // three 512-thread workgroups per CU
+#endif
+#if defined(PHA_FUSED_DEBUG)
+__device__ uint32_t g_fused_dbg[8];
+#endif
+struct FusedArgs {
+    uint32_t *cls;         // [8] XCC_ID + 1 of each workgroup class (0 = not recorded yet); [8] = units finished
+    uint32_t *flags;       // [units][2]: tiles of the unit's first pass that have been written, consumers that have seen that
+    uint32_t units, slots, tpl, lag, count;   // count = limbs per polynomial (unit = z * count + y)
+    uint32_t active_units; // units that are not excluded
+};
+__device__ __forceinline__ void l2_arrive(uint32_t *p) {
+    asm volatile("global_atomic_add %0, %1, off" ::"v"(p), "v"(1u) : "memory");
+}
+__device__ __forceinline__ uint32_t l2_fetch_or(uint32_t *p, uint32_t v) {
+    uint32_t r;
+    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint32_t l2_fetch_add(uint32_t *p, uint32_t v) {
+    uint32_t r;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ void l2_store(uint32_t *p, uint32_t v) {
+    asm volatile("global_atomic_swap %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+// run configuration C on 4096-coefficient tile `tile` with the 512 threads of the workgroup: a 512-thread configuration
+// directly, a one-wavefront configuration (512-coefficient tiles) as eight independent wavefronts
+template <class C, bool FWD, int EPI, bool FOLD, bool COH>
+__device__ __forceinline__ void fused_run_tile(const NttKArgs &k, uint32_t twr, uint32_t z, uint32_t tile, u64 *lds) {
+    static_assert(C::THREADS == 512 || C::THREADS == 64, "the one-launch transform runs 512-thread workgroups");
+    PassArgs a;
+    if constexpr (C::THREADS == 512) {
+        full_tile_args<C, FWD, EPI, FOLD>(k, twr, z, tile, a);
+        exec_pass<C, FWD, EPI, FOLD, 0, COH>(a, lds, threadIdx.x);
+    } else {
+        const uint32_t wave = threadIdx.x >> 6;
+        full_tile_args<C, FWD, EPI, FOLD>(k, twr, z, tile * 8 + wave, a);
+        exec_pass<C, FWD, EPI, FOLD, 0, COH>(a, lds + (size_t)wave * C::LDS_WORDS, threadIdx.x & 63);
+    }
+}
+
+template <class PS, class PC, bool FWD, int EPI, bool FOLD>   // PS: strided pass (512 threads), PC: contiguous pass
+__global__ __launch_bounds__(512, PHA_FUSED_MIN_WAVES) void ntt_fused_kernel(const NttKArgs kA, const NttKArgs kB, const FusedArgs f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *lds = reinterpret_cast<u64 *>(smem);
+    const uint32_t b = blockIdx.x, xcd = b & 7u, within = b >> 3, tile = within % f.tpl, slot = within / f.tpl;
+    const uint32_t uA = slot * 8 + xcd;
+    const bool has_a = slot < f.slots && uA < f.units && !limb_excluded(kA, kA.sel.start + uA % f.count, uA / f.count);
+    const uint32_t uB = (slot - f.lag) * 8 + xcd;   // (wraps when slot < lag: has_b is false then)
+    const bool has_b = slot >= f.lag && uB < f.units && !limb_excluded(kB, kB.sel.start + uB % f.count, uB / f.count);
+    if (!has_a && !has_b) return;   // (and never touches the class words: see the clean-up rule above)
+    uint32_t cls_seen = 0, cls_mine = 0;
+    if (threadIdx.x == 0) {   // class check, part 1 (the answer is looked at after the first pass)
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        cls_mine = (id & 7u) + 1;
+        uint32_t expected = 0;
+        __hip_atomic_compare_exchange_strong(f.cls + xcd, &expected, cls_mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cls_seen = expected;
+    }
+    if (has_a) {
+        const uint32_t z = uA / f.count, twr = kA.sel.start + uA % f.count;
+        if (FWD) fused_run_tile<PS, true, EPI_NONE, false, false>(kA, twr, z, tile, lds);
+        else fused_run_tile<PC, false, EPI_NONE, false, false>(kA, twr, z, tile, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's stores have reached the L2
+        __syncthreads();
+        if (threadIdx.x == 0) l2_arrive(f.flags + 2 * (size_t)uA);
+    }
+    if (threadIdx.x == 0 && cls_seen != 0 && cls_seen != cls_mine) {   // class check, part 2
+#if defined(PHA_FUSED_DEBUG)
+        if (atomicAdd(&g_fused_dbg[0], 1u) == 0) { g_fused_dbg[1] = b; g_fused_dbg[2] = cls_mine; g_fused_dbg[3] = cls_seen; }
+#else
+        __builtin_trap();   // two workgroups of one class on different XCDs: the hand-off below would not be coherent
+#endif
+    }
+    if (!has_b) return;
+    const uint32_t z = uB / f.count, twr = kB.sel.start + uB % f.count;
+    uint32_t *flag = f.flags + 2 * (size_t)uB;
+    uint32_t consumers_before = 0;
+    if (threadIdx.x == 0) {
+        uint32_t spins = 0;
+        while (l2_fetch_or(flag, 0u) < f.tpl) {
+            __builtin_amdgcn_s_sleep(8);
+#if defined(PHA_FUSED_DEBUG)
+            if (++spins > (1u << 16)) { atomicAdd(&g_fused_dbg[4], 1u); break; }
+#else
+            if (++spins > (1u << 24)) __builtin_trap();   // never hang the device on a broken assumption
+#endif
+        }
+        // counted in as "has seen the unit complete"; the answer is only looked at after the second pass
+        consumers_before = __hip_atomic_fetch_add(flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();   // also: pass A no longer uses the LDS
+    if (FWD) fused_run_tile<PC, true, EPI, false, true>(kB, twr, z, tile, lds);
+    else fused_run_tile<PS, false, EPI, FOLD, true>(kB, twr, z, tile, lds);
+    if (threadIdx.x == 0 && consumers_before == f.tpl - 1) {   // every consumer of this unit has seen it complete
+        l2_store(flag, 0u);
+        l2_store(flag + 1, 0u);
+        if (__hip_atomic_fetch_add(f.cls + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.active_units - 1) {
+            for (int i = 0; i < 9; i++) __hip_atomic_store(f.cls + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <class C, bool FWD, int EPI, bool FOLD>
@@ -197,6 +346,39 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     check_launch();
 }
 
+template <class PS, class PC, bool FWD, int EPI, bool FOLD>
+static bool launch_fused(Context &c, const NttKArgs &kA, const NttKArgs &kB, hipStream_t s) {
+    static_assert(PS::THREADS == 512 && PS::LOGTILE == 12, "strided pass: one 4096-coefficient tile per 512-thread workgroup");
+    const size_t n = (size_t)1 << kA.log_n;
+    FusedArgs f{};
+    f.count = kA.sel.count;
+    f.units = kA.sel.count * kA.batch;
+    f.slots = (f.units + 7) / 8;
+    f.tpl = (uint32_t)(n >> 12);
+    f.lag = (uint32_t)g_fused_lag.load(std::memory_order_relaxed);
+    f.cls = c.ntt_flags(s, f.units);
+    if (!f.cls) return false;   // no counter arena for this stream: the caller takes the two launches
+    f.flags = f.cls + 16;
+    f.active_units = 0;
+    for (uint32_t z = 0; z < kA.batch; z++) {   // the same rule as limb_excluded()
+        const uint32_t zd = kA.excl_mod ? z % kA.excl_mod : z;
+        const uint32_t es = kA.sel.excl_start + zd * kA.excl_step;
+        uint32_t ee = es + (kA.sel.excl_end - kA.sel.excl_start);
+        ee = ee < kA.excl_limit ? ee : kA.excl_limit;
+        const uint32_t lo = es > kA.sel.start ? es : kA.sel.start;
+        const uint32_t hi = ee < kA.sel.start + kA.sel.count ? ee : kA.sel.start + kA.sel.count;
+        f.active_units += kA.sel.count - (hi > lo ? hi - lo : 0);
+    }
+    if (f.active_units == 0) return true;
+    const size_t lds_a = (size_t)PS::LDS_WORDS * sizeof(u64);
+    const size_t lds_b = (size_t)PC::LDS_WORDS * sizeof(u64) * (PC::THREADS == 64 ? 8 : 1);
+    const size_t lds_bytes = lds_a > lds_b ? lds_a : lds_b;
+    const unsigned blocks = (f.slots + f.lag) * f.tpl * 8;
+    hipLaunchKernelGGL((ntt_fused_kernel<PS, PC, FWD, EPI, FOLD>), dim3(blocks), dim3(512), lds_bytes, s, kA, kB, f);
+    check_launch();
+    return true;
+}
+
 // N = 4096 / 8192 as ONE pass (the transform fits a tile): T1 = 1, T2 = N
 template <class W>
 static void forward_whole(NttKArgs k, int epi, hipStream_t s) {
@@ -217,7 +399,7 @@ static void inverse_whole(NttKArgs k, int epi, hipStream_t s) {
 }
 
 template <int LOGN, int VARIANT>
-static void forward_impl(NttKArgs k, int epi, hipStream_t s) {
+static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nullptr) {
     using P1 = typename NttPlan<LOGN, VARIANT>::P1;
     using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     k.t1 = P1::T;
@@ -226,10 +408,20 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s) {
     const size_t final_stride = k.out_stride;
     k.out = k.mid;
     k.out_stride = k.poly_stride;
-    launch_pass<P1, true, EPI_NONE, false>(k, s);
+    const NttKArgs k1 = k;
     k.in = k.mid;
     k.out = final_out;
     k.out_stride = final_stride;
+    k.pro_src = nullptr;   // the rescale prologue belongs to the first pass
+    if constexpr (P1::THREADS == 512 && P1::LOGTILE == 12 && P2::THREADS == 64) {
+        if (fused) {   // both passes in one launch
+            const bool done = epi == EPI_FWD_MODDOWN ? launch_fused<P1, P2, true, EPI_FWD_MODDOWN, false>(*fused, k1, k, s)
+                              : epi == EPI_FWD_MODDOWN_ADD ? launch_fused<P1, P2, true, EPI_FWD_MODDOWN_ADD, false>(*fused, k1, k, s)
+                                                           : launch_fused<P1, P2, true, EPI_FWD_CANON, false>(*fused, k1, k, s);
+            if (done) return;
+        }
+    }
+    launch_pass<P1, true, EPI_NONE, false>(k1, s);
     // pass 1 ran in -> mid with the input stride; pass 2 reads mid and writes out with the output stride
     if (epi == EPI_FWD_MODDOWN) launch_pass<P2, true, EPI_FWD_MODDOWN, false>(k, s);
     else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<P2, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
@@ -237,7 +429,7 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s) {
 }
 
 template <int LOGN, int VARIANT>
-static void inverse_impl(NttKArgs k, int epi, hipStream_t s) {
+static void inverse_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nullptr) {
     using P1 = typename NttPlan<LOGN, VARIANT>::P1;
     using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     k.t1 = P1::T;
@@ -246,10 +438,18 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s) {
     const size_t final_stride = k.out_stride;
     k.out = k.mid;
     k.out_stride = k.poly_stride;
-    launch_pass<P2, false, EPI_NONE, false>(k, s);
+    const NttKArgs k1 = k;
     k.in = k.mid;
     k.out = final_out;
     k.out_stride = final_stride;
+    if constexpr (P1::THREADS == 512 && P1::LOGTILE == 12 && P2::THREADS == 64) {
+        if (fused) {
+            const bool done = epi == EPI_INV_SCALE ? launch_fused<P1, P2, false, EPI_INV_SCALE, true>(*fused, k1, k, s)
+                                                   : launch_fused<P1, P2, false, EPI_INV_CANON, true>(*fused, k1, k, s);
+            if (done) return;
+        }
+    }
+    launch_pass<P2, false, EPI_NONE, false>(k1, s);
     if (epi == EPI_INV_SCALE) launch_pass<P1, false, EPI_INV_SCALE, true>(k, s);
     else launch_pass<P1, false, EPI_INV_CANON, true>(k, s);
 }
@@ -312,6 +512,10 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
     const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
+    // both passes in one launch (hand-off through the XCD's L2): launches of >= g_fused_min_tiles tiles (bit 9: every
+    // launch; bit 10: never), only where workgroup b is known to run on XCD b % 8
+    Context *const fz = (c.xcd_round_robin && wave && !(vv & 1024) &&
+                         ((vv & 512) || tiles >= (size_t)g_fused_min_tiles.load(std::memory_order_relaxed))) ? &c : nullptr;
     if (c.log_n == 12 && !(vv & 128)) {  // bit 7 clear (default): N = 4096 in one launch
         forward_whole<WholePlan12>(k, epi, s);
         return;
@@ -323,13 +527,19 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
         forward_whole<WholePlan13>(k, epi, s);
         return;
     }
+    // N = 16384 in one launch (one 1024-thread workgroup per limb, 144 KiB of LDS): from g_whole14_min limb-polynomials
+    // per launch (r02 sweep); bit 8 forces it for every size (tests), bit 7 keeps the two passes
+    if (c.log_n == 14 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= (size_t)g_whole14_min.load(std::memory_order_relaxed))) {
+        forward_whole<WholePlan14>(k, epi, s);
+        return;
+    }
     switch (c.log_n) {
-        case 12: if (v == 4) forward_impl<12, 4>(k, epi, s); else if (v == 3) forward_impl<12, 3>(k, epi, s); else if (v == 2) forward_impl<12, 2>(k, epi, s); else if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
-        case 13: if (v == 4) forward_impl<13, 4>(k, epi, s); else if (v == 3) forward_impl<13, 3>(k, epi, s); else if (v == 2) forward_impl<13, 2>(k, epi, s); else if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
-        case 14: if (v == 4) forward_impl<14, 4>(k, epi, s); else if (v == 3) forward_impl<14, 3>(k, epi, s); else if (v == 2) forward_impl<14, 2>(k, epi, s); else if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
-        case 15: if (v == 4) forward_impl<15, 4>(k, epi, s); else if (v == 3) forward_impl<15, 3>(k, epi, s); else if (v == 2) forward_impl<15, 2>(k, epi, s); else if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
-        case 16: if (v == 4) forward_impl<16, 4>(k, epi, s); else if (v == 3) forward_impl<16, 3>(k, epi, s); else if (v == 2) forward_impl<16, 2>(k, epi, s); else if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
-        case 17: if (v == 4) forward_impl<17, 4>(k, epi, s); else if (v == 3) forward_impl<17, 3>(k, epi, s); else if (v == 2) forward_impl<17, 2>(k, epi, s); else if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
+        case 12: if (v == 4) forward_impl<12, 4>(k, epi, s, fz); else if (v == 3) forward_impl<12, 3>(k, epi, s, fz); else if (v == 2) forward_impl<12, 2>(k, epi, s); else if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
+        case 13: if (v == 4) forward_impl<13, 4>(k, epi, s, fz); else if (v == 3) forward_impl<13, 3>(k, epi, s, fz); else if (v == 2) forward_impl<13, 2>(k, epi, s); else if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
+        case 14: if (v == 4) forward_impl<14, 4>(k, epi, s, fz); else if (v == 3) forward_impl<14, 3>(k, epi, s, fz); else if (v == 2) forward_impl<14, 2>(k, epi, s); else if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
+        case 15: if (v == 4) forward_impl<15, 4>(k, epi, s, fz); else if (v == 3) forward_impl<15, 3>(k, epi, s, fz); else if (v == 2) forward_impl<15, 2>(k, epi, s); else if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
+        case 16: if (v == 4) forward_impl<16, 4>(k, epi, s, fz); else if (v == 3) forward_impl<16, 3>(k, epi, s, fz); else if (v == 2) forward_impl<16, 2>(k, epi, s); else if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
+        case 17: if (v == 4) forward_impl<17, 4>(k, epi, s, fz); else if (v == 3) forward_impl<17, 3>(k, epi, s, fz); else if (v == 2) forward_impl<17, 2>(k, epi, s); else if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -345,6 +555,10 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
     const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
+    // both passes in one launch (hand-off through the XCD's L2): launches of >= g_fused_min_tiles tiles (bit 9: every
+    // launch; bit 10: never), only where workgroup b is known to run on XCD b % 8
+    Context *const fz = (c.xcd_round_robin && wave && !(vv & 1024) &&
+                         ((vv & 512) || tiles >= (size_t)g_fused_min_tiles.load(std::memory_order_relaxed))) ? &c : nullptr;
     if (c.log_n == 12 && !(vv & 128)) {
         inverse_whole<WholePlan12>(k, epi, s);
         return;
@@ -353,13 +567,17 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
         inverse_whole<WholePlan13>(k, epi, s);
         return;
     }
+    if (c.log_n == 14 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= (size_t)g_whole14_min.load(std::memory_order_relaxed))) {
+        inverse_whole<WholePlan14>(k, epi, s);
+        return;
+    }
     switch (c.log_n) {
-        case 12: if (v == 4) inverse_impl<12, 4>(k, epi, s); else if (v == 3) inverse_impl<12, 3>(k, epi, s); else if (v == 2) inverse_impl<12, 2>(k, epi, s); else if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
-        case 13: if (v == 4) inverse_impl<13, 4>(k, epi, s); else if (v == 3) inverse_impl<13, 3>(k, epi, s); else if (v == 2) inverse_impl<13, 2>(k, epi, s); else if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
-        case 14: if (v == 4) inverse_impl<14, 4>(k, epi, s); else if (v == 3) inverse_impl<14, 3>(k, epi, s); else if (v == 2) inverse_impl<14, 2>(k, epi, s); else if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
-        case 15: if (v == 4) inverse_impl<15, 4>(k, epi, s); else if (v == 3) inverse_impl<15, 3>(k, epi, s); else if (v == 2) inverse_impl<15, 2>(k, epi, s); else if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
-        case 16: if (v == 4) inverse_impl<16, 4>(k, epi, s); else if (v == 3) inverse_impl<16, 3>(k, epi, s); else if (v == 2) inverse_impl<16, 2>(k, epi, s); else if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
-        case 17: if (v == 4) inverse_impl<17, 4>(k, epi, s); else if (v == 3) inverse_impl<17, 3>(k, epi, s); else if (v == 2) inverse_impl<17, 2>(k, epi, s); else if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
+        case 12: if (v == 4) inverse_impl<12, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<12, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<12, 2>(k, epi, s); else if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
+        case 13: if (v == 4) inverse_impl<13, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<13, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<13, 2>(k, epi, s); else if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
+        case 14: if (v == 4) inverse_impl<14, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<14, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<14, 2>(k, epi, s); else if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
+        case 15: if (v == 4) inverse_impl<15, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<15, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<15, 2>(k, epi, s); else if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
+        case 16: if (v == 4) inverse_impl<16, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<16, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<16, 2>(k, epi, s); else if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
+        case 17: if (v == 4) inverse_impl<17, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<17, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<17, 2>(k, epi, s); else if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -545,6 +763,9 @@ int pha_nwt_2d_radix8_backward_inplace_batched(pha_context_t ctx, uint64_t *inou
     PHA_API_END
 }
 
+#if defined(PHA_FUSED_DEBUG)
+int pha_fused_debug_read(uint32_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_dbg), sizeof(uint32_t) * 8); }
+#endif
 #if defined(PHA_EXP_STAMPS)
 int pha_exp_read_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
@@ -557,10 +778,19 @@ int pha_exp_read_wg_times(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 511 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 2047 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);
+    } else if (key == 2) {
+        if (value < 1) throw std::invalid_argument("threshold must be positive");
+        g_whole14_min.store(value);
+    } else if (key == 3) {
+        if (value < 0 || value > 64) throw std::invalid_argument("lag out of range");
+        g_fused_lag.store(value);
+    } else if (key == 4) {
+        if (value < 1) throw std::invalid_argument("threshold must be positive");
+        g_fused_min_tiles.store(value);
     } else {
         throw std::invalid_argument("unknown tuning key");
     }

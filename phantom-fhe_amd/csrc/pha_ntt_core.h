@@ -62,7 +62,7 @@ struct PassCfg {
     static constexpr int LOGTILE = LOGTILE_;
     static constexpr int TILE = 1 << LOGTILE_;
     static constexpr int THREADS = TILE / EPT_;
-    static_assert(LOGTILE_ >= LOGT_ && LOGTILE_ <= 13, "a tile holds whole transforms and fits the LDS budget");
+    static_assert(LOGTILE_ >= LOGT_ && LOGTILE_ <= 14, "a tile holds whole transforms and fits the LDS budget (2^14 words + padding = 144 KiB of the 160 KiB)");
     // one wavefront per workgroup: every exchange between rounds stays inside it, no workgroup barrier
     static constexpr bool WAVE_LOCAL = TILE / EPT_ == 64;
     static constexpr bool WHOLE = WHOLE_ && !STRIDED_;
@@ -75,7 +75,7 @@ struct PassCfg {
     static constexpr bool STRIDED = STRIDED_;
     static constexpr int NR = R3_ ? 4 : R2_ ? 3 : 2;
     static_assert(R0_ + R1_ + R2_ + R3_ == LOGT_, "round schedule must cover all stages");
-    static_assert(LOGT_ >= 4 && LOGT_ <= 13, "tile transform length out of range");
+    static_assert(LOGT_ >= 4 && LOGT_ <= 14, "tile transform length out of range");
     static_assert(THREADS >= 64, "a workgroup is at least one wavefront");
     static constexpr int r(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : i == 2 ? R2_ : R3_; }
     // twiddle registers per thread: round i holds G_i groups x (2^r_i - 1) pairs
@@ -355,8 +355,20 @@ PHA_HD u64 apply_epilogue(u64 x, const PassArgs &a, size_t gi) {
     return apply_epilogue_v<EPI>(x, a, aux, acc);
 }
 
+// A load that is never served by this CU's vector L1 (agent-scope relaxed: `global_load_dwordx2 ... sc1`, answered
+// by the XCD's L2): what the second pass of the one-launch transform reads its intermediate with, because another CU
+// of the same XCD wrote it during this launch (MI355X_MICROARCH.md, inter-workgroup visibility).
+PHA_HD u64 coherent_load(const u64 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+
 // Load one round's registers: from global memory on the first round, else from LDS.
-template <class C, int RI, bool FROM_GLOBAL>
+// COH: the global input was produced by other workgroups of this launch (see coherent_load).
+template <class C, int RI, bool FROM_GLOBAL, bool COH = false>
 PHA_HD void round_load(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
     constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r, s0 = C::s0(RI);
     constexpr int LOGD = C::LOGT - s0 - r;
@@ -366,7 +378,10 @@ PHA_HD void round_load(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
         decode_group<C, RI>(tid + C::THREADS * gi, v, hi, lo);
         u64 *rg = reg + gi * K;
         const int e0 = (hi << (LOGD + r)) + lo;
-        if (FROM_GLOBAL) {
+        if (FROM_GLOBAL && COH) {
+#pragma unroll
+            for (int k = 0; k < K; k++) rg[k] = coherent_load(a.in + global_index<C>(a, e0 + (k << LOGD), v));
+        } else if (FROM_GLOBAL) {
             if (!C::STRIDED && LOGD == 0) {  // K contiguous coefficients: 16-byte loads
                 const u64x2 *p = reinterpret_cast<const u64x2 *>(a.in + global_index<C>(a, e0, v));
 #pragma unroll
@@ -535,7 +550,7 @@ PHA_HD void tile_sync() {
 #endif
 }
 
-template <class C, bool FWD, int EPI, bool FOLD, int HOIST = 1>
+template <class C, bool FWD, int EPI, bool FOLD, int HOIST = 1, bool COH = false>
 struct PassProgram {
     static constexpr int NSEG = C::NR;
     static constexpr int THREADS = C::THREADS;
@@ -583,12 +598,20 @@ struct PassProgram {
         constexpr int RI = FWD ? SEG : C::NR - 1 - SEG;
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
         segment_twiddles<SEG>(a, tid, twreg);
-        round_load<C, RI, first>(a, lds, tid, reg);
+        round_load<C, RI, first, COH>(a, lds, tid, reg);
         if (first && FWD && FIRST_PASS && a.pro_reduce) {  // uniform per workgroup
 #pragma unroll
             for (int i = 0; i < C::EPT; i++) reg[i] = barrett64(reg[i], a.q, a.pro_ratio1);
         }
         if (first) fp_after_global_load(a, reg);
+        // FP64 forward, whole-transform plans beyond 13 stages: magnitudes grow by q/2 + 1 per stage, and the exactness
+        // budget of pha_arith.h (|x| < 2^52.6 ~ 6 q at 50 bits going into a multiply) is spent after 13 of them (q + 13 (q/2 + 1)
+        // = 7.5 q < 2^52.9 still passes, 14 stages reach 8 q = 2^53), so the registers are re-centred once, after the
+        // first 8 stages (3 operations per coefficient)
+        if (FWD && C::WHOLE && C::LOGT >= 14 && SEG == 2 && PHA_FPSEL(a)) {
+#pragma unroll
+            for (int i = 0; i < C::EPT; i++) reg[i] = as_u64(fp_reduce(as_f64(reg[i]), a.fpm));
+        }
         round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
         if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
@@ -655,5 +678,9 @@ template <> struct NttPlan<17, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  us
 using WholePlan12 = PassCfg<12, false, 4, 4, 4, 16, false, 12, true>;
 // N = 8192: the same with a fourth (radix-2) round: one 8192-coefficient tile, 512 threads, 72 KiB of LDS
 using WholePlan13 = PassCfg<13, false, 4, 4, 4, 16, false, 13, true, 1>;
+// N = 16384: one 16384-coefficient tile = 128 KiB (+ padding: 144 KiB of gfx950's 160 KiB of LDS), 1024 threads x 16
+// coefficients, rounds 16-16-16-4: one workgroup per CU, the intermediate never leaves the chip (fntt_2d.cu:620-653 /
+// intt_2d.cu:724-757 at BASELINE config 2's degree)
+using WholePlan14 = PassCfg<14, false, 4, 4, 4, 16, false, 14, true, 2>;
 
 }  // namespace pha

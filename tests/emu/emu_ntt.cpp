@@ -13,7 +13,7 @@
 
 using namespace pha;
 
-static u64x2 g_twregs[512][64];
+static u64x2 g_twregs[1024][64];
 
 template <class Prog, int SEG>
 static void run_segments(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
@@ -28,7 +28,7 @@ static void run_segments(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
 template <class C, bool FWD, int EPI, bool FOLD>
 static void run_pass(PassArgs a, size_t n) {
     std::vector<u64> lds(C::LDS_WORDS);
-    static u64 regs[512][16];
+    static u64 regs[1024][16];
     const u32 tiles = (u32)(n >> C::LOGTILE);
     for (u32 t = 0; t < tiles; t++) {
         a.tile = t;
@@ -139,6 +139,7 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
     if (variant == 6) {
         if (log_n == 12) emu_whole<WholePlan12>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
         else if (log_n == 13) emu_whole<WholePlan13>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else if (log_n == 14) emu_whole<WholePlan14>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
         else return -2;
         return 0;
     }

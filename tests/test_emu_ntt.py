@@ -36,8 +36,8 @@ def pair(v, q):
 @pytest.mark.parametrize("bits", [40, 42, 43, 47, 48, 50, 60, 61])   # 42 / 47: just under the light-butterfly thresholds
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
 def test_thread_program_matches_oracle(emu, log_n, bits, variant):
-    if variant == 6 and log_n not in (12, 13):
-        pytest.skip("the one-launch plans exist for N = 4096 and 8192 only")
+    if variant == 6 and log_n not in (12, 13, 14):
+        pytest.skip("the one-launch plans exist for N = 4096, 8192 and 16384 only")
     n = 1 << log_n
     code = log_n | (variant << 8)   # variant 1 = 8 coefficients per thread (512-thread workgroups); 2 = 1 + on-the-fly twiddles
     q = int(O.get_primes(n, bits, 1)[0])
@@ -83,6 +83,10 @@ def test_thread_program_matches_oracle(emu, log_n, bits, variant):
             for y in (np.full(n, q - 1, dtype=np.uint64), np.where(np.arange(n) % 2 == 0, q - 1, 0).astype(np.uint64), near_q):
                 assert emu.emu_ntt(fcode, 0, 3, p(y), p(back_f), q, p(fpairs(itw_p)), p(fpair1(ni)), p(fpair1(int(itw[1]))), p(z), p(z)) == 0
                 assert np.array_equal(back_f, c.nwt_backward(y.reshape(1, n), 1)[0])
+            if variant == 6:   # the forward's magnitudes grow by q/2 per stage: 14 stages in one pass need the re-centring
+                for y in (np.full(n, q - 1, dtype=np.uint64), near_q):
+                    assert emu.emu_ntt(fcode, 1, 1, p(y), p(out_f), q, p(fpairs(tw)), p(z), p(z), p(z), p(z)) == 0
+                    assert np.array_equal(out_f, c.nwt_forward(y.reshape(1, n), 1)[0])
         s2 = int(r.integers(1, q))
         assert emu.emu_ntt(fcode, 0, 4, p(ref), p(back_f), q, p(fpairs(itw_p)), p(fpair1(ni)), p(fpair1(int(itw[1]))), p(pair(s2, q)), p(z)) == 0
         assert np.array_equal(back_f, c.multiply_scalar(x.reshape(1, n), np.array([s2], dtype=np.uint64), 1)[0])

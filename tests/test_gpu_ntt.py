@@ -39,7 +39,11 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
     assert np.array_equal(P.to_host(d2), oc.nwt_backward(x, L, 0))
 
 
-@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361], ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave", "two-pass-4096", "one-launch-8192", "one-launch-8192-int"])
+# 353 / 361: bit 8 forces the one-launch plans of N = 8192 and N = 16384 for every launch size
+# 609 / 617 / 625: bit 9 sends every launch through the one-launch form (both passes in one kernel, L2 hand-off)
+@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361, 609, 617, 625, 1121],
+                ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave",
+                     "two-pass-4096", "one-launch-8192-16384", "one-launch-8192-16384-int", "fused", "fused-int", "fused-ot", "never-fused"])
 def ntt_variant(request):
     """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
     import phantom_fhe_amd as P
@@ -335,3 +339,31 @@ def test_one_launch_8192_takes_over_for_large_launches(gpu):
     assert np.array_equal(P.to_host(d), want)
     ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
     assert np.array_equal(P.to_host(d), x)
+
+
+@pytest.mark.parametrize("lag", [0, 1, 2, 5])
+@pytest.mark.parametrize("name,batch", [("c2_ntt14", 3), ("c4_bfv15", 2), ("c3_ckks16", 2)])
+def test_one_launch_transform_lags_and_batches(name, batch, lag, gpu):
+    """Both passes in one launch (the intermediate handed over through the XCD's L2) for every lag between the
+    passes, batches of polynomials, forward and inverse: bit-identical to the oracle, and the hand-off counters are
+    clean again afterwards (a second call gives the same answer)."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L = len(primes)
+    x = np.stack([uniform_poly(rng_for(300 + z), primes, n) for z in range(batch)])
+    P.set_tuning(0, 1 | 32 | 64 | 512)
+    P.set_tuning(3, lag)
+    try:
+        for rep in range(2):
+            d = P.to_device(x, gpu)
+            ctx.nwt_2d_radix8_forward_inplace_batched(d, L, 0, batch, L * n)
+            got = P.to_host(d)
+            for z in range(batch):
+                assert np.array_equal(got[z], oc.nwt_forward(x[z], L, 0)), (rep, z)
+            ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
+            assert np.array_equal(P.to_host(d), x)
+    finally:
+        P.set_tuning(0, 1 | 32 | 64)
+        P.set_tuning(3, 2)

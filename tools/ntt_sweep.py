@@ -8,11 +8,16 @@ import phantom_fhe_amd as P
 
 print("| N | limbs | forward µs | inverse µs | forward M limb-NTT/s | % of 8 TB/s (16 B x N x limbs) |")
 print("|---|---|---|---|---|---|")
-for log_n in (12, 13, 14, 15, 16, 17):
+if os.environ.get("PHA_NTT_VARIANT"):
+    P.set_tuning(0, int(os.environ["PHA_NTT_VARIANT"]))
+for kv in filter(None, os.environ.get("PHA_TUNING", "").split(",")):
+    P.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+LOGNS = [int(v) for v in os.environ.get("SWEEP_LOGNS", "12,13,14,15,16,17").split(",")]
+for log_n in LOGNS:
     n = 1 << log_n
     primes = [int(p) for p in P.coeff_modulus_create(n, [50] * 60)]
     ctx = P.PhantomContext(log_n, primes, 0, device=0)
-    for limbs, batch in ((1, 1), (10, 1), (60, 1), (60, 4), (60, 17)):
+    for limbs, batch in ((1, 1), (10, 1), (60, 1), (60, 4), (60, 17), (60, 68)):
         total = limbs * batch
         if total * n * 8 > (2 << 30):
             continue
