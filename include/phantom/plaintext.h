@@ -1,0 +1,7 @@
+// plaintext.h -- stands in for the reference's include/plaintext.h (installed as include/phantom/plaintext.h, CMakeLists.txt:67-70):
+// PhantomPlaintext.
+// The declarations live in one header, phantom-fhe_amd/host/phantom.h (the MI355X host mirror over the C ABI of
+// include/phantom_amd.h); this file only gives it the reference's file name, so that `#include "plaintext.h"` (with
+// -I include/phantom) and `#include <phantom/plaintext.h>` (with -I include) resolve as they do against the reference.
+#pragma once
+#include "../../phantom-fhe_amd/host/phantom.h"

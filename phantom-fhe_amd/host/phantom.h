@@ -24,6 +24,7 @@
 #include <string>
 #include <tuple>
 #include <istream>
+#include <limits>
 #include <ostream>
 #include <vector>
 
@@ -167,8 +168,45 @@ public:
     [[nodiscard]] bool is_zero() const { return value_ == 0; }
 };
 
-// CoeffModulus::Create (src/host/modulus.cu:82-111), computed by the library
+// sec_level_type (include/host/modulus.h:217-232)
+enum class sec_level_type : int { none = 0, tc128 = 128, tc192 = 192, tc256 = 256 };
+
+namespace default_tables {
+struct DefaultModuliRow {
+    int level;
+    size_t degree;
+    int max_bit_count;
+    std::vector<uint64_t> primes;
+};
+// the reference's literal tables (src/host/globals.cu:51-361, include/host/hestdparms.h), as data
+inline const std::vector<DefaultModuliRow> &default_moduli() {
+    static const std::vector<DefaultModuliRow> rows = {
+#include "default_coeff_modulus.inc"
+    };
+    return rows;
+}
+}  // namespace default_tables
+
+// CoeffModulus::Create (src/host/modulus.cu:82-111), computed by the library; BFVDefault / MaxBitCount
+// (src/host/modulus.cu:57-80, include/host/modulus.h:244-276) from the reference's tables
 struct CoeffModulus {
+    [[nodiscard]] static int MaxBitCount(size_t poly_modulus_degree, sec_level_type sec_level = sec_level_type::tc128) {
+        if (sec_level == sec_level_type::none) return (std::numeric_limits<int>::max)();
+        for (const auto &r : default_tables::default_moduli())
+            if (r.level == static_cast<int>(sec_level) && r.degree == poly_modulus_degree) return r.max_bit_count;
+        return 0;
+    }
+    [[nodiscard]] static std::vector<Modulus> BFVDefault(size_t poly_modulus_degree, sec_level_type sec_level = sec_level_type::tc128) {
+        if (!MaxBitCount(poly_modulus_degree, sec_level)) throw std::invalid_argument("non-standard poly_modulus_degree");
+        if (sec_level == sec_level_type::none) throw std::invalid_argument("invalid security level");
+        for (const auto &r : default_tables::default_moduli())
+            if (r.level == static_cast<int>(sec_level) && r.degree == poly_modulus_degree) {
+                std::vector<Modulus> out;
+                for (uint64_t q : r.primes) out.emplace_back(q);
+                return out;
+            }
+        throw std::runtime_error("invalid security level");
+    }
     static std::vector<Modulus> Create(size_t poly_modulus_degree, const std::vector<int> &bit_sizes) {
         std::vector<uint64_t> v(bit_sizes.size());
         util::check_pha(pha_coeff_modulus_create(poly_modulus_degree, bit_sizes.data(), bit_sizes.size(), v.data()));
@@ -184,9 +222,6 @@ struct PlainModulus {
         return CoeffModulus::Create(poly_modulus_degree, {bit_size})[0];
     }
 };
-
-// sec_level_type (include/host/modulus.h:217-232)
-enum class sec_level_type : int { none = 0, tc128 = 128, tc192 = 192, tc256 = 256 };
 
 }  // namespace arith
 
@@ -217,15 +252,125 @@ public:
     [[nodiscard]] const std::vector<uint32_t> &galois_elts() const { return galois_elts_; }
 };
 
-// ContextData (include/context.cuh:19-131): the parameters of one level of the modulus chain
+}  // namespace phantom
+
+// DModulus (include/ntt.cuh:6-32): value + Barrett ratio; here a host-side copy (the device table lives in the library)
+class DModulus {
+    uint64_t value_ = 0;
+    uint64_t const_ratio_[2] = {0, 0};
+
+public:
+    DModulus() = default;
+    DModulus(uint64_t value, uint64_t ratio0, uint64_t ratio1) : value_(value), const_ratio_{ratio0, ratio1} {}
+    [[nodiscard]] uint64_t value() const { return value_; }
+    [[nodiscard]] const uint64_t (&const_ratio() const)[2] { return const_ratio_; }
+};
+
+// DNTTTable (include/ntt.cuh:34-129): the NTT tables of the QP primes.  Here a thin handle on the library's context,
+// which owns one table set per prime (own layout: interleaved (w, w') pairs, FP64 copies for primes below 2^50);
+// the launchers of include/ntt.cuh take it exactly as in the reference: nwt_2d_radix8_forward_inplace(p, ctx.gpu_rns_tables(), ...).
+class DNTTTable {
+    pha_context_t ctx_ = nullptr;
+    uint64_t n_ = 0, size_ = 0;
+
+public:
+    DNTTTable() = default;
+    DNTTTable(pha_context_t ctx, uint64_t n, uint64_t size) : ctx_(ctx), n_(n), size_(size) {}
+    [[nodiscard]] uint64_t n() const { return n_; }
+    [[nodiscard]] uint64_t size() const { return size_; }
+    [[nodiscard]] pha_context_t amd() const { return ctx_; }
+    // host copies of what the reference keeps on the device (twiddle(): [size][n], which = 0 forward, 1 forward Shoup, 2 inverse, 3 inverse Shoup)
+    [[nodiscard]] DModulus modulus(size_t index) const {
+        uint64_t v = 0, ratio[2] = {0, 0}, root = 0, ninv = 0;
+        phantom::util::check_pha(pha_context_prime_info(ctx_, static_cast<uint32_t>(index), &v, ratio, &root, &ninv));
+        return DModulus(v, ratio[0], ratio[1]);
+    }
+    [[nodiscard]] std::vector<uint64_t> twiddle_row(size_t index, int which) const {
+        std::vector<uint64_t> row(n_);
+        phantom::util::check_pha(pha_context_download_twiddle(ctx_, static_cast<uint32_t>(index), which, row.data()));
+        return row;
+    }
+};
+
+// DBaseConverter (include/rns_bconv.cuh:3-87) between two bases given as rows of the context's prime table
+class DBaseConverter {
+    pha_base_converter_t conv_ = nullptr;
+
+public:
+    DBaseConverter() = default;
+    DBaseConverter(pha_context_t ctx, const std::vector<uint32_t> &ibase, const std::vector<uint32_t> &obase) {
+        phantom::util::check_pha(pha_base_converter_create(ctx, ibase.data(), ibase.size(), obase.data(), obase.size(), &conv_));
+    }
+    DBaseConverter(const DBaseConverter &) = delete;
+    DBaseConverter &operator=(const DBaseConverter &) = delete;
+    DBaseConverter(DBaseConverter &&o) noexcept : conv_(o.conv_) { o.conv_ = nullptr; }
+    DBaseConverter &operator=(DBaseConverter &&o) noexcept {
+        if (this != &o) { if (conv_) pha_base_converter_destroy(conv_); conv_ = o.conv_; o.conv_ = nullptr; }
+        return *this;
+    }
+    ~DBaseConverter() { if (conv_) pha_base_converter_destroy(conv_); }
+    // (n = poly degree: the reference passes it along; the converter knows its context's)
+    void bConv_BEHZ(uint64_t *dst, const uint64_t *src, size_t /*n*/, const cudaStream_t &stream) const {
+        phantom::util::check_pha(pha_bConv_BEHZ(conv_, dst, src, stream));
+    }
+    void bConv_HPS(uint64_t *dst, const uint64_t *src, size_t /*n*/, const cudaStream_t &stream) const {
+        phantom::util::check_pha(pha_bConv_HPS(conv_, dst, src, stream));
+    }
+};
+
+namespace phantom {
+
+// DRNSTool (include/rns.cuh:13-236) of one level: a handle (context, |Ql|) on the library's lazily built per-level
+// constants; the hot-path methods with the reference's signatures (include/rns.cuh:156-205)
+class DRNSTool {
+    pha_context_t ctx_ = nullptr;
+    size_t size_Ql_ = 0;
+
+public:
+    DRNSTool() = default;
+    DRNSTool(pha_context_t ctx, size_t size_Ql) : ctx_(ctx), size_Ql_(size_Ql) {}
+    [[nodiscard]] pha_context_t amd() const { return ctx_; }
+    [[nodiscard]] size_t size_Ql() const { return size_Ql_; }
+    [[nodiscard]] size_t v_base_part_Ql_to_compl_part_QlP_conv_size() const {   // beta (rns.cu:152)
+        uint32_t beta = 0;
+        util::check_pha(pha_tool_beta(ctx_, static_cast<uint32_t>(size_Ql_), &beta));
+        return beta;
+    }
+    void modup(uint64_t *dst, const uint64_t *cks, const DNTTTable &, const scheme_type &scheme, const cudaStream_t &stream) const {
+        util::check_pha(pha_modup(ctx_, size_Ql_, dst, cks, static_cast<int>(scheme), stream));
+    }
+    void moddown_from_NTT(uint64_t *ct_i, uint64_t *cx_i, const DNTTTable &, const scheme_type &scheme, const cudaStream_t &stream) const {
+        util::check_pha(pha_moddown_from_NTT(ctx_, size_Ql_, ct_i, cx_i, static_cast<int>(scheme), stream));
+    }
+    void divide_and_round_q_last(const uint64_t *src, size_t cipher_size, uint64_t *dst, const cudaStream_t &stream) const {
+        util::check_pha(pha_divide_and_round_q_last(ctx_, size_Ql_, src, cipher_size, dst, stream));
+    }
+    void divide_and_round_q_last_ntt(uint64_t *src, size_t cipher_size, const DNTTTable &, uint64_t *dst, const cudaStream_t &stream) const {
+        util::check_pha(pha_divide_and_round_q_last_ntt(ctx_, size_Ql_, src, cipher_size, dst, stream));
+    }
+    void mod_t_and_divide_q_last_ntt(uint64_t *src, size_t cipher_size, const DNTTTable &, uint64_t *dst, const cudaStream_t &stream) const {
+        util::check_pha(pha_mod_t_and_divide_q_last_ntt(ctx_, size_Ql_, src, cipher_size, dst, stream));
+    }
+    void scaleAndRound_HPS_Q_Ql(uint64_t *dst, const uint64_t *src, const cudaStream_t &stream) const {
+        util::check_pha(pha_scaleAndRound_HPS_Q_Ql(ctx_, size_Ql_, dst, src, stream));
+    }
+    void ExpandCRTBasis_Ql_Q(uint64_t *dst, const uint64_t *src, const cudaStream_t &stream) const {
+        util::check_pha(pha_ExpandCRTBasis_Ql_Q(ctx_, size_Ql_, dst, src, stream));
+    }
+};
+
+// ContextData (include/context.cuh:19-131): the parameters of one level of the modulus chain and its DRNSTool
 class ContextData {
     EncryptionParameters parms_;
     size_t chain_index_ = 0;
+    DRNSTool gpu_rns_tool_;
 
 public:
     ContextData(EncryptionParameters parms, size_t chain_index) : parms_(std::move(parms)), chain_index_(chain_index) {}
+    void bind_tool(pha_context_t ctx, size_t size_Ql) { gpu_rns_tool_ = DRNSTool(ctx, size_Ql); }
     [[nodiscard]] const EncryptionParameters &parms() const { return parms_; }
     [[nodiscard]] size_t chain_index() const { return chain_index_; }
+    [[nodiscard]] const DRNSTool &gpu_rns_tool() const noexcept { return gpu_rns_tool_; }
 };
 
 }  // namespace phantom
@@ -240,6 +385,7 @@ class PhantomContext {
     size_t first_parm_index_ = 0;
     size_t poly_degree_ = 0;
     size_t coeff_mod_size_ = 0;
+    DNTTTable gpu_rns_tables_;
 
 public:
     explicit PhantomContext(const phantom::EncryptionParameters &params, int device = -1) {
@@ -274,12 +420,18 @@ public:
         // DRNSTool receives the plain modulus for BFV / BGV (src/context.cu:200-216 -> src/rns.cu:196-285)
         if ((params.scheme() == scheme_type::bgv || params.scheme() == scheme_type::bfv) && params.plain_modulus().value() != 0)
             util::check_pha(pha_context_set_plain_modulus(amd_, params.plain_modulus().value()));
+        gpu_rns_tables_ = DNTTTable(amd_, n, qp.size());
+        const size_t size_q_all = qp.size() - sp;
+        for (auto &cd : context_data_)   // index 0 (key level) and 1 share |Q|; 1 + l drops l primes (context.cu:186-229)
+            cd.bind_tool(amd_, cd.chain_index() <= 1 ? size_q_all : size_q_all - (cd.chain_index() - 1));
     }
     PhantomContext(const PhantomContext &) = delete;
     PhantomContext &operator=(const PhantomContext &) = delete;
     ~PhantomContext() { pha_context_destroy(amd_); }
 
     [[nodiscard]] pha_context_t amd() const { return amd_; }
+    [[nodiscard]] const DNTTTable &gpu_rns_tables() const noexcept { return gpu_rns_tables_; }
+    [[nodiscard]] const phantom::DRNSTool &get_context_data_rns_tool(size_t index) const { return get_context_data(index).gpu_rns_tool(); }
     [[nodiscard]] const phantom::ContextData &get_context_data(size_t index) const {
         if (index >= context_data_.size()) throw std::invalid_argument("index is out of range");
         return context_data_[index];
@@ -1162,5 +1314,123 @@ inline PhantomCiphertext rotate(const PhantomContext &c, const PhantomCiphertext
 inline PhantomCiphertext add_plain(const PhantomContext &c, const PhantomCiphertext &e, const PhantomPlaintext &p) { PhantomCiphertext d = e; add_plain_inplace(c, d, p); return d; }
 inline PhantomCiphertext sub_plain(const PhantomContext &c, const PhantomCiphertext &e, const PhantomPlaintext &p) { PhantomCiphertext d = e; sub_plain_inplace(c, d, p); return d; }
 inline PhantomCiphertext multiply_plain(const PhantomContext &c, const PhantomCiphertext &e, const PhantomPlaintext &p) { PhantomCiphertext d = e; multiply_plain_inplace(c, d, p); return d; }
+
+}  // namespace phantom
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The launcher level of the reference (include/ntt.cuh:157-226, include/evaluate.cuh:25-27, include/polymath.cuh): the same
+// names, argument order and meaning, forwarding to the C ABI.  `const DNTTTable &` is the handle PhantomContext::gpu_rns_tables().
+// ------------------------------------------------------------------------------------------------------------------------
+#define PHA_NTT_FWD_(call) phantom::util::check_pha(call)
+inline void nwt_2d_radix8_forward_inplace(uint64_t *inout, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                          size_t start_modulus_idx, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_forward_inplace(ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx, stream));
+}
+inline void nwt_2d_radix8_forward_inplace_fuse_moddown(uint64_t *ct, const uint64_t *cx, const uint64_t *bigPInv_mod_q,
+                                                       const uint64_t *bigPInv_mod_q_shoup, uint64_t *delta, const DNTTTable &ntt_tables,
+                                                       size_t coeff_modulus_size, size_t start_modulus_idx, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_forward_inplace_fuse_moddown(ntt_tables.amd(), ct, cx, bigPInv_mod_q, bigPInv_mod_q_shoup, delta,
+                                                                coeff_modulus_size, start_modulus_idx, stream));
+}
+inline void nwt_2d_radix8_forward_inplace_include_temp_mod(uint64_t *inout, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                                           size_t start_modulus_idx, size_t total_modulus_size, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_forward_inplace_include_temp_mod(ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx,
+                                                                    total_modulus_size, stream));
+}
+inline void nwt_2d_radix8_forward_inplace_include_special_mod(uint64_t *inout, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                                              size_t start_modulus_idx, size_t size_QP, size_t size_P,
+                                                              const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_forward_inplace_include_special_mod(ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx,
+                                                                       size_QP, size_P, stream));
+}
+inline void nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(uint64_t *inout, const DNTTTable &ntt_tables,
+                                                                            size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                                            size_t size_QP, size_t size_P, size_t excluded_range_start,
+                                                                            size_t excluded_range_end, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(
+        ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx, size_QP, size_P, excluded_range_start, excluded_range_end, stream));
+}
+inline void nwt_2d_radix8_forward_modup_fuse(uint64_t *out, const uint64_t *in, size_t modulus_index, const DNTTTable &ntt_tables,
+                                             size_t coeff_modulus_size, size_t start_modulus_idx, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_forward_modup_fuse(ntt_tables.amd(), out, in, modulus_index, coeff_modulus_size, start_modulus_idx, stream));
+}
+inline void nwt_2d_radix8_backward_inplace(uint64_t *inout, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                           size_t start_modulus_idx, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_backward_inplace(ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx, stream));
+}
+inline void nwt_2d_radix8_backward(uint64_t *out, const uint64_t *in, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                   size_t start_modulus_idx, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_backward(ntt_tables.amd(), out, in, coeff_modulus_size, start_modulus_idx, stream));
+}
+inline void nwt_2d_radix8_backward_scale(uint64_t *out, const uint64_t *in, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                         size_t start_modulus_idx, const uint64_t *scale, const uint64_t *scale_shoup,
+                                         const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_backward_scale(ntt_tables.amd(), out, in, coeff_modulus_size, start_modulus_idx, scale, scale_shoup, stream));
+}
+inline void nwt_2d_radix8_backward_inplace_scale(uint64_t *inout, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                                 size_t start_modulus_idx, const uint64_t *scale, const uint64_t *scale_shoup,
+                                                 const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_backward_inplace_scale(ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx, scale, scale_shoup, stream));
+}
+inline void nwt_2d_radix8_backward_inplace_include_special_mod(uint64_t *inout, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                                               size_t start_modulus_idx, size_t size_QP, size_t size_P,
+                                                               const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_backward_inplace_include_special_mod(ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx,
+                                                                        size_QP, size_P, stream));
+}
+inline void nwt_2d_radix8_backward_inplace_include_temp_mod_scale(uint64_t *inout, const DNTTTable &ntt_tables, size_t coeff_modulus_size,
+                                                                  size_t start_modulus_idx, size_t total_modulus_size, const uint64_t *scale,
+                                                                  const uint64_t *scale_shoup, const cudaStream_t &stream) {
+    PHA_NTT_FWD_(pha_nwt_2d_radix8_backward_inplace_include_temp_mod_scale(ntt_tables.amd(), inout, coeff_modulus_size, start_modulus_idx,
+                                                                           total_modulus_size, scale, scale_shoup, stream));
+}
+#undef PHA_NTT_FWD_
+
+namespace phantom {
+
+// phantom::key_switch_inner_prod (include/evaluate.cuh:25-27, src/eval_key_switch.cu:71-92).  modulus_QP is the device
+// table the reference's kernel indexes (the library owns its own copy) and reduction_threshold its dead branch
+// (SURVEY.md R6): both are accepted and unused.
+inline void key_switch_inner_prod(uint64_t *p_cx, const uint64_t *p_t_mod_up, const uint64_t *const *rlk, const DRNSTool &rns_tool,
+                                  const DModulus * /*modulus_QP*/, size_t /*reduction_threshold*/, const cudaStream_t &stream) {
+    util::check_pha(pha_key_switch_inner_prod(rns_tool.amd(), rns_tool.size_Ql(), p_cx, p_t_mod_up, rlk, stream));
+}
+
+// The residue-wise kernels of include/polymath.cuh are `__global__` symbols the reference launches itself with
+// <<<n * limbs / 128, 128>>>; here they are host launchers of the same names whose first argument is the table handle in
+// place of the launch configuration: multiply_rns_poly<<<g, b, 0, s>>>(a, b, modulus, r, n, limbs) becomes
+// multiply_rns_poly(tables, a, b, r, limbs, start_modulus_idx, s).
+inline void add_rns_poly(const DNTTTable &t, const uint64_t *op1, const uint64_t *op2, uint64_t *result, size_t coeff_mod_size,
+                         size_t start_modulus_idx, const cudaStream_t &stream) {
+    util::check_pha(pha_add_rns_poly(t.amd(), op1, op2, result, coeff_mod_size, start_modulus_idx, stream));
+}
+inline void sub_rns_poly(const DNTTTable &t, const uint64_t *op1, const uint64_t *op2, uint64_t *result, size_t coeff_mod_size,
+                         size_t start_modulus_idx, const cudaStream_t &stream) {
+    util::check_pha(pha_sub_rns_poly(t.amd(), op1, op2, result, coeff_mod_size, start_modulus_idx, stream));
+}
+inline void negate_rns_poly(const DNTTTable &t, const uint64_t *operand, uint64_t *result, size_t coeff_mod_size, size_t start_modulus_idx,
+                            const cudaStream_t &stream) {
+    util::check_pha(pha_negate_rns_poly(t.amd(), operand, result, coeff_mod_size, start_modulus_idx, stream));
+}
+inline void multiply_rns_poly(const DNTTTable &t, const uint64_t *op1, const uint64_t *op2, uint64_t *result, size_t coeff_mod_size,
+                              size_t start_modulus_idx, const cudaStream_t &stream) {
+    util::check_pha(pha_multiply_rns_poly(t.amd(), op1, op2, result, coeff_mod_size, start_modulus_idx, stream));
+}
+inline void multiply_and_add_rns_poly(const DNTTTable &t, const uint64_t *op1, const uint64_t *op2, const uint64_t *op3, uint64_t *result,
+                                      size_t coeff_mod_size, size_t start_modulus_idx, const cudaStream_t &stream) {
+    util::check_pha(pha_multiply_and_add_rns_poly(t.amd(), op1, op2, op3, result, coeff_mod_size, start_modulus_idx, stream));
+}
+inline void multiply_scalar_rns_poly(const DNTTTable &t, const uint64_t *operand, const uint64_t *scalar, const uint64_t *scalar_shoup,
+                                     uint64_t *result, size_t coeff_mod_size, size_t start_modulus_idx, const cudaStream_t &stream) {
+    util::check_pha(pha_multiply_scalar_rns_poly(t.amd(), operand, scalar, scalar_shoup, result, coeff_mod_size, start_modulus_idx, stream));
+}
+inline void tensor_prod_2x2_rns_poly(const DNTTTable &t, const uint64_t *op1, const uint64_t *op2, uint64_t *result, size_t coeff_mod_size,
+                                     const cudaStream_t &stream) {
+    util::check_pha(pha_tensor_prod_2x2_rns_poly(t.amd(), op1, op2, result, coeff_mod_size, stream));
+}
+inline void tensor_square_2x2_rns_poly(const DNTTTable &t, const uint64_t *op, uint64_t *result, size_t coeff_mod_size,
+                                       const cudaStream_t &stream) {
+    util::check_pha(pha_tensor_square_2x2_rns_poly(t.amd(), op, result, coeff_mod_size, stream));
+}
 
 }  // namespace phantom

@@ -89,3 +89,86 @@ def test_config5_diagonal_matvec_row_blocks(name, ql, n_blocks, n_diag, gpu):
                 got[i] = P.to_host(o)
         assert sorted(got) == list(range(n_blocks))
         assert all(np.array_equal(got[i], full[i]) for i in range(n_blocks))
+
+
+def _gpu_uniform(primes, n, gpu, gen):
+    import torch
+    out = torch.empty((len(primes), n), dtype=torch.int64, device=gpu)
+    for i, q in enumerate(primes):
+        out[i] = torch.randint(0, int(q), (n,), dtype=torch.int64, device=gpu, generator=gen)
+    return out
+
+
+def test_config4_batch_64_at_its_stated_shape(gpu):
+    """BASELINE config 4 as written: BFV relinearize + Galois rotate at N = 2^15, 30 + 15 limbs, a batch of 64
+    ciphertexts.  Four sampled ciphertexts are checked against the oracle's composition of the reference steps; the
+    whole batch must give the same per-ciphertext digests for every chunking of the batched key switch and for every
+    world size 1 / 2 / 4 / 8 ("identical results on 1/2/4/8 GPUs")."""
+    import torch
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    name, ql, batch, elt = "c4_bfv15", 30, 64, 3
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(4064)
+    rlk, glk = _keys(r, primes, n, size_q // size_p), _keys(r, primes, n, size_q // size_p)
+    d_rlk, d_glk = P.PhantomRelinKey.from_numpy(rlk, gpu), P.PhantomRelinKey.from_numpy(glk, gpu)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(0x5EED4064)
+    ct3 = torch.stack([torch.stack([_gpu_uniform(primes[:ql], n, gpu, gen) for _ in range(3)]) for _ in range(batch)])
+
+    def digests(t):   # one wrapping 64-bit sum per ciphertext
+        return [int(x) for x in t.reshape(t.shape[0], -1).sum(dim=1).cpu()]
+
+    full = W.relinearize_rotate_batch(ctx, ql, ct3, d_rlk, d_glk, elt, O.BFV)            # chunks of 8 (the default)
+    want = digests(full)
+    for b in (0, 21, 42, 63):                                                             # oracle, ciphertext by ciphertext
+        x = P.to_host(ct3[b])
+        ct = tool.keyswitch_inplace(x[:2], x[2], [rlk[i] for i in range(tool.beta)], O.BFV)
+        g = [oc.apply_galois_coeff(ct[p], elt, ql) for p in range(2)]
+        ref = tool.keyswitch_inplace(np.stack([g[0], np.zeros_like(g[0])]), g[1], [glk[i] for i in range(tool.beta)], O.BFV)
+        assert np.array_equal(P.to_host(full[b]), ref), b
+    del full
+    for chunk in (1, 16, 64):
+        assert digests(W.relinearize_rotate_batch(ctx, ql, ct3, d_rlk, d_glk, elt, O.BFV, chunk=chunk)) == want, chunk
+    for world in (2, 4, 8):
+        got = []
+        for rank in range(world):
+            mine, res = W.relinearize_rotate_sharded(ctx, ql, ct3, d_rlk, d_glk, elt, O.BFV, rank=rank, world=world)
+            assert len(mine) == batch // world
+            got += digests(res)
+        assert got == want, world
+
+
+def test_config5_128_diagonals_at_the_c3_parameter_set(gpu):
+    """BASELINE config 5's building block at its stated size: one 128-diagonal block of the encrypted matrix-vector
+    product (127 hoisted rotations + the main diagonal behind ONE mod-up and ONE mod-down) at the CKKS set N = 2^16,
+    45 + 15 limbs, against the oracle's hoisting_weighted.  The 127 Galois keys cycle over 3 distinct key buffers and
+    the 128 diagonals over 4 distinct plaintexts (the arithmetic does not depend on the data; 127 distinct keys would
+    be 23 GB on the host side of the oracle) -- the launches, the pointer tables and the 128-term accumulation are the
+    real ones."""
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    name, ql, n_diag = "c3_ckks16", 45, 128
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(5128)
+    elts = [1] + [int(pow(5, k, 2 * n)) for k in range(1, n_diag)]
+    key_pool = [_keys(r, primes, n, size_q // size_p) for _ in range(3)]
+    qlp_primes = [primes[i] for i in list(range(ql)) + [size_q + j for j in range(size_p)]]
+    w_pool = [uniform_poly(r, qlp_primes, n) for _ in range(4)]
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    d_key_pool = [P.PhantomRelinKey.from_numpy(k, gpu) for k in key_pool]
+    d_w_pool = [P.to_device(w, gpu) for w in w_pool]
+    d_keys = [None] + [d_key_pool[k % 3] for k in range(1, n_diag)]
+    d_ws = [d_w_pool[k % 4] for k in range(n_diag)]
+    out = P.to_host(W.diag_matvec(ctx, ql, P.to_device(ct, gpu), elts, d_keys, d_ws, O.CKKS))
+    okeys = [None] + [[key_pool[k % 3][i] for i in range(tool.beta)] for k in range(1, n_diag)]
+    want = tool.hoisting_weighted(ct, elts, okeys, [w_pool[k % 4] for k in range(n_diag)], O.CKKS)
+    assert np.array_equal(out, want)

@@ -634,3 +634,36 @@ def test_plaintext_ops_of_the_oracle(t):
         for p in range(2):
             want = oc.nwt_backward(oc.multiply(oc.nwt_forward(ct[p], ql, 0), oc.nwt_forward(centred, ql, 0), ql), ql, 0)
             assert np.array_equal(prod[p], want)
+
+
+def test_every_literal_default_prime_of_the_reference_is_an_ntt_prime_for_the_oracle():
+    """All three literal tables of src/host/globals.cu:51-361 (fixture: tests/golden/default_coeff_modulus.json, extracted
+    by tests/golden/make_default_moduli.py): the oracle's primality test accepts every entry, every entry is = 1 mod 2N
+    (so the oracle's root search and table builder apply to it), entries of one row are distinct, and the row respects
+    the reference's own bit budget (include/host/hestdparms.h; one row of the reference is a bit over: recorded)."""
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "default_coeff_modulus.json")))
+    rows = 0
+    for level, table in doc["coeff_modulus"].items():
+        for deg, primes in table.items():
+            n, ps = int(deg), [int(p, 16) for p in primes]
+            assert len(set(ps)) == len(ps)
+            prod = 1
+            for p in ps:
+                assert O.is_prime(p), (level, deg, hex(p))
+                assert (p - 1) % (2 * n) == 0, (level, deg, hex(p))
+                assert p.bit_length() <= 60
+                prod *= p
+            assert prod.bit_length() <= doc["max_bit_count"][level][deg] or (level, deg) == ("192", "8192")
+            rows += 1
+    assert rows == 21
+    # the rows BASELINE config 0 uses: tables and a round trip through the oracle's NTT for BFVDefault(4096) and (8192)
+    for deg in ("4096", "8192"):
+        ps = [int(p, 16) for p in doc["coeff_modulus"]["128"][deg]]
+        n = int(deg)
+        c = O.Ctx(n.bit_length() - 1, ps, 1)
+        x = np.stack([np.random.default_rng(7).integers(0, q, n, dtype=np.uint64) for q in ps])
+        assert np.array_equal(c.nwt_backward(c.nwt_forward(x, len(ps), 0), len(ps), 0), x)
+        for i, q in enumerate(ps):
+            assert pow(O.minimal_primitive_root(2 * n, q), n, q) == q - 1
