@@ -326,11 +326,10 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     const size_t n = (size_t)1 << k.log_n;
     const size_t lds_bytes = (size_t)C::LDS_WORDS * sizeof(u64);
     const unsigned tiles_per_limb = (unsigned)(n >> C::LOGTILE);
-    const unsigned total = k.active * tiles_per_limb;
-    // (a persistent software-pipelined form and twiddle-prefetch policies were measured and dropped:
-    //  DESIGN.md section 7)
+    // (a persistent software-pipelined form was measured and dropped: DESIGN.md section 7)
     dim3 grid(tiles_per_limb, k.sel.count, k.batch);
-    (void)total;
+    // (requesting all rounds' twiddles up front, HOIST 1, was measured again in r02 for the small launches of mod-down and
+    //  rescale: no gain at any size)
     if (lds_bytes > 64 * 1024) {   // beyond the default dynamic LDS limit: raise it once per kernel and device
         static std::atomic<uint64_t> raised{0};
         int dev = 0;
@@ -728,14 +727,19 @@ int pha_nwt_2d_radix8_forward_modup_fuse(pha_context_t ctx, uint64_t *out, const
     need(out); need(in);
     Context &c = ctx->c;
     if (modulus_index >= c.size_qp) throw std::invalid_argument("modulus_index out of range");
-    for (size_t limb = start; limb < start + cms; limb++) {
-        LimbSel sel = plain_sel(limb, 1);
-        sel.remap_from = (uint32_t)limb;
-        sel.remap_add = (uint32_t)modulus_index - (uint32_t)limb;
-        NttExtra x;
-        x.pro_src = in + limb * c.n;
-        ntt_forward(c, out, out, out, sel, EPI_FWD_CANON, x, as_stream(stream));
-    }
+    if (cms == 0) return 0;
+    if (cms > 65535) throw std::invalid_argument("coeff_modulus_size out of range");
+    // ONE launch pair for all limbs: limb start + z is "polynomial" z of a batch of one-limb polynomials that sit n
+    // coefficients apart, all of them transformed with table row modulus_index
+    LimbSel sel = plain_sel(start, 1);
+    sel.remap_from = (uint32_t)start;
+    sel.remap_add = (uint32_t)modulus_index - (uint32_t)start;
+    NttExtra x;
+    x.batch = (uint32_t)cms;
+    x.poly_stride = c.n;
+    x.pro_src = in + start * c.n;
+    x.pro_stride = c.n;
+    ntt_forward(c, out, out, out, sel, EPI_FWD_CANON, x, as_stream(stream));
     PHA_API_END
 }
 
