@@ -379,6 +379,36 @@ PHA_HD void round_load(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
         u64 *rg = reg + gi * K;
         const int e0 = (hi << (LOGD + r)) + lo;
         if (FROM_GLOBAL && COH) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (!C::STRIDED && K == 8 && G == 1 && LOGD >= 1 && LOGD <= 6) {
+                // 16-byte L2-served loads (the 8-byte agent-scope form runs at 0.54-0.70x their rate, MI355X_MICROARCH.md):
+                // the lanes of a pair (lo = 2m, 2m + 1) need the SAME 16-byte words (k, {2m, 2m + 1}), k = 0..7, one half
+                // each; the even lane fetches them for k = 0..3, the odd lane for k = 4..7, and they trade the halves the
+                // other one needs with one DPP lane swap per word
+                const bool odd = lo & 1;
+                const u64 *base = a.in + global_index<C>(a, e0 - (odd ? 1 : 0) + ((odd ? 4 : 0) << LOGD), v);
+                u64x2 w0, w1, w2, w3;
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                             "global_load_dwordx4 %1, %4, off offset:%5 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:%6 sc1\n\t"
+                             "global_load_dwordx4 %3, %4, off offset:%7 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                             : "v"(base), "n"(8 << LOGD), "n"(16 << LOGD), "n"(24 << LOGD)
+                             : "memory");
+                const u64x2 w[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u64 send = odd ? w[j].x : w[j].y;
+                    const u32 slo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)send, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
+                    const u32 shi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(send >> 32), 0xB1, 0xF, 0xF, false);
+                    const u64 recv = ((u64)shi << 32) | slo;
+                    rg[j] = odd ? recv : w[j].x;          // element (k = j,     lo)
+                    rg[4 + j] = odd ? w[j].y : recv;      // element (k = 4 + j, lo)
+                }
+                continue;
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < K; k++) rg[k] = coherent_load(a.in + global_index<C>(a, e0 + (k << LOGD), v));
         } else if (FROM_GLOBAL) {
