@@ -136,6 +136,27 @@ PHA_HD u64 shoup_lazy4(u64 Y, u64x2 w, u64 nq) {
     return ((u64)hi << 32) | (u32)T;
 }
 
+// Exact floor(a*b / 2^64) and (a*b mod 2^64) from v_mad_u64_u32 / v_mul_lo_u32 only (the compiler's __umul64hi goes through
+// v_mul_hi_u32, which issues at half their rate)
+PHA_HD u64 mulhi64_mad(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = mul_u64_u32(a0, b0);
+    const u64 p01 = mad_u64_u32(a0, b1, p00 >> 32);     // (2^32-1)^2 + 2^32-1 < 2^64
+    const u64 p10 = mad_u64_u32(a1, b0, (u32)p01);
+    return mad_u64_u32(a1, b1, p01 >> 32) + (p10 >> 32);
+}
+PHA_HD u64 mullo64_mad(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    return mul_u64_u32(a0, b0) + ((u64)(u32)(a0 * b1 + a1 * b0) << 32);
+}
+// Montgomery reduction: (hi:lo) * 2^-64 mod p, canonical, for odd p, (hi:lo) < 2^64 * p and ninv = -p^-1 mod 2^64.
+// m = lo * ninv makes (hi:lo) + m * p divisible by 2^64; the quotient is hi + floor(m * p / 2^64) + (lo != 0) < 2p.
+PHA_HD u64 mont_redc128(u64 lo, u64 hi, u64 p, u64 ninv) {
+    const u64 m = mullo64_mad(lo, ninv);
+    const u64 t = hi + mulhi64_mad(m, p) + (lo != 0 ? 1 : 0);
+    return csub(t, p);
+}
+
 // Butterflies on the [0,8q) / [0,4q) lazy ranges that shoup_lazy4 needs (q < 2^61). q4 = 4q.
 // CT: X,Y in [0,8q) -> [0,8q)
 PHA_HD void ct_bfly4(u64 &X, u64 &Y, u64x2 w, u64 q4, u64 nq) {

@@ -322,7 +322,7 @@ uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_l
 }
 
 void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
-    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.isz, b.osz, 0xffffffffu, 0, 0, 0}});
+    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz, 0xffffffffu, 0, 0, 0}});
 }
 
 // DRNSTool constructor, HPS multiply part (src/rns.cu:687-790; converters src/host/rns.cu:282-337,438-466).
@@ -641,23 +641,40 @@ Behz &Context::behz() {
 
 // q-hat_i^-1 mod q_i and q-hat_i mod p_j for an (ibase -> obase) converter: src/host/rns.cu:282-337,438-457
 // upload converter constants: hat_inv [isz] (value, Shoup), mat [osz][isz]
-static void upload_bconv(BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
+static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
                          const std::vector<u64x2> &hat_inv, const std::vector<u64> &mat) {
     b.isz = (uint32_t)ip.size();
     b.osz = (uint32_t)op.size();
     b.iprime = ip;
     b.oprime = op;
+    // Montgomery form for the split-accumulator kernel: rows hold qhat_i * 2^64 mod p_j, so that REDC of the accumulated
+    // sum gives sum_i y_i * qhat_i mod p_j directly (valid for odd p_j; the BEHZ converter with m_tilde = 2^32 keeps Barrett)
+    b.mont = true;
+    for (uint32_t j = 0; j < b.osz; j++) b.mont = b.mont && (c.primes[op[j]] & 1);
+    std::vector<u64> oninv(b.osz, 0);
+    if (b.mont)
+        for (uint32_t j = 0; j < b.osz; j++) {
+            const u64 pj = c.primes[op[j]];
+            u64 inv = pj;                                        // Newton: inv * pj = 1 mod 2^(3 * 2^k)
+            for (int it = 0; it < 6; it++) inv *= 2 - pj * inv;
+            oninv[j] = 0 - inv;
+        }
     std::vector<uint32_t> mat30((size_t)b.osz * kBcRowPad * 2, 0u);
     if (b.isz <= (uint32_t)kBcRowPad)
         for (uint32_t j = 0; j < b.osz; j++)
             for (uint32_t i = 0; i < b.isz; i++) {
-                const u64 m = mat[(size_t)j * b.isz + i];
+                u64 m = mat[(size_t)j * b.isz + i];
+                if (b.mont) {
+                    const u64 pj = c.primes[op[j]];
+                    m = (u64)((((unsigned __int128)m) << 64) % pj);
+                }
                 mat30[((size_t)j * kBcRowPad + i) * 2] = (uint32_t)(m & 0x3fffffffu);
                 mat30[((size_t)j * kBcRowPad + i) * 2 + 1] = (uint32_t)(m >> 30);
             }
     b.hat_inv.upload(hat_inv);
     b.mat.upload(mat);
     b.mat30.upload(mat30);
+    b.oninv.upload(oninv);
     b.d_iprime.upload(ip);
     b.d_oprime.upload(op);
 }
@@ -683,7 +700,7 @@ void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const st
             mat[(size_t)j * isz + i] = h;
         }
     }
-    upload_bconv(b, ip, op, hat_inv, mat);
+    upload_bconv(c, b, ip, op, hat_inv, mat);
 }
 
 // bConv_BEHZ_var1 (src/rns_bconv.cu:231-246, constants src/host/rns.cu:469-496): the quotient-style conversion
@@ -705,7 +722,7 @@ void build_bconv_var1(Context &c, BConv &b, const std::vector<uint32_t> &ip, con
         const u64 pj = c.primes[op[j]];
         for (uint32_t i = 0; i < isz; i++) mat[(size_t)j * isz + i] = h_invmod(c.primes[ip[i]] % pj, pj);
     }
-    upload_bconv(b, ip, op, hat_inv, mat);
+    upload_bconv(c, b, ip, op, hat_inv, mat);
 }
 
 Tool &Context::tool(uint32_t size_ql) {
@@ -792,7 +809,7 @@ Tool &Context::tool(uint32_t size_ql) {
         }
         // device descriptors for the batched launches
         auto describe = [](const BConv &b, uint32_t pad_start, uint32_t pad_len, uint32_t src_limb, uint32_t copy_own) {
-            return BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.isz, b.osz,
+            return BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz,
                             pad_start, pad_len, src_limb, copy_own};
         };
         std::vector<BConvDev> dd;

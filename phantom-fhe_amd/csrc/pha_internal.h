@@ -112,7 +112,9 @@ struct BConvDev {
     const uint32_t *iprime;      // [isz] rows of the QP table
     const uint32_t *oprime;      // [osz]
     const u64 *mat;              // [osz][isz] qhat_i mod p_j
-    const uint32_t *mat30;       // [osz][kBcRowPad][2] the same, split into 30-bit halves, rows zero-padded
+    const uint32_t *mat30;       // [osz][kBcRowPad][2] 30-bit halves, rows zero-padded, of qhat_i mod p_j -- or, when oninv is set,
+                                 //   of its Montgomery form qhat_i * 2^64 mod p_j (the split kernel then reduces with REDC)
+    const u64 *oninv;            // [osz] -p_j^-1 mod 2^64, or null (an even output modulus: Barrett)
     uint32_t isz, osz;
     uint32_t pad_start, pad_len; // output j goes to limb j + (j >= pad_start ? pad_len : 0)
     uint32_t src_limb;           // first input limb inside the source polynomial
@@ -125,7 +127,9 @@ struct BConv {
     std::vector<uint32_t> iprime, oprime;  // indices into the QP table
     DevBuf<u64x2> hat_inv;                 // [isz]  qhat_i^-1 mod q_i (+Shoup)
     DevBuf<u64> mat;                       // [osz][isz]  qhat_i mod p_j
-    DevBuf<uint32_t> mat30;                // [osz][kBcRowPad][2] 30-bit halves of mat, zero-padded rows
+    DevBuf<uint32_t> mat30;                // [osz][kBcRowPad][2] 30-bit halves of mat (Montgomery form when mont), zero-padded rows
+    DevBuf<u64> oninv;                     // [osz] -p_j^-1 mod 2^64
+    bool mont = false;                     // every output modulus is odd: the split kernel reduces with Montgomery
     DevBuf<uint32_t> d_iprime, d_oprime;
 };
 

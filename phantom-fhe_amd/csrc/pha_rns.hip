@@ -64,21 +64,34 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)who.grp * L.src_group_stride + (size_t)d.src_limb * n;
     const u64 *own = L.own + (size_t)who.grp * L.own_group_stride;
     u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
-    const uint32_t isz = d.isz;
+    const uint32_t isz = d.isz, osz = d.osz;
     const uint32_t j0 = blockIdx.y * L.out_per_block;
-    const uint32_t j1 = min(j0 + L.out_per_block, d.osz);
-    // SPLIT: this block's matrix rows (out_per_block x 16 entries of two dwords) go through LDS once; the MAC
-    // loop then reads them as broadcast ds_read_b64 instead of stalling on scalar loads
+    const uint32_t j1 = min(j0 + L.out_per_block, osz);
+    const bool mont = SPLIT && d.oninv != nullptr;
+    // Everything the output loop needs per output prime goes through LDS once per workgroup: the matrix rows (SPLIT:
+    // out_per_block x 16 entries of two dwords, read back as broadcast ds_read_b64) and the prime's constants and
+    // destination limb.  (r02: the loop used to fetch oprime[j] and then mod[oprime[j]] from global memory for every
+    // output -- two dependent vector loads per iteration, which made the kernel latency-bound at 2.3x its VALU time.)
     __shared__ uint2 s_rows[kBcMaxOutPerBlock * kBcRowPad];
+    __shared__ u64 s_p[kBcMaxOutPerBlock], s_c0[kBcMaxOutPerBlock], s_c1[kBcMaxOutPerBlock];
+    __shared__ uint32_t s_jo[kBcMaxOutPerBlock];
     if (SPLIT) {
-        const uint32_t limit = d.osz * kBcRowPad;
+        const uint32_t limit = osz * kBcRowPad;
         for (uint32_t e = threadIdx.x; e < L.out_per_block * kBcRowPad; e += kBcThreads) {
             const uint32_t base = j0 * kBcRowPad + e;
             s_rows[e] = base < limit ? reinterpret_cast<const uint2 *>(d.mat30)[base] : uint2{0u, 0u};
         }
-        __syncthreads();
     }
-    if (j0 >= d.osz) return;  // (after the barrier) nothing to produce for this group
+    if (threadIdx.x < L.out_per_block && j0 + threadIdx.x < osz) {
+        const uint32_t j = j0 + threadIdx.x;
+        const DModulus m = L.mod[d.oprime[j]];
+        s_p[threadIdx.x] = m.value;
+        s_c0[threadIdx.x] = mont ? d.oninv[j] : m.ratio0;   // Montgomery: -p^-1 mod 2^64; Barrett: floor(2^128 / p)
+        s_c1[threadIdx.x] = m.ratio1;
+        s_jo[threadIdx.x] = j + (j >= d.pad_start ? d.pad_len : 0);
+    }
+    __syncthreads();
+    if (j0 >= osz) return;  // (after the barrier) nothing to produce for this group
     u64 y[ISZ_PAD];
     u32 ylo[ISZ_PAD], yhi[ISZ_PAD];  // SPLIT: 30-bit halves, cut once per input
 #pragma unroll
@@ -96,12 +109,12 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         for (uint32_t i = 0; i < isz; i++)
             dst[(size_t)(d.src_limb + i) * n + coeff] = own[(size_t)(d.src_limb + i) * n + coeff];
     }
-    for (uint32_t j = j0; j < j1; j++) {
-        const DModulus m = L.mod[d.oprime[j]];
+    const uint32_t count = j1 - j0;
+    for (uint32_t e = 0; e < count; e++) {
         u64 lo, hi;
         if (SPLIT) {
             // rows are zero-padded to kBcRowPad entries, and y[i] = 0 beyond isz: no per-term branch
-            const uint2 *row = s_rows + (j - j0) * kBcRowPad;
+            const uint2 *row = s_rows + e * kBcRowPad;
             u64 ll = 0, lh = 0, hl = 0, hh = 0;
 #pragma unroll
             for (int i = 0; i < ISZ_PAD; i++) {
@@ -125,15 +138,20 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
             lo += t2;
             hi += (lo < t2) + (hh >> 4);
         } else {
-            const u64 *row = d.mat + (size_t)j * isz;
+            const u64 *row = d.mat + (size_t)(j0 + e) * isz;
             lo = 0;
             hi = 0;
 #pragma unroll
             for (int i = 0; i < ISZ_PAD; i++)
                 if (i < (int)isz) mac128(y[i], row[i], lo, hi);
         }
-        const uint32_t jo = j + (j >= d.pad_start ? d.pad_len : 0);
-        dst[(size_t)jo * n + coeff] = barrett128(lo, hi, m);
+        // SPLIT rows are in Montgomery form when the converter has oninv (uniform): sum_i y_i * (qhat_i 2^64) < 16 * 2^60 * p
+        // = 2^64 p, and REDC brings it to sum_i y_i * qhat_i mod p with a third of Barrett-128's multiplies
+        const u64 p = s_p[e];
+        u64 r;
+        if (mont) r = mont_redc128(lo, hi, p, s_c0[e]);
+        else r = barrett128(lo, hi, DModulus{p, s_c0[e], s_c1[e]});
+        dst[(size_t)s_jo[e] * n + coeff] = r;
     }
 }
 
