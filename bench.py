@@ -172,9 +172,17 @@ def main():
     if world > 1 and not share and torch.cuda.device_count() < world:
         raise SystemExit(f"bench: --gpus {world} but only {torch.cuda.device_count()} HIP device(s) visible "
                          "(PHA_BENCH_SHARE_GPU=1 puts all ranks on cuda:0 over gloo: a functional test, not a measurement)")
-    if world > 1:
+    # PHA_BENCH_FORCE_DIST=1: initialise the process group (RCCL) even for one rank, so that the broadcast / all-reduce /
+    # all-gather calls below really go through RCCL on a one-GPU box
+    force_dist = os.environ.get("PHA_BENCH_FORCE_DIST") == "1" and world == 1
+    if force_dist:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://")   # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -197,7 +205,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
 
     def broadcast(keys):
@@ -330,8 +338,7 @@ def main():
         out = torch.zeros((2, size_q - 1, n), dtype=torch.int64, device=dev)
 
         def hommul():
-            buf[:2].copy_(ct1)
-            ctx.tensor_prod_2x2_rns_poly(buf, ct2, buf, size_q)                              # multiply_inplace
+            ctx.tensor_prod_2x2_rns_poly(ct1, ct2, buf, size_q)                              # multiply: (ct1, ct2) -> 3 polynomials
             ctx.keyswitch_inplace(size_q, buf, buf[2], rlk.public_keys_ptr, P.scheme_type.ckks)  # relinearize
             ctx.divide_and_round_q_last_ntt(size_q, buf, 2, out)                             # rescale_to_next
 
@@ -452,6 +459,8 @@ def main():
                                      note=f"one 45-limb polynomial per launch pair, rotating over {nb} buffers")},
             "hommul_relin_rescale": hm,
             "keyswitch_c4": c4,
+            "collectives": ("RCCL (torch.distributed backend nccl)" if (world > 1 or force_dist) and not share else
+                            "gloo (PHA_BENCH_SHARE_GPU)" if share and world > 1 else "none (one rank, no process group)"),
         }
         if hm is not None and traffic and traffic.get("hommul_bytes_per_op"):
             hm["traffic"] = traffic["hommul_bytes_per_op"]
@@ -465,7 +474,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -13,6 +13,11 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _group():
+    """True when a process group exists (also a one-rank group: its collectives still run through the backend)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -26,7 +31,7 @@ def shard_range(batch, rank_, world_):
 
 def broadcast_keys(keys, src=0):
     """Broadcast every key tensor ([2][#QP][N] int64) from src to all ranks, in place."""
-    if world() == 1:
+    if not _group():
         return keys
     for k in keys:
         dist.broadcast(k, src=src)
@@ -35,7 +40,7 @@ def broadcast_keys(keys, src=0):
 
 def max_over_ranks(seconds, device=None):
     """Whole-job time of a region = the slowest rank's time."""
-    if world() == 1:
+    if not _group():
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -44,7 +49,7 @@ def max_over_ranks(seconds, device=None):
 
 def gather_checksums(local, device=None):
     """All-gather one int64 checksum per rank (used to check that N-GPU runs reproduce 1-GPU results)."""
-    if world() == 1:
+    if not _group():
         return [int(local)]
     t = torch.tensor([local], dtype=torch.int64, device=device)
     out = [torch.zeros_like(t) for _ in range(world())]

@@ -56,3 +56,13 @@ def test_bench_two_ranks_self_spawned_reproduce_one_rank(gpu):
     assert two["keyswitch_c4"]["per_rank_ciphertexts"] == [3, 3] and one["keyswitch_c4"]["per_rank_ciphertexts"] == [6]
     assert one["keyswitch_c4"]["checksum"] == two["keyswitch_c4"]["checksum"]
     assert two["value"] > 0 and two["hommul_relin_rescale"]["value"] > 0
+
+
+def test_bench_one_rank_through_rccl(gpu):
+    """PHA_BENCH_FORCE_DIST=1: one rank with an RCCL process group (backend "nccl"), so that the key broadcast, the
+    max-over-ranks all-reduce, the barriers and the checksum all-gather of the multi-GPU path really execute RCCL
+    collectives on this one-GPU box; results equal the plain one-rank run."""
+    plain = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph"], PHA_BENCH_SMALL="1")
+    rccl = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph"], PHA_BENCH_SMALL="1", PHA_BENCH_FORCE_DIST="1")
+    assert rccl["collectives"].startswith("RCCL") and plain["collectives"].startswith("none")
+    assert rccl["keyswitch_c4"]["checksum"] == plain["keyswitch_c4"]["checksum"] and rccl["n_gpus"] == 1
