@@ -448,6 +448,9 @@ struct SubMulArgs {
     const u64x2 *cst;  // per-limb constant (Shoup pair)
     const DModulus *mod;
     uint32_t n;
+    // polynomial blockIdx.z of a batch: element strides (0 for a single polynomial)
+    size_t dst_stride = 0, cx_stride = 0, delta_stride = 0;
+    uint32_t accumulate = 0;   // dst += result (the add_to_ct_kernel of keyswitch_inplace, rns_bconv.cu:763-769, fused)
 };
 template <bool REDUCE_LAST>
 __global__ __launch_bounds__(256) void sub_mul_kernel(const SubMulArgs k) {
@@ -455,9 +458,14 @@ __global__ __launch_bounds__(256) void sub_mul_kernel(const SubMulArgs k) {
     const DModulus m = k.mod[limb];
     const u64x2 cst = k.cst[limb];
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
-    u64 d = REDUCE_LAST ? barrett64(k.delta[coeff], m.value, m.ratio1) : k.delta[(size_t)limb * k.n + coeff];
-    const u64 t = sub_mod(k.cx[(size_t)limb * k.n + coeff], d, m.value);
-    k.dst[(size_t)limb * k.n + coeff] = shoup(t, cst, m.value);
+    const u64 *delta = k.delta + (size_t)blockIdx.z * k.delta_stride;
+    const u64 *cx = k.cx + (size_t)blockIdx.z * k.cx_stride;
+    u64 *dst = k.dst + (size_t)blockIdx.z * k.dst_stride;
+    u64 d = REDUCE_LAST ? barrett64(delta[coeff], m.value, m.ratio1) : delta[(size_t)limb * k.n + coeff];
+    const u64 t = sub_mod(cx[(size_t)limb * k.n + coeff], d, m.value);
+    u64 r = shoup(t, cst, m.value);
+    if (k.accumulate) r = add_mod(dst[(size_t)limb * k.n + coeff], r, m.value);
+    dst[(size_t)limb * k.n + coeff] = r;
 }
 
 // ---- BGV (plain modulus t): base_P_to_t_conv (rns.cu:283) as one thread per coefficient, writing over
@@ -492,16 +500,18 @@ struct BgvDownArgs {
     u64x2 pinv_t;
     u64 t;
     uint32_t n;
+    size_t dst_stride = 0, cx_stride = 0, delta_stride = 0;   // polynomial blockIdx.z of a batch (cp_t moves with cx)
 };
 __global__ __launch_bounds__(256) void bgv_moddown_kernel(const BgvDownArgs k) {
     const uint32_t limb = blockIdx.y;
     const u64 q = k.mod[limb].value;
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
     const size_t id = (size_t)limb * k.n + coeff;
-    const u64 u = shoup(k.cp_t[coeff], k.pinv_t, k.t);
+    const size_t z = blockIdx.z;
+    const u64 u = shoup(k.cp_t[z * k.cx_stride + coeff], k.pinv_t, k.t);
     const u64 corr = shoup(u, k.p_mod_q[limb], q);
-    const u64 d = add_mod(sub_mod(k.cx[id], k.delta[id], q), corr, q);
-    k.dst[id] = shoup(d, k.pinv[limb], q);
+    const u64 d = add_mod(sub_mod(k.cx[z * k.cx_stride + id], k.delta[z * k.delta_stride + id], q), corr, q);
+    k.dst[z * k.dst_stride + id] = shoup(d, k.pinv[limb], q);
 }
 
 struct BgvSwitchArgs {
@@ -707,11 +717,13 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
                     c.d_mod.p, t.t_mod, t.alpha, (uint32_t)n};
         hipLaunchKernelGGL(p_to_t_kernel, dim3((unsigned)(n / 256), polys), dim3(256), 0, s, pk);
         check_launch();
-        for (uint32_t z = 0; z < polys; z++) {
-            u64 *out = accumulate ? delta + z * d_stride : ct + z * ct_stride;
-            BgvDownArgs k{out, cx + z * cx_stride, delta + z * d_stride, cx + z * cx_stride + (size_t)ql * n,
-                          t.p_mod_q2.p, t.pinv2.p, c.d_mod.p, t.pinv_mod_t, t.t_mod.value, (uint32_t)n};
-            hipLaunchKernelGGL(bgv_moddown_kernel, dim3((unsigned)(n / 256), ql), dim3(256), 0, s, k);
+        {   // every polynomial in one launch
+            BgvDownArgs k{accumulate ? delta : ct, cx, delta, cx + (size_t)ql * n, t.p_mod_q2.p, t.pinv2.p, c.d_mod.p,
+                          t.pinv_mod_t, t.t_mod.value, (uint32_t)n};
+            k.dst_stride = accumulate ? d_stride : ct_stride;
+            k.cx_stride = cx_stride;
+            k.delta_stride = d_stride;
+            hipLaunchKernelGGL(bgv_moddown_kernel, dim3((unsigned)(n / 256), ql, polys), dim3(256), 0, s, k);
             check_launch();
         }
         NttExtra x;
@@ -733,13 +745,14 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         x.aux_stride = cx_stride;
         ntt_forward(c, delta, delta, ct, plain_sel(0, ql), accumulate ? EPI_FWD_MODDOWN_ADD : EPI_FWD_MODDOWN, x, s);
     } else {
-        for (uint32_t z = 0; z < polys; z++) {
-            u64 *out = accumulate ? delta + z * d_stride : ct + z * ct_stride;
-            SubMulArgs k{out, cx + z * cx_stride, delta + z * d_stride, t.pinv2.p, c.d_mod.p, (uint32_t)n};
-            hipLaunchKernelGGL(sub_mul_kernel<false>, dim3((unsigned)(n / 256), ql), dim3(256), 0, s, k);
-            check_launch();
-            if (accumulate) launch_add(c, ct + z * ct_stride, out, ct + z * ct_stride, ql, 0, s);
-        }
+        // BFV (moddown_kernel rns_bconv.cu:680-689): every polynomial in ONE launch, ct (+)= (cx - delta) * P^-1
+        SubMulArgs k{ct, cx, delta, t.pinv2.p, c.d_mod.p, (uint32_t)n};
+        k.dst_stride = ct_stride;
+        k.cx_stride = cx_stride;
+        k.delta_stride = d_stride;
+        k.accumulate = accumulate ? 1 : 0;
+        hipLaunchKernelGGL(sub_mul_kernel<false>, dim3((unsigned)(n / 256), ql, polys), dim3(256), 0, s, k);
+        check_launch();
     }
 }
 
@@ -1075,13 +1088,15 @@ int pha_divide_and_round_q_last(pha_context_t ctx, size_t size_Ql, const uint64_
     if (size_Ql < 2) throw std::invalid_argument("cannot switch down the last remaining modulus");
     Tool &t = c.tool((uint32_t)size_Ql);
     const size_t n = c.n, nl = size_Ql - 1;
-    for (size_t p = 0; p < cipher_size; p++) {
-        SubMulArgs k{dst + p * nl * n, src + p * size_Ql * n, src + p * size_Ql * n + nl * n, t.inv_q_last2.p,
-                     c.d_mod.p, (uint32_t)n};
-        hipLaunchKernelGGL(sub_mul_kernel<true>, dim3((unsigned)(n / 256), (unsigned)nl), dim3(256), 0,
-                           as_stream(stream), k);
-        check_launch();
-    }
+    if (cipher_size == 0) return 0;
+    if (cipher_size > 65535) throw std::invalid_argument("cipher_size out of range");
+    SubMulArgs k{dst, src, src + nl * n, t.inv_q_last2.p, c.d_mod.p, (uint32_t)n};   // every polynomial in one launch
+    k.dst_stride = nl * n;
+    k.cx_stride = size_Ql * n;
+    k.delta_stride = size_Ql * n;
+    hipLaunchKernelGGL(sub_mul_kernel<true>, dim3((unsigned)(n / 256), (unsigned)nl, (unsigned)cipher_size), dim3(256), 0,
+                       as_stream(stream), k);
+    check_launch();
     PHA_API_END
 }
 
