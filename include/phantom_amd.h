@@ -355,6 +355,12 @@ int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint
  * table permutation, else the coefficient-domain one with its sign) */
 int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint32_t galois_elt,
                              size_t coeff_mod_size, size_t polys, int ntt_form, void *stream);
+/* Build-defined helper for rotate on batches (BASELINE config 4): the automorphism of `batch` size-2 ciphertexts
+   src [batch][2][Ql][N], written in the layout the key switch that follows needs (rotate_internal / apply_galois_inplace,
+   src/evaluate.cu:1567-1624): dst_ct [batch][2][Ql][N] receives (galois(c0), 0), dst_c2 [batch][Ql][N] receives galois(c1).
+   ntt_form != 0: NTT-domain permutation (ckks / bgv); 0: coefficient-domain with sign (bfv). */
+int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint64_t *dst_ct, uint64_t *dst_c2,
+                                   uint32_t galois_elt, size_t size_Ql, size_t batch, int ntt_form, void *stream);
 
 /* ---- tuning knob for A/B measurements: key 0 = NTT thread geometry (0: 16 coefficients per thread,
  *      256-thread workgroups; bit 0: 8 per thread, 512-thread workgroups; bit 3: integer butterflies for every

@@ -33,66 +33,9 @@ struct DModulus {
     u64 ratio1;
 };
 
-PHA_HD u64 mulhi64(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
-#else
-    return (u64)(((unsigned __int128)a * b) >> 64);
-#endif
-}
-
-PHA_HD void mul128(u64 a, u64 b, u64 &lo, u64 &hi) {
-    lo = a * b;
-    hi = mulhi64(a, b);
-}
-
-// csub_q (uintmodmath.cuh:18-21)
-PHA_HD u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
-PHA_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
-PHA_HD u64 sub_mod(u64 a, u64 b, u64 q) { return csub(a + q - b, q); }
-PHA_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
-
-// multiply_and_reduce_shoup_lazy (uintmodmath.cuh:223-231): any 64-bit a, result in [0,2q)
-PHA_HD u64 shoup_lazy(u64 a, u64x2 w, u64 q) { return a * w.x - mulhi64(a, w.y) * q; }
-// multiply_and_reduce_shoup (:207-215): canonical
-PHA_HD u64 shoup(u64 a, u64x2 w, u64 q) { return csub(shoup_lazy(a, w, q), q); }
-
-// barrett_reduce_uint128_uint64 (uintmodmath.cuh:96-136): (hi:lo) mod q, canonical.
-PHA_HD u64 barrett128(u64 lo, u64 hi, const DModulus &m) {
-    u64 carry = mulhi64(lo, m.ratio0);
-    u64 t_lo, t_hi;
-    mul128(lo, m.ratio1, t_lo, t_hi);
-    u64 tmp1 = t_lo + carry;
-    u64 tmp3 = t_hi + (tmp1 < t_lo);
-    mul128(hi, m.ratio0, t_lo, t_hi);
-    u64 s = tmp1 + t_lo;
-    carry = t_hi + (s < tmp1);
-    u64 quo = hi * m.ratio1 + tmp3 + carry;
-    return csub(lo - quo * m.value, m.value);
-}
-// multiply_and_barrett_reduce_uint64 (:160-198)
-PHA_HD u64 mul_mod(u64 a, u64 b, const DModulus &m) {
-    u64 lo, hi;
-    mul128(a, b, lo, hi);
-    return barrett128(lo, hi, m);
-}
-// barrett_reduce_uint64_uint64 (:144-151)
-PHA_HD u64 barrett64(u64 x, u64 q, u64 ratio1) { return csub(x - mulhi64(x, ratio1) * q, q); }
-
-// 128-bit accumulate helper
-PHA_HD void mac128(u64 a, u64 b, u64 &lo, u64 &hi) {
-    u64 pl, ph;
-    mul128(a, b, pl, ph);
-    lo += pl;
-    hi += ph + (lo < pl);
-}
-
-// ---- gfx950-tuned lazy Shoup multiply ---------------------------------------------------------------
-// v_mul_hi_u32 issues at 1/8 of the FP32 rate on gfx950, v_mad_u64_u32 at 1/4 and delivers the full
-// 64-bit product (profiles/r01_microbench_gfx950.txt), so the quotient estimate is built from three
-// v_mad_u64_u32 (the compiler would pick v_mul_hi_u32, hence the asm), drops the a0*b0 term and the
-// middle carry (estimate in [Q-2, Q]), and the remainder Y*w - Q*q is one v_mad chain against -q.
-// Result in [0, 4q); any 64-bit Y.  Measured 87.7 vs 106 cycles per wave-butterfly.
+// v_mad_u64_u32 helpers.  v_mul_hi_u32 issues at 1/8 of the FP32 rate on gfx950, v_mad_u64_u32 / v_mul_lo_u32 at 1/4, and the mad
+// delivers the full 64-bit product (profiles/r01_microbench_gfx950.txt), so every 64 x 64 product below is built from them
+// (the compiler's own expansion of __umul64hi and of a 64-bit `a * b` goes through v_mul_hi_u32).
 PHA_HD u64 mad_u64_u32(u32 a, u32 b, u64 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     u64 d, carry;
@@ -120,6 +63,87 @@ PHA_HD u64 add_u64_u32(u64 c, u32 a) {  // c + a without a carry chain through V
     return c + a;
 #endif
 }
+// exact floor(a*b / 2^64) and a*b mod 2^64
+PHA_HD u64 mulhi64_mad(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = mul_u64_u32(a0, b0);
+    const u64 p01 = mad_u64_u32(a0, b1, p00 >> 32);     // (2^32-1)^2 + 2^32-1 < 2^64
+    const u64 p10 = mad_u64_u32(a1, b0, (u32)p01);
+    return mad_u64_u32(a1, b1, p01 >> 32) + (p10 >> 32);
+}
+PHA_HD u64 mullo64_mad(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    return mul_u64_u32(a0, b0) + ((u64)(u32)(a0 * b1 + a1 * b0) << 32);
+}
+
+PHA_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return mulhi64_mad(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+PHA_HD u64 mullo64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return mullo64_mad(a, b);
+#else
+    return a * b;
+#endif
+}
+
+PHA_HD void mul128(u64 a, u64 b, u64 &lo, u64 &hi) {
+    lo = mullo64(a, b);
+    hi = mulhi64(a, b);
+}
+
+// csub_q (uintmodmath.cuh:18-21)
+PHA_HD u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+PHA_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
+PHA_HD u64 sub_mod(u64 a, u64 b, u64 q) { return csub(a + q - b, q); }
+PHA_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// multiply_and_reduce_shoup_lazy (uintmodmath.cuh:223-231): any 64-bit a, result in [0,2q)
+PHA_HD u64 shoup_lazy(u64 a, u64x2 w, u64 q) { return mullo64(a, w.x) - mullo64(mulhi64(a, w.y), q); }
+// multiply_and_reduce_shoup (:207-215): canonical
+PHA_HD u64 shoup(u64 a, u64x2 w, u64 q) { return csub(shoup_lazy(a, w, q), q); }
+
+// barrett_reduce_uint128_uint64 (uintmodmath.cuh:96-136): (hi:lo) mod q, canonical.
+PHA_HD u64 barrett128(u64 lo, u64 hi, const DModulus &m) {
+    u64 carry = mulhi64(lo, m.ratio0);
+    u64 t_lo, t_hi;
+    mul128(lo, m.ratio1, t_lo, t_hi);
+    u64 tmp1 = t_lo + carry;
+    u64 tmp3 = t_hi + (tmp1 < t_lo);
+    mul128(hi, m.ratio0, t_lo, t_hi);
+    u64 s = tmp1 + t_lo;
+    carry = t_hi + (s < tmp1);
+    u64 quo = mullo64(hi, m.ratio1) + tmp3 + carry;
+    return csub(lo - mullo64(quo, m.value), m.value);
+}
+// multiply_and_barrett_reduce_uint64 (:160-198)
+PHA_HD u64 mul_mod(u64 a, u64 b, const DModulus &m) {
+    u64 lo, hi;
+    mul128(a, b, lo, hi);
+    return barrett128(lo, hi, m);
+}
+// barrett_reduce_uint64_uint64 (:144-151)
+PHA_HD u64 barrett64(u64 x, u64 q, u64 ratio1) { return csub(x - mullo64(mulhi64(x, ratio1), q), q); }
+
+// 128-bit accumulate helper
+PHA_HD void mac128(u64 a, u64 b, u64 &lo, u64 &hi) {
+    u64 pl, ph;
+    mul128(a, b, pl, ph);
+    lo += pl;
+    hi += ph + (lo < pl);
+}
+
+// ---- gfx950-tuned lazy Shoup multiply ---------------------------------------------------------------
+// v_mul_hi_u32 issues at 1/8 of the FP32 rate on gfx950, v_mad_u64_u32 at 1/4 and delivers the full
+// 64-bit product (profiles/r01_microbench_gfx950.txt), so the quotient estimate is built from three
+// v_mad_u64_u32 (the compiler would pick v_mul_hi_u32, hence the asm), drops the a0*b0 term and the
+// middle carry (estimate in [Q-2, Q]), and the remainder Y*w - Q*q is one v_mad chain against -q.
+// Result in [0, 4q); any 64-bit Y.  Measured 87.7 vs 106 cycles per wave-butterfly.
 // floor(a*b / 2^64) - e, e in {0,1,2}
 PHA_HD u64 mulhi64_approx(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -136,19 +160,6 @@ PHA_HD u64 shoup_lazy4(u64 Y, u64x2 w, u64 nq) {
     return ((u64)hi << 32) | (u32)T;
 }
 
-// Exact floor(a*b / 2^64) and (a*b mod 2^64) from v_mad_u64_u32 / v_mul_lo_u32 only (the compiler's __umul64hi goes through
-// v_mul_hi_u32, which issues at half their rate)
-PHA_HD u64 mulhi64_mad(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 p00 = mul_u64_u32(a0, b0);
-    const u64 p01 = mad_u64_u32(a0, b1, p00 >> 32);     // (2^32-1)^2 + 2^32-1 < 2^64
-    const u64 p10 = mad_u64_u32(a1, b0, (u32)p01);
-    return mad_u64_u32(a1, b1, p01 >> 32) + (p10 >> 32);
-}
-PHA_HD u64 mullo64_mad(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    return mul_u64_u32(a0, b0) + ((u64)(u32)(a0 * b1 + a1 * b0) << 32);
-}
 // Montgomery reduction: (hi:lo) * 2^-64 mod p, canonical, for odd p, (hi:lo) < 2^64 * p and ninv = -p^-1 mod 2^64.
 // m = lo * ninv makes (hi:lo) + m * p divisible by 2^64; the quotient is hi + floor(m * p / 2^64) + (lo != 0) < 2p.
 PHA_HD u64 mont_redc128(u64 lo, u64 hi, u64 p, u64 ninv) {

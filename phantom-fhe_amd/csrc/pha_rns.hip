@@ -588,6 +588,28 @@ __global__ __launch_bounds__(256) void galois_coeff_kernel(u64 *dst, const u64 *
     dst[(size_t)limb * n + (raw & (n - 1))] = v;
 }
 
+// Galois automorphism of a batch of size-2 ciphertexts laid out for the key switch that follows it (rotate_internal /
+// apply_galois_inplace, src/evaluate.cu:1567-1624): polynomial 0 goes to dst_ct[b][0], dst_ct[b][1] is zeroed and polynomial 1
+// goes to the dense key-switch operand dst_c2[b] -- one kernel instead of permutation + memset + two strided copies.
+// blockIdx.z = 2 b + p.  `table` != null: NTT-domain gather; null: coefficient-domain scatter with sign (galois.cu:11-39).
+__global__ __launch_bounds__(256) void galois_split_kernel(u64 *dst_ct, u64 *dst_c2, const u64 *src, const uint32_t *table,
+                                                           const DModulus *mod, uint32_t elt, uint32_t n, uint32_t ql) {
+    const uint32_t limb = blockIdx.y, b = blockIdx.z >> 1, p = blockIdx.z & 1;
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    const u64 *in = src + ((size_t)(2 * b + p) * ql + limb) * n;
+    u64 *out = p ? dst_c2 + ((size_t)b * ql + limb) * n : dst_ct + ((size_t)(2 * b) * ql + limb) * n;
+    if (!p) dst_ct[((size_t)(2 * b + 1) * ql + limb) * n + coeff] = 0;
+    if (table) {
+        out[coeff] = in[table[coeff]];
+    } else {
+        const u64 q = mod[limb].value;
+        const uint32_t raw = (uint32_t)(((u64)coeff * elt) & (2 * (u64)n - 1));
+        u64 v = in[coeff];
+        if (raw >= n) v = neg_mod(v, q);
+        out[raw & (n - 1)] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // drivers
 // ------------------------------------------------------------------------------------------------
@@ -1134,6 +1156,23 @@ int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *d
         hipLaunchKernelGGL(galois_coeff_kernel, dim3((unsigned)(c.n / 256), (unsigned)cms, (unsigned)polys), dim3(256), 0,
                            as_stream(stream), dst, src, c.d_mod.p, 0u, galois_elt, (uint32_t)c.n);
     }
+    check_launch();
+    PHA_API_END
+}
+
+int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint64_t *dst_ct, uint64_t *dst_c2,
+                                   uint32_t galois_elt, size_t size_Ql, size_t batch, int ntt_form, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(src); need(dst_ct); need(dst_c2);
+    if (src == dst_ct || src == dst_c2) throw std::invalid_argument("apply_galois cannot run in place");
+    Context &c = ctx->c;
+    if (!(galois_elt & 1) || galois_elt >= 2 * c.n) throw std::invalid_argument("Galois element is not valid");
+    if (size_Ql == 0 || size_Ql > c.size_q) throw std::invalid_argument("size_Ql out of range");
+    if (batch == 0) return 0;
+    if (2 * batch > 65535) throw std::invalid_argument("batch out of range");
+    const uint32_t *tab = ntt_form ? c.galois_table(galois_elt) : nullptr;
+    hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(c.n / 256), (unsigned)size_Ql, (unsigned)(2 * batch)), dim3(256), 0,
+                       as_stream(stream), dst_ct, dst_c2, src, tab, c.d_mod.p, galois_elt, (uint32_t)c.n, (uint32_t)size_Ql);
     check_launch();
     PHA_API_END
 }

@@ -369,6 +369,12 @@ class PhantomContext:
     def apply_galois_batched(self, src, dst, galois_elt, cms, polys, ntt_form):
         _lib.check(self._L.pha_apply_galois_batched(self._h, _ptr(src), _ptr(dst), galois_elt, cms, polys, int(bool(ntt_form)), _stream()))
 
+    def apply_galois_for_keyswitch(self, src, dst_ct, dst_c2, galois_elt, size_Ql, batch, ntt_form):
+        """src [batch][2][Ql][N] -> dst_ct = (galois(c0), 0), dst_c2 [batch][Ql][N] = galois(c1): the operands of the key switch
+        of a rotation, in one kernel (build-defined; BASELINE config 4)."""
+        _lib.check(self._L.pha_apply_galois_for_keyswitch(self._h, _ptr(src), _ptr(dst_ct), _ptr(dst_c2), galois_elt, size_Ql,
+                                                          batch, int(bool(ntt_form)), _stream()))
+
     # -- measurement ------------------------------------------------------------------------------
     def time_forward_ntt(self, inout, cms, iters):
         ms = C.c_float()

@@ -96,6 +96,7 @@ _SIGS = {
     "pha_apply_galois_ntt": [vp, vp, vp, C.c_uint32, sz, vp],
     "pha_apply_galois": [vp, vp, vp, C.c_uint32, sz, sz, vp],
     "pha_apply_galois_batched": [vp, vp, vp, C.c_uint32, sz, sz, C.c_int, vp],
+    "pha_apply_galois_for_keyswitch": [vp, vp, vp, vp, C.c_uint32, sz, sz, C.c_int, vp],
     "pha_set_tuning": [C.c_int, C.c_int],
     "pha_time_forward_ntt": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)],
 }

@@ -34,11 +34,12 @@ def _relinearize_rotate_chunk(ctx, size_Ql, ct3, relin_key, galois_key, galois_e
     B = ct3.shape[0]
     ct = ct3[:, :2].clone(memory_format=torch.contiguous_format)   # never a view: the key switch works in place
     ctx.keyswitch_inplace_batched(size_Ql, ct, ct3[:, 2].contiguous(), B, relin_key.public_keys_ptr, scheme)
-    g = torch.empty_like(ct)
-    ctx.apply_galois_batched(ct, g, galois_elt, size_Ql, 2 * B, int(scheme) != int(scheme_type.bfv))
-    rot = torch.zeros_like(ct)
-    rot[:, 0] = g[:, 0]
-    ctx.keyswitch_inplace_batched(size_Ql, rot, g[:, 1].contiguous(), B, galois_key.public_keys_ptr, scheme)
+    # rotate: (galois(c0), 0) += key switch of galois(c1) (apply_galois_inplace, src/evaluate.cu:1567-1624); one kernel
+    # writes both operands in the layout the key switch wants
+    rot = torch.empty_like(ct)
+    g1 = torch.empty_like(ct[:, 0])
+    ctx.apply_galois_for_keyswitch(ct, rot, g1, galois_elt, size_Ql, B, int(scheme) != int(scheme_type.bfv))
+    ctx.keyswitch_inplace_batched(size_Ql, rot, g1, B, galois_key.public_keys_ptr, scheme)
     return rot
 
 

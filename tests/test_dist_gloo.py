@@ -93,6 +93,12 @@ class _StubCtx:
     def apply_galois_batched(self, src, dst, elt, ql, polys, ntt_form):
         dst.copy_(src.flip(-1) + elt)
 
+    def apply_galois_for_keyswitch(self, src, dst_ct, dst_c2, elt, ql, batch, ntt_form):
+        g = src.flip(-1) + elt
+        dst_ct[:, 0] = g[:, 0]
+        dst_ct[:, 1] = 0
+        dst_c2.copy_(g[:, 1])
+
     def hoisting_weighted(self, ql, ct, elts, keys, weights, scheme):
         acc = sum(w[:ql] * int(e) for w, e in zip(weights, elts))
         ct *= acc[None]
