@@ -316,9 +316,18 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
                  hipStream_t s);
 
 // shared launchers (pha_rns.hip / pha_poly.hip)
+// optional epilogue of a conversion: store dst_j (+)= (cx_j - converted_j) * cst_j instead of converted_j (BFV mod-down)
+struct BConvEpilogue {
+    const u64 *cx;
+    u64 *dst;
+    const u64x2 *cst;
+    size_t cx_stride, dst_stride;
+    bool accumulate;
+};
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                   uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
-                  const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0);
+                  const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0,
+                  const BConvEpilogue *epi = nullptr);
 // converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)
 void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
 void build_bconv_var1(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);

@@ -42,6 +42,13 @@ struct BConvLaunch {
     // conv_count = 0: every z has its own converter index z (one ciphertext) or shares converter 0 (conv_step 0)
     uint32_t conv_count;
     size_t src_group_stride, own_group_stride;  // per ciphertext
+    // optional epilogue (BFV mod-down, moddown_kernel rns_bconv.cu:680-689 + add_to_ct_kernel :763-769 fused into the conversion):
+    // instead of storing delta_j the kernel stores epi_dst_j (+)= (epi_cx_j - delta_j) * epi_cst_j; null epi_cx = off
+    const u64 *epi_cx;
+    u64 *epi_dst;
+    const u64x2 *epi_cst;        // [limb] constant with its Shoup quotient (P^-1 mod q_j)
+    size_t epi_cx_stride, epi_dst_stride;
+    uint32_t epi_acc;
 };
 struct BConvWho {
     uint32_t ci, grp;
@@ -75,6 +82,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     __shared__ uint2 s_rows[kBcMaxOutPerBlock * kBcRowPad];
     __shared__ u64 s_p[kBcMaxOutPerBlock], s_c0[kBcMaxOutPerBlock], s_c1[kBcMaxOutPerBlock];
     __shared__ uint32_t s_jo[kBcMaxOutPerBlock];
+    __shared__ u64x2 s_e[kBcMaxOutPerBlock];
     if (SPLIT) {
         const uint32_t limit = osz * kBcRowPad;
         for (uint32_t e = threadIdx.x; e < L.out_per_block * kBcRowPad; e += kBcThreads) {
@@ -88,7 +96,9 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         s_p[threadIdx.x] = m.value;
         s_c0[threadIdx.x] = mont ? d.oninv[j] : m.ratio0;   // Montgomery: -p^-1 mod 2^64; Barrett: floor(2^128 / p)
         s_c1[threadIdx.x] = m.ratio1;
-        s_jo[threadIdx.x] = j + (j >= d.pad_start ? d.pad_len : 0);
+        const uint32_t jo = j + (j >= d.pad_start ? d.pad_len : 0);
+        s_jo[threadIdx.x] = jo;
+        if (L.epi_cx) s_e[threadIdx.x] = L.epi_cst[jo];
     }
     __syncthreads();
     if (j0 >= osz) return;  // (after the barrier) nothing to produce for this group
@@ -151,7 +161,16 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         u64 r;
         if (mont) r = mont_redc128(lo, hi, p, s_c0[e]);
         else r = barrett128(lo, hi, DModulus{p, s_c0[e], s_c1[e]});
-        dst[(size_t)s_jo[e] * n + coeff] = r;
+        const size_t id = (size_t)s_jo[e] * n + coeff;
+        if (L.epi_cx) {
+            const u64 t = sub_mod(L.epi_cx[(size_t)blockIdx.z * L.epi_cx_stride + id], r, p);
+            u64 o = shoup(t, s_e[e], p);
+            u64 *out = L.epi_dst + (size_t)blockIdx.z * L.epi_dst_stride + id;
+            if (L.epi_acc) o = add_mod(*out, o, p);
+            *out = o;
+        } else {
+            dst[id] = r;
+        }
     }
 }
 
@@ -189,8 +208,13 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                          uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src,
                          size_t src_stride, const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count,
-                         size_t group_stride) {
+                         size_t group_stride, const BConvEpilogue *epi) {
     BConvLaunch L{};
+    if (epi) {
+        if (max_isz > 32) throw std::logic_error("the fused mod-down epilogue needs the register-resident converter");
+        L.epi_cx = epi->cx; L.epi_dst = epi->dst; L.epi_cst = epi->cst;
+        L.epi_cx_stride = epi->cx_stride; L.epi_dst_stride = epi->dst_stride; L.epi_acc = epi->accumulate ? 1 : 0;
+    }
     L.conv_count = conv_count; L.src_group_stride = group_stride; L.own_group_stride = group_stride;
     L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;
     L.dst_stride = dst_stride; L.src_stride = src_stride; L.mod = c.d_mod.p; L.n = (uint32_t)c.n;
@@ -730,8 +754,10 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
             check_launch();
         }
     } else {
+        // BFV: (cx - delta) * P^-1 (+ add_to_ct) rides on the conversion's output loop, delta is never stored
+        BConvEpilogue e{cx, ct, t.pinv2.p, cx_stride, ct_stride, accumulate};
         launch_bconv(c, t.d_p_to_ql_conv.p, 0, polys, t.alpha, ql, t.split_ok, delta, d_stride, cx, cx_stride,
-                     nullptr, !prescaled, s);
+                     nullptr, !prescaled, s, 0, 0, scheme == PHA_SCHEME_BFV ? &e : nullptr);
     }
     if (scheme == PHA_SCHEME_BGV) {
         // [cx_P]_t lands in the first P limb of each polynomial, then the t-corrected division and the NTT
@@ -766,8 +792,9 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         x.out_stride = ct_stride;
         x.aux_stride = cx_stride;
         ntt_forward(c, delta, delta, ct, plain_sel(0, ql), accumulate ? EPI_FWD_MODDOWN_ADD : EPI_FWD_MODDOWN, x, s);
-    } else {
-        // BFV (moddown_kernel rns_bconv.cu:680-689): every polynomial in ONE launch, ct (+)= (cx - delta) * P^-1
+    } else if (t.alpha == 1) {
+        // BFV, alpha = 1 (moddown_kernel rns_bconv.cu:680-689): every polynomial in ONE launch, ct (+)= (cx - delta) * P^-1
+        // (for alpha > 1 this already happened inside the base conversion above)
         SubMulArgs k{ct, cx, delta, t.pinv2.p, c.d_mod.p, (uint32_t)n};
         k.dst_stride = ct_stride;
         k.cx_stride = cx_stride;
