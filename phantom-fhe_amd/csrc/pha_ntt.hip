@@ -21,6 +21,7 @@ __device__ unsigned long long g_wg_times[2048];
 #endif
 extern std::atomic<int> g_bconv_split;  // pha_rns.hip
 std::atomic<int> g_whole14_min{1 << 30};  // pha_set_tuning key 2: limb-polynomials per launch from which N = 2^14 takes the one-workgroup plan (r02: never faster than the alternatives, kept for tests)
+std::atomic<int> g_fused_split{0};        // pha_set_tuning key 5: one pass per workgroup in the one-launch transform (0: both passes in one workgroup; r02: the split form is slower still, 380-420 vs 345 us per step)
 std::atomic<int> g_fused_lag{2};          // pha_set_tuning key 3: lag (in units per XCD) between the two passes of the one-launch transform
 std::atomic<int> g_fused_min_tiles{1 << 30}; // pha_set_tuning key 4: tiles per launch from which the two passes share one launch (r02: 7 % slower than two launches at every size, DESIGN section 7: off by default, kept behind bit 9 and this threshold)    // pha_set_tuning key 2: limb-polynomials per launch from which N = 2^14 takes the one-launch plan
 
@@ -224,6 +225,7 @@ struct FusedArgs {
     uint32_t *flags;       // [units][2]: tiles of the unit's first pass that have been written, consumers that have seen that
     uint32_t units, slots, tpl, lag, count;   // count = limbs per polynomial (unit = z * count + y)
     uint32_t active_units; // units that are not excluded
+    uint32_t split;        // 1: a workgroup runs ONE pass (even positions of a class: first pass, odd: second pass of the lagged unit)
 };
 __device__ __forceinline__ void l2_arrive(uint32_t *p) {
     asm volatile("global_atomic_add %0, %1, off" ::"v"(p), "v"(1u) : "memory");
@@ -262,11 +264,15 @@ template <class PS, class PC, bool FWD, int EPI, bool FOLD>   // PS: strided pas
 __global__ __launch_bounds__(512, PHA_FUSED_MIN_WAVES) void ntt_fused_kernel(const NttKArgs kA, const NttKArgs kB, const FusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *lds = reinterpret_cast<u64 *>(smem);
-    const uint32_t b = blockIdx.x, xcd = b & 7u, within = b >> 3, tile = within % f.tpl, slot = within / f.tpl;
+    const uint32_t b = blockIdx.x, xcd = b & 7u, within = b >> 3;
+    // split form: the positions of a class alternate between first-pass and second-pass workgroups, so that a workgroup
+    // lives for one pass only and the second pass's wavefronts are not tied to a first pass's barrier schedule
+    const uint32_t role = f.split ? (within & 1u) : 2u, idx = f.split ? (within >> 1) : within;
+    const uint32_t tile = idx % f.tpl, slot = idx / f.tpl;
     const uint32_t uA = slot * 8 + xcd;
-    const bool has_a = slot < f.slots && uA < f.units && !limb_excluded(kA, kA.sel.start + uA % f.count, uA / f.count);
+    const bool has_a = role != 1u && slot < f.slots && uA < f.units && !limb_excluded(kA, kA.sel.start + uA % f.count, uA / f.count);
     const uint32_t uB = (slot - f.lag) * 8 + xcd;   // (wraps when slot < lag: has_b is false then)
-    const bool has_b = slot >= f.lag && uB < f.units && !limb_excluded(kB, kB.sel.start + uB % f.count, uB / f.count);
+    const bool has_b = role != 0u && slot >= f.lag && uB < f.units && !limb_excluded(kB, kB.sel.start + uB % f.count, uB / f.count);
     if (!has_a && !has_b) return;   // (and never touches the class words: see the clean-up rule above)
     uint32_t cls_seen = 0, cls_mine = 0;
     if (threadIdx.x == 0) {   // class check, part 1 (the answer is looked at after the first pass)
@@ -295,8 +301,11 @@ __global__ __launch_bounds__(512, PHA_FUSED_MIN_WAVES) void ntt_fused_kernel(con
     if (!has_b) return;
     const uint32_t z = uB / f.count, twr = kB.sel.start + uB % f.count;
     uint32_t *flag = f.flags + 2 * (size_t)uB;
-    uint32_t consumers_before = 0;
-    if (threadIdx.x == 0) {
+    // wait until every tile of the unit's first pass has been written.  One lane polls for the workgroup -- or, when the
+    // second pass is the barrier-free contiguous one, one lane per wavefront, so that no wavefront waits for another's poll
+    constexpr bool kWaveConsumer = FWD && PC::THREADS == 64;
+    const bool poller = kWaveConsumer && f.split ? (threadIdx.x & 63) == 0 : threadIdx.x == 0;
+    if (poller) {
         uint32_t spins = 0;
         while (l2_fetch_or(flag, 0u) < f.tpl) {
             __builtin_amdgcn_s_sleep(8);
@@ -306,13 +315,14 @@ __global__ __launch_bounds__(512, PHA_FUSED_MIN_WAVES) void ntt_fused_kernel(con
             if (++spins > (1u << 24)) __builtin_trap();   // never hang the device on a broken assumption
 #endif
         }
-        // counted in as "has seen the unit complete"; the answer is only looked at after the second pass
-        consumers_before = __hip_atomic_fetch_add(flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __syncthreads();   // also: pass A no longer uses the LDS
+    if (!(kWaveConsumer && f.split)) __syncthreads();   // also: pass A no longer uses the LDS
     if (FWD) fused_run_tile<PC, true, EPI, false, true>(kB, twr, z, tile, lds);
     else fused_run_tile<PS, false, EPI, FOLD, true>(kB, twr, z, tile, lds);
-    if (threadIdx.x == 0 && consumers_before == f.tpl - 1) {   // every consumer of this unit has seen it complete
+    // every wavefront of this workgroup has seen the unit complete: count the workgroup in; the last one of the unit puts
+    // the unit's words back to zero (nobody polls them any more)
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == f.tpl - 1) {
         l2_store(flag, 0u);
         l2_store(flag + 1, 0u);
         if (__hip_atomic_fetch_add(f.cls + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.active_units - 1) {
@@ -372,7 +382,8 @@ static bool launch_fused(Context &c, const NttKArgs &kA, const NttKArgs &kB, hip
     const size_t lds_a = (size_t)PS::LDS_WORDS * sizeof(u64);
     const size_t lds_b = (size_t)PC::LDS_WORDS * sizeof(u64) * (PC::THREADS == 64 ? 8 : 1);
     const size_t lds_bytes = lds_a > lds_b ? lds_a : lds_b;
-    const unsigned blocks = (f.slots + f.lag) * f.tpl * 8;
+    f.split = g_fused_split.load(std::memory_order_relaxed) ? 1u : 0u;
+    const unsigned blocks = (f.slots + f.lag) * f.tpl * 8 * (f.split ? 2u : 1u);
     hipLaunchKernelGGL((ntt_fused_kernel<PS, PC, FWD, EPI, FOLD>), dim3(blocks), dim3(512), lds_bytes, s, kA, kB, f);
     check_launch();
     return true;
@@ -792,6 +803,8 @@ int pha_set_tuning(int key, int value) {
     } else if (key == 3) {
         if (value < 0 || value > 64) throw std::invalid_argument("lag out of range");
         g_fused_lag.store(value);
+    } else if (key == 5) {
+        g_fused_split.store(value ? 1 : 0);
     } else if (key == 4) {
         if (value < 1) throw std::invalid_argument("threshold must be positive");
         g_fused_min_tiles.store(value);
