@@ -157,6 +157,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the HIP runtime starts: RCCL needs dmabuf IPC on this driver
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
