@@ -497,6 +497,9 @@ public:
     [[nodiscard]] double scale() const { return scale_; }
     [[nodiscard]] uint64_t correction_factor() const { return correction_factor_; }
     [[nodiscard]] uint64_t *data() const { return data_.get(); }
+    // take over a device buffer of the same shape (the old one is released on its stream): lets an out-of-place kernel
+    // produce the new contents without a copy back
+    void replace_data(phantom::util::cuda_auto_ptr<uint64_t> &&fresh) { data_ = std::move(fresh); }
 
     // On-disk format of include/ciphertext.h:173-214: the nine metadata fields as raw host-endian values, then
     // size * coeff_modulus_size * poly_modulus_degree words.  Files are interchangeable with the reference's.
@@ -1232,21 +1235,16 @@ inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertex
     if (it == elts.end()) throw std::invalid_argument("Galois elt not present");
     const size_t idx = static_cast<size_t>(it - elts.begin());
     const auto &s = cudaStreamPerThread;
-    auto temp = util::make_cuda_auto_ptr<uint64_t>(L * N, s);
-    uint64_t *c0 = encrypted.data(), *c1 = encrypted.data() + L * N;
-    // execution order matters: the permutation is not in place (:1597-1622)
-    if (parms.scheme() == scheme_type::bfv) {
-        util::check_pha(pha_apply_galois(context.amd(), c0, temp.get(), static_cast<uint32_t>(galois_elt), L, 0, s));
-        util::check_hip(hipMemcpyAsync(c0, temp.get(), L * N * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-        util::check_pha(pha_apply_galois(context.amd(), c1, temp.get(), static_cast<uint32_t>(galois_elt), L, 0, s));
-    } else if (parms.scheme() == scheme_type::ckks || parms.scheme() == scheme_type::bgv) {
-        util::check_pha(pha_apply_galois_ntt(context.amd(), c0, temp.get(), static_cast<uint32_t>(galois_elt), L, s));
-        util::check_hip(hipMemcpyAsync(c0, temp.get(), L * N * 8, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-        util::check_pha(pha_apply_galois_ntt(context.amd(), c1, temp.get(), static_cast<uint32_t>(galois_elt), L, s));
-    } else {
+    if (parms.scheme() != scheme_type::bfv && parms.scheme() != scheme_type::ckks && parms.scheme() != scheme_type::bgv)
         throw std::logic_error("scheme not implemented");
-    }
-    util::check_hip(hipMemsetAsync(c1, 0, L * N * 8, s), "hipMemsetAsync");
+    // the reference permutes c0 through a temporary, copies it back, permutes c1 into the temporary and clears c1
+    // (:1597-1622); here one kernel writes (galois(c0), 0) into a fresh ciphertext buffer and galois(c1) into the key-switch
+    // operand, and the ciphertext adopts the fresh buffer
+    auto temp = util::make_cuda_auto_ptr<uint64_t>(L * N, s);
+    auto fresh = util::make_cuda_auto_ptr<uint64_t>(2 * L * N, s);
+    util::check_pha(pha_apply_galois_for_keyswitch(context.amd(), encrypted.data(), fresh.get(), temp.get(), static_cast<uint32_t>(galois_elt),
+                                                   L, 1, parms.scheme() == scheme_type::bfv ? 0 : 1, s));
+    encrypted.replace_data(std::move(fresh));
     keyswitch_inplace(context, encrypted, temp.get(), galois_keys.get_relin_keys(idx), false, s);
 }
 
