@@ -151,3 +151,72 @@ def test_two_rank_config4_and_config5_sharding_reproduces_one_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok4 and ok5
+
+
+def _gpu_workload_worker(rank, world, port, q):
+    """The real PhantomContext on cuda:0 in every rank (the GPU box has one device; gloo carries the key broadcast and the
+    gather): config-4 composition on this rank's shard with keys that exist only on rank 0 before the broadcast."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "phantom-fhe_amd"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import dist as pd
+    from phantom_fhe_amd import workloads as W
+    from oracle import oracle as O
+    from util import oracle_ctx, primes_of, rng_for, uniform_poly
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        name, ql, batch, elt = "hyb12_a2", 6, 5, 3
+        log_n, primes, size_p = primes_of(name)
+        n = 1 << log_n
+        size_q = len(primes) - size_p
+        dev = torch.device("cuda:0")
+        ctx = P.PhantomContext(log_n, list(primes), size_p, device=dev)
+        r = rng_for(4242)                                   # same stream in every rank: inputs are common knowledge ...
+        ct3 = np.stack([np.stack([uniform_poly(r, primes[:ql], n) for _ in range(3)]) for _ in range(batch)])
+        keys = [np.stack([uniform_poly(r, primes, n), uniform_poly(r, primes, n)]) for _ in range(2 * (size_q // size_p))]
+        host = [torch.from_numpy(k.view(np.int64)) if rank == 0 else torch.zeros((2, len(primes), n), dtype=torch.int64) for k in keys]
+        pd.broadcast_keys(host, src=0)                      # ... the keys are not: ranks > 0 only have them after this
+        d_keys = [h.to(dev) for h in host]
+        half = len(d_keys) // 2
+        rlk, glk = P.PhantomRelinKey(d_keys[:half]), P.PhantomRelinKey(d_keys[half:])
+        mine, res = W.relinearize_rotate_sharded(ctx, ql, P.to_device(ct3, dev), rlk, glk, elt, O.BFV)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (list(mine), P.to_host(res)))
+        if rank == 0:
+            idx = sum((g[0] for g in gathered), [])
+            got = np.concatenate([g[1] for g in gathered])
+            oc = oracle_ctx(name)
+            tool = O.Tool(oc, ql)
+            ok = idx == list(range(batch))
+            for b in range(batch):
+                ct = tool.keyswitch_inplace(ct3[b, :2], ct3[b, 2], [keys[i] for i in range(tool.beta)], O.BFV)
+                g = [oc.apply_galois_coeff(ct[p], elt, ql) for p in range(2)]
+                want = tool.keyswitch_inplace(np.stack([g[0], np.zeros_like(g[0])]), g[1], [keys[half + i] for i in range(tool.beta)], O.BFV)
+                ok = ok and np.array_equal(got[b], want)
+            q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_real_context_reproduce_the_oracle(gpu):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_workload_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok
