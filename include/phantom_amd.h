@@ -367,8 +367,12 @@ int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint6
  *      prime (FP64 path off); bit 4: on-the-fly twiddles in the contiguous pass; bit 5: bit 4 automatically for
  *      launches of >= 1024 tiles; bit 6: one wavefront per workgroup in the contiguous pass; bit 7: N = 4096 / 8192
  *      through the two-pass plans instead of the one-launch ones; bit 8: the one-launch plan at N = 8192 for every
- *      launch size (default: from 64 limb-polynomials); default 1|32|64); key 1 = base-conversion MAC (1: carry-free split
- *      accumulators, 0: 128-bit carry chain).  Results are identical for every setting. ---- */
+ *      launch size (default: from 64 limb-polynomials), bit 9 / bit 10 = always / never both NTT passes in one launch (hand-off through the
+ *      XCD's L2; r02: slower than two launches, off by default); default 1|32|64); key 1 = base-conversion MAC (1: carry-free split
+ *      accumulators, 0: 128-bit carry chain); key 2 = limb-polynomials per launch from which N = 2^14 takes its one-workgroup plan
+ *      (default: never); keys 3 / 4 / 5 = lag, minimum tiles and split form of the one-launch transform.  Results are identical for every
+ *      setting.  The knobs are PROCESS-GLOBAL (they change kernel selection for every context and thread): a development aid for the
+ *      parity tests and the measurements, not something a concurrent caller should flip. ---- */
 int pha_set_tuning(int key, int value);
 
 /* ---- measurement hook used by bench.py: time `iters` back-to-back launches of the forward NTT
