@@ -375,6 +375,12 @@ int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint6
  *      parity tests and the measurements, not something a concurrent caller should flip. ---- */
 int pha_set_tuning(int key, int value);
 
+/* ---- measurement hook used by bench.py: enqueue `repeats` back-to-back forward transforms of a batch of polynomials
+ *      (pha_nwt_2d_radix8_forward_inplace_batched `repeats` times) from C, so that a timed region of K steps holds the
+ *      2 K kernel launches and no per-step host work. ---- */
+int pha_repeat_forward_ntt_batched(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, size_t start_modulus_idx,
+                                   size_t batch, size_t poly_stride, int repeats, void *stream);
+
 /* ---- measurement hook used by bench.py: time `iters` back-to-back launches of the forward NTT
  *      with hipEvents on `stream`; returns average milliseconds per launch in *ms_out. ---- */
 int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, int iters,

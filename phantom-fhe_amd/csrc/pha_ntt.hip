@@ -814,6 +814,21 @@ int pha_set_tuning(int key, int value) {
     PHA_API_END
 }
 
+// measurement helper: `repeats` back-to-back forward transforms of the batch, enqueued from C (no per-step host work
+// between the launches), nothing else
+int pha_repeat_forward_ntt_batched(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start, size_t batch,
+                                   size_t poly_stride, int repeats, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(inout);
+    if (batch == 0 || batch > 65535) throw std::invalid_argument("batch out of range");
+    NttExtra x;
+    x.batch = (uint32_t)batch;
+    x.poly_stride = poly_stride;
+    for (int i = 0; i < repeats; i++)
+        ntt_forward(ctx->c, inout, inout, inout, plain_sel(start, cms), EPI_FWD_CANON, x, as_stream(stream));
+    PHA_API_END
+}
+
 int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t cms, int iters, void *stream, float *ms_out) {
     PHA_CTX_BEGIN(ctx)
     need(inout);

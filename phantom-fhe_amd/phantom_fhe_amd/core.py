@@ -376,6 +376,10 @@ class PhantomContext:
                                                           batch, int(bool(ntt_form)), _stream()))
 
     # -- measurement ------------------------------------------------------------------------------
+    def repeat_forward_ntt_batched(self, inout, cms, start, batch, poly_stride, repeats):
+        """`repeats` back-to-back batched forward transforms enqueued from C (bench.py's timed region)."""
+        _lib.check(self._L.pha_repeat_forward_ntt_batched(self._h, _ptr(inout), cms, start, batch, poly_stride, repeats, _stream()))
+
     def time_forward_ntt(self, inout, cms, iters):
         ms = C.c_float()
         _lib.check(self._L.pha_time_forward_ntt(self._h, _ptr(inout), cms, iters, _stream(), C.byref(ms)))

@@ -99,6 +99,7 @@ _SIGS = {
     "pha_apply_galois_for_keyswitch": [vp, vp, vp, vp, C.c_uint32, sz, sz, C.c_int, vp],
     "pha_set_tuning": [C.c_int, C.c_int],
     "pha_time_forward_ntt": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)],
+    "pha_repeat_forward_ntt_batched": [vp, vp, sz, sz, sz, sz, C.c_int, vp],
 }
 _SPECIAL = {
     "pha_last_error": (C.c_char_p, []),
