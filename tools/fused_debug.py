@@ -1,4 +1,7 @@
-"""Debug aid for the one-launch NTT (PHA_FUSED_DEBUG build, PHA_LIB_OVERRIDE=tools/libphantom_dbg.so): counts workgroups
+"""Debug aid for the one-launch NTT.  Build the instrumented library first (it is not part of the normal build):
+  cd phantom-fhe_amd/csrc && for f in *.hip; do hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DPHA_FUSED_DEBUG -c $f -o /tmp/dbg_${f%.hip}.o; done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libphantom_dbg.so /tmp/dbg_*.o
+then run with PHA_LIB_OVERRIDE=$PWD/tools/libphantom_dbg.so.  It counts workgroups
 whose XCC_ID differs from blockIdx.x % 8 and polls that ran out, for eager launches and for a hipGraph replay."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
