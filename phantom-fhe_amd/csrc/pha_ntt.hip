@@ -13,8 +13,8 @@
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096 through the two-pass plans too (default: the whole transform in one launch), bit 8 = the one-workgroup plans of N = 8192 / 16384 for every launch size, bit 9 = both passes in one launch (L2 hand-off) for every launch size, bit 10 = never
-std::atomic<int> g_ntt_variant{1 | 32 | 64};  // default: 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles
+// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096 through the two-pass plans too (default: the whole transform in one launch), bit 8 = the one-workgroup plans of N = 8192 / 16384 for every launch size, bit 9 = both passes in one launch (L2 hand-off) for every launch size, bit 10 = never, bit 11 = polynomial-fastest, XCD-grouped block order in the contiguous pass of batched launches
+std::atomic<int> g_ntt_variant{1 | 32 | 64 | 2048};  // default: 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles of fewer than 4 polynomials, polynomial-fastest block order in batched contiguous passes
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_wg_times[2048];
@@ -48,6 +48,9 @@ struct NttKArgs {
     uint32_t excl_step, excl_limit, excl_mod;
     const u64 *pro_src;      // rescale prologue: every limb of polynomial z reads pro_src + z * pro_stride instead
     size_t pro_stride;
+    // batched launches, polynomial-fastest order: a 1-D grid in which the `batch` polynomials of one (tile, limb) run back to
+    // back on ONE XCD (block b -> XCD b % 8), so that the twiddle rows they share are fetched into that L2 once
+    uint32_t zfast_tiles;    // 0 = plain 3-D grid (tile, limb, polynomial); else tiles per limb of the 1-D form
 };
 
 // Per-tile arguments of limb `twr` (absolute limb index in the buffer), tile `tile`.
@@ -170,10 +173,19 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *lds = reinterpret_cast<u64 *>(smem);
 
-    const uint32_t twr = k.sel.start + blockIdx.y;  // limb in the buffer (uniform)
-    if (limb_excluded(k, twr, blockIdx.z)) return;
+    uint32_t tile = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (k.zfast_tiles) {
+        const uint32_t b = blockIdx.x, q = b >> 3;
+        z = q % k.batch;
+        const uint32_t group = (q / k.batch) * 8 + (b & 7u);
+        if (group >= k.zfast_tiles * k.sel.count) return;
+        tile = group % k.zfast_tiles;
+        y = group / k.zfast_tiles;
+    }
+    const uint32_t twr = k.sel.start + y;  // limb in the buffer (uniform)
+    if (limb_excluded(k, twr, z)) return;
     PassArgs a;
-    full_tile_args<C, FWD, EPI, FOLD>(k, twr, blockIdx.z, blockIdx.x, a);
+    full_tile_args<C, FWD, EPI, FOLD>(k, twr, z, tile, a);
 #if defined(PHA_EXP_STAMPS)
     const unsigned long long wg_t0 = wall_clock64();
 #endif
@@ -338,6 +350,13 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     const unsigned tiles_per_limb = (unsigned)(n >> C::LOGTILE);
     // (a persistent software-pipelined form was measured and dropped: DESIGN.md section 7)
     dim3 grid(tiles_per_limb, k.sel.count, k.batch);
+    NttKArgs kk = k;
+    kk.zfast_tiles = 0;   // (k.zfast_tiles is only the caller's request flag)
+    if (!C::STRIDED && !C::WHOLE && k.zfast_tiles) {
+        kk.zfast_tiles = tiles_per_limb;
+        const unsigned groups = tiles_per_limb * k.sel.count;
+        grid = dim3(((groups + 7) / 8) * 8 * k.batch, 1, 1);
+    }
     // (requesting all rounds' twiddles up front, HOIST 1, was measured again in r02 for the small launches of mod-down and
     //  rescale: no gain at any size)
     if (lds_bytes > 64 * 1024) {   // beyond the default dynamic LDS limit: raise it once per kernel and device
@@ -351,14 +370,16 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
             raised.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, k);
+    hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, kk);
     check_launch();
 }
 
 template <class PS, class PC, bool FWD, int EPI, bool FOLD>
-static bool launch_fused(Context &c, const NttKArgs &kA, const NttKArgs &kB, hipStream_t s) {
+static bool launch_fused(Context &c, const NttKArgs &kA_in, const NttKArgs &kB_in, hipStream_t s) {
     static_assert(PS::THREADS == 512 && PS::LOGTILE == 12, "strided pass: one 4096-coefficient tile per 512-thread workgroup");
+    NttKArgs kA = kA_in, kB = kB_in;
     const size_t n = (size_t)1 << kA.log_n;
+    kA.zfast_tiles = kB.zfast_tiles = 0;   // (the request flag of the two-launch form means nothing here)
     FusedArgs f{};
     f.count = kA.sel.count;
     f.units = kA.sel.count * kA.batch;
@@ -520,8 +541,14 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
     // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
-    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
+    // bit 11 (default): batched launches run the polynomials of a (tile, limb) back to back on one XCD, which then fetches the
+    // twiddle rows they share once; from 4 polynomials per launch that beats forming the last round's twiddles on the fly
+    // (measured r02: +4.6 % on 16 x 45 limbs at N = 2^16; -3 % on the 16-polynomial launches of config 4 at N = 2^15 and on the
+    // 2- / 3-polynomial launches of a key switch, hence the size rule)
+    const bool shared_tables = (vv & 2048) && (x.batch ? x.batch : 1) >= 8 && tiles >= 8192;
+    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024 && !shared_tables), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
+    k.zfast_tiles = shared_tables ? 1u : 0u;   // request: launch_pass turns it into the tile count of the contiguous pass
     // both passes in one launch (hand-off through the XCD's L2): launches of >= g_fused_min_tiles tiles (bit 9: every
     // launch; bit 10: never), only where workgroup b is known to run on XCD b % 8
     Context *const fz = (c.xcd_round_robin && wave && !(vv & 1024) &&
@@ -563,8 +590,14 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
     // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
     const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
-    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024), wave = (vv & 64) && (vv & 1);
+    // bit 11 (default): batched launches run the polynomials of a (tile, limb) back to back on one XCD, which then fetches the
+    // twiddle rows they share once; from 4 polynomials per launch that beats forming the last round's twiddles on the fly
+    // (measured r02: +4.6 % on 16 x 45 limbs at N = 2^16; -3 % on the 16-polynomial launches of config 4 at N = 2^15 and on the
+    // 2- / 3-polynomial launches of a key switch, hence the size rule)
+    const bool shared_tables = (vv & 2048) && (x.batch ? x.batch : 1) >= 8 && tiles >= 8192;
+    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024 && !shared_tables), wave = (vv & 64) && (vv & 1);
     const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
+    k.zfast_tiles = shared_tables ? 1u : 0u;   // request: launch_pass turns it into the tile count of the contiguous pass
     // both passes in one launch (hand-off through the XCD's L2): launches of >= g_fused_min_tiles tiles (bit 9: every
     // launch; bit 10: never), only where workgroup b is known to run on XCD b % 8
     Context *const fz = (c.xcd_round_robin && wave && !(vv & 1024) &&
@@ -793,7 +826,7 @@ int pha_exp_read_wg_times(unsigned long long *out) {
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
-        if (value < 0 || value > 2047 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
+        if (value < 0 || value > 4095 || (value & 6)) throw std::invalid_argument("unknown NTT variant");
         g_ntt_variant.store(value);
     } else if (key == 1) {
         g_bconv_split.store(value ? 1 : 0);

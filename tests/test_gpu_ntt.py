@@ -41,15 +41,17 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
 
 # 353 / 361: bit 8 forces the one-launch plans of N = 8192 and N = 16384 for every launch size
 # 609 / 617 / 625: bit 9 sends every launch through the one-launch form (both passes in one kernel, L2 hand-off)
-@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361, 609, 617, 625, 1121],
+# 2145: the default (bit 11: polynomial-fastest block order in batched contiguous passes)
+@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361, 609, 617, 625, 1121, 2145],
                 ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave",
-                     "two-pass-4096", "one-launch-8192-16384", "one-launch-8192-16384-int", "fused", "fused-int", "fused-ot", "never-fused"])
+                     "two-pass-4096", "one-launch-8192-16384", "one-launch-8192-16384-int", "fused", "fused-int", "fused-ot", "never-fused",
+                     "default"])
 def ntt_variant(request):
     """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
     import phantom_fhe_amd as P
     P.set_tuning(0, request.param)
     yield request.param
-    P.set_tuning(0, 1 | 32 | 64)
+    P.set_tuning(0, 1 | 32 | 64 | 2048)
 
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
@@ -365,5 +367,31 @@ def test_one_launch_transform_lags_and_batches(name, batch, lag, gpu):
             ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
             assert np.array_equal(P.to_host(d), x)
     finally:
-        P.set_tuning(0, 1 | 32 | 64)
+        P.set_tuning(0, 1 | 32 | 64 | 2048)
         P.set_tuning(3, 2)
+
+
+@pytest.mark.parametrize("name,batch", [("c2_ntt14", 5), ("c4_bfv15", 3), ("c3_ckks16", 4)])
+def test_batched_launches_in_both_block_orders(name, batch, gpu):
+    """The polynomial-fastest, XCD-grouped block order of batched contiguous passes (default) against the plain 3-D grid:
+    identical results, forward and inverse, batch sizes on both sides of the on-the-fly-twiddle rule."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L = len(primes)
+    x = np.stack([uniform_poly(rng_for(400 + z), primes, n) for z in range(batch)])
+    outs = []
+    try:
+        for variant in (1 | 32 | 64, 1 | 32 | 64 | 2048):
+            P.set_tuning(0, variant)
+            d = P.to_device(x, gpu)
+            ctx.nwt_2d_radix8_forward_inplace_batched(d, L, 0, batch, L * n)
+            outs.append(P.to_host(d))
+            ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
+            assert np.array_equal(P.to_host(d), x)
+    finally:
+        P.set_tuning(0, 1 | 32 | 64 | 2048)
+    assert np.array_equal(outs[0], outs[1])
+    for z in range(batch):
+        assert np.array_equal(outs[1][z], oc.nwt_forward(x[z], L, 0))

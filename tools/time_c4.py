@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "phantom-fhe_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import phantom_fhe_amd as P
+for _kv in filter(None, os.environ.get("PHA_TUNING", "").split(",")):
+    P.set_tuning(int(_kv.split("=")[0]), int(_kv.split("=")[1]))
 from phantom_fhe_amd import workloads as W
 from util import primes_of
 
