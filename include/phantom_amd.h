@@ -254,6 +254,17 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
  * base-conversion launches are batch times larger (the throughput regime of the kernels). */
 int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2, size_t batch,
                                   const uint64_t *const *rlk, int scheme, void *stream);
+
+/* Build-defined fusion (no reference launcher): key switch followed by the CKKS rescale, i.e. the relinearize -> rescale_to_next
+ * pair of src/evaluate.cu:1029-1075,1376-1427 (keyswitch_inplace eval_key_switch.cu:95-182 then divide_and_round_q_last_ntt
+ * rns.cu:1160-1184) as ONE call: dst [2][Ql-1][N] = rescale(ct + keyswitch(c2)), bit-identical to the two calls.  ct [2][Ql][N]
+ * (NTT form) and c2 [Ql][N] are only read; dst must not overlap them.  The mod-down's forward transform over 2 x Ql limbs and
+ * the rescale's own last-limb inverse disappear (NTT is linear: both subtractions ride on one forward transform).  ckks only. */
+int pha_keyswitch_rescale(pha_context_t ctx, size_t size_Ql, const uint64_t *ct, const uint64_t *c2,
+                          const uint64_t *const *rlk, uint64_t *dst, void *stream);
+/* the same for `batch` ciphertexts ct [batch][2][Ql][N], c2 [batch][Ql][N] -> dst [batch][2][Ql-1][N] against one key */
+int pha_keyswitch_rescale_batched(pha_context_t ctx, size_t size_Ql, const uint64_t *ct, const uint64_t *c2, size_t batch,
+                                  const uint64_t *const *rlk, uint64_t *dst, void *stream);
 /* tensor_prod_2x2_rns_poly for `batch` ciphertext pairs in the layout above: operands [batch][2][L][N],
  * res01 [batch][2][L][N] receives (c0, c1), res2 [batch][L][N] receives c2; res01 may alias operand1 */
 int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *operand1, const uint64_t *operand2, uint64_t *res01,
@@ -361,30 +372,6 @@ int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *d
    ntt_form != 0: NTT-domain permutation (ckks / bgv); 0: coefficient-domain with sign (bfv). */
 int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint64_t *dst_ct, uint64_t *dst_c2,
                                    uint32_t galois_elt, size_t size_Ql, size_t batch, int ntt_form, void *stream);
-
-/* ---- tuning knob for A/B measurements: key 0 = NTT thread geometry (0: 16 coefficients per thread,
- *      256-thread workgroups; bit 0: 8 per thread, 512-thread workgroups; bit 3: integer butterflies for every
- *      prime (FP64 path off); bit 4: on-the-fly twiddles in the contiguous pass; bit 5: bit 4 automatically for
- *      launches of >= 1024 tiles; bit 6: one wavefront per workgroup in the contiguous pass; bit 7: N = 4096 / 8192
- *      through the two-pass plans instead of the one-launch ones; bit 8: the one-launch plan at N = 8192 for every
- *      launch size (default: from 64 limb-polynomials), bit 9 / bit 10 = always / never both NTT passes in one launch (hand-off through the
- *      XCD's L2; r02: slower than two launches, off by default); default 1|32|64); key 1 = base-conversion MAC (1: carry-free split
- *      accumulators, 0: 128-bit carry chain); key 2 = limb-polynomials per launch from which N = 2^14 takes its one-workgroup plan
- *      (default: never); keys 3 / 4 / 5 = lag, minimum tiles and split form of the one-launch transform.  Results are identical for every
- *      setting.  The knobs are PROCESS-GLOBAL (they change kernel selection for every context and thread): a development aid for the
- *      parity tests and the measurements, not something a concurrent caller should flip. ---- */
-int pha_set_tuning(int key, int value);
-
-/* ---- measurement hook used by bench.py: enqueue `repeats` back-to-back forward transforms of a batch of polynomials
- *      (pha_nwt_2d_radix8_forward_inplace_batched `repeats` times) from C, so that a timed region of K steps holds the
- *      2 K kernel launches and no per-step host work. ---- */
-int pha_repeat_forward_ntt_batched(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, size_t start_modulus_idx,
-                                   size_t batch, size_t poly_stride, int repeats, void *stream);
-
-/* ---- measurement hook used by bench.py: time `iters` back-to-back launches of the forward NTT
- *      with hipEvents on `stream`; returns average milliseconds per launch in *ms_out. ---- */
-int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, int iters,
-                         void *stream, float *ms_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,29 @@
+/* phantom_amd_bench.h -- measurement hooks of libphantom_amd.so used by bench.py and tools/ only.
+ *
+ * Not part of the drop-in boundary (include/phantom_amd.h): no reference launcher corresponds to them.  They exist so that a
+ * timed region can hold nothing but kernel launches of the product path. */
+#ifndef PHANTOM_AMD_BENCH_H
+#define PHANTOM_AMD_BENCH_H
+#include "phantom_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enqueue `repeats` back-to-back forward transforms of a batch of polynomials (pha_nwt_2d_radix8_forward_inplace_batched
+ * `repeats` times) from C, so that a timed region of K steps holds the 2 K kernel launches and no per-step host work */
+int pha_repeat_forward_ntt_batched(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, size_t start_modulus_idx,
+                                   size_t batch, size_t poly_stride, int repeats, void *stream);
+
+/* time `iters` back-to-back launches of the forward NTT with hipEvents on `stream`; average milliseconds per launch in *ms_out */
+int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, int iters,
+                         void *stream, float *ms_out);
+
+/* device-to-device streaming copy of `bytes` bytes (a multiple of 16) with the library's own 16-byte-per-lane kernel, `iters`
+ * times, timed with hipEvents on `stream`: bytes moved per second (read + write) in *bytes_per_s.  The calibrated counterpart of
+ * the nominal 8 TB/s that the roofline object quotes beside it. */
+int pha_time_stream_copy(uint64_t *dst, const uint64_t *src, size_t bytes, int iters, void *stream, double *bytes_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -181,11 +181,17 @@ static void build_prime_tables(Context &c, uint32_t row, uint32_t i, std::vector
     }
 }
 
+#if defined(PHA_EXPERIMENTS)
+// (experiments library only: the one-launch NTT needs it; the product library neither launches the census nor allocates counters)
 // XCD placement census: the first workgroup of each class b % 8 records its XCC_ID, the others compare
 __global__ void xcd_census_kernel(uint32_t *cls, uint32_t *mismatch) {
     if (threadIdx.x == 0) {
         uint32_t id;
+#if defined(__gfx942__) || defined(__gfx950__)
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+#else
+        id = blockIdx.x;   // no XCC_ID register: report the classes as if round-robin placement held (one die)
+#endif
         const uint32_t mine = (id & 7u) + 1;
         const uint32_t seen = atomicCAS(cls + (blockIdx.x & 7u), 0u, mine);
         if (seen != 0 && seen != mine) atomicAdd(mismatch, 1u);
@@ -202,10 +208,24 @@ static bool xcd_placement_is_round_robin() {
     }
     uint32_t h[9];
     PHA_HIP(hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost));
-    bool distinct = true;   // eight classes on eight different XCDs (a device with fewer XCDs would share them: still fine)
-    (void)distinct;
     return h[8] == 0;
 }
+
+// Lazily, the first time the one-launch transform is asked for (pha_set_tuning key 0 bit 9 / key 4): three census launches on
+// the null stream and the counter pool.  Not to be triggered inside a stream capture.
+bool Context::xcd_placement_round_robin() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (xcd_checked) return xcd_round_robin;
+    DeviceGuard on_device(device);
+    xcd_round_robin = xcd_placement_is_round_robin();
+    if (xcd_round_robin) {
+        flag_pool.alloc(Context::kFlagArenas * (2 * Context::kFlagUnits + 16));
+        PHA_HIP(hipMemset(flag_pool.p, 0, flag_pool.count * sizeof(uint32_t)));
+    }
+    xcd_checked = true;
+    return xcd_round_robin;
+}
+#endif  // PHA_EXPERIMENTS
 
 static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uint32_t size_qp, uint32_t size_p,
                          int device) {
@@ -217,11 +237,6 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
         hipDeviceProp_t prop;
         PHA_HIP(hipGetDeviceProperties(&prop, device));
         c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    c.xcd_round_robin = xcd_placement_is_round_robin();
-    if (c.xcd_round_robin) {
-        c.flag_pool.alloc(Context::kFlagArenas * (2 * Context::kFlagUnits + 16));
-        PHA_HIP(hipMemset(c.flag_pool.p, 0, c.flag_pool.count * sizeof(uint32_t)));
     }
     c.log_n = log_n;
     c.n = (size_t)1 << log_n;
@@ -273,8 +288,6 @@ static void context_init(Context &c, uint32_t log_n, const uint64_t *primes, uin
     c.d_fpinfo.upload(fp.info);
     c.rows = size_qp;
 }
-
-void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
 
 // Append auxiliary moduli to the context's prime / table arrays: `ntt_primes` get full NTT tables, then one more
 // modulus without tables (m_tilde = 2^32 of BEHZ).  Returns the row of the first one.  Nothing may be in flight.
@@ -679,7 +692,10 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
     b.d_oprime.upload(op);
 }
 
-void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op) {
+// out_scale (optional, [osz]): row j of the matrix is multiplied by out_scale[j] mod p_j, i.e. the converter delivers
+// out_scale[j] * (converted value) mod p_j at no extra cost (pha_keyswitch_rescale: P^-1 mod q_j)
+void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
+                 const std::vector<u64> *out_scale) {
     const uint32_t isz = (uint32_t)ip.size(), osz = (uint32_t)op.size();
     std::vector<u64x2> hat_inv(isz);
     for (uint32_t i = 0; i < isz; i++) {
@@ -694,7 +710,7 @@ void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const st
     for (uint32_t j = 0; j < osz; j++) {
         const u64 pj = c.primes[op[j]];
         for (uint32_t i = 0; i < isz; i++) {
-            u64 h = 1;
+            u64 h = out_scale ? (*out_scale)[j] % pj : 1;
             for (uint32_t k = 0; k < isz; k++)
                 if (k != i) h = h_mulmod(h, c.primes[ip[k]] % pj, pj);
             mat[(size_t)j * isz + i] = h;
@@ -798,6 +814,7 @@ Tool &Context::tool(uint32_t size_ql) {
         for (uint32_t i = 0; i < size_p; i++) ip.push_back(size_q + i);
         for (uint32_t i = 0; i < size_ql; i++) op.push_back(i);
         build_bconv(*this, t->p_to_ql, ip, op);
+        build_bconv(*this, t->p_to_ql_pinv, ip, op, &v);   // the same converter delivering P^-1 * (.) mod q_j (key switch + rescale)
         {   // the P -> Ql converter's phase-1 factors, addressable by the limb index of a [Ql || P] buffer
             std::vector<u64x2> hi(size_p);
             PHA_HIP(hipMemcpy(hi.data(), t->p_to_ql.hat_inv.p, size_p * sizeof(u64x2), hipMemcpyDeviceToHost));
@@ -819,6 +836,7 @@ Tool &Context::tool(uint32_t size_ql) {
         }
         t->d_digit_convs.upload(dd);
         t->d_p_to_ql_conv.upload({describe(t->p_to_ql, 0xffffffffu, 0, size_ql, 0)});
+        t->d_p_to_ql_pinv_conv.upload({describe(t->p_to_ql_pinv, 0xffffffffu, 0, size_ql, 0)});
         t->split_ok = true;
         for (uint32_t i = 0; i < t->size_qlp; i++)
             if (primes[t->qlp_prime[i]] >> 60) t->split_ok = false;

@@ -141,7 +141,8 @@ struct Tool {
     DevBuf<u64> part_hat_inv, part_hat_inv_shoup;  // partQlHatInv_mod_Ql_concat (rns.cu:152-182)
     std::vector<BConv> digit;                      // part Ql -> complement of QlP, per digit
     BConv p_to_ql;                                 // base_P_to_Ql_conv (rns.cu:196-198)
-    DevBuf<BConvDev> d_digit_convs, d_p_to_ql_conv; // device descriptors used by the batched launches
+    BConv p_to_ql_pinv;                            // the same with every output row pre-multiplied by P^-1 mod q_j
+    DevBuf<BConvDev> d_digit_convs, d_p_to_ql_conv, d_p_to_ql_pinv_conv; // device descriptors used by the batched launches
     bool split_ok = false;                         // every prime <= 60 bits: carry-free split MAC is valid
     DevBuf<u64> pinv, pinv_shoup;                  // bigPInv_mod_q (rns.cu:110-123)
     DevBuf<u64> inv_q_last, inv_q_last_shoup;      // rns.cu:66-80
@@ -264,7 +265,8 @@ struct Context {
     uint32_t *ntt_flags(void *stream, size_t units);   // null: no arena left or too many units (caller takes two launches)
     // do all workgroups b of a 1-D grid with the same b % 8 run on one XCD?  (observed placement, checked once per
     // context by a census launch and again inside every one-launch NTT, which needs it and is disabled without it)
-    bool xcd_round_robin = false;
+    bool xcd_round_robin = false, xcd_checked = false;
+    bool xcd_placement_round_robin();              // (experiments library) census + counter pool on first use
     const uint32_t *galois_table(uint32_t elt);
 };
 
@@ -301,6 +303,9 @@ inline LimbSel special_sel(size_t start, size_t count, size_t size_QP, size_t si
 struct NttExtra {
     const u64 *scale = nullptr, *scale_shoup = nullptr;  // indexed by absolute limb
     const u64 *aux = nullptr;                            // fuse_moddown: cx base
+    const u64 *aux2 = nullptr;                           // EPI_FWD_KSRESCALE: ct base, with its own polynomial stride
+    const u64 *scale2 = nullptr, *scale2_shoup = nullptr; //   and PInv per limb
+    size_t aux2_stride = 0;
     uint32_t batch = 1;                                  // polynomials per launch (blockIdx.z)
     size_t poly_stride = 0;                              // elements between consecutive polynomials of in / mid
     size_t out_stride = 0, aux_stride = 0;               // same for out and aux (0 = poly_stride)
@@ -329,7 +334,8 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
                   const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0,
                   const BConvEpilogue *epi = nullptr);
 // converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)
-void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
+void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
+                 const std::vector<u64> *out_scale = nullptr);
 void build_bconv_var1(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
 void describe_conv(const BConv &b, DevBuf<BConvDev> &out);
 void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,

@@ -7,23 +7,40 @@
 // (canonicalise / fused mod-down / scale), instead of 25 hand-copied kernels.
 #include "../../include/phantom_amd.h"
 #include "pha_internal.h"
+#include "pha_experiments.h"
 #include "pha_ntt_core.h"
 
 #include <atomic>
 
 namespace pha {
 
-// tuning knob (pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096 through the two-pass plans too (default: the whole transform in one launch), bit 8 = the one-workgroup plans of N = 8192 / 16384 for every launch size, bit 9 = both passes in one launch (L2 hand-off) for every launch size, bit 10 = never, bit 11 = polynomial-fastest, XCD-grouped block order in the contiguous pass of batched launches
-std::atomic<int> g_ntt_variant{1 | 32 | 64 | 2048};  // default: 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles of fewer than 4 polynomials, polynomial-fastest block order in batched contiguous passes
+// Kernel selection.  The product library holds ONE plan per degree and launch size (constants below, chosen from the r01 / r02
+// sweeps); every other geometry that was built and measured (16 coefficients per thread, 512-thread contiguous passes, the
+// one-workgroup N = 2^14 plan, both passes in one launch with the L2 hand-off, ...) lives behind -DPHA_EXPERIMENTS in the test-only
+// library libphantom_amd_exp.so (csrc/pha_experiments.h: pha_set_tuning), because the extra instantiations alone cost ~30 us per
+// key switch when they sat in the product code object.
+// Variant bits (experiments build: pha_set_tuning key 0): bit 0 = 8 coefficients/thread (else 16), bit 3 = integer butterflies for
+// every prime (FP64 path off), bit 4 = on-the-fly twiddles in the contiguous pass (implies bit 0), bit 5 = bit 4 automatically for
+// launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096
+// through the two-pass plans too, bit 8 = the one-workgroup plans of N = 8192 / 16384 for every launch size, bit 9 / 10 = always /
+// never both passes in one launch (L2 hand-off), bit 11 = polynomial-fastest, XCD-grouped block order in the contiguous pass of
+// batched launches.
+constexpr int kDefaultVariant = 1 | 32 | 64 | 2048;   // 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles of fewer than 8 polynomials, polynomial-fastest block order in large batched contiguous passes
+#if defined(PHA_EXPERIMENTS)
+std::atomic<int> g_ntt_variant{kDefaultVariant};
+static inline int ntt_variant() { return g_ntt_variant.load(std::memory_order_relaxed); }
+std::atomic<int> g_whole14_min{1 << 30};     // key 2: limb-polynomials per launch from which N = 2^14 takes the one-workgroup plan (r02: never faster)
+std::atomic<int> g_fused_split{0};           // key 5: one pass per workgroup in the one-launch transform (r02: slower still)
+std::atomic<int> g_fused_lag{2};             // key 3: lag (in units per XCD) between the two passes of the one-launch transform
+std::atomic<int> g_fused_min_tiles{1 << 30}; // key 4: tiles per launch from which the two passes share one launch (r02: 7 % slower at every size)
+extern std::atomic<int> g_bconv_split;       // pha_rns.hip (key 1)
+#else
+static constexpr int ntt_variant() { return kDefaultVariant; }
+#endif
 #if defined(PHA_EXP_STAMPS)
 __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_wg_times[2048];
 #endif
-extern std::atomic<int> g_bconv_split;  // pha_rns.hip
-std::atomic<int> g_whole14_min{1 << 30};  // pha_set_tuning key 2: limb-polynomials per launch from which N = 2^14 takes the one-workgroup plan (r02: never faster than the alternatives, kept for tests)
-std::atomic<int> g_fused_split{0};        // pha_set_tuning key 5: one pass per workgroup in the one-launch transform (0: both passes in one workgroup; r02: the split form is slower still, 380-420 vs 345 us per step)
-std::atomic<int> g_fused_lag{2};          // pha_set_tuning key 3: lag (in units per XCD) between the two passes of the one-launch transform
-std::atomic<int> g_fused_min_tiles{1 << 30}; // pha_set_tuning key 4: tiles per launch from which the two passes share one launch (r02: 7 % slower than two launches at every size, DESIGN section 7: off by default, kept behind bit 9 and this threshold)    // pha_set_tuning key 2: limb-polynomials per launch from which N = 2^14 takes the one-launch plan
 
 struct NttKArgs {
     const u64 *in;
@@ -39,6 +56,9 @@ struct NttKArgs {
     const u64 *scale;        // [limb] or null
     const u64 *scale_shoup;  // [limb] or null
     const u64 *aux;          // fuse_moddown: cx base
+    const u64 *aux2;         // EPI_FWD_KSRESCALE: ct base; scale2 / scale2_shoup [limb]: PInv
+    const u64 *scale2, *scale2_shoup;
+    size_t aux2_stride;
     LimbSel sel;
     uint32_t log_n;
     uint32_t t1, t2;         // N = t1 * t2
@@ -85,11 +105,16 @@ __device__ __forceinline__ void tile_args(const NttKArgs &k, uint32_t twr, uint3
             }
         }
     }
-    if (EPI == EPI_INV_SCALE || EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) {
+    if (EPI == EPI_INV_SCALE || EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) {
         a.scale.x = k.scale[twr];
         a.scale.y = k.scale_shoup[twr];
     }
-    a.aux = (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) ? k.aux + (size_t)twr * n : nullptr;
+    a.aux = (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) ? k.aux + (size_t)twr * n : nullptr;
+    if (EPI == EPI_FWD_KSRESCALE) {
+        a.scale2.x = k.scale2[twr];
+        a.scale2.y = k.scale2_shoup[twr];
+        a.aux2 = k.aux2 + (size_t)twr * n;
+    }
 }
 
 #if defined(PHA_PASS_OCC)
@@ -119,7 +144,8 @@ __device__ __forceinline__ void full_tile_args(const NttKArgs &k, uint32_t twr, 
     if (k.batch > 1) {  // same limbs of several polynomials in one launch
         a.in += (size_t)z * k.poly_stride;
         a.out += (size_t)z * k.out_stride;
-        if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) a.aux += (size_t)z * k.aux_stride;
+        if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) a.aux += (size_t)z * k.aux_stride;
+        if (EPI == EPI_FWD_KSRESCALE) a.aux2 += (size_t)z * k.aux2_stride;
     }
     if (FWD && (C::STRIDED || C::WHOLE) && k.pro_src) {  // rescale prologue: transform (the last limb of polynomial z) mod this prime
         const uint32_t prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
@@ -201,6 +227,7 @@ __global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(cons
 #endif
 }
 
+#if defined(PHA_EXPERIMENTS)
 // ---- both passes in ONE launch, the intermediate handed over through the XCD's own L2 -------------------------------
 // (r02; tools/handoff_bench.hip is the memory-side experiment behind it: the two access patterns at 720 limbs take
 // 286 us as two launches and 211 us in this form, because the intermediate never crosses the fabric a second time.)
@@ -343,6 +370,8 @@ __global__ __launch_bounds__(512, PHA_FUSED_MIN_WAVES) void ntt_fused_kernel(con
     }
 }
 
+#endif  // PHA_EXPERIMENTS
+
 template <class C, bool FWD, int EPI, bool FOLD>
 static void launch_pass(const NttKArgs &k, hipStream_t s) {
     const size_t n = (size_t)1 << k.log_n;
@@ -374,6 +403,7 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     check_launch();
 }
 
+#if defined(PHA_EXPERIMENTS)
 template <class PS, class PC, bool FWD, int EPI, bool FOLD>
 static bool launch_fused(Context &c, const NttKArgs &kA_in, const NttKArgs &kB_in, hipStream_t s) {
     static_assert(PS::THREADS == 512 && PS::LOGTILE == 12, "strided pass: one 4096-coefficient tile per 512-thread workgroup");
@@ -410,6 +440,8 @@ static bool launch_fused(Context &c, const NttKArgs &kA_in, const NttKArgs &kB_i
     return true;
 }
 
+#endif  // PHA_EXPERIMENTS
+
 // N = 4096 / 8192 as ONE pass (the transform fits a tile): T1 = 1, T2 = N
 template <class W>
 static void forward_whole(NttKArgs k, int epi, hipStream_t s) {
@@ -418,6 +450,7 @@ static void forward_whole(NttKArgs k, int epi, hipStream_t s) {
     k.mid = k.out;
     if (epi == EPI_FWD_MODDOWN) launch_pass<W, true, EPI_FWD_MODDOWN, false>(k, s);
     else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<W, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
+    else if (epi == EPI_FWD_KSRESCALE) launch_pass<W, true, EPI_FWD_KSRESCALE, false>(k, s);
     else launch_pass<W, true, EPI_FWD_CANON, false>(k, s);
 }
 template <class W>
@@ -444,18 +477,23 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     k.out = final_out;
     k.out_stride = final_stride;
     k.pro_src = nullptr;   // the rescale prologue belongs to the first pass
+#if defined(PHA_EXPERIMENTS)
     if constexpr (P1::THREADS == 512 && P1::LOGTILE == 12 && P2::THREADS == 64) {
-        if (fused) {   // both passes in one launch
+        if (fused && epi != EPI_FWD_KSRESCALE) {   // both passes in one launch
             const bool done = epi == EPI_FWD_MODDOWN ? launch_fused<P1, P2, true, EPI_FWD_MODDOWN, false>(*fused, k1, k, s)
                               : epi == EPI_FWD_MODDOWN_ADD ? launch_fused<P1, P2, true, EPI_FWD_MODDOWN_ADD, false>(*fused, k1, k, s)
                                                            : launch_fused<P1, P2, true, EPI_FWD_CANON, false>(*fused, k1, k, s);
             if (done) return;
         }
     }
+#else
+    (void)fused;
+#endif
     launch_pass<P1, true, EPI_NONE, false>(k1, s);
     // pass 1 ran in -> mid with the input stride; pass 2 reads mid and writes out with the output stride
     if (epi == EPI_FWD_MODDOWN) launch_pass<P2, true, EPI_FWD_MODDOWN, false>(k, s);
     else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<P2, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
+    else if (epi == EPI_FWD_KSRESCALE) launch_pass<P2, true, EPI_FWD_KSRESCALE, false>(k, s);
     else launch_pass<P2, true, EPI_FWD_CANON, false>(k, s);
 }
 
@@ -473,6 +511,7 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     k.in = k.mid;
     k.out = final_out;
     k.out_stride = final_stride;
+#if defined(PHA_EXPERIMENTS)
     if constexpr (P1::THREADS == 512 && P1::LOGTILE == 12 && P2::THREADS == 64) {
         if (fused) {
             const bool done = epi == EPI_INV_SCALE ? launch_fused<P1, P2, false, EPI_INV_SCALE, true>(*fused, k1, k, s)
@@ -480,6 +519,9 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
             if (done) return;
         }
     }
+#else
+    (void)fused;
+#endif
     launch_pass<P2, false, EPI_NONE, false>(k1, s);
     if (epi == EPI_INV_SCALE) launch_pass<P1, false, EPI_INV_SCALE, true>(k, s);
     else launch_pass<P1, false, EPI_INV_CANON, true>(k, s);
@@ -495,7 +537,7 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.mod = c.d_mod.p;
     k.ninv = c.d_ninv.p;
     k.w1ninv = c.d_w1ninv.p;
-    const bool use_fp = !(g_ntt_variant.load(std::memory_order_relaxed) & 8);
+    const bool use_fp = !(ntt_variant() & 8);
     k.twf = fwd ? c.d_twf.p : c.d_itwf.p;
     k.ninvf = c.d_ninvf.p;
     k.w1ninvf = c.d_w1ninvf.p;
@@ -503,6 +545,10 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.scale = x.scale;
     k.scale_shoup = x.scale_shoup;
     k.aux = x.aux;
+    k.aux2 = x.aux2;
+    k.scale2 = x.scale2;
+    k.scale2_shoup = x.scale2_shoup;
+    k.aux2_stride = x.aux2_stride ? x.aux2_stride : x.poly_stride;
     k.sel = sel;
     k.log_n = c.log_n;
     k.batch = x.batch ? x.batch : 1;
@@ -532,51 +578,99 @@ static void check_sel(Context &c, const LimbSel &sel) {
     if (prime_last >= c.rows) throw std::invalid_argument("modulus index out of range of the NTT tables");
 }
 
+// What a launch of `count` limbs x `batch` polynomials takes (measured rules):
+//   * N = 4096: the whole transform in one launch; N = 8192: the same from 64 limb-polynomials per launch (one 512-thread
+//     workgroup per limb: 1 / 10 / 60 / 240 / 1020 limbs 10.4 / 10.8 / 11.5 / 13.7 / 53.8 us against 8.7 / 9.4 / 12.0 / 26.2 / 58.2
+//     in two passes);
+//   * otherwise two passes, 8 coefficients per thread, one-wavefront workgroups in the contiguous pass;
+//   * launches of >= 8 polynomials and >= 8192 tiles run the polynomials of a (tile, limb) back to back on one XCD, which then
+//     fetches the twiddle rows they share once (r02: +4.6 % on 16 x 45 limbs at N = 2^16; -3 % on the 16-polynomial launches of
+//     config 4 at N = 2^15 and on the 2- / 3-polynomial launches of a key switch, hence the size rule);
+//   * other launches of >= 1024 tiles (the memory-bound throughput regime) form the last round's twiddles on the fly; small ones
+//     are latency-bound and keep the table-driven last round (r01c).
+struct NttChoice {
+    int v;            // NttPlan variant of the two-pass form (product: 3 or 4)
+    int whole;        // 0: two passes; 12 / 13 / 14: the one-workgroup plan of that degree
+    bool zfast;       // polynomial-fastest block order in the contiguous pass
+    Context *fused;   // experiments: both passes in one launch
+};
+static inline bool has(int vv, int mask) { return (vv & mask) != 0; }
+static NttChoice choose_plan(Context &c, const LimbSel &sel, const NttExtra &x) {
+    const int vv = ntt_variant();
+    const size_t batch = x.batch ? x.batch : 1;
+    const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * batch, limb_polys = (size_t)sel.count * batch;
+    const bool shared_tables = has(vv, 2048) && batch >= 8 && tiles >= 8192;
+    const bool ot = has(vv, 16) || (has(vv, 32) && has(vv, 1) && tiles >= 1024 && !shared_tables), wave = has(vv, 64) && has(vv, 1);
+    NttChoice ch{ot ? (wave ? 4 : 2) : wave ? 3 : has(vv, 1), 0, shared_tables, nullptr};
+    if (c.log_n == 12 && !has(vv, 128)) ch.whole = 12;
+    if (c.log_n == 13 && !has(vv, 128) && (has(vv, 256) || limb_polys >= 64)) ch.whole = 13;
+#if defined(PHA_EXPERIMENTS)
+    if (c.log_n == 14 && !has(vv, 128) && (has(vv, 256) || limb_polys >= (size_t)g_whole14_min.load(std::memory_order_relaxed))) ch.whole = 14;
+    // both passes in one launch (hand-off through the XCD's L2): launches of >= g_fused_min_tiles tiles (bit 9: every
+    // launch; bit 10: never), only where workgroup b is known to run on XCD b % 8
+    if (c.xcd_placement_round_robin() && wave && !has(vv, 1024) &&
+        (has(vv, 512) || tiles >= (size_t)g_fused_min_tiles.load(std::memory_order_relaxed)))
+        ch.fused = &c;
+#endif
+    return ch;
+}
+
+// the two-pass plans of one degree: the product library instantiates variants 3 and 4 only (and nothing for N = 4096, which
+// always takes its one-launch plan there)
+template <int LOGN>
+static void forward_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream_t s) {
+#if defined(PHA_EXPERIMENTS)
+    switch (ch.v) {
+        case 4: forward_impl<LOGN, 4>(k, epi, s, ch.fused); return;
+        case 3: forward_impl<LOGN, 3>(k, epi, s, ch.fused); return;
+        case 2: forward_impl<LOGN, 2>(k, epi, s); return;
+        case 1: forward_impl<LOGN, 1>(k, epi, s); return;
+        default: forward_impl<LOGN, 0>(k, epi, s); return;
+    }
+#else
+    if constexpr (LOGN == 12) throw std::logic_error("N = 4096 has no two-pass plan in the product library");
+    else if constexpr (LOGN == 13) forward_impl<LOGN, 3>(k, epi, s);   // (below 64 limb-polynomials: never 1024 tiles)
+    else if (ch.v == 4) forward_impl<LOGN, 4>(k, epi, s);
+    else forward_impl<LOGN, 3>(k, epi, s);
+#endif
+}
+template <int LOGN>
+static void inverse_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream_t s) {
+#if defined(PHA_EXPERIMENTS)
+    switch (ch.v) {
+        case 4: inverse_impl<LOGN, 4>(k, epi, s, ch.fused); return;
+        case 3: inverse_impl<LOGN, 3>(k, epi, s, ch.fused); return;
+        case 2: inverse_impl<LOGN, 2>(k, epi, s); return;
+        case 1: inverse_impl<LOGN, 1>(k, epi, s); return;
+        default: inverse_impl<LOGN, 0>(k, epi, s); return;
+    }
+#else
+    if constexpr (LOGN == 12) throw std::logic_error("N = 4096 has no two-pass plan in the product library");
+    else if constexpr (LOGN == 13) inverse_impl<LOGN, 3>(k, epi, s);
+    else if (ch.v == 4) inverse_impl<LOGN, 4>(k, epi, s);
+    else inverse_impl<LOGN, 3>(k, epi, s);
+#endif
+}
+
 void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
                  hipStream_t s) {
     if (sel.count == 0) return;
     check_sel(c, sel);
     NttKArgs k = make_args(c, in, mid, out, sel, x, true);
-    const int vv = g_ntt_variant.load(std::memory_order_relaxed);
-    // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
-    // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
-    const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
-    // bit 11 (default): batched launches run the polynomials of a (tile, limb) back to back on one XCD, which then fetches the
-    // twiddle rows they share once; from 4 polynomials per launch that beats forming the last round's twiddles on the fly
-    // (measured r02: +4.6 % on 16 x 45 limbs at N = 2^16; -3 % on the 16-polynomial launches of config 4 at N = 2^15 and on the
-    // 2- / 3-polynomial launches of a key switch, hence the size rule)
-    const bool shared_tables = (vv & 2048) && (x.batch ? x.batch : 1) >= 8 && tiles >= 8192;
-    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024 && !shared_tables), wave = (vv & 64) && (vv & 1);
-    const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
-    k.zfast_tiles = shared_tables ? 1u : 0u;   // request: launch_pass turns it into the tile count of the contiguous pass
-    // both passes in one launch (hand-off through the XCD's L2): launches of >= g_fused_min_tiles tiles (bit 9: every
-    // launch; bit 10: never), only where workgroup b is known to run on XCD b % 8
-    Context *const fz = (c.xcd_round_robin && wave && !(vv & 1024) &&
-                         ((vv & 512) || tiles >= (size_t)g_fused_min_tiles.load(std::memory_order_relaxed))) ? &c : nullptr;
-    if (c.log_n == 12 && !(vv & 128)) {  // bit 7 clear (default): N = 4096 in one launch
-        forward_whole<WholePlan12>(k, epi, s);
-        return;
-    }
-    // N = 8192 in one launch pays from about 64 limb-polynomials per launch (one 512-thread workgroup per limb: 1 / 10 /
-    // 60 / 240 / 1020 limbs 10.4 / 10.8 / 11.5 / 13.7 / 53.8 us against 8.7 / 9.4 / 12.0 / 26.2 / 58.2 in two passes);
-    // bit 8 forces it for every size (tests)
-    if (c.log_n == 13 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= 64)) {
-        forward_whole<WholePlan13>(k, epi, s);
-        return;
-    }
-    // N = 16384 in one launch (one 1024-thread workgroup per limb, 144 KiB of LDS): from g_whole14_min limb-polynomials
-    // per launch (r02 sweep); bit 8 forces it for every size (tests), bit 7 keeps the two passes
-    if (c.log_n == 14 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= (size_t)g_whole14_min.load(std::memory_order_relaxed))) {
-        forward_whole<WholePlan14>(k, epi, s);
-        return;
-    }
+    const NttChoice ch = choose_plan(c, sel, x);
+    k.zfast_tiles = ch.zfast ? 1u : 0u;   // request: launch_pass turns it into the tile count of the contiguous pass
+    if (ch.whole == 12) return forward_whole<WholePlan12>(k, epi, s);
+    if (ch.whole == 13) return forward_whole<WholePlan13>(k, epi, s);
+#if defined(PHA_EXPERIMENTS)
+    if (ch.whole == 14) return forward_whole<WholePlan14>(k, epi, s);
+#endif
     switch (c.log_n) {
-        case 12: if (v == 4) forward_impl<12, 4>(k, epi, s, fz); else if (v == 3) forward_impl<12, 3>(k, epi, s, fz); else if (v == 2) forward_impl<12, 2>(k, epi, s); else if (v) forward_impl<12, 1>(k, epi, s); else forward_impl<12, 0>(k, epi, s); break;
-        case 13: if (v == 4) forward_impl<13, 4>(k, epi, s, fz); else if (v == 3) forward_impl<13, 3>(k, epi, s, fz); else if (v == 2) forward_impl<13, 2>(k, epi, s); else if (v) forward_impl<13, 1>(k, epi, s); else forward_impl<13, 0>(k, epi, s); break;
-        case 14: if (v == 4) forward_impl<14, 4>(k, epi, s, fz); else if (v == 3) forward_impl<14, 3>(k, epi, s, fz); else if (v == 2) forward_impl<14, 2>(k, epi, s); else if (v) forward_impl<14, 1>(k, epi, s); else forward_impl<14, 0>(k, epi, s); break;
-        case 15: if (v == 4) forward_impl<15, 4>(k, epi, s, fz); else if (v == 3) forward_impl<15, 3>(k, epi, s, fz); else if (v == 2) forward_impl<15, 2>(k, epi, s); else if (v) forward_impl<15, 1>(k, epi, s); else forward_impl<15, 0>(k, epi, s); break;
-        case 16: if (v == 4) forward_impl<16, 4>(k, epi, s, fz); else if (v == 3) forward_impl<16, 3>(k, epi, s, fz); else if (v == 2) forward_impl<16, 2>(k, epi, s); else if (v) forward_impl<16, 1>(k, epi, s); else forward_impl<16, 0>(k, epi, s); break;
-        case 17: if (v == 4) forward_impl<17, 4>(k, epi, s, fz); else if (v == 3) forward_impl<17, 3>(k, epi, s, fz); else if (v == 2) forward_impl<17, 2>(k, epi, s); else if (v) forward_impl<17, 1>(k, epi, s); else forward_impl<17, 0>(k, epi, s); break;
+        case 12: forward_two_pass<12>(k, epi, ch, s); break;
+        case 13: forward_two_pass<13>(k, epi, ch, s); break;
+        case 14: forward_two_pass<14>(k, epi, ch, s); break;
+        case 15: forward_two_pass<15>(k, epi, ch, s); break;
+        case 16: forward_two_pass<16>(k, epi, ch, s); break;
+        case 17: forward_two_pass<17>(k, epi, ch, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -586,41 +680,20 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
     if (sel.count == 0) return;
     check_sel(c, sel);
     NttKArgs k = make_args(c, in, mid, out, sel, x, false);
-    const int vv = g_ntt_variant.load(std::memory_order_relaxed);
-    // bit 5 (default): large launches (>= 1024 tiles: the memory-bound throughput regime) take the on-the-fly
-    // twiddle plan; small ones are latency-bound and keep the table-driven last round (r01c measurements)
-    const size_t tiles = ((size_t)c.n / kTileElems) * sel.count * (x.batch ? x.batch : 1);
-    // bit 11 (default): batched launches run the polynomials of a (tile, limb) back to back on one XCD, which then fetches the
-    // twiddle rows they share once; from 4 polynomials per launch that beats forming the last round's twiddles on the fly
-    // (measured r02: +4.6 % on 16 x 45 limbs at N = 2^16; -3 % on the 16-polynomial launches of config 4 at N = 2^15 and on the
-    // 2- / 3-polynomial launches of a key switch, hence the size rule)
-    const bool shared_tables = (vv & 2048) && (x.batch ? x.batch : 1) >= 8 && tiles >= 8192;
-    const bool ot = (vv & 16) || ((vv & 32) && (vv & 1) && tiles >= 1024 && !shared_tables), wave = (vv & 64) && (vv & 1);
-    const int v = ot ? (wave ? 4 : 2) : wave ? 3 : (vv & 1);
-    k.zfast_tiles = shared_tables ? 1u : 0u;   // request: launch_pass turns it into the tile count of the contiguous pass
-    // both passes in one launch (hand-off through the XCD's L2): launches of >= g_fused_min_tiles tiles (bit 9: every
-    // launch; bit 10: never), only where workgroup b is known to run on XCD b % 8
-    Context *const fz = (c.xcd_round_robin && wave && !(vv & 1024) &&
-                         ((vv & 512) || tiles >= (size_t)g_fused_min_tiles.load(std::memory_order_relaxed))) ? &c : nullptr;
-    if (c.log_n == 12 && !(vv & 128)) {
-        inverse_whole<WholePlan12>(k, epi, s);
-        return;
-    }
-    if (c.log_n == 13 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= 64)) {
-        inverse_whole<WholePlan13>(k, epi, s);
-        return;
-    }
-    if (c.log_n == 14 && !(vv & 128) && ((vv & 256) || (size_t)sel.count * (x.batch ? x.batch : 1) >= (size_t)g_whole14_min.load(std::memory_order_relaxed))) {
-        inverse_whole<WholePlan14>(k, epi, s);
-        return;
-    }
+    const NttChoice ch = choose_plan(c, sel, x);
+    k.zfast_tiles = ch.zfast ? 1u : 0u;
+    if (ch.whole == 12) return inverse_whole<WholePlan12>(k, epi, s);
+    if (ch.whole == 13) return inverse_whole<WholePlan13>(k, epi, s);
+#if defined(PHA_EXPERIMENTS)
+    if (ch.whole == 14) return inverse_whole<WholePlan14>(k, epi, s);
+#endif
     switch (c.log_n) {
-        case 12: if (v == 4) inverse_impl<12, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<12, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<12, 2>(k, epi, s); else if (v) inverse_impl<12, 1>(k, epi, s); else inverse_impl<12, 0>(k, epi, s); break;
-        case 13: if (v == 4) inverse_impl<13, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<13, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<13, 2>(k, epi, s); else if (v) inverse_impl<13, 1>(k, epi, s); else inverse_impl<13, 0>(k, epi, s); break;
-        case 14: if (v == 4) inverse_impl<14, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<14, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<14, 2>(k, epi, s); else if (v) inverse_impl<14, 1>(k, epi, s); else inverse_impl<14, 0>(k, epi, s); break;
-        case 15: if (v == 4) inverse_impl<15, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<15, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<15, 2>(k, epi, s); else if (v) inverse_impl<15, 1>(k, epi, s); else inverse_impl<15, 0>(k, epi, s); break;
-        case 16: if (v == 4) inverse_impl<16, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<16, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<16, 2>(k, epi, s); else if (v) inverse_impl<16, 1>(k, epi, s); else inverse_impl<16, 0>(k, epi, s); break;
-        case 17: if (v == 4) inverse_impl<17, 4>(k, epi, s, fz); else if (v == 3) inverse_impl<17, 3>(k, epi, s, fz); else if (v == 2) inverse_impl<17, 2>(k, epi, s); else if (v) inverse_impl<17, 1>(k, epi, s); else inverse_impl<17, 0>(k, epi, s); break;
+        case 12: inverse_two_pass<12>(k, epi, ch, s); break;
+        case 13: inverse_two_pass<13>(k, epi, ch, s); break;
+        case 14: inverse_two_pass<14>(k, epi, ch, s); break;
+        case 15: inverse_two_pass<15>(k, epi, ch, s); break;
+        case 16: inverse_two_pass<16>(k, epi, ch, s); break;
+        case 17: inverse_two_pass<17>(k, epi, ch, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
 }
@@ -823,6 +896,7 @@ int pha_exp_read_wg_times(unsigned long long *out) {
 }
 #endif
 
+#if defined(PHA_EXPERIMENTS)
 int pha_set_tuning(int key, int value) {
     PHA_API_BEGIN
     if (key == 0) {
@@ -846,40 +920,6 @@ int pha_set_tuning(int key, int value) {
     }
     PHA_API_END
 }
-
-// measurement helper: `repeats` back-to-back forward transforms of the batch, enqueued from C (no per-step host work
-// between the launches), nothing else
-int pha_repeat_forward_ntt_batched(pha_context_t ctx, uint64_t *inout, size_t cms, size_t start, size_t batch,
-                                   size_t poly_stride, int repeats, void *stream) {
-    PHA_CTX_BEGIN(ctx)
-    need(inout);
-    if (batch == 0 || batch > 65535) throw std::invalid_argument("batch out of range");
-    NttExtra x;
-    x.batch = (uint32_t)batch;
-    x.poly_stride = poly_stride;
-    for (int i = 0; i < repeats; i++)
-        ntt_forward(ctx->c, inout, inout, inout, plain_sel(start, cms), EPI_FWD_CANON, x, as_stream(stream));
-    PHA_API_END
-}
-
-int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t cms, int iters, void *stream, float *ms_out) {
-    PHA_CTX_BEGIN(ctx)
-    need(inout);
-    hipStream_t s = as_stream(stream);
-    hipEvent_t e0, e1;
-    PHA_HIP(hipEventCreate(&e0));
-    PHA_HIP(hipEventCreate(&e1));
-    PHA_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; i++)
-        ntt_forward(ctx->c, inout, inout, inout, plain_sel(0, cms), EPI_FWD_CANON, NttExtra{}, s);
-    PHA_HIP(hipEventRecord(e1, s));
-    PHA_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    PHA_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *ms_out = ms / (float)iters;
-    PHA_API_END
-}
+#endif  // PHA_EXPERIMENTS
 
 }  // extern "C"

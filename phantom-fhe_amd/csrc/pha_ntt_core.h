@@ -36,6 +36,9 @@ enum Epilogue {
     EPI_INV_CANON = 3,    // inverse: csub q                     (intt_2d.cu:201-205)
     EPI_INV_SCALE = 4,    // inverse: full Shoup multiply by per-limb scale (intt_2d.cu:305-309)
     EPI_FWD_MODDOWN_ADD = 5,  // forward: out += (cx - NTT(delta)) * PInv  (mod-down fused with add_to_ct_kernel)
+    // forward: out = (ct + cx * PInv - NTT(v)) * q_last^-1 -- the mod-down epilogue (ntt_moddown.cu:203-208), add_to_ct
+    // (rns_bconv.cu:763-769) and the rescale epilogue (rns.cu:1141-1158) of key switch + rescale in one (pha_keyswitch_rescale)
+    EPI_FWD_KSRESCALE = 6,
 };
 
 // Round schedule of one pass: LOGT stages split into NR rounds of R0,R1,R2 stages (forward order).
@@ -115,8 +118,10 @@ struct PassArgs {
     // inverse last stage: N^-1 and itw[1]*N^-1 (intt_2d.cu:195-198 / host/ntt.cu:53-55)
     u64x2 ninv, w1ninv;
     // epilogue operands
-    u64x2 scale;       // EPI_INV_SCALE: per-limb scale ; EPI_FWD_MODDOWN: PInv mod q
+    u64x2 scale;       // EPI_INV_SCALE: per-limb scale ; EPI_FWD_MODDOWN: PInv mod q ; EPI_FWD_KSRESCALE: q_last^-1 mod q
     const u64 *aux;    // EPI_FWD_MODDOWN: cx limb base
+    u64x2 scale2;      // EPI_FWD_KSRESCALE: PInv mod q
+    const u64 *aux2;   // EPI_FWD_KSRESCALE: ct limb base
     // FP64 path (q < 2^50): twd / ninv.x / w1ninv.x then hold W as a double; registers, LDS and the
     // inter-pass buffer carry doubles; global inputs and outputs stay canonical integers
     bool fp;
@@ -342,6 +347,11 @@ PHA_HD u64 apply_epilogue_v(u64 x, const PassArgs &a, u64 aux, u64 acc) {
         const u64 r = shoup(sub_mod(aux, t, q), a.scale, q);
         return EPI == EPI_FWD_MODDOWN_ADD ? add_mod(acc, r, q) : r;
     }
+    if (EPI == EPI_FWD_KSRESCALE) {   // acc carries the ct word
+        const u64 t = PHA_FPSEL(a) ? x : csub(csub(csub(x, q << 2), q << 1), q);
+        const u64 u = add_mod(acc, shoup(aux, a.scale2, q), q);
+        return shoup(sub_mod(u, t, q), a.scale, q);
+    }
     if (EPI == EPI_INV_CANON) return PHA_FPSEL(a) ? x : csub(csub(x, q << 1), q);
     if (EPI == EPI_INV_SCALE) return shoup(x, a.scale, q);
     return x;
@@ -350,8 +360,9 @@ PHA_HD u64 apply_epilogue_v(u64 x, const PassArgs &a, u64 aux, u64 acc) {
 template <int EPI>
 PHA_HD u64 apply_epilogue(u64 x, const PassArgs &a, size_t gi) {
     u64 aux = 0, acc = 0;
-    if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) aux = a.aux[gi];
+    if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) aux = a.aux[gi];
     if (EPI == EPI_FWD_MODDOWN_ADD) acc = a.out[gi];
+    if (EPI == EPI_FWD_KSRESCALE) acc = a.aux2[gi];
     return apply_epilogue_v<EPI>(x, a, aux, acc);
 }
 
@@ -537,9 +548,10 @@ PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
 #pragma unroll
                 for (int k = 0; k < K; k += 2) {
                     u64x2 aux{0, 0}, acc{0, 0};
-                    if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD)
+                    if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE)
                         aux = reinterpret_cast<const u64x2 *>(a.aux + g0)[k >> 1];
                     if (EPI == EPI_FWD_MODDOWN_ADD) acc = p[k >> 1];
+                    if (EPI == EPI_FWD_KSRESCALE) acc = reinterpret_cast<const u64x2 *>(a.aux2 + g0)[k >> 1];
                     u64x2 t;
                     t.x = apply_epilogue_v<EPI>(rg[k], a, aux.x, acc.x);
                     t.y = apply_epilogue_v<EPI>(rg[k + 1], a, aux.y, acc.y);

@@ -22,8 +22,13 @@ namespace pha {
 
 void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s);
 
-// tuning knob (pha_set_tuning key 1): carry-free split-accumulator MAC in base conversion
+// carry-free split-accumulator MAC in base conversion (experiments library: pha_set_tuning key 1 switches it off)
+#if defined(PHA_EXPERIMENTS)
 std::atomic<int> g_bconv_split{1};
+static inline bool bconv_split_on() { return g_bconv_split.load(std::memory_order_relaxed) != 0; }
+#else
+static constexpr bool bconv_split_on() { return true; }
+#endif
 
 constexpr int kBcThreads = 256;
 constexpr int kBcMaxOutPerBlock = 24;  // output primes per workgroup (upper bound; the launch balances the groups)
@@ -224,7 +229,7 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
     dim3 grid((unsigned)(c.n / kBcThreads), groups, batch);
     dim3 block(kBcThreads);
     // the carry-free split accumulators hold at most 16 terms; wider bases take the 128-bit accumulate
-    const bool split = split_ok && max_isz <= 16 && g_bconv_split.load(std::memory_order_relaxed);
+    const bool split = split_ok && max_isz <= 16 && bconv_split_on();
 #define PHA_BC(P)                                                                                        \
     do {                                                                                                 \
         if (scale_in && split) hipLaunchKernelGGL((bconv_kernel<P, true, true>), grid, block, 0, s, L);   \
@@ -242,6 +247,90 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
     else hipLaunchKernelGGL((bconv_wide_kernel<false>), grid, block, 0, s, L);
 #undef PHA_BC
     check_launch();
+}
+
+// ---- pha_keyswitch_rescale: the P -> Ql conversion of mod-down with the rescale's last-limb work folded in ----------------
+// Per coefficient (one thread), with y_i the P residues of cx in coefficient form, already scaled by phat_i^-1 (the inverse
+// transform's epilogue did that) and M' the converter whose rows carry P^-1 (Tool::p_to_ql_pinv):
+//   dP_j   = sum_i y_i M'_ij mod q_j            = delta_j * P^-1        (moddown_from_NTT rns_bconv.cu:776-828 up to its NTT)
+//   c_last = t_last - dP_last mod q_last          t_last = iNTT(ct_last + cx_last P^-1): coefficient form of the key-switched
+//                                                 ciphertext's last limb (rns.cu:1171 after rns_bconv.cu:763-769)
+//   v_j    = dP_j + (c_last mod q_j) mod q_j      j < Ql - 1
+// One forward transform of v then gives out_j = (ct_j + cx_j P^-1 - NTT(v)_j) q_last^-1 (EPI_FWD_KSRESCALE), bit for bit what
+// keyswitch_inplace followed by divide_and_round_q_last_ntt stores (NTT is linear; every stored value is canonical).
+struct BConvRescaleLaunch {
+    const BConvDev *conv;        // P -> Ql with P^-1 folded into the rows (Montgomery form)
+    u64 *dst;                    // v: polynomial z at dst + z * dst_stride, [Ql - 1][N]
+    const u64 *cx;               // polynomial z at cx + z * cx_stride: [QlP][N], limb Ql - 1 = t_last, limbs >= Ql = y
+    size_t dst_stride, cx_stride;
+    const DModulus *mod;
+    uint32_t n, ql, out_per_block;
+};
+template <int ISZ_PAD>
+__global__ __launch_bounds__(kBcThreads) void bconv_rescale_kernel(const BConvRescaleLaunch L) {
+    const BConvDev &d = *L.conv;
+    const uint32_t coeff = blockIdx.x * kBcThreads + threadIdx.x;
+    const uint32_t n = L.n, nl = L.ql - 1;
+    const u64 *cx = L.cx + (size_t)blockIdx.z * L.cx_stride;
+    const u64 *src = cx + (size_t)L.ql * n;
+    u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
+    const uint32_t j0 = blockIdx.y * L.out_per_block;
+    const uint32_t j1 = min(j0 + L.out_per_block, nl);
+    // rows / constants of this group's outputs, plus (slot out_per_block) those of the last data limb
+    __shared__ uint2 s_rows[(kBcMaxOutPerBlock + 1) * kBcRowPad];
+    __shared__ u64 s_p[kBcMaxOutPerBlock + 1], s_c0[kBcMaxOutPerBlock + 1], s_c1[kBcMaxOutPerBlock + 1];
+    for (uint32_t e = threadIdx.x; e < (L.out_per_block + 1) * kBcRowPad; e += kBcThreads) {
+        const uint32_t slot = e / kBcRowPad, i = e % kBcRowPad;
+        const uint32_t j = slot == L.out_per_block ? nl : j0 + slot;
+        s_rows[e] = j <= nl ? reinterpret_cast<const uint2 *>(d.mat30)[j * kBcRowPad + i] : uint2{0u, 0u};
+    }
+    if (threadIdx.x <= L.out_per_block) {
+        const uint32_t j = threadIdx.x == L.out_per_block ? nl : j0 + threadIdx.x;
+        if (j <= nl) {
+            const DModulus m = L.mod[d.oprime[j]];
+            s_p[threadIdx.x] = m.value;
+            s_c0[threadIdx.x] = d.oninv[j];
+            s_c1[threadIdx.x] = m.ratio1;
+        }
+    }
+    __syncthreads();
+    if (j0 >= nl) return;
+    u32 ylo[ISZ_PAD], yhi[ISZ_PAD];
+#pragma unroll
+    for (int i = 0; i < ISZ_PAD; i++) {
+        const u64 y = i < (int)d.isz ? src[(size_t)i * n + coeff] : 0;
+        ylo[i] = (u32)y & 0x3fffffffu;
+        yhi[i] = (u32)(y >> 30);
+    }
+    auto convert = [&](uint32_t slot) -> u64 {   // sum_i y_i * row_i, reduced (REDC) modulo the slot's prime
+        const uint2 *row = s_rows + slot * kBcRowPad;
+        u64 ll = 0, lh = 0, hl = 0, hh = 0;
+#pragma unroll
+        for (int i = 0; i < ISZ_PAD; i++) {
+            const uint2 mm = row[i];
+            ll = (u64)ylo[i] * mm.x + ll;
+            lh = (u64)ylo[i] * mm.y + lh;
+            hl = (u64)yhi[i] * mm.x + hl;
+            hh = (u64)yhi[i] * mm.y + hh;
+        }
+        const u64 mid = lh + hl, mid_c = mid < lh ? 1 : 0;
+        u64 lo = ll, hi = 0;
+        const u64 t1 = mid << 30;
+        lo += t1;
+        hi += (lo < t1) + (mid >> 34) + (mid_c << 30);
+        const u64 t2 = hh << 60;
+        lo += t2;
+        hi += (lo < t2) + (hh >> 4);
+        return mont_redc128(lo, hi, s_p[slot], s_c0[slot]);
+    };
+    const u64 q_last = s_p[L.out_per_block];
+    const u64 c_last = sub_mod(cx[(size_t)nl * n + coeff], convert(L.out_per_block), q_last);
+    const uint32_t count = j1 - j0;
+    for (uint32_t e = 0; e < count; e++) {
+        const u64 p = s_p[e];
+        const u64 r = barrett64(c_last, p, s_c1[e]);   // divide_and_round_reduce_q_last_kernel rns.cu:1128-1139
+        dst[(size_t)(j0 + e) * n + coeff] = add_mod(convert(e), r, p);
+    }
 }
 
 // ---- alpha == 1 fast paths (rns_bconv.cu:432-453, :691-707) -------------------------------------
@@ -277,7 +366,23 @@ struct InnerArgs {
     const uint32_t *qlp_prime;
     uint32_t n, beta;
     size_t qlp_n, qp_n;
+    // pha_keyswitch_rescale: limb fix_limb of cx (the last data limb) receives ct_last + cx_last * P^-1 instead of cx_last
+    // (its inverse transform is the first half of c_last; rns.cu:1171 after rns_bconv.cu:763-769); 0xffffffff = off
+    uint32_t fix_limb;
+    u64x2 fix_cst;           // P^-1 mod q_last
+    const u64 *fix_ct;       // ct [2][Ql][N] of the (first) ciphertext
+    size_t fix_ct_stride;    // Ql * N
 };
+__device__ __forceinline__ void inner_fix(const InnerArgs &k, uint32_t nid, const DModulus &m, size_t coeff, uint32_t b,
+                                          u64x2 &r0, u64x2 &r1) {
+    if (nid != k.fix_limb) return;   // uniform per workgroup
+    const u64 *ct0 = k.fix_ct + (size_t)(2 * b) * k.fix_ct_stride + (size_t)nid * k.n + coeff;
+    const u64x2 c0 = *reinterpret_cast<const u64x2 *>(ct0), c1 = *reinterpret_cast<const u64x2 *>(ct0 + k.fix_ct_stride);
+    r0.x = add_mod(c0.x, shoup(r0.x, k.fix_cst, m.value), m.value);
+    r0.y = add_mod(c0.y, shoup(r0.y, k.fix_cst, m.value), m.value);
+    r1.x = add_mod(c1.x, shoup(r1.x, k.fix_cst, m.value), m.value);
+    r1.y = add_mod(c1.y, shoup(r1.y, k.fix_cst, m.value), m.value);
+}
 __global__ __launch_bounds__(256) void inner_prod_kernel(const InnerArgs k) {
     const uint32_t nid = blockIdx.y;          // limb in [Ql || P]
     const uint32_t twr = k.qlp_prime[nid];    // its row in the key (keys live at full QP width)
@@ -298,6 +403,7 @@ __global__ __launch_bounds__(256) void inner_prod_kernel(const InnerArgs k) {
     }
     u64x2 r0{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
     u64x2 r1{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
+    inner_fix(k, nid, m, coeff, 0, r0, r1);
     *reinterpret_cast<u64x2 *>(k.cx + c2_id) = r0;
     *reinterpret_cast<u64x2 *>(k.cx + c2_id + k.qlp_n) = r1;
 }
@@ -331,8 +437,11 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
             mac128(v.x, ka[i].x, b0l, b0h);
             mac128(v.y, ka[i].y, b1l, b1h);
         }
-        *reinterpret_cast<u64x2 *>(cx) = u64x2{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
-        *reinterpret_cast<u64x2 *>(cx + k.qlp_n) = u64x2{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
+        u64x2 r0{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
+        u64x2 r1{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
+        inner_fix(k, nid, m, coeff, b, r0, r1);
+        *reinterpret_cast<u64x2 *>(cx) = r0;
+        *reinterpret_cast<u64x2 *>(cx + k.qlp_n) = r1;
     }
 }
 
@@ -695,12 +804,29 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
     ntt_forward(c, dst, dst, dst, sel, EPI_FWD_CANON, x, s);
 }
 
+// P^-1 mod q_limb (bigPInv_mod_q rns.cu:110-123) on the host
+static u64 h_invmod_p(Context &c, uint32_t limb) {
+    const u64 q = c.primes[limb];
+    u64 p = 1;
+    for (uint32_t k = 0; k < c.size_p; k++) p = h_mulmod(p, c.primes[c.size_q + k] % q, q);
+    return h_invmod(p, q);
+}
+
 // phantom::key_switch_inner_prod eval_key_switch.cu:71-92
+// fix_ct != null (pha_keyswitch_rescale): cx's last data limb receives ct_last + cx_last * P^-1 (see InnerArgs)
 static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s,
-                       uint32_t batch = 1) {
+                       uint32_t batch = 1, const u64 *fix_ct = nullptr) {
     InnerArgs k{};
     k.cx = cx; k.t_mod_up = t_mod_up; k.evks = rlk; k.mod = c.d_mod.p; k.qlp_prime = t.d_qlp_prime.p;
     k.n = (uint32_t)c.n; k.beta = t.beta; k.qlp_n = (size_t)t.size_qlp * c.n; k.qp_n = (size_t)c.size_qp * c.n;
+    k.fix_limb = 0xffffffffu;
+    if (fix_ct) {
+        const u64 pinv_last = h_invmod_p(c, t.size_ql - 1);
+        k.fix_limb = t.size_ql - 1;
+        k.fix_cst = u64x2{pinv_last, h_shoup(pinv_last, c.primes[t.size_ql - 1])};
+        k.fix_ct = fix_ct;
+        k.fix_ct_stride = (size_t)t.size_ql * c.n;
+    }
     const dim3 grid((unsigned)(c.n / 512), t.size_qlp), block(256);
     if (batch > 1 && t.beta <= 4) {  // key limbs stay in registers across the ciphertexts
         switch (t.beta) {
@@ -717,6 +843,7 @@ static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const 
         check_launch();
         k.t_mod_up += (size_t)t.beta * k.qlp_n;
         k.cx += 2 * k.qlp_n;
+        if (k.fix_ct) k.fix_ct += 2 * k.fix_ct_stride;
     }
 }
 
@@ -803,6 +930,81 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         hipLaunchKernelGGL(sub_mul_kernel<false>, dim3((unsigned)(n / 256), ql, polys), dim3(256), 0, s, k);
         check_launch();
     }
+}
+
+// DRNSTool::divide_and_round_q_last_ntt rns.cu:1160-1184 on `polys` polynomials src [polys][Ql][N] -> dst [polys][Ql-1][N]
+static void rescale_ntt(Context &c, Tool &t, u64 *src, uint32_t polys, u64 *dst, hipStream_t s) {
+    const size_t n = c.n, size_Ql = t.size_ql, nl = size_Ql - 1;
+    // all polynomials of the ciphertext in one launch each (blockIdx.z = polynomial)
+    NttExtra xi;
+    xi.batch = polys;
+    xi.poly_stride = size_Ql * n;
+    ntt_inverse(c, src, src, src, plain_sel(nl, 1), EPI_INV_CANON, xi, s);  // ci[last] -> coefficients (rns.cu:1171)
+    // NTT(ci[last] mod qj) fused with (ci[j] - .) * q_last^-1 (rns.cu:1173-1182): the reduction modulo qj
+    // (divide_and_round_reduce_q_last_kernel) happens as the first pass loads ci[last]; dst doubles as the
+    // buffer between the two passes
+    NttExtra x;
+    x.scale = t.inv_q_last.p;
+    x.scale_shoup = t.inv_q_last_shoup.p;
+    x.aux = src;
+    x.batch = polys;
+    x.poly_stride = nl * n;
+    x.out_stride = nl * n;
+    x.aux_stride = size_Ql * n;
+    x.pro_src = src + nl * n;
+    x.pro_stride = size_Ql * n;
+    ntt_forward(c, dst, dst, dst, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
+}
+
+// Key switch + CKKS rescale in one (build-defined fusion; equals keyswitch_inplace eval_key_switch.cu:95-182 followed by
+// divide_and_round_q_last_ntt rns.cu:1160-1184 bit for bit): dst [B][2][Ql-1][N] = rescale(ct + keyswitch(c2)).
+// Against the two calls it drops the mod-down's forward transform over 2 x Ql limbs and the rescale's separate last-limb inverse
+// (their work rides on one inverse over the P limbs + the last data limb and ONE forward over 2 x (Ql - 1) limbs), and ct is
+// never written.  scratch `base` as laid out by the callers.
+static bool keyswitch_rescale_fusable(const Tool &t) {
+    return t.alpha > 1 && t.alpha <= (uint32_t)kBcRowPad && t.split_ok && t.p_to_ql_pinv.mont && t.size_ql >= 2;
+}
+static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2, const u64 *const *rlk, u64 *dst, uint32_t B,
+                              u64 *base, hipStream_t s) {
+    const size_t n = c.n, ql = t.size_ql, ql_n = ql * n, qlp_n = (size_t)t.size_qlp * n, nl = ql - 1;
+    u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n;
+    modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B);
+    inner_prod(c, t, cx, t_mod_up, rlk, s, B, ct);          // cx_last <- ct_last + cx_last * P^-1
+    {   // coefficient form of the P limbs (x phat_i^-1, bconv phase 1) and of the last data limb, both polynomials, one launch pair
+        NttExtra xb;
+        xb.batch = 2 * B;
+        xb.poly_stride = qlp_n;
+        xb.scale = t.p_hat_inv_by_limb.p;
+        xb.scale_shoup = t.p_hat_inv_by_limb_shoup.p;
+        ntt_inverse(c, cx, cx, cx, special_sel(nl, c.size_p + 1, c.size_qp, c.size_p), EPI_INV_SCALE, xb, s);
+    }
+    {   // v_j = delta_j P^-1 + (c_last mod q_j)
+        BConvRescaleLaunch L{};
+        L.conv = t.d_p_to_ql_pinv_conv.p; L.dst = tmp; L.cx = cx; L.dst_stride = ql_n; L.cx_stride = qlp_n;
+        L.mod = c.d_mod.p; L.n = (uint32_t)n; L.ql = (uint32_t)ql;
+        const uint32_t groups = ((uint32_t)nl + kBcMaxOutPerBlock - 1) / kBcMaxOutPerBlock;
+        L.out_per_block = ((uint32_t)nl + groups - 1) / groups;
+        const dim3 grid((unsigned)(n / kBcThreads), groups, 2 * B), block(kBcThreads);
+        if (t.alpha <= 2) hipLaunchKernelGGL(bconv_rescale_kernel<2>, grid, block, 0, s, L);
+        else if (t.alpha <= 4) hipLaunchKernelGGL(bconv_rescale_kernel<4>, grid, block, 0, s, L);
+        else if (t.alpha <= 8) hipLaunchKernelGGL(bconv_rescale_kernel<8>, grid, block, 0, s, L);
+        else if (t.alpha == 15) hipLaunchKernelGGL(bconv_rescale_kernel<15>, grid, block, 0, s, L);
+        else hipLaunchKernelGGL(bconv_rescale_kernel<16>, grid, block, 0, s, L);
+        check_launch();
+    }
+    NttExtra x;   // out_j = (ct_j + cx_j P^-1 - NTT(v)_j) q_last^-1
+    x.scale = t.inv_q_last.p;
+    x.scale_shoup = t.inv_q_last_shoup.p;
+    x.scale2 = t.pinv.p;
+    x.scale2_shoup = t.pinv_shoup.p;
+    x.aux = cx;
+    x.aux2 = ct;
+    x.batch = 2 * B;
+    x.poly_stride = ql_n;
+    x.out_stride = nl * n;
+    x.aux_stride = qlp_n;
+    x.aux2_stride = ql_n;
+    ntt_forward(c, tmp, tmp, dst, plain_sel(0, nl), EPI_FWD_KSRESCALE, x, s);
 }
 
 static void check_level(Context &c, size_t size_Ql, bool need_p) {
@@ -905,6 +1107,45 @@ int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *c
     // 2B polynomials: ct [B][2][Ql][N] and cx [B][2][QlP][N] are uniformly strided
     moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2 * B, scheme, true, tmp, s);
     PHA_API_END
+}
+
+static bool overlaps(const u64 *a, size_t na, const u64 *b, size_t nb) { return a < b + nb && b < a + na; }
+
+int pha_keyswitch_rescale_batched(pha_context_t ctx, size_t size_Ql, const uint64_t *ct, const uint64_t *c2, size_t batch,
+                                  const uint64_t *const *rlk, uint64_t *dst, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(ct); need(c2); need(rlk); need(dst);
+    if (batch == 0) return 0;
+    if (batch > 1024) throw std::invalid_argument("batch out of range");
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    if (size_Ql < 2) throw std::invalid_argument("cannot rescale the last remaining modulus");
+    Tool &t = c.tool((uint32_t)size_Ql);
+    if ((size_t)t.beta * batch > 65535 || 2 * batch > 65535) throw std::invalid_argument("batch out of range");
+    hipStream_t s = as_stream(stream);
+    const uint32_t B = (uint32_t)batch;
+    const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
+    if (overlaps(dst, B * 2 * (size_Ql - 1) * n, ct, B * 2 * ql_n) || overlaps(dst, B * 2 * (size_Ql - 1) * n, c2, B * ql_n))
+        throw std::invalid_argument("dst must not overlap ct or c2");
+    // scratch: t_cks / v [B][2][Ql][N] | t_mod_up [B][beta][QlP][N] | cx [B][2][QlP][N] (| ct copy [B][2][Ql][N] for the fallback)
+    const size_t words = B * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n);
+    if (keyswitch_rescale_fusable(t)) {
+        keyswitch_rescale(c, t, ct, c2, rlk, dst, B, c.scratch(stream, words), s);
+    } else {   // alpha = 1, wide primes, wide P: the two reference steps on a copy of ct
+        u64 *base = c.scratch(stream, words + B * 2 * ql_n);
+        u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n, *work = base + words;
+        PHA_HIP(hipMemcpyAsync(work, ct, B * 2 * ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B);
+        inner_prod(c, t, cx, t_mod_up, rlk, s, B);
+        moddown_from_ntt(c, t, work, ql_n, cx, qlp_n, 2 * B, PHA_SCHEME_CKKS, true, tmp, s);
+        rescale_ntt(c, t, work, 2 * B, dst, s);
+    }
+    PHA_API_END
+}
+
+int pha_keyswitch_rescale(pha_context_t ctx, size_t size_Ql, const uint64_t *ct, const uint64_t *c2,
+                          const uint64_t *const *rlk, uint64_t *dst, void *stream) {
+    return pha_keyswitch_rescale_batched(ctx, size_Ql, ct, c2, 1, rlk, dst, stream);
 }
 
 int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
@@ -1045,29 +1286,9 @@ int pha_divide_and_round_q_last_ntt(pha_context_t ctx, size_t size_Ql, uint64_t 
     check_level(c, size_Ql, false);
     if (size_Ql < 2) throw std::invalid_argument("cannot rescale the last remaining modulus");
     Tool &t = c.tool((uint32_t)size_Ql);
-    hipStream_t s = as_stream(stream);
-    const size_t n = c.n, nl = size_Ql - 1;
     if (cipher_size == 0) return 0;
     if (cipher_size > 65535) throw std::invalid_argument("cipher_size out of range");
-    // all polynomials of the ciphertext in one launch each (blockIdx.z = polynomial)
-    NttExtra xi;
-    xi.batch = (uint32_t)cipher_size;
-    xi.poly_stride = size_Ql * n;
-    ntt_inverse(c, src, src, src, plain_sel(nl, 1), EPI_INV_CANON, xi, s);  // ci[last] -> coefficients (rns.cu:1171)
-    // NTT(ci[last] mod qj) fused with (ci[j] - .) * q_last^-1 (rns.cu:1173-1182): the reduction modulo qj
-    // (divide_and_round_reduce_q_last_kernel) happens as the first pass loads ci[last]; dst doubles as the
-    // buffer between the two passes
-    NttExtra x;
-    x.scale = t.inv_q_last.p;
-    x.scale_shoup = t.inv_q_last_shoup.p;
-    x.aux = src;
-    x.batch = (uint32_t)cipher_size;
-    x.poly_stride = nl * n;
-    x.out_stride = nl * n;
-    x.aux_stride = size_Ql * n;
-    x.pro_src = src + nl * n;
-    x.pro_stride = size_Ql * n;
-    ntt_forward(c, dst, dst, dst, plain_sel(0, nl), EPI_FWD_MODDOWN, x, s);
+    rescale_ntt(c, t, src, (uint32_t)cipher_size, dst, as_stream(stream));
     PHA_API_END
 }
 

@@ -46,8 +46,25 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def stream_copy_rate(dst, src, iters=10):
+    """bytes per second (read + write) of the library's own 16-byte-per-lane device-to-device copy (phantom_amd_bench.h)."""
+    rate = C.c_double()
+    nbytes = min(dst.numel() * dst.element_size(), src.numel() * src.element_size())
+    _lib.check(_lib.load().pha_time_stream_copy(_ptr(dst), _ptr(src), nbytes - nbytes % 16, iters, _stream(), C.byref(rate)))
+    return rate.value
+
+
+def has_tuning():
+    """True when the loaded library is the test-only experiments build (PHA_LIB_OVERRIDE=.../libphantom_amd_exp.so)."""
+    return hasattr(_lib.load(), "pha_set_tuning")
+
+
 def set_tuning(key, value):
-    """A/B knob (include/phantom_amd.h pha_set_tuning); results never change."""
+    """A/B knob of the experiments library (csrc/pha_experiments.h); results never change.  The product library's kernel
+    selection is fixed: it does not export the symbol."""
+    if not has_tuning():
+        raise RuntimeError("pha_set_tuning exists only in libphantom_amd_exp.so (set PHA_LIB_OVERRIDE to it): "
+                           "the product library has one plan per launch shape")
     _lib.check(_lib.load().pha_set_tuning(int(key), int(value)))
 
 
@@ -267,6 +284,15 @@ class PhantomContext:
         """`batch` ciphertexts through one set of launches: ct [batch][2][Ql][N] += KS(c2 [batch][Ql][N])."""
         _lib.check(self._L.pha_keyswitch_inplace_batched(self._h, size_Ql, _ptr(ct), _ptr(c2), batch, _ptr(rlk_ptrs),
                                                          int(scheme), _stream()))
+
+    def keyswitch_rescale(self, size_Ql, ct, c2, rlk_ptrs, dst):
+        """dst [2][Ql-1][N] = rescale(ct + keyswitch(c2)) in one call (ckks): bit-identical to keyswitch_inplace followed by
+        divide_and_round_q_last_ntt, one forward NTT fewer; ct and c2 are only read."""
+        _lib.check(self._L.pha_keyswitch_rescale(self._h, size_Ql, _ptr(ct), _ptr(c2), _ptr(rlk_ptrs), _ptr(dst), _stream()))
+
+    def keyswitch_rescale_batched(self, size_Ql, ct, c2, batch, rlk_ptrs, dst):
+        _lib.check(self._L.pha_keyswitch_rescale_batched(self._h, size_Ql, _ptr(ct), _ptr(c2), batch, _ptr(rlk_ptrs), _ptr(dst),
+                                                         _stream()))
 
     def tensor_prod_2x2_batched(self, op1, op2, res01, res2, cms, batch):
         _lib.check(self._L.pha_tensor_prod_2x2_batched(self._h, _ptr(op1), _ptr(op2), _ptr(res01), _ptr(res2), cms,

@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PHA_LIB_OVERRIDE") or os.path.join(_HERE, "libphantom_amd.so")  # override: experiments only
+EXP_LIB_PATH = os.path.join(_HERE, "libphantom_amd_exp.so")   # test-only build with every NTT variant and pha_set_tuning
 
 u64p = C.POINTER(C.c_uint64)
 vp = C.c_void_p
@@ -49,6 +50,8 @@ _SIGS = {
     "pha_moddown_from_NTT": [vp, sz, vp, vp, C.c_int, vp],
     "pha_keyswitch_inplace": [vp, sz, vp, vp, vp, C.c_int, vp],
     "pha_keyswitch_inplace_batched": [vp, sz, vp, vp, sz, vp, C.c_int, vp],
+    "pha_keyswitch_rescale": [vp, sz, vp, vp, vp, vp, vp],
+    "pha_keyswitch_rescale_batched": [vp, sz, vp, vp, sz, vp, vp, vp],
     "pha_tensor_prod_2x2_batched": [vp, vp, vp, vp, vp, sz, sz, vp],
     "pha_bfv_multiply_behz": [vp, vp, vp, vp, vp],
     "pha_bfv_multiply_hps": [vp, vp, vp, vp, vp],
@@ -97,9 +100,14 @@ _SIGS = {
     "pha_apply_galois": [vp, vp, vp, C.c_uint32, sz, sz, vp],
     "pha_apply_galois_batched": [vp, vp, vp, C.c_uint32, sz, sz, C.c_int, vp],
     "pha_apply_galois_for_keyswitch": [vp, vp, vp, vp, C.c_uint32, sz, sz, C.c_int, vp],
-    "pha_set_tuning": [C.c_int, C.c_int],
+    # include/phantom_amd_bench.h (measurement hooks)
     "pha_time_forward_ntt": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)],
     "pha_repeat_forward_ntt_batched": [vp, vp, sz, sz, sz, sz, C.c_int, vp],
+    "pha_time_stream_copy": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_double)],
+}
+# exported by the test-only experiments library alone (csrc/pha_experiments.h); bound when present
+_OPTIONAL = {
+    "pha_set_tuning": [C.c_int, C.c_int],
 }
 _SPECIAL = {
     "pha_last_error": (C.c_char_p, []),
@@ -140,6 +148,11 @@ def load():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = res
+    for name, args in _OPTIONAL.items():
+        f = getattr(L, name, None)
+        if f is not None:
+            f.argtypes = args
+            f.restype = C.c_int
     _lib = L
     return L
 

@@ -9,10 +9,31 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "phantom_amd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pha_[a-zA-Z0-9_]+)\s*\(", text)))
+def _declared(headers=("phantom_amd.h", "phantom_amd_bench.h")):
+    """Every pha_* function declared by include/*.h: the drop-in boundary and the bench-only hooks."""
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(pha_[a-zA-Z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_every_public_header_is_covered():
+    assert sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")) == ["phantom_amd.h", "phantom_amd_bench.h"]
+
+
+def test_product_library_has_no_tuning_knob_and_experiments_library_has():
+    import phantom_fhe_amd as P
+    if not os.path.exists(P.LIB_PATH) or not os.path.exists(P.EXP_LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    assert not hasattr(ctypes.CDLL(P.LIB_PATH), "pha_set_tuning")
+    exp = ctypes.CDLL(P.EXP_LIB_PATH)
+    assert hasattr(exp, "pha_set_tuning")
+    for name in _declared():
+        assert hasattr(exp, name), name
+    assert "pha_repeat_forward_ntt_batched" not in _declared(("phantom_amd.h",))   # bench hooks are not in the boundary header
 
 
 def test_library_exports_every_declared_symbol():

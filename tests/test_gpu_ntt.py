@@ -2,6 +2,8 @@
 
 Reference analogue: test/ntt_test.cu:71-122 (round trip) -- here the forward values themselves are
 pinned against the oracle, plus the variants used by key switching (include/ntt.cuh:178-226)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,13 @@ from oracle import oracle as O
 from util import oracle_ctx, primes_of, rng_for, uniform_poly
 
 pytestmark = pytest.mark.gpu
+
+# The product library has ONE plan per launch shape.  Every other geometry that was built and measured lives in the test-only
+# experiments library (csrc/pha_experiments.h: pha_set_tuning); tests/test_gpu_ntt_variants.py re-runs this file in a process
+# that loads it (PHA_LIB_OVERRIDE), which turns the variant sweep below on.
+EXPERIMENTS = os.path.basename(os.environ.get("PHA_LIB_OVERRIDE", "")) == "libphantom_amd_exp.so"
+needs_experiments = pytest.mark.skipif(not EXPERIMENTS, reason="needs libphantom_amd_exp.so (run by test_gpu_ntt_variants.py)")
+DEFAULT_VARIANT = 1 | 32 | 64 | 2048
 
 
 def _ctx(name, gpu):
@@ -42,16 +51,24 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
 # 353 / 361: bit 8 forces the one-launch plans of N = 8192 and N = 16384 for every launch size
 # 609 / 617 / 625: bit 9 sends every launch through the one-launch form (both passes in one kernel, L2 hand-off)
 # 2145: the default (bit 11: polynomial-fastest block order in batched contiguous passes)
-@pytest.fixture(params=[0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361, 609, 617, 625, 1121, 2145],
-                ids=["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave",
-                     "two-pass-4096", "one-launch-8192-16384", "one-launch-8192-16384-int", "fused", "fused-int", "fused-ot", "never-fused",
-                     "default"])
+_VARIANTS = [0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361, 609, 617, 625, 1121, 2145]
+_VARIANT_IDS = ["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave",
+                "two-pass-4096", "one-launch-8192-16384", "one-launch-8192-16384-int", "fused", "fused-int", "fused-ot", "never-fused",
+                "default"]
+
+
+@pytest.fixture(params=_VARIANTS if EXPERIMENTS else [DEFAULT_VARIANT], ids=_VARIANT_IDS if EXPERIMENTS else ["product"])
 def ntt_variant(request):
-    """Both thread geometries of the NTT (pha_set_tuning key 0) must give identical results."""
+    """Every thread geometry of the NTT (experiments library: pha_set_tuning key 0) must give identical results; the product
+    library runs its one plan."""
     import phantom_fhe_amd as P
+    if not EXPERIMENTS:
+        assert not P.has_tuning()      # the product library does not export the knob
+        yield request.param
+        return
     P.set_tuning(0, request.param)
     yield request.param
-    P.set_tuning(0, 1 | 32 | 64 | 2048)
+    P.set_tuning(0, DEFAULT_VARIANT)
 
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
@@ -343,6 +360,7 @@ def test_one_launch_8192_takes_over_for_large_launches(gpu):
     assert np.array_equal(P.to_host(d), x)
 
 
+@needs_experiments
 @pytest.mark.parametrize("lag", [0, 1, 2, 5])
 @pytest.mark.parametrize("name,batch", [("c2_ntt14", 3), ("c4_bfv15", 2), ("c3_ckks16", 2)])
 def test_one_launch_transform_lags_and_batches(name, batch, lag, gpu):
@@ -371,6 +389,7 @@ def test_one_launch_transform_lags_and_batches(name, batch, lag, gpu):
         P.set_tuning(3, 2)
 
 
+@needs_experiments
 @pytest.mark.parametrize("name,batch", [("c2_ntt14", 5), ("c4_bfv15", 3), ("c3_ckks16", 4)])
 def test_batched_launches_in_both_block_orders(name, batch, gpu):
     """The polynomial-fastest, XCD-grouped block order of batched contiguous passes (default) against the plain 3-D grid:

@@ -290,6 +290,50 @@ def test_hommul_relin_rescale_c3(gpu):
     assert np.array_equal(P.to_host(dst), tool.rescale_ntt(ref2, 2))
 
 
+# (config, live data limbs, batch): alpha = 2 / 3 / 15 incl. short last digits, the alpha = 1 fallback, both BASELINE sizes
+KSR_CASES = [("hyb12_a2", 6, 1), ("hyb12_a2", 5, 2), ("hyb12_a2", 2, 1), ("hyb13_a3", 9, 1), ("hyb13_a3", 7, 3), ("hyb13_a3", 4, 1),
+             ("c1_bfv4096", 2, 2), ("c2_ckks14", 8, 2), ("hyb14_a4", 8, 1), ("hyb14_a4", 5, 2), ("c4_bfv15", 30, 2), ("c4_bfv15", 17, 1), ("c3_ckks16", 45, 1), ("c3_ckks16", 31, 2)]
+
+
+@pytest.mark.parametrize("name,ql,batch", KSR_CASES)
+def test_keyswitch_rescale_equals_keyswitch_then_rescale(name, ql, batch, gpu):
+    """pha_keyswitch_rescale(_batched) -- ONE forward transform for mod-down + rescale -- against the oracle's composition
+    keyswitch_inplace (eval_key_switch.cu:95-182) then divide_and_round_q_last_ntt (rns.cu:1160-1184), bit for bit; the inputs
+    are left as they were; the two-call path of the library gives the same words."""
+    import phantom_fhe_amd as P
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(170 + ql)
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    ct = np.stack([np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)]) for _ in range(batch)])
+    c2 = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(batch)])
+    if name == "hyb12_a2" and ql == 6:       # extreme residues: everything at q - 1
+        ct[0] = np.stack([np.stack([np.full(n, int(q) - 1, dtype=np.uint64) for q in primes[:ql]])] * 2)
+        c2[0] = ct[0][0]
+    d_ct, d_c2 = P.to_device(ct, gpu), P.to_device(c2, gpu)
+    dst = P.to_device(np.zeros((batch, 2, ql - 1, n), dtype=np.uint64), gpu)
+    if batch == 1:
+        ctx.keyswitch_rescale(ql, d_ct[0], d_c2[0], rlk.public_keys_ptr, dst[0])
+    else:
+        ctx.keyswitch_rescale_batched(ql, d_ct, d_c2, batch, rlk.public_keys_ptr, dst)
+    got = P.to_host(dst)
+    keys = [evk[i] for i in range(tool.beta)]
+    for b in range(batch):
+        ref = tool.rescale_ntt(tool.keyswitch_inplace(ct[b], c2[b], keys, O.CKKS), 2)
+        assert np.array_equal(got[b], ref), f"ciphertext {b}"
+    assert np.array_equal(P.to_host(d_ct), ct) and np.array_equal(P.to_host(d_c2), c2)      # inputs untouched
+    two = P.to_device(np.zeros((batch, 2, ql - 1, n), dtype=np.uint64), gpu)
+    ctx.keyswitch_inplace_batched(ql, d_ct, d_c2, batch, rlk.public_keys_ptr, O.CKKS)
+    ctx.divide_and_round_q_last_ntt(ql, d_ct, 2 * batch, two)
+    assert np.array_equal(P.to_host(two), got)
+    with pytest.raises(ValueError):           # dst must not overlap ct
+        ctx.keyswitch_rescale(ql, d_ct[0], d_c2[0], rlk.public_keys_ptr, d_ct[0])
+
+
 def _ternary_sk(oc, rng, primes, n):
     s_small = rng.integers(-1, 2, n)
     sk = np.stack([(s_small % int(q)).astype(np.uint64) for q in primes])

@@ -16,6 +16,8 @@ CONFIGS = {
     "hyb13_a3": (13, [60] + [50] * 8 + [60] * 3, 3),  # 9 data limbs (dnum 3); lower levels have a short last digit
     "c3_ckks16": (16, [60] + [50] * 44 + [60] * 15, 15),  # examples/3_ckks.cu:729-739
     "c4_bfv15": (15, [60] + [50] * 29 + [60] * 15, 15),   # benchmark/keyswitch_bench.cu:25-34
+    "c2_ckks14": (14, [60] + [40] * 7 + [60], 1),         # benchmark/ckks_bench.cu:255 (8 data limbs + 1 special)
+    "hyb14_a4": (14, [60] + [50] * 7 + [60] * 4, 4),      # 8 data limbs in 2 digits of 4
     "bfv13_50": (13, [50] * 4 + [60, 60], 2),             # uniform data primes: what the HPS variant of BFV multiply needs
 }
 

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "phantom-fhe_amd
 import torch
 import phantom_fhe_amd as P
 
-for kv in filter(None, os.environ.get("PHA_TUNING", "").split(",")):
+for kv in filter(None, os.environ.get("PHA_TUNING", "").split(",")):   # experiments library only (PHA_LIB_OVERRIDE)
     P.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 log_n = int(os.environ.get("PHA_OPS_LOGN", "16"))
 n = 1 << log_n
@@ -54,6 +54,10 @@ def relinearize():        # relinearize_inplace :1028-1077
     ctx.keyswitch_inplace(size_q, ct3, ct3[2], rlk.public_keys_ptr, S)
 def rescale():            # rescale_to_next_inplace :1376-1427
     ctx.divide_and_round_q_last_ntt(size_q, ct1, 2, resc)
+def relin_rescale():      # relinearize_inplace + rescale_to_next_inplace as one entry point (build-defined fusion, same result)
+    ctx.keyswitch_rescale(size_q, ct3, ct3[2], rlk.public_keys_ptr, resc)
+def hommul():             # multiply + relinearize + rescale
+    ctx.tensor_prod_2x2_rns_poly(ct1, ct2, out3, size_q); ctx.keyswitch_rescale(size_q, out3, out3[2], rlk.public_keys_ptr, resc)
 def rotate():             # rotate_inplace -> apply_galois_inplace :1567-1624 (NTT-domain permutation + key switch)
     ctx.apply_galois_ntt(ct1[0], g[0], elt, size_q); ctx.apply_galois_ntt(ct1[1], g[1], elt, size_q)
     rot[0].copy_(g[0]); rot[1].zero_()
@@ -65,6 +69,7 @@ print(f"CKKS N = 2^{log_n}, {size_q} + {alpha} limbs, one MI355X; 100 iterations
 print("| operation | median µs | mean µs |")
 print("|---|---|---|")
 for name, fn in (("multiply (tensor product)", multiply), ("relinearize (key switch)", relinearize), ("rescale_to_next", rescale),
+                 ("relinearize + rescale, one entry (pha_keyswitch_rescale)", relin_rescale), ("multiply + relinearize + rescale", hommul),
                  ("rotate (Galois + key switch)", rotate), ("add", add)):
     med, mean = stats(fn)
     print(f"| {name} | {med:.1f} | {mean:.1f} |")
