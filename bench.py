@@ -42,26 +42,56 @@ PEAK_HBM = 8.0e12                     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 C4_LOG_N = 15
 C4_BITS = [60] + [50] * 29 + [60] * 15  # benchmark/keyswitch_bench.cu:25-34
 C4_BATCH = 64
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes (tools/traffic_from_pmc.py)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes (tools/traffic.sh)
+STAGES_FILE = os.path.join(ROOT, "profiles", "stages.json")     # per-kernel GPU times of one HomMul (tools/stage_table.py over a committed kernel trace)
+C5_DIAGS = 128                        # BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block
+C5_BLOCKS = 8                         # row blocks of the job (split over the ranks)
 
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` with no launcher: start N ranks of this script (one per GPU, RCCL rendezvous on
-    127.0.0.1), pass rank 0's stdout through, return the worst exit code."""
+    127.0.0.1) and pass rank 0's stdout through.  The first rank that fails ends the job: its stderr tail is printed, its
+    siblings (which would otherwise wait inside a collective for ever) are terminated, and its exit code is returned."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        log = tempfile.TemporaryFile(mode="w+b")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=log))
+    rc, failed = 0, None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc, failed = code, r
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    for r, log in enumerate(logs):   # a failing rank's stderr in full (tail), the others' only if they said anything
+        log.seek(0)
+        text = log.read().decode("utf-8", "replace")
+        if text.strip() and (failed is None or r == failed):
+            sys.stderr.write(f"---- rank {r} stderr ----\n{text[-4000:]}\n")
+    if failed is not None:
+        sys.stderr.write(f"bench: rank {failed} exited with code {rc}; the other ranks were terminated\n")
     return rc
 
 
@@ -144,6 +174,17 @@ def load_traffic():
         return None
 
 
+def load_stages():
+    try:
+        raw = open(STAGES_FILE, "rb").read()
+        t = json.loads(raw)
+        t["file"] = os.path.relpath(STAGES_FILE, ROOT)
+        t["file_sha16"] = hashlib.sha256(raw).hexdigest()[:16]
+        return t
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +193,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the K steps from one hipGraph")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the K steps one by one from Python")
-    ap.add_argument("--only-ntt", action="store_true", help="skip the HomMul and config-4 legs (profiling runs)")
+    ap.add_argument("--only-ntt", action="store_true", help="skip the HomMul and config-4 / config-5 legs (profiling runs)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-5 leg (23 GB of Galois keys)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -188,6 +230,15 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # what the communicator itself reports (so that a multi-GPU record can show that RCCL saw N ranks on N devices)
+    comm = None
+    if world > 1 or force_dist:
+        props = torch.cuda.get_device_properties(dev_index)
+        mine_info = {"rank": dist.get_rank(), "device_index": dev_index, "device": props.name,
+                     "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+        infos = [None] * dist.get_world_size()
+        dist.all_gather_object(infos, mine_info)
+        comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "per_rank": infos}
     small = os.environ.get("PHA_BENCH_SMALL") == "1"    # functional test of the multi-rank path: smaller batches
 
     import phantom_fhe_amd as P
@@ -442,6 +493,62 @@ def main():
               "checksum_note": "sum mod 2^64 of all output words of the 64 ciphertexts; identical for every --gpus",
               "config": "BFV N=2^15, 30 data + 15 special limbs (keyswitch_bench.cu:25-34), keys broadcast from rank 0"}
 
+    c5 = None
+    if not args.only_ntt and not args.no_c5:
+        # ---- BASELINE config 5: encrypted 128-slot matrix-vector product in diagonal form at the C3 set: C5_BLOCKS row blocks
+        #      (split over the ranks), each one 128-diagonal block = 127 hoisted rotations + the main diagonal behind ONE mod-up
+        #      and ONE mod-down (pha_hoisting_weighted); the 127 Galois keys are generated on rank 0 and broadcast once ----
+        del ctx4
+        torch.cuda.empty_cache()
+        n_diag = 8 if small else C5_DIAGS
+        n_blocks = 2 if small else C5_BLOCKS
+        dnum5 = size_q // SIZE_P
+        kg = torch.Generator(device=dev)
+        kg.manual_seed(0x5EED0000 + 5)
+
+        def below_every_prime(shape, g):   # residues below 2^49 < every prime of the set (the arithmetic is data-independent)
+            return torch.randint(0, 1 << 49, shape, dtype=torch.int64, device=dev, generator=g)
+
+        elts = [1] + [pow(5, k, 2 * n) for k in range(1, n_diag)]
+        gkeys = [[torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum5)] for _ in elts[1:]]
+        if rank == 0:
+            for key in gkeys:
+                for d in key:
+                    d.copy_(below_every_prime((2, len(primes), n), kg))
+        t_b0 = time.perf_counter()
+        broadcast([d for key in gkeys for d in key])      # one-time RCCL broadcast of the Galois keys from rank 0
+        torch.cuda.synchronize()
+        bcast_s = time.perf_counter() - t_b0
+        glks = [None] + [P.PhantomRelinKey(key) for key in gkeys]
+        kg.manual_seed(0x5EED5000)
+        ct5 = below_every_prime((2, size_q, n), kg)        # the same input ciphertext on every rank
+        mine5 = pdist.shard_range(n_blocks, rank, world)
+        blocks5 = []
+        for b in mine5:                                    # block b's diagonals from its own seed: world-size independent
+            kg.manual_seed(0x5EED5100 + b)
+            blocks5.append([below_every_prime((size_q + SIZE_P, n), kg) for _ in elts])
+        res5 = [None]
+
+        def c5_step():
+            res5[0] = [W.diag_matvec(ctx, size_q, ct5, elts, glks, blk, P.scheme_type.ckks) for blk in blocks5]
+
+        c5_step()
+        c5_steps = 1 if small else 2
+        c5_elapsed = timed(c5_step, c5_steps)
+        local5 = sum(int(o.sum().item()) for o in res5[0]) & ((1 << 64) - 1) if blocks5 else 0
+        sums5 = pdist.gather_checksums(local5 - (1 << 64) if local5 >= (1 << 63) else local5, device=red_dev)
+        key_bytes = (n_diag - 1) * dnum5 * 2 * len(primes) * n * 8
+        c5 = {"value": n_blocks * c5_steps / c5_elapsed, "unit": "128-diagonal blocks/s (whole job)", "blocks": n_blocks,
+              "diagonals_per_block": n_diag, "scaling": "strong",
+              "ms_per_block": 1e3 * c5_elapsed / (c5_steps * max(len(pdist.shard_range(n_blocks, r, world)) for r in range(world))),
+              "per_rank_blocks": [len(pdist.shard_range(n_blocks, r, world)) for r in range(world)],
+              "galois_key_bytes": key_bytes, "key_broadcast_s": bcast_s if (world > 1 or force_dist) else None,
+              "checksum": f"{sum(sums5) & ((1 << 64) - 1):016x}",
+              "checksum_note": "sum mod 2^64 of all output words of the row blocks; identical for every --gpus",
+              "config": "CKKS N=2^16, 45 + 15 limbs; out_b = sum_k diag_{b,k} (.) rotate_k(ct), hoisted (no reference counterpart: "
+                        "SURVEY 8(0) row C5; building blocks src/evaluate.cu:1670-1866, :1297-1340)"}
+        del gkeys, glks, blocks5, res5
+
     if rank == 0:
         alg_bytes = 16.0 * n * size_q * nb             # 8 B read + 8 B write per coefficient
         achieved = alg_bytes / (kernel_ms * 1e-3)
@@ -488,12 +595,17 @@ def main():
                                      note=f"one 45-limb polynomial per launch pair, rotating over {nb} buffers")},
             "hommul_relin_rescale": hm,
             "keyswitch_c4": c4,
+            "matvec_c5": c5,
+            "rccl": comm,
             "collectives": ("RCCL (torch.distributed backend nccl)" if (world > 1 or force_dist) and not share else
                             "gloo (PHA_BENCH_SHARE_GPU)" if share and world > 1 else "none (one rank, no process group)"),
         }
         if hm is not None and traffic and traffic.get("hommul_bytes_per_op"):
             hm["traffic"] = traffic["hommul_bytes_per_op"]
             hm["traffic_ratio"] = traffic["hommul_bytes_per_op"] / hm["algorithmic_bytes_per_op"]
+        stages = load_stages()
+        if hm is not None and stages:
+            hm["stages"] = stages      # per-kernel us, algorithmic bytes and fraction of 8 TB/s from the committed kernel trace
         if not args.no_cpu_baseline and world == 1:
             def gpu_forward(host_poly):   # the product path on the baseline's own input
                 d = P.to_device(host_poly, dev)

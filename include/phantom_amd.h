@@ -373,6 +373,23 @@ int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *d
 int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint64_t *dst_ct, uint64_t *dst_c2,
                                    uint32_t galois_elt, size_t size_Ql, size_t batch, int ntt_form, void *stream);
 
+/* BASELINE config 4 as one call (build-defined composition of relinearize_inplace src/evaluate.cu:1028-1077 and
+ * apply_galois_inplace :1567-1624 over a batch, no reference launcher): out [batch][2][Ql][N] =
+ * rotate_{galois_elt}(relinearize(ct3 [batch][3][Ql][N])), i.e. per ciphertext keyswitch_inplace with rlk, the automorphism, and
+ * keyswitch_inplace with glk -- bit-identical to those calls.  ct3 is only read (out must not overlap it); the batch runs
+ * `chunk` ciphertexts per set of launches (0 = sized so that a set's mod-up digits stay within the 256 MiB MALL); no copies. */
+int pha_relinearize_rotate_batched(pha_context_t ctx, size_t size_Ql, const uint64_t *ct3, size_t batch,
+                                   const uint64_t *const *rlk, const uint64_t *const *glk, uint32_t galois_elt, int scheme,
+                                   uint64_t *out, size_t chunk, void *stream);
+
+/* ---- multi-GPU (the reference has none): one-time RCCL broadcast of evaluation / Galois keys.  keys[i] (HOST array
+ *      of n_keys DEVICE buffers, words_per_key uint64 words each -- for a PhantomRelinKey the dnum buffers of 2 * #QP * N words,
+ *      include/secretkey.h:102-165) are sent from rank `root` of `nccl_comm` (an ncclComm_t the caller created for its ranks, one
+ *      per GPU) to every other rank, in place, as one RCCL group on `stream`.  No collective exists on the data path: after this
+ *      call every rank key-switches its own ciphertexts.  RCCL is resolved with dlopen at first use (no link-time dependency). ---- */
+int pha_broadcast_keys(pha_context_t ctx, uint64_t *const *keys, size_t n_keys, size_t words_per_key, int root, void *nccl_comm,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

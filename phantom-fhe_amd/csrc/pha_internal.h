@@ -309,6 +309,7 @@ struct NttExtra {
     uint32_t batch = 1;                                  // polynomials per launch (blockIdx.z)
     size_t poly_stride = 0;                              // elements between consecutive polynomials of in / mid
     size_t out_stride = 0, aux_stride = 0;               // same for out and aux (0 = poly_stride)
+    size_t in_stride = 0;                                // polynomials of `in` when it is strided differently from mid (0 = poly_stride)
     const u64 *pro_src = nullptr;                        // forward only: every limb of polynomial z transforms
     size_t pro_stride = 0;                               //   (pro_src + z * pro_stride) mod its own prime; `in` unused
     uint32_t excl_step = 0;                              // polynomial z skips [excl_start + z*step, min(+len, limit))
@@ -332,7 +333,7 @@ struct BConvEpilogue {
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                   uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
                   const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0,
-                  const BConvEpilogue *epi = nullptr);
+                  const BConvEpilogue *epi = nullptr, size_t own_group_stride = 0);
 // converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)
 void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
                  const std::vector<u64> *out_scale = nullptr);

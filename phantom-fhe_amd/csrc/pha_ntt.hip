@@ -65,6 +65,7 @@ struct NttKArgs {
     uint32_t active;         // processed limbs = sel.count minus the excluded range (pipelined kernel)
     uint32_t batch;          // polynomials per launch (blockIdx.z)
     size_t poly_stride, out_stride, aux_stride;
+    size_t in_stride;        // elements between the polynomials of `in` (first pass; the second pass reads mid at poly_stride)
     uint32_t excl_step, excl_limit, excl_mod;
     const u64 *pro_src;      // rescale prologue: every limb of polynomial z reads pro_src + z * pro_stride instead
     size_t pro_stride;
@@ -142,7 +143,7 @@ template <class C, bool FWD, int EPI, bool FOLD>
 __device__ __forceinline__ void full_tile_args(const NttKArgs &k, uint32_t twr, uint32_t z, uint32_t tile, PassArgs &a) {
     tile_args<FWD, EPI, FOLD>(k, twr, tile, a);
     if (k.batch > 1) {  // same limbs of several polynomials in one launch
-        a.in += (size_t)z * k.poly_stride;
+        a.in += (size_t)z * k.in_stride;
         a.out += (size_t)z * k.out_stride;
         if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) a.aux += (size_t)z * k.aux_stride;
         if (EPI == EPI_FWD_KSRESCALE) a.aux2 += (size_t)z * k.aux2_stride;
@@ -474,6 +475,7 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     k.out_stride = k.poly_stride;
     const NttKArgs k1 = k;
     k.in = k.mid;
+    k.in_stride = k.poly_stride;
     k.out = final_out;
     k.out_stride = final_stride;
     k.pro_src = nullptr;   // the rescale prologue belongs to the first pass
@@ -509,6 +511,7 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     k.out_stride = k.poly_stride;
     const NttKArgs k1 = k;
     k.in = k.mid;
+    k.in_stride = k.poly_stride;
     k.out = final_out;
     k.out_stride = final_stride;
 #if defined(PHA_EXPERIMENTS)
@@ -553,6 +556,7 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.log_n = c.log_n;
     k.batch = x.batch ? x.batch : 1;
     k.poly_stride = x.poly_stride;
+    k.in_stride = x.in_stride ? x.in_stride : x.poly_stride;
     k.out_stride = x.out_stride ? x.out_stride : x.poly_stride;
     k.aux_stride = x.aux_stride ? x.aux_stride : x.poly_stride;
     k.excl_step = x.excl_step;

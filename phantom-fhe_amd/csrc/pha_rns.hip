@@ -213,14 +213,14 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                          uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src,
                          size_t src_stride, const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count,
-                         size_t group_stride, const BConvEpilogue *epi) {
+                         size_t group_stride, const BConvEpilogue *epi, size_t own_group_stride) {
     BConvLaunch L{};
     if (epi) {
         if (max_isz > 32) throw std::logic_error("the fused mod-down epilogue needs the register-resident converter");
         L.epi_cx = epi->cx; L.epi_dst = epi->dst; L.epi_cst = epi->cst;
         L.epi_cx_stride = epi->cx_stride; L.epi_dst_stride = epi->dst_stride; L.epi_acc = epi->accumulate ? 1 : 0;
     }
-    L.conv_count = conv_count; L.src_group_stride = group_stride; L.own_group_stride = group_stride;
+    L.conv_count = conv_count; L.src_group_stride = group_stride; L.own_group_stride = own_group_stride ? own_group_stride : group_stride;
     L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;
     L.dst_stride = dst_stride; L.src_stride = src_stride; L.mod = c.d_mod.p; L.n = (uint32_t)c.n;
     // balanced output groups: 45 outputs -> 2 groups of 23 (6 wavefronts per SIMD at C3 mod-up: one resident round)
@@ -725,19 +725,27 @@ __global__ __launch_bounds__(256) void galois_coeff_kernel(u64 *dst, const u64 *
 // apply_galois_inplace, src/evaluate.cu:1567-1624): polynomial 0 goes to dst_ct[b][0], dst_ct[b][1] is zeroed and polynomial 1
 // goes to the dense key-switch operand dst_c2[b] -- one kernel instead of permutation + memset + two strided copies.
 // blockIdx.z = 2 b + p.  `table` != null: NTT-domain gather; null: coefficient-domain scatter with sign (galois.cu:11-39).
+// `add` != null: the automorphism is applied to src + add (mod q), add being polynomial p of ciphertext b at add + (b * add_ct_polys
+// + p) * Ql * N -- the sum ct + keyswitch(c2) of a relinearization that was never stored (pha_relinearize_rotate_batched).
 __global__ __launch_bounds__(256) void galois_split_kernel(u64 *dst_ct, u64 *dst_c2, const u64 *src, const uint32_t *table,
-                                                           const DModulus *mod, uint32_t elt, uint32_t n, uint32_t ql) {
+                                                           const DModulus *mod, uint32_t elt, uint32_t n, uint32_t ql,
+                                                           const u64 *add, uint32_t add_ct_polys) {
     const uint32_t limb = blockIdx.y, b = blockIdx.z >> 1, p = blockIdx.z & 1;
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
     const u64 *in = src + ((size_t)(2 * b + p) * ql + limb) * n;
+    const u64 *in2 = add ? add + ((size_t)(add_ct_polys * b + p) * ql + limb) * n : nullptr;
     u64 *out = p ? dst_c2 + ((size_t)b * ql + limb) * n : dst_ct + ((size_t)(2 * b) * ql + limb) * n;
     if (!p) dst_ct[((size_t)(2 * b + 1) * ql + limb) * n + coeff] = 0;
+    const u64 q = mod[limb].value;
     if (table) {
-        out[coeff] = in[table[coeff]];
+        const uint32_t from = table[coeff];
+        u64 v = in[from];
+        if (in2) v = add_mod(v, in2[from], q);
+        out[coeff] = v;
     } else {
-        const u64 q = mod[limb].value;
         const uint32_t raw = (uint32_t)(((u64)coeff * elt) & (2 * (u64)n - 1));
         u64 v = in[coeff];
+        if (in2) v = add_mod(v, in2[coeff], q);
         if (raw >= n) v = neg_mod(v, q);
         out[raw & (n - 1)] = v;
     }
@@ -755,15 +763,18 @@ static bool ntt_domain_scheme(int scheme) {
 // DRNSTool::modup rns_bconv.cu:530-627.  All beta digits go through ONE base-conversion launch and ONE
 // forward-NTT launch pair (blockIdx.z = digit; digit z skips its own limbs, ntt_modup.cu:422).
 // `batch` ciphertexts at once: cks / t_cks are [batch][Ql][N], dst is [batch][beta][QlP][N].
+// cks_stride: elements between the c2 polynomials of consecutive ciphertexts (0 = dense, Ql * N)
 static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64 *t_cks, hipStream_t s,
-                  uint32_t batch = 1) {
+                  uint32_t batch = 1, size_t cks_stride = 0) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp, alpha = t.alpha;
     const bool ntt_dom = ntt_domain_scheme(scheme);
+    if (!cks_stride) cks_stride = (size_t)ql * n;
     if (ntt_dom) {
         NttExtra x;
         x.batch = batch;
         x.poly_stride = (size_t)ql * n;
+        x.in_stride = cks_stride;
         if (alpha == 1) {
             ntt_inverse(c, cks, t_cks, t_cks, plain_sel(0, ql), EPI_INV_CANON, x, s);
         } else {
@@ -776,9 +787,9 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
     if (alpha == 1) {
         for (uint32_t g = 0; g < batch; g++)
             for (uint32_t b = 0; b < t.beta; b++) {
-                const size_t off = (size_t)g * ql * n + (size_t)b * n;
+                const size_t off = (size_t)g * ql * n + (size_t)b * n, off_c = (size_t)g * cks_stride + (size_t)b * n;
                 u64 *out = dst + ((size_t)g * t.beta + b) * qlp * n;
-                SinglePArgs k{out, cks + off, (ntt_dom ? t_cks : cks) + off, c.d_mod.p, t.d_qlp_prime.p, b, (uint32_t)n};
+                SinglePArgs k{out, cks + off_c, ntt_dom ? t_cks + off : cks + off_c, c.d_mod.p, t.d_qlp_prime.p, b, (uint32_t)n};
                 hipLaunchKernelGGL(single_p_kernel, dim3((unsigned)(n / 256), qlp), dim3(256), 0, s, k);
                 check_launch();
             }
@@ -787,8 +798,11 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         // BFV still needs the q-hat^-1 scaling (bconv_mult_kernel :603-607), ckks/bgv got it in the iNTT
         uint32_t max_osz = 0;
         for (const BConv &b : t.digit) max_osz = b.osz > max_osz ? b.osz : max_osz;
+        // (coefficient-form input: the conversion reads c2 itself, at its own stride; NTT form: the dense t_cks, and c2 only
+        //  for the verbatim copy of the digit's own limbs)
         launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.split_ok, dst, (size_t)qlp * n,
-                     ntt_dom ? t_cks : cks, 0, cks, !ntt_dom, s, batch > 1 ? t.beta : 0, (size_t)ql * n);
+                     ntt_dom ? t_cks : cks, 0, cks, !ntt_dom, s, batch > 1 ? t.beta : 0, ntt_dom ? (size_t)ql * n : cks_stride,
+                     nullptr, cks_stride);
     }
     LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);
     NttExtra x;
@@ -1148,6 +1162,56 @@ int pha_keyswitch_rescale(pha_context_t ctx, size_t size_Ql, const uint64_t *ct,
     return pha_keyswitch_rescale_batched(ctx, size_Ql, ct, c2, 1, rlk, dst, stream);
 }
 
+// BASELINE config 4 as one call (build-defined composition of relinearize_inplace src/evaluate.cu:1028-1077 and
+// apply_galois_inplace :1567-1624 over a batch): out [B][2][Ql][N] = rotate_elt(relinearize(ct3 [B][3][Ql][N])).
+// Against the host composition of the two batched key switches it makes no copies at all: the first key switch reads c2 in
+// place (strided) and stores only keyswitch(c2); the Galois kernel forms ct + keyswitch(c2) as it permutes, writing the
+// operands of the second key switch straight into `out`, which that key switch then completes in place.
+int pha_relinearize_rotate_batched(pha_context_t ctx, size_t size_Ql, const uint64_t *ct3, size_t batch,
+                                   const uint64_t *const *rlk, const uint64_t *const *glk, uint32_t galois_elt, int scheme,
+                                   uint64_t *out, size_t chunk, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(ct3); need(rlk); need(glk); need(out);
+    if (batch == 0) return 0;
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    if (!(galois_elt & 1) || galois_elt >= 2 * c.n) throw std::invalid_argument("Galois element is not valid");
+    Tool &t = c.tool((uint32_t)size_Ql);
+    const bool ntt_dom = ntt_domain_scheme(scheme);
+    if (scheme == PHA_SCHEME_BGV && !t.bgv_ready) throw std::invalid_argument("bgv needs a plain modulus (pha_context_set_plain_modulus)");
+    hipStream_t s = as_stream(stream);
+    const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
+    if (overlaps(out, batch * 2 * ql_n, ct3, batch * 3 * ql_n)) throw std::invalid_argument("out must not overlap ct3");
+    // ciphertexts per set of launches: the mod-up digits of a set (beta x (l + alpha) limbs each) should stay within the MALL
+    // (measured at N = 2^15 / 30 + 15 limbs: 8 per set 233 us per ciphertext, all 64 at once 268, one by one 334)
+    if (chunk == 0) chunk = std::max<size_t>(1, ((size_t)192 << 20) / ((size_t)t.beta * qlp_n * sizeof(u64)));
+    chunk = std::min<size_t>(std::min<size_t>(chunk, batch), 1024);
+    while ((size_t)t.beta * chunk > 65535 || 2 * chunk > 65535) chunk /= 2;
+    const uint32_t *tab = ntt_dom ? c.galois_table(galois_elt) : nullptr;
+    // scratch: tmp [C][2][Ql][N] | t_mod_up [C][beta][QlP][N] | cx [C][2][QlP][N] | ks [C][2][Ql][N] | g1 [C][Ql][N]
+    const size_t C = chunk;
+    u64 *base = c.scratch(stream, C * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n + 3 * ql_n));
+    u64 *tmp = base, *t_mod_up = base + C * 2 * ql_n, *cx = t_mod_up + C * (size_t)t.beta * qlp_n, *ks = cx + C * 2 * qlp_n,
+        *g1 = ks + C * 2 * ql_n;
+    for (size_t b0 = 0; b0 < batch; b0 += C) {
+        const uint32_t B = (uint32_t)std::min(C, batch - b0);
+        const u64 *in = ct3 + b0 * 3 * ql_n;
+        u64 *o = out + b0 * 2 * ql_n;
+        // relinearize: ks = keyswitch(c2), c2 read where it lies (every third polynomial)
+        modup(c, t, t_mod_up, in + 2 * ql_n, scheme, tmp, s, B, 3 * ql_n);
+        inner_prod(c, t, cx, t_mod_up, rlk, s, B);
+        moddown_from_ntt(c, t, ks, ql_n, cx, qlp_n, 2 * B, scheme, false, tmp, s);
+        // rotate: (galois(c0 + ks0), 0) and galois(c1 + ks1) in the layout of the second key switch (apply_galois_inplace)
+        hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql, 2 * B), dim3(256), 0, s, o, g1, ks, tab,
+                           c.d_mod.p, galois_elt, (uint32_t)n, (uint32_t)size_Ql, in, 3u);
+        check_launch();
+        modup(c, t, t_mod_up, g1, scheme, tmp, s, B);
+        inner_prod(c, t, cx, t_mod_up, glk, s, B);
+        moddown_from_ntt(c, t, o, ql_n, cx, qlp_n, 2 * B, scheme, true, tmp, s);
+    }
+    PHA_API_END
+}
+
 int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                  const uint64_t *const *const *glk, int scheme, void *stream) {
     PHA_CTX_BEGIN(ctx)
@@ -1420,7 +1484,8 @@ int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint6
     if (2 * batch > 65535) throw std::invalid_argument("batch out of range");
     const uint32_t *tab = ntt_form ? c.galois_table(galois_elt) : nullptr;
     hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(c.n / 256), (unsigned)size_Ql, (unsigned)(2 * batch)), dim3(256), 0,
-                       as_stream(stream), dst_ct, dst_c2, src, tab, c.d_mod.p, galois_elt, (uint32_t)c.n, (uint32_t)size_Ql);
+                       as_stream(stream), dst_ct, dst_c2, src, tab, c.d_mod.p, galois_elt, (uint32_t)c.n, (uint32_t)size_Ql,
+                       (const u64 *)nullptr, 0u);
     check_launch();
     PHA_API_END
 }

@@ -686,6 +686,20 @@ public:
         upload_pointers(cudaStreamPerThread);
         gen_flag_ = true;
     }
+    // Extension (the reference is single-GPU): replicate the key generated on rank `root` on every rank of
+    // `nccl_comm` (an ncclComm_t with one rank per GPU), in place, with ONE RCCL group over xGMI.  Ranks other than the root
+    // call allocate_like() first, so that every rank holds buffers of the same shape.  Nothing else is ever communicated.
+    void allocate_like(const PhantomContext &context, size_t dnum, const cudaStream_t &stream = cudaStreamPerThread) {
+        allocate(context, dnum, stream);
+        gen_flag_ = true;
+    }
+    void broadcast(const PhantomContext &context, int root, void *nccl_comm, const cudaStream_t &stream = cudaStreamPerThread) {
+        if (!gen_flag_) throw std::invalid_argument("PhantomRelinKey has not been generated (non-root ranks: allocate_like)");
+        std::vector<uint64_t *> ptrs;
+        for (auto &pk : public_keys_) ptrs.push_back(pk.data());
+        const size_t words = 2 * context.coeff_mod_size() * context.poly_degree();
+        phantom::util::check_pha(pha_broadcast_keys(context.amd(), ptrs.data(), ptrs.size(), words, root, nccl_comm, stream));
+    }
     [[nodiscard]] uint64_t **public_keys_ptr() const { return public_keys_ptr_.get(); }
     [[nodiscard]] const PhantomCiphertext &public_key(size_t d) const { return public_keys_.at(d); }
     [[nodiscard]] size_t dnum() const { return public_keys_.size(); }
@@ -704,6 +718,10 @@ public:
     }
     [[nodiscard]] const std::vector<uint32_t> &galois_elts() const { return galois_elts_; }
     [[nodiscard]] const PhantomRelinKey &get_relin_keys(size_t index) const { return relin_keys_.at(index); }
+    // Extension: every key of the set from rank `root` to all ranks of `nccl_comm` (see PhantomRelinKey::broadcast)
+    void broadcast(const PhantomContext &context, int root, void *nccl_comm, const cudaStream_t &stream = cudaStreamPerThread) {
+        for (auto &rlk : relin_keys_) rlk.broadcast(context, root, nccl_comm, stream);
+    }
     // include/secretkey.h:196-220: the number of keys, then every relin key.  The file does not name the Galois
     // elements (the reference pairs key i with the context's i-th element), so load() takes them.
     void save(std::ostream &stream) const {

@@ -401,6 +401,22 @@ class PhantomContext:
         _lib.check(self._L.pha_apply_galois_for_keyswitch(self._h, _ptr(src), _ptr(dst_ct), _ptr(dst_c2), galois_elt, size_Ql,
                                                           batch, int(bool(ntt_form)), _stream()))
 
+    def relinearize_rotate_batched(self, size_Ql, ct3, batch, rlk_ptrs, glk_ptrs, galois_elt, scheme, out, chunk=0):
+        """BASELINE config 4 in one call: out [batch][2][Ql][N] = rotate(relinearize(ct3 [batch][3][Ql][N])); no copies."""
+        _lib.check(self._L.pha_relinearize_rotate_batched(self._h, size_Ql, _ptr(ct3), batch, _ptr(rlk_ptrs), _ptr(glk_ptrs),
+                                                          galois_elt, int(scheme), _ptr(out), chunk, _stream()))
+
+    def broadcast_keys(self, key_tensors, root, nccl_comm):
+        """RCCL-direct broadcast (pha_broadcast_keys) of a list of equally sized key tensors from rank `root` of the raw
+        ncclComm_t handle `nccl_comm` (an integer / ctypes pointer), in place."""
+        if not key_tensors:
+            return
+        words = key_tensors[0].numel()
+        if any(k.numel() != words for k in key_tensors):
+            raise ValueError("keys of one broadcast must have the same size")
+        arr = (C.c_void_p * len(key_tensors))(*[_ptr(k) for k in key_tensors])
+        _lib.check(self._L.pha_broadcast_keys(self._h, arr, len(key_tensors), words, int(root), C.c_void_p(nccl_comm), _stream()))
+
     # -- measurement ------------------------------------------------------------------------------
     def repeat_forward_ntt_batched(self, inout, cms, start, batch, poly_stride, repeats):
         """`repeats` back-to-back batched forward transforms enqueued from C (bench.py's timed region)."""

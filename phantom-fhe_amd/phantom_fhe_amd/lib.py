@@ -100,6 +100,8 @@ _SIGS = {
     "pha_apply_galois": [vp, vp, vp, C.c_uint32, sz, sz, vp],
     "pha_apply_galois_batched": [vp, vp, vp, C.c_uint32, sz, sz, C.c_int, vp],
     "pha_apply_galois_for_keyswitch": [vp, vp, vp, vp, C.c_uint32, sz, sz, C.c_int, vp],
+    "pha_broadcast_keys": [vp, C.POINTER(vp), sz, sz, C.c_int, vp, vp],
+    "pha_relinearize_rotate_batched": [vp, sz, vp, sz, vp, vp, C.c_uint32, C.c_int, vp, sz, vp],
     # include/phantom_amd_bench.h (measurement hooks)
     "pha_time_forward_ntt": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)],
     "pha_repeat_forward_ntt_batched": [vp, vp, sz, sz, sz, sz, C.c_int, vp],

@@ -17,12 +17,23 @@ from . import dist as pdist
 from .core import scheme_type
 
 
-def relinearize_rotate_batch(ctx, size_Ql, ct3, relin_key, galois_key, galois_elt, scheme, chunk=8):
+def relinearize_rotate_batch(ctx, size_Ql, ct3, relin_key, galois_key, galois_elt, scheme, chunk=0):
     """ct3 [B][3][Ql][N] (a batch of size-3 ciphertexts) -> [B][2][Ql][N]: relinearize, then rotate by
     galois_elt.  BFV ciphertexts are in coefficient form, CKKS / BGV in NTT form, as in the reference.
-    The batch goes through the batched key switch `chunk` ciphertexts at a time: the mod-up digits of a chunk
-    (chunk x beta x (l + alpha) limbs) should stay within the 256 MB MALL; at N = 2^15 / 30 + 15 limbs 8 per launch set
-    measured fastest (233 us per ciphertext against 268 us for all 64 at once and 334 us one by one)."""
+    One library call (pha_relinearize_rotate_batched): the batch goes through the batched key switches `chunk` ciphertexts
+    at a time (0: sized so that the mod-up digits of a set stay within the 256 MiB MALL -- 8 at N = 2^15 / 30 + 15 limbs, where
+    that measured fastest), with no copy between the stages."""
+    B = ct3.shape[0]
+    out = torch.empty_like(ct3[:, :2])
+    if B:
+        ctx.relinearize_rotate_batched(size_Ql, ct3.contiguous(), B, relin_key.public_keys_ptr, galois_key.public_keys_ptr,
+                                       galois_elt, scheme, out, chunk)
+    return out
+
+
+def relinearize_rotate_batch_host(ctx, size_Ql, ct3, relin_key, galois_key, galois_elt, scheme, chunk=8):
+    """The same from the two batched key switches and the Galois helper, composed on the host (the r02 form: three
+    polynomial copies per ciphertext more); kept as the cross-check of the one-call form."""
     B = ct3.shape[0]
     out = torch.empty_like(ct3[:, :2])
     for b0 in range(0, B, max(1, chunk)):

@@ -99,6 +99,14 @@ class _StubCtx:
         dst_ct[:, 1] = 0
         dst_c2.copy_(g[:, 1])
 
+    def relinearize_rotate_batched(self, ql, ct3, batch, rlk, glk, elt, scheme, out, chunk=0):
+        assert ct3.shape[0] == batch == out.shape[0]
+        ct = ct3[:, :2] + ct3[:, 2][:, None] * 3          # the stub key switch
+        g = ct.flip(-1) + elt                             # the stub automorphism
+        out[:, 0] = g[:, 0]
+        out[:, 1] = 0
+        out += g[:, 1][:, None] * 3
+
     def hoisting_weighted(self, ql, ct, elts, keys, weights, scheme):
         acc = sum(w[:ql] * int(e) for w, e in zip(weights, elts))
         ct *= acc[None]

@@ -20,7 +20,9 @@ def _keys(rng, primes, n, dnum):
     return np.stack([np.stack([uniform_poly(rng, primes, n), uniform_poly(rng, primes, n)]) for _ in range(dnum)])
 
 
-@pytest.mark.parametrize("name,scheme,ql,batch", [("hyb12_a2", O.BFV, 6, 5), ("hyb12_a2", O.CKKS, 4, 3), ("c4_bfv15", O.BFV, 30, 2)])
+@pytest.mark.parametrize("name,scheme,ql,batch", [("hyb12_a2", O.BFV, 6, 5), ("hyb12_a2", O.CKKS, 4, 3), ("c4_bfv15", O.BFV, 30, 2),
+                                                  ("hyb13_a3", O.CKKS, 7, 3), ("hyb13_a3", O.BFV, 9, 2), ("c1_bfv4096", O.BFV, 2, 4),
+                                                  ("c1_bfv4096", O.CKKS, 2, 1), ("hyb12_a2", O.BGV, 6, 2)])
 def test_config4_relinearize_rotate_batch(name, scheme, ql, batch, gpu):
     import phantom_fhe_amd as P
     from phantom_fhe_amd import workloads as W
@@ -29,13 +31,20 @@ def test_config4_relinearize_rotate_batch(name, scheme, ql, batch, gpu):
     size_q = len(primes) - size_p
     oc, ctx = oracle_ctx(name), _ctx(name, gpu)
     tool = O.Tool(oc, ql)
+    if scheme == O.BGV:
+        ctx.set_plain_modulus(65537)
+        tool.set_plain_modulus(65537)
     r = rng_for(800 + batch)
     rlk, glk = _keys(r, primes, n, size_q // size_p), _keys(r, primes, n, size_q // size_p)
     elt = 3
     ct3 = np.stack([np.stack([uniform_poly(r, primes[:ql], n) for _ in range(3)]) for _ in range(batch)])
     d_rlk, d_glk = P.PhantomRelinKey.from_numpy(rlk, gpu), P.PhantomRelinKey.from_numpy(glk, gpu)
     d_ct3 = P.to_device(ct3, gpu)
-    full = P.to_host(W.relinearize_rotate_batch(ctx, ql, d_ct3, d_rlk, d_glk, elt, scheme))
+    full = P.to_host(W.relinearize_rotate_batch(ctx, ql, d_ct3, d_rlk, d_glk, elt, scheme))      # pha_relinearize_rotate_batched
+    assert np.array_equal(P.to_host(d_ct3), ct3)                                                  # the input is only read
+    for chunk in (1, 2, 0):
+        assert np.array_equal(P.to_host(W.relinearize_rotate_batch(ctx, ql, d_ct3, d_rlk, d_glk, elt, scheme, chunk=chunk)), full)
+    assert np.array_equal(P.to_host(W.relinearize_rotate_batch_host(ctx, ql, d_ct3, d_rlk, d_glk, elt, scheme)), full)
     # the oracle's composition of the same reference steps, ciphertext by ciphertext
     table = O.galois_ntt_table(log_n, elt)
     for b in range(batch):
