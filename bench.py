@@ -44,7 +44,7 @@ C4_BITS = [60] + [50] * 29 + [60] * 15  # benchmark/keyswitch_bench.cu:25-34
 C4_BATCH = 64
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes (tools/traffic.sh)
 STAGES_FILE = os.path.join(ROOT, "profiles", "stages.json")     # per-kernel GPU times of one HomMul (tools/stage_table.py over a committed kernel trace)
-C5_DIAGS = 128                        # BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block
+C5_BABY, C5_GIANT = 32, 4             # BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block = 32 baby x 4 giant steps (tools/time_bsgs.py: 16x8 4.28, 32x4 3.59, 64x2 4.32 ms)
 C5_BLOCKS = 8                         # row blocks of the job (split over the ranks)
 
 
@@ -500,7 +500,8 @@ def main():
         #      and ONE mod-down (pha_hoisting_weighted); the 127 Galois keys are generated on rank 0 and broadcast once ----
         del ctx4
         torch.cuda.empty_cache()
-        n_diag = 8 if small else C5_DIAGS
+        nbaby, ngiant = (4, 2) if small else (C5_BABY, C5_GIANT)
+        n_diag = nbaby * ngiant
         n_blocks = 2 if small else C5_BLOCKS
         dnum5 = size_q // SIZE_P
         kg = torch.Generator(device=dev)
@@ -509,8 +510,11 @@ def main():
         def below_every_prime(shape, g):   # residues below 2^49 < every prime of the set (the arithmetic is data-independent)
             return torch.randint(0, 1 << 49, shape, dtype=torch.int64, device=dev, generator=g)
 
-        elts = [1] + [pow(5, k, 2 * n) for k in range(1, n_diag)]
-        gkeys = [[torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum5)] for _ in elts[1:]]
+        # diagonal k = i * nbaby + j: baby step j (rotation by j slots), giant step i (rotation by i * nbaby slots); element 5^r
+        baby_elts = [pow(5, j, 2 * n) for j in range(nbaby)]
+        giant_elts = [pow(5, nbaby * i, 2 * n) for i in range(ngiant)]
+        n_keys = nbaby - 1 + ngiant - 1
+        gkeys = [[torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum5)] for _ in range(n_keys)]
         if rank == 0:
             for key in gkeys:
                 for d in key:
@@ -519,34 +523,39 @@ def main():
         broadcast([d for key in gkeys for d in key])      # one-time RCCL broadcast of the Galois keys from rank 0
         torch.cuda.synchronize()
         bcast_s = time.perf_counter() - t_b0
-        glks = [None] + [P.PhantomRelinKey(key) for key in gkeys]
+        glks = [P.PhantomRelinKey(key) for key in gkeys]
+        baby_keys = [None] + glks[:nbaby - 1]
+        giant_keys = [None] + glks[nbaby - 1:]
         kg.manual_seed(0x5EED5000)
         ct5 = below_every_prime((2, size_q, n), kg)        # the same input ciphertext on every rank
         mine5 = pdist.shard_range(n_blocks, rank, world)
         blocks5 = []
         for b in mine5:                                    # block b's diagonals from its own seed: world-size independent
             kg.manual_seed(0x5EED5100 + b)
-            blocks5.append([below_every_prime((size_q + SIZE_P, n), kg) for _ in elts])
+            blocks5.append([[below_every_prime((size_q + SIZE_P, n), kg) for _ in range(nbaby)] for _ in range(ngiant)])
         res5 = [None]
 
         def c5_step():
-            res5[0] = [W.diag_matvec(ctx, size_q, ct5, elts, glks, blk, P.scheme_type.ckks) for blk in blocks5]
+            res5[0] = [W.diag_matvec_bsgs(ctx, size_q, ct5, baby_elts, baby_keys, giant_elts, giant_keys, blk, P.scheme_type.ckks)
+                       for blk in blocks5]
 
         c5_step()
-        c5_steps = 1 if small else 2
+        c5_steps = 1 if small else 3
         c5_elapsed = timed(c5_step, c5_steps)
         local5 = sum(int(o.sum().item()) for o in res5[0]) & ((1 << 64) - 1) if blocks5 else 0
         sums5 = pdist.gather_checksums(local5 - (1 << 64) if local5 >= (1 << 63) else local5, device=red_dev)
-        key_bytes = (n_diag - 1) * dnum5 * 2 * len(primes) * n * 8
+        key_bytes = n_keys * dnum5 * 2 * len(primes) * n * 8
         c5 = {"value": n_blocks * c5_steps / c5_elapsed, "unit": "128-diagonal blocks/s (whole job)", "blocks": n_blocks,
-              "diagonals_per_block": n_diag, "scaling": "strong",
+              "diagonals_per_block": n_diag, "baby_steps": nbaby, "giant_steps": ngiant, "scaling": "strong",
               "ms_per_block": 1e3 * c5_elapsed / (c5_steps * max(len(pdist.shard_range(n_blocks, r, world)) for r in range(world))),
               "per_rank_blocks": [len(pdist.shard_range(n_blocks, r, world)) for r in range(world)],
-              "galois_key_bytes": key_bytes, "key_broadcast_s": bcast_s if (world > 1 or force_dist) else None,
+              "galois_keys": n_keys, "galois_key_bytes": key_bytes,
+              "key_broadcast_s": bcast_s if (world > 1 or force_dist) else None,
               "checksum": f"{sum(sums5) & ((1 << 64) - 1):016x}",
               "checksum_note": "sum mod 2^64 of all output words of the row blocks; identical for every --gpus",
-              "config": "CKKS N=2^16, 45 + 15 limbs; out_b = sum_k diag_{b,k} (.) rotate_k(ct), hoisted (no reference counterpart: "
-                        "SURVEY 8(0) row C5; building blocks src/evaluate.cu:1670-1866, :1297-1340)"}
+              "config": f"CKKS N=2^16, 45 + 15 limbs; out_b = sum_i rot_(nb i)(sum_j diag_(b, nb i + j) (.) rot_j(ct)), nb = {nbaby}: baby-step / "
+                        f"giant-step with double hoisting (pha_hoisting_weighted_bsgs), {n_keys} Galois keys instead of {n_diag - 1}; no reference counterpart "
+                        "(SURVEY 8(0) row C5; building blocks src/evaluate.cu:1670-1866, :1297-1340)"}
         del gkeys, glks, blocks5, res5
 
     if rank == 0:

@@ -283,6 +283,19 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
  * [Ql + size_P][N].  Galois element 1 (main diagonal) takes no key: glk[e] may be NULL there. */
 int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *galois_elts, size_t n_elts,
                           const uint64_t *const *const *glk, const uint64_t *const *weights, int scheme, void *stream);
+
+/* Baby-step / giant-step form of the same sum (build-defined, BASELINE config 5): with d = n_giant * n_baby diagonals
+ *     ct <- sum_i rot_{giant_elts[i]}( sum_j weights[i * n_baby + j] (.) rot_{baby_elts[j]}(ct) )
+ * from n_baby - 1 + n_giant - 1 Galois keys instead of d - 1 (element 1 = no rotation, no key; a null weight = no such term).
+ * The baby rotations share one mod-up and stay in the extended base ("double hoisting"): giant step i is exactly
+ * pha_hoisting_weighted(ct, baby_elts, baby_glk, weights[i * n_baby ..]) -- B_i, one mod-down each, all in one batched launch set --
+ * and the giant rotations share ONE mod-down of the sum of their key-switch inner products:
+ *     ct <- (sum_i perm_i(B_i0), sum_{identity i} B_i1) + moddown( sum_{keyed i} <modup(perm_i(B_i1)), giant_glk[i]> ).
+ * weights[.] are device buffers [Ql + P][N] (NTT form) like pha_hoisting_weighted's, the tables are HOST arrays. ckks / bgv.
+ * At most 63 keyed baby steps and 63 / beta keyed giant steps per call. */
+int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *baby_elts, size_t n_baby,
+                               const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t n_giant,
+                               const uint64_t *const *const *giant_glk, const uint64_t *const *weights, int scheme, void *stream);
 /* PhantomSecretKey::generate_one_kswitch_key (src/secretkey.cu:297-341 with encrypt_zero_symmetric :232-295),
  * arithmetic part; the randomness comes from the caller because the PRNG (sample_uniform_poly /
  * sample_error_poly, src/prng.cu) is outside the accelerated path.  All buffers on the device:

@@ -540,6 +540,46 @@ class Tool:
         self.L.orc_hoisting_weighted(self.h, _p(ct), _p32(elts), len(elts), outer, warr, scheme)
         return ct.reshape(2, self.size_ql, self.n)
 
+    def hoisting_weighted_bsgs(self, ct, baby_elts, baby_glk, giant_elts, giant_glk, weights, scheme):
+        """Baby-step / giant-step form of hoisting_weighted (build-defined, BASELINE config 5), composed from the restated
+        reference steps: B_i = hoisting_weighted(ct, baby steps, weights[i]) for every giant step i (hoisting_inplace
+        src/evaluate.cu:1670-1866 with plaintext weights), then the giant rotations with ONE shared mod-down:
+        (sum_i perm_i(B_i0), sum_{identity i} B_i1) + moddown(sum_{keyed i} key_switch_inner_prod(modup(perm_i(B_i1)), key_i))
+        (apply_galois_ntt src/galois.cu:11-39, modup rns_bconv.cu:530-627, inner product eval_key_switch.cu:14-69, mod-down
+        rns_bconv.cu:776-828).  weights[i][j] may be None (no such term); keys may be None for element 1."""
+        n, ql, qlp = self.n, self.size_ql, self.size_qlp
+        primes_ql = [int(self.ctx.primes[i]) for i in range(ql)]
+        primes_qlp = primes_ql + [int(self.ctx.primes[self.ctx.size_q + i]) for i in range(self.ctx.size_p)]
+        zero = np.zeros((qlp, n), dtype=np.uint64)
+        ct = np.ascontiguousarray(ct, dtype=np.uint64).reshape(2, ql, n)
+        r0 = np.zeros((ql, n), dtype=np.uint64)
+        r1 = np.zeros((ql, n), dtype=np.uint64)
+        cx = np.zeros((2, qlp, n), dtype=np.uint64)
+
+        def add(a, b, primes):
+            out = np.empty_like(a)
+            for j, q in enumerate(primes):
+                s_ = a[j] + b[j]                       # both below 2^61: no wrap
+                out[j] = np.where(s_ >= np.uint64(q), s_ - np.uint64(q), s_)
+            return out
+
+        keyed = False
+        for i, ge in enumerate(giant_elts):
+            Bi = self.hoisting_weighted(ct, baby_elts, baby_glk, [w if w is not None else zero for w in weights[i]], scheme)
+            table = galois_ntt_table(self.ctx.log_n, int(ge))
+            r0 = add(r0, apply_galois_ntt(Bi[0], table, n, ql), primes_ql)
+            if int(ge) == 1:
+                r1 = add(r1, Bi[1], primes_ql)
+                continue
+            keyed = True
+            mu = self.modup(apply_galois_ntt(Bi[1], table, n, ql), scheme)
+            ip = self.key_switch_inner_prod(mu, giant_glk[i])
+            cx = np.stack([add(cx[p], ip[p], primes_qlp) for p in range(2)])
+        if keyed:
+            r0 = add(r0, self.moddown_from_ntt(cx[0], scheme), primes_ql)
+            r1 = add(r1, self.moddown_from_ntt(cx[1], scheme), primes_ql)
+        return np.stack([r0, r1])
+
     def set_plain_modulus(self, t):
         """BGV constants of the tool (rns.cu:196-285)."""
         if self.L.orc_tool_set_plain_modulus(self.h, int(t)) != 0:

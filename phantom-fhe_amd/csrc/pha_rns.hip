@@ -460,7 +460,51 @@ struct HoistArgs {
     uint32_t n, beta, n_elts, accumulate;  // accumulate: add to what cx already holds (split calls)
     size_t qlp_n, qp_n;
 };
+// BETA is a template parameter and every load of an element (2 x BETA gathered digit words, 4 x BETA key words, the next element's
+// permutation entry) is issued before the first multiply (r03: the run-time digit loop serialised one memory round trip per digit)
+template <int BETA>
 __global__ __launch_bounds__(256) void hoist_inner_prod_kernel(const HoistArgs k) {
+    const uint32_t nid = blockIdx.y;
+    const uint32_t twr = k.qlp_prime[nid];
+    const DModulus m = k.mod[twr];
+    const size_t coeff = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t out_id = (size_t)nid * k.n + coeff;
+    const size_t evk_id = (size_t)twr * k.n + coeff;
+    u64 a0l = 0, a0h = 0, a1l = 0, a1h = 0, b0l = 0, b0h = 0, b1l = 0, b1h = 0;
+    if (k.accumulate) {
+        const u64x2 p0 = *reinterpret_cast<const u64x2 *>(k.cx + out_id);
+        const u64x2 p1 = *reinterpret_cast<const u64x2 *>(k.cx + out_id + k.qlp_n);
+        a0l = p0.x; a1l = p0.y; b0l = p1.x; b1l = p1.y;
+    }
+    uint2 idx = *reinterpret_cast<const uint2 *>(k.tables[0] + coeff);
+    for (uint32_t e = 0; e < k.n_elts; e++) {
+        const uint2 idx_next = *reinterpret_cast<const uint2 *>(k.tables[e + 1 < k.n_elts ? e + 1 : e] + coeff);
+        const u64 *const *keys = k.keys[e];
+        u64 v0[BETA], v1[BETA];
+        u64x2 kb[BETA], ka[BETA];
+#pragma unroll
+        for (int i = 0; i < BETA; i++) {
+            const u64 *digit = k.t_mod_up + (size_t)i * k.qlp_n + (size_t)nid * k.n;
+            const u64 *key = keys[i];
+            v0[i] = digit[idx.x];
+            v1[i] = digit[idx.y];
+            kb[i] = *reinterpret_cast<const u64x2 *>(key + evk_id);
+            ka[i] = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+        }
+#pragma unroll
+        for (int i = 0; i < BETA; i++) {
+            mac128(v0[i], kb[i].x, a0l, a0h);
+            mac128(v1[i], kb[i].y, a1l, a1h);
+            mac128(v0[i], ka[i].x, b0l, b0h);
+            mac128(v1[i], ka[i].y, b1l, b1h);
+        }
+        idx = idx_next;
+    }
+    *reinterpret_cast<u64x2 *>(k.cx + out_id) = u64x2{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
+    *reinterpret_cast<u64x2 *>(k.cx + out_id + k.qlp_n) = u64x2{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
+}
+// any number of digits (run-time loop)
+__global__ __launch_bounds__(256) void hoist_inner_prod_generic_kernel(const HoistArgs k) {
     const uint32_t nid = blockIdx.y;
     const uint32_t twr = k.qlp_prime[nid];
     const DModulus m = k.mod[twr];
@@ -511,6 +555,7 @@ struct HoistWArgs {
     HoistArgs h;
     const u64 *const *weights;        // device array [n_elts] of weights [QlP][N] (NTT form)
 };
+template <int BETA>   // 0: run-time digit loop
 __global__ __launch_bounds__(256) void hoist_weighted_inner_prod_kernel(const HoistWArgs kw) {
     const HoistArgs &k = kw.h;
     const uint32_t nid = blockIdx.y;
@@ -525,26 +570,49 @@ __global__ __launch_bounds__(256) void hoist_weighted_inner_prod_kernel(const Ho
         const u64x2 p1 = *reinterpret_cast<const u64x2 *>(k.cx + out_id + k.qlp_n);
         a0l = p0.x; a1l = p0.y; b0l = p1.x; b1l = p1.y;
     }
+    uint2 idx = *reinterpret_cast<const uint2 *>(k.tables[0] + coeff);
     for (uint32_t e = 0; e < k.n_elts; e++) {
-        const uint2 idx = *reinterpret_cast<const uint2 *>(k.tables[e] + coeff);
+        const uint2 idx_next = *reinterpret_cast<const uint2 *>(k.tables[e + 1 < k.n_elts ? e + 1 : e] + coeff);
         const u64 *const *keys = k.keys[e];
-        u64 s0l = 0, s0h = 0, s1l = 0, s1h = 0, t0l = 0, t0h = 0, t1l = 0, t1h = 0;
-        for (uint32_t i = 0; i < k.beta; i++) {
-            const u64 *digit = k.t_mod_up + (size_t)i * k.qlp_n + (size_t)nid * k.n;
-            const u64 v0 = digit[idx.x], v1 = digit[idx.y];
-            const u64 *key = keys[i];
-            const u64x2 kb = *reinterpret_cast<const u64x2 *>(key + evk_id);
-            const u64x2 ka = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
-            mac128(v0, kb.x, s0l, s0h);
-            mac128(v1, kb.y, s1l, s1h);
-            mac128(v0, ka.x, t0l, t0h);
-            mac128(v1, ka.y, t1l, t1h);
-        }
         const u64x2 w = *reinterpret_cast<const u64x2 *>(kw.weights[e] + out_id);
+        u64 s0l = 0, s0h = 0, s1l = 0, s1h = 0, t0l = 0, t0h = 0, t1l = 0, t1h = 0;
+        if constexpr (BETA > 0) {   // every load of the element before the first multiply
+            u64 v0[BETA], v1[BETA];
+            u64x2 kb[BETA], ka[BETA];
+#pragma unroll
+            for (int i = 0; i < BETA; i++) {
+                const u64 *digit = k.t_mod_up + (size_t)i * k.qlp_n + (size_t)nid * k.n;
+                const u64 *key = keys[i];
+                v0[i] = digit[idx.x];
+                v1[i] = digit[idx.y];
+                kb[i] = *reinterpret_cast<const u64x2 *>(key + evk_id);
+                ka[i] = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+            }
+#pragma unroll
+            for (int i = 0; i < BETA; i++) {
+                mac128(v0[i], kb[i].x, s0l, s0h);
+                mac128(v1[i], kb[i].y, s1l, s1h);
+                mac128(v0[i], ka[i].x, t0l, t0h);
+                mac128(v1[i], ka[i].y, t1l, t1h);
+            }
+        } else {
+            for (uint32_t i = 0; i < k.beta; i++) {
+                const u64 *digit = k.t_mod_up + (size_t)i * k.qlp_n + (size_t)nid * k.n;
+                const u64 v0 = digit[idx.x], v1 = digit[idx.y];
+                const u64 *key = keys[i];
+                const u64x2 kb = *reinterpret_cast<const u64x2 *>(key + evk_id);
+                const u64x2 ka = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+                mac128(v0, kb.x, s0l, s0h);
+                mac128(v1, kb.y, s1l, s1h);
+                mac128(v0, ka.x, t0l, t0h);
+                mac128(v1, ka.y, t1l, t1h);
+            }
+        }
         mac128(barrett128(s0l, s0h, m), w.x, a0l, a0h);
         mac128(barrett128(s1l, s1h, m), w.y, a1l, a1h);
         mac128(barrett128(t0l, t0h, m), w.x, b0l, b0h);
         mac128(barrett128(t1l, t1h, m), w.y, b1l, b1h);
+        idx = idx_next;
     }
     *reinterpret_cast<u64x2 *>(k.cx + out_id) = u64x2{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
     *reinterpret_cast<u64x2 *>(k.cx + out_id + k.qlp_n) = u64x2{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
@@ -571,6 +639,171 @@ __global__ __launch_bounds__(256) void hoist_weighted_c_kernel(u64 *dst, const u
         }
     }
     dst[p * poly_stride + id] = barrett128(lo, hi, m);
+}
+
+// CPT consecutive words as one access
+template <int CPT>
+__device__ __forceinline__ void load_words(const u64 *p, u64 (&v)[CPT]) {
+    if constexpr (CPT == 2) {
+        const u64x2 t = *reinterpret_cast<const u64x2 *>(p);
+        v[0] = t.x;
+        v[1] = t.y;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int CPT>
+__device__ __forceinline__ void store_words(u64 *p, const u64 (&v)[CPT]) {
+    if constexpr (CPT == 2) *reinterpret_cast<u64x2 *>(p) = u64x2{v[0], v[1]};
+    else *p = v[0];
+}
+
+// ---- baby-step / giant-step form of the weighted hoisted rotations (BASELINE config 5, build-defined) -----------------------
+//      out = sum_i rot_{G_i}( sum_j w_ij (.) rot_{B_j}(ct) ):  d = ng * nb diagonals from nb - 1 baby keys and ng - 1 giant keys
+//      instead of d - 1 keys (24 GB of Galois keys per 128-diagonal block at C3 -> 4 GB).  "Double hoisting": the baby rotations
+//      share ONE mod-up of c1 and their inner products stay in the extended base [Q_l || P]; every giant step i weights them with
+//      its own plaintexts w_ij (given over [Q_l || P], as in pha_hoisting_weighted) and pays one mod-down; the giant rotations
+//      share ONE final mod-down of the sum of their inner products.
+// One thread = one coefficient of one limb; the accumulators of NG giant steps live in registers, so the baby keys, the gathered
+// digits and the per-baby Barrett reductions are paid once for all of them.
+struct BsgsArgs {
+    u64 *acc;                         // [ng][2][QlP][N]
+    const u64 *t_mod_up;              // [beta][QlP][N]
+    const u64 *const *const *keys;    // device [nb]: key table of baby j ([beta] keys), null for the identity
+    const uint32_t *const *tables;    // device [nb]: NTT-domain permutation of baby j
+    const u64 *const *weights;        // device [ng][nb]: w_ij over [QlP][N], null = no such term
+    const DModulus *mod;
+    const uint32_t *qlp_prime;
+    uint32_t n, beta, nb, g0;         // g0: first giant step of this launch
+    size_t qlp_n, qp_n;
+    const u64 *cc;                    // the input ciphertext (c0, c1), [2][Ql][N]
+    const u64x2 *p_mod_q;             // [Ql] P mod q_j with its Shoup quotient
+    uint32_t ql;
+    size_t ql_n;
+};
+// The c0 / c1 terms ride in the same accumulators: on a data limb j the value added is P * x mod q_j, which the mod-down that
+// follows (it divides by P exactly: (cx_j - conv(cx_P)_j) P^-1) turns back into x, and on the P limbs P * x = 0 -- so
+// moddown(acc + P * y) = moddown(acc) + y, word for word what a separate weighted sum over Q_l would add afterwards.
+// Every load of a baby step (3 gathered digits, the c0 word, 2 x BETA key words, NG weights, the next step's permutation
+// entry) is issued before the first multiply: the first version branched per giant step on a null weight and looped over the
+// digits at run time, which serialised ~12 memory round trips per baby step (2.9 TB/s); missing weights now point at a zero
+// plane supplied by the driver.
+template <int NG, int BETA>
+__global__ __launch_bounds__(256) void hoist_bsgs_inner_prod_kernel(const BsgsArgs k) {
+    const uint32_t nid = blockIdx.y;
+    const uint32_t twr = k.qlp_prime[nid];
+    const DModulus m = k.mod[twr];
+    const size_t coeff = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t out_id = (size_t)nid * k.n + coeff;
+    const size_t evk_id = (size_t)twr * k.n + coeff;
+    const bool data_limb = nid < k.ql;          // uniform
+    const u64x2 pq = data_limb ? k.p_mod_q[nid] : u64x2{0, 0};
+    const u64 *cc0 = k.cc + (size_t)(data_limb ? nid : 0) * k.n;   // (P limbs: any valid row, the value is multiplied by 0)
+    u64 al[NG], ah[NG], bl[NG], bh[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) al[g] = ah[g] = bl[g] = bh[g] = 0;
+    uint32_t idx = k.tables[0][coeff];
+    for (uint32_t j = 0; j < k.nb; j++) {
+        const u64 *const *keys = k.keys[j];
+        const uint32_t idx_next = k.tables[j + 1 < k.nb ? j + 1 : j][coeff];
+        // loads first
+        u64 wv[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) wv[g] = k.weights[(size_t)(k.g0 + g) * k.nb + j][out_id];
+        const u64 x0 = cc0[idx];
+        u64 s, t;
+        if (keys) {   // uniform
+            u64 v[BETA], kb[BETA], ka[BETA];
+#pragma unroll
+            for (int i = 0; i < BETA; i++) {
+                const u64 *key = keys[i];
+                v[i] = k.t_mod_up[(size_t)i * k.qlp_n + (size_t)nid * k.n + idx];
+                kb[i] = key[evk_id];
+                ka[i] = key[evk_id + k.qp_n];
+            }
+            u64 sl = 0, sh = 0, tl = 0, th = 0;
+#pragma unroll
+            for (int i = 0; i < BETA; i++) {
+                mac128(v[i], kb[i], sl, sh);
+                mac128(v[i], ka[i], tl, th);
+            }
+            s = barrett128(sl, sh, m);
+            t = barrett128(tl, th, m);
+            if (data_limb) s = add_mod(s, shoup(x0, pq, m.value), m.value);          // + P * rot_j(c0)
+        } else {      // identity baby step: (P c0, P c1) on the data limbs, nothing on the P limbs
+            s = data_limb ? shoup(x0, pq, m.value) : 0;
+            t = data_limb ? shoup(k.cc[k.ql_n + (size_t)nid * k.n + idx], pq, m.value) : 0;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            mac128(s, wv[g], al[g], ah[g]);
+            mac128(t, wv[g], bl[g], bh[g]);
+        }
+        idx = idx_next;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        u64 *acc = k.acc + (size_t)(k.g0 + g) * 2 * k.qlp_n + out_id;
+        acc[0] = barrett128(al[g], ah[g], m);
+        acc[k.qlp_n] = barrett128(bl[g], bh[g], m);
+    }
+}
+
+// giant steps, part 1: ct0 = sum_i B_i0[perm_Gi], ct1 = sum over the identity giant steps of B_i1, and the dense operands
+// g1[z] = B_i1[perm_Gi] of the keyed giant steps (z = their rank among the keyed ones)
+__global__ __launch_bounds__(256) void bsgs_combine_kernel(u64 *ct, u64 *g1, const u64 *B, const uint32_t *const *tables,
+                                                           const uint32_t *keyed_rank, uint32_t ng, const DModulus *mod, uint32_t n,
+                                                           size_t poly_stride) {
+    const uint32_t limb = blockIdx.y;
+    const u64 q = mod[limb].value;
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    const size_t id = (size_t)limb * n + coeff;
+    u64 r0 = 0, r1 = 0;
+    for (uint32_t i = 0; i < ng; i++) {
+        const uint32_t from = tables[i][coeff];
+        const u64 *b = B + (size_t)(2 * i) * poly_stride + (size_t)limb * n;
+        r0 = add_mod(r0, b[from], q);
+        const uint32_t z = keyed_rank[i];
+        if (z == 0xffffffffu) r1 = add_mod(r1, b[poly_stride + coeff], q);     // identity giant step
+        else g1[(size_t)z * poly_stride + id] = b[poly_stride + from];
+    }
+    ct[id] = r0;
+    ct[poly_stride + id] = r1;
+}
+
+// giant steps, part 2: cx = sum_z <modup(g1[z]), key_z> in one pass (the inner products of nk key switches that share a mod-down)
+struct MultiInnerArgs {
+    u64 *cx;                        // [2][QlP][N]
+    const u64 *t_mod_up;            // [nk][beta][QlP][N]
+    const u64 *const *const *keys;  // device [nk] -> [beta]
+    const DModulus *mod;
+    const uint32_t *qlp_prime;
+    uint32_t n, beta, nk;
+    size_t qlp_n, qp_n;
+};
+__global__ __launch_bounds__(256) void inner_prod_multi_kernel(const MultiInnerArgs k) {
+    const uint32_t nid = blockIdx.y;
+    const uint32_t twr = k.qlp_prime[nid];
+    const DModulus m = k.mod[twr];
+    const size_t coeff = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const size_t c2_id = (size_t)nid * k.n + coeff;
+    const size_t evk_id = (size_t)twr * k.n + coeff;
+    u64 a0l = 0, a0h = 0, a1l = 0, a1h = 0, b0l = 0, b0h = 0, b1l = 0, b1h = 0;
+    for (uint32_t z = 0; z < k.nk; z++) {
+        const u64 *const *keys = k.keys[z];
+        for (uint32_t i = 0; i < k.beta; i++) {
+            const u64 *key = keys[i];
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(k.t_mod_up + ((size_t)z * k.beta + i) * k.qlp_n + c2_id);
+            const u64x2 kb = *reinterpret_cast<const u64x2 *>(key + evk_id);
+            const u64x2 ka = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+            mac128(v.x, kb.x, a0l, a0h);
+            mac128(v.y, kb.y, a1l, a1h);
+            mac128(v.x, ka.x, b0l, b0h);
+            mac128(v.y, ka.y, b1l, b1h);
+        }
+    }
+    *reinterpret_cast<u64x2 *>(k.cx + c2_id) = u64x2{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
+    *reinterpret_cast<u64x2 *>(k.cx + c2_id + k.qlp_n) = u64x2{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
 }
 
 // ---- (cx - delta) * c element-wise: moddown_kernel rns_bconv.cu:680-689 and
@@ -1256,7 +1489,14 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
         k.qlp_prime = t.d_qlp_prime.p; k.n = (uint32_t)n; k.beta = t.beta;
         k.n_elts = (uint32_t)std::min(per_call, n_elts - e0); k.accumulate = e0 ? 1 : 0;
         k.qlp_n = qlp_n; k.qp_n = (size_t)c.size_qp * n;
-        hipLaunchKernelGGL(hoist_inner_prod_kernel, dim3((unsigned)(n / 512), t.size_qlp), dim3(256), 0, s, k);
+        const dim3 hgrid((unsigned)(n / 512), t.size_qlp), hblock(256);
+        switch (t.beta) {
+            case 1: hipLaunchKernelGGL(hoist_inner_prod_kernel<1>, hgrid, hblock, 0, s, k); break;
+            case 2: hipLaunchKernelGGL(hoist_inner_prod_kernel<2>, hgrid, hblock, 0, s, k); break;
+            case 3: hipLaunchKernelGGL(hoist_inner_prod_kernel<3>, hgrid, hblock, 0, s, k); break;
+            case 4: hipLaunchKernelGGL(hoist_inner_prod_kernel<4>, hgrid, hblock, 0, s, k); break;
+            default: hipLaunchKernelGGL(hoist_inner_prod_generic_kernel, hgrid, hblock, 0, s, k); break;
+        }
         check_launch();
     }
     // ct0 <- sum_e galois_e(c0) ; ct1 <- 0 ; then both += moddown(acc_cx) (fused into the NTT epilogue)
@@ -1330,7 +1570,14 @@ int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
             k.n_elts = (uint32_t)std::min(per_call, n_ks - e0); k.accumulate = e0 ? 1 : 0;
             k.qlp_n = qlp_n; k.qp_n = (size_t)c.size_qp * n;
             kw.weights = d_w + e0;
-            hipLaunchKernelGGL(hoist_weighted_inner_prod_kernel, dim3((unsigned)(n / 512), t.size_qlp), dim3(256), 0, s, kw);
+            const dim3 hgrid((unsigned)(n / 512), t.size_qlp), hblock(256);
+            switch (t.beta) {
+                case 1: hipLaunchKernelGGL(hoist_weighted_inner_prod_kernel<1>, hgrid, hblock, 0, s, kw); break;
+                case 2: hipLaunchKernelGGL(hoist_weighted_inner_prod_kernel<2>, hgrid, hblock, 0, s, kw); break;
+                case 3: hipLaunchKernelGGL(hoist_weighted_inner_prod_kernel<3>, hgrid, hblock, 0, s, kw); break;
+                case 4: hipLaunchKernelGGL(hoist_weighted_inner_prod_kernel<4>, hgrid, hblock, 0, s, kw); break;
+                default: hipLaunchKernelGGL(hoist_weighted_inner_prod_kernel<0>, hgrid, hblock, 0, s, kw); break;
+            }
             check_launch();
         }
     }
@@ -1339,6 +1586,119 @@ int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
                        d_tabs, d_w, (uint32_t)n_elts, (uint32_t)n_ks, c.d_mod.p, (uint32_t)n, ql_n);
     check_launch();
     if (n_ks) moddown_from_ntt(c, t, ct, ql_n, acc_cx, qlp_n, 2, scheme, true, tmp, s);
+    PHA_API_END
+}
+
+int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *baby_elts, size_t n_baby,
+                               const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t n_giant,
+                               const uint64_t *const *const *giant_glk, const uint64_t *const *weights, int scheme, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(ct); need(baby_elts); need(baby_glk); need(giant_elts); need(giant_glk); need(weights);
+    if (n_baby == 0 || n_giant == 0) throw std::invalid_argument("steps must not be empty");
+    if (!ntt_domain_scheme(scheme)) throw std::invalid_argument("weighted hoisting takes NTT-form ciphertexts (ckks / bgv)");
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    Tool &t = c.tool((uint32_t)size_Ql);
+    hipStream_t s = as_stream(stream);
+    const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n, nb = n_baby, ng = n_giant;
+    // 128-bit accumulators: every weighted term is below 2^122 (61-bit primes), 63 of them fit; the giant inner products are
+    // plain products (2^120 each for 60-bit primes)
+    size_t nbk = 0, nk = 0;
+    for (size_t j = 0; j < nb; j++) {
+        if (baby_elts[j] != 1 && !baby_glk[j]) throw std::logic_error("Galois key not present in hoisting");
+        nbk += baby_elts[j] != 1;
+    }
+    for (size_t i = 0; i < ng; i++) {
+        if (giant_elts[i] != 1 && !giant_glk[i]) throw std::logic_error("Galois key not present in hoisting");
+        nk += giant_elts[i] != 1;
+    }
+    if (nbk > 63 || nk * t.beta > 63 || 2 * ng > 65535) throw std::invalid_argument("too many steps for one call (at most 63 keyed baby steps)");
+    if (t.beta > 4) throw std::invalid_argument("more than 4 key-switch digits are not supported by the baby-step / giant-step form");
+    bool any_null = false;
+    for (size_t i = 0; i < ng * nb; i++) any_null = any_null || !weights[i];
+    std::vector<const void *> h_btab(nb), h_bkeys(nb), h_gtab(ng), h_gkeys;
+    std::vector<uint32_t> h_rank(ng);
+    for (size_t j = 0; j < nb; j++) {
+        h_btab[j] = c.galois_table(baby_elts[j]);
+        h_bkeys[j] = baby_elts[j] == 1 ? nullptr : baby_glk[j];
+    }
+    for (size_t i = 0; i < ng; i++) {
+        h_gtab[i] = c.galois_table(giant_elts[i]);
+        h_rank[i] = giant_elts[i] == 1 ? 0xffffffffu : (uint32_t)h_gkeys.size();
+        if (giant_elts[i] != 1) h_gkeys.push_back(giant_glk[i]);
+    }
+    // scratch: cc [2][Ql][N] | tmp [max(2 ng, nk)][Ql][N] | mod-up [beta][QlP][N] | acc [ng][2][QlP][N] | B [ng][2][Ql][N] |
+    //          g1 [nk][Ql][N] | giant mod-up [nk][beta][QlP][N] | cx [2][QlP][N] | pointer tables
+    const size_t n_tmp = std::max<size_t>(2 * ng, std::max<size_t>(nk, 2));
+    const size_t ptr_words = 2 * nb + ng * nb + 2 * ng + nk + (any_null ? qlp_n : 0);   // (+ a zero plane for the missing weights)
+    u64 *base = c.scratch(stream, 2 * ql_n + n_tmp * ql_n + (size_t)t.beta * qlp_n + ng * 2 * qlp_n + ng * 2 * ql_n + nk * ql_n +
+                                      nk * (size_t)t.beta * qlp_n + 2 * qlp_n + ptr_words);
+    u64 *cc = base, *tmp = cc + 2 * ql_n, *t_mod_up = tmp + n_tmp * ql_n, *acc = t_mod_up + (size_t)t.beta * qlp_n,
+        *B = acc + ng * 2 * qlp_n, *g1 = B + ng * 2 * ql_n, *mu_g = g1 + nk * ql_n, *cxg = mu_g + nk * (size_t)t.beta * qlp_n,
+        *d_ptrs = cxg + 2 * qlp_n;
+    u64 *p_btab = d_ptrs, *p_bkeys = p_btab + nb, *p_w = p_bkeys + nb, *p_gtab = p_w + ng * nb, *p_rank = p_gtab + ng, *p_gkeys = p_rank + ng;
+    PHA_HIP(hipMemcpyAsync(p_btab, h_btab.data(), nb * sizeof(void *), hipMemcpyHostToDevice, s));
+    PHA_HIP(hipMemcpyAsync(p_bkeys, h_bkeys.data(), nb * sizeof(void *), hipMemcpyHostToDevice, s));
+    std::vector<const void *> h_w(weights, weights + ng * nb);
+    if (any_null) {
+        u64 *zero = p_gkeys + nk;
+        PHA_HIP(hipMemsetAsync(zero, 0, qlp_n * sizeof(u64), s));
+        for (auto &w : h_w)
+            if (!w) w = zero;
+    }
+    PHA_HIP(hipMemcpyAsync(p_w, h_w.data(), ng * nb * sizeof(void *), hipMemcpyHostToDevice, s));
+    PHA_HIP(hipMemcpyAsync(p_gtab, h_gtab.data(), ng * sizeof(void *), hipMemcpyHostToDevice, s));
+    PHA_HIP(hipMemcpyAsync(p_rank, h_rank.data(), ng * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (nk) PHA_HIP(hipMemcpyAsync(p_gkeys, h_gkeys.data(), nk * sizeof(void *), hipMemcpyHostToDevice, s));
+    const uint32_t *const *d_btab = reinterpret_cast<const uint32_t *const *>(p_btab);
+    const u64 *const *const *d_bkeys = reinterpret_cast<const u64 *const *const *>(p_bkeys);
+    const u64 *const *d_w = reinterpret_cast<const u64 *const *>(p_w);
+    const uint32_t *const *d_gtab = reinterpret_cast<const uint32_t *const *>(p_gtab);
+    const u64 *const *const *d_gkeys = reinterpret_cast<const u64 *const *const *>(p_gkeys);
+
+    PHA_HIP(hipMemcpyAsync(cc, ct, 2 * ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    // baby steps: one mod-up of c1, then every giant step's weighted sum of the hoisted inner products (and of the c0 / c1
+    // terms, pre-multiplied by P) in one pass over the baby keys; B_i = moddown(acc_i), all giant steps in one batched launch set
+    if (nbk) modup(c, t, t_mod_up, ct + ql_n, scheme, tmp, s);
+    {
+        BsgsArgs k{};
+        k.acc = acc; k.t_mod_up = t_mod_up; k.keys = d_bkeys; k.tables = d_btab; k.weights = d_w; k.mod = c.d_mod.p;
+        k.qlp_prime = t.d_qlp_prime.p; k.n = (uint32_t)n; k.beta = t.beta; k.nb = (uint32_t)nb;
+        k.qlp_n = qlp_n; k.qp_n = (size_t)c.size_qp * n;
+        k.cc = cc; k.p_mod_q = t.p_mod_q2.p; k.ql = (uint32_t)size_Ql; k.ql_n = ql_n;
+        const dim3 grid((unsigned)(n / 256), t.size_qlp), block(256);
+#define PHA_BSGS_GO(NG)                                                                                                   \
+    do {                                                                                                                  \
+        switch (t.beta) {                                                                                                 \
+            case 1: hipLaunchKernelGGL((hoist_bsgs_inner_prod_kernel<NG, 1>), grid, block, 0, s, k); break;              \
+            case 2: hipLaunchKernelGGL((hoist_bsgs_inner_prod_kernel<NG, 2>), grid, block, 0, s, k); break;              \
+            case 3: hipLaunchKernelGGL((hoist_bsgs_inner_prod_kernel<NG, 3>), grid, block, 0, s, k); break;              \
+            default: hipLaunchKernelGGL((hoist_bsgs_inner_prod_kernel<NG, 4>), grid, block, 0, s, k); break;             \
+        }                                                                                                                 \
+    } while (0)
+        for (size_t g0 = 0; g0 < ng;) {
+            const size_t left = ng - g0;
+            k.g0 = (uint32_t)g0;
+            if (left >= 8) { PHA_BSGS_GO(8); g0 += 8; }
+            else if (left >= 4) { PHA_BSGS_GO(4); g0 += 4; }
+            else if (left >= 2) { PHA_BSGS_GO(2); g0 += 2; }
+            else { PHA_BSGS_GO(1); g0 += 1; }
+            check_launch();
+        }
+#undef PHA_BSGS_GO
+    }
+    moddown_from_ntt(c, t, B, ql_n, acc, qlp_n, (uint32_t)(2 * ng), scheme, false, tmp, s);
+    // giant steps: permutations, then ONE mod-down for the sum of their key-switch inner products
+    hipLaunchKernelGGL(bsgs_combine_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql), dim3(256), 0, s, ct, g1, B, d_gtab,
+                       reinterpret_cast<const uint32_t *>(p_rank), (uint32_t)ng, c.d_mod.p, (uint32_t)n, ql_n);
+    check_launch();
+    if (nk) {
+        modup(c, t, mu_g, g1, scheme, tmp, s, (uint32_t)nk);
+        MultiInnerArgs k{cxg, mu_g, d_gkeys, c.d_mod.p, t.d_qlp_prime.p, (uint32_t)n, t.beta, (uint32_t)nk, qlp_n, (size_t)c.size_qp * n};
+        hipLaunchKernelGGL(inner_prod_multi_kernel, dim3((unsigned)(n / 512), t.size_qlp), dim3(256), 0, s, k);
+        check_launch();
+        moddown_from_ntt(c, t, ct, ql_n, cxg, qlp_n, 2, scheme, true, tmp, s);
+    }
     PHA_API_END
 }
 

@@ -350,6 +350,21 @@ class PhantomContext:
         _lib.check(self._L.pha_hoisting_weighted(self._h, size_Ql, _ptr(ct), elts, len(galois_elts), tabs, ws, int(scheme),
                                                  _stream()))
 
+    def hoisting_weighted_bsgs(self, size_Ql, ct, baby_elts, baby_keys, giant_elts, giant_keys, weights, scheme):
+        """Baby-step / giant-step form (pha_hoisting_weighted_bsgs): ct <- sum_i rot_{giant_elts[i]}(sum_j weights[i][j] (.)
+        rot_{baby_elts[j]}(ct)); weights is a list (per giant step) of lists (per baby step) of device tensors [Ql + size_P][N] or
+        None; keys may be None for element 1."""
+        be = (C.c_uint32 * len(baby_elts))(*[int(e) for e in baby_elts])
+        ge = (C.c_uint32 * len(giant_elts))(*[int(e) for e in giant_elts])
+        bk = (C.c_void_p * len(baby_keys))(*[k.public_keys_ptr.data_ptr() if k is not None else None for k in baby_keys])
+        gk = (C.c_void_p * len(giant_keys))(*[k.public_keys_ptr.data_ptr() if k is not None else None for k in giant_keys])
+        flat = [w for row in weights for w in row]
+        if len(flat) != len(baby_elts) * len(giant_elts):
+            raise ValueError("weights must be [n_giant][n_baby]")
+        ws = (C.c_void_p * len(flat))(*[_ptr(w) for w in flat])
+        _lib.check(self._L.pha_hoisting_weighted_bsgs(self._h, size_Ql, _ptr(ct), be, len(baby_elts), bk, ge, len(giant_elts), gk, ws,
+                                                      int(scheme), _stream()))
+
     def divide_and_round_q_last_ntt(self, size_Ql, src, cipher_size, dst):
         _lib.check(self._L.pha_divide_and_round_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
                                                            _stream()))

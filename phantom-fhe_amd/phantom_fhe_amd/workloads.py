@@ -75,6 +75,16 @@ def diag_matvec(ctx, size_Ql, ct, galois_elts, galois_keys, diagonals, scheme):
     return out
 
 
+def diag_matvec_bsgs(ctx, size_Ql, ct, baby_elts, baby_keys, giant_elts, giant_keys, diagonals, scheme):
+    """The same block in baby-step / giant-step form (pha_hoisting_weighted_bsgs): with d = n_giant * n_baby diagonals,
+    out = sum_i rot_{giant_elts[i]}(sum_j diagonals[i][j] (.) rot_{baby_elts[j]}(ct)) from n_baby + n_giant - 2 Galois keys instead of
+    d - 1.  diagonals[i][j] is diagonal i * n_baby + j of the matrix, rotated back by giant step i and encoded over [Q_l || P]
+    ([Ql + size_P][N], NTT form) -- the usual offline preparation of the BSGS matrix-vector product."""
+    out = ct.clone()
+    ctx.hoisting_weighted_bsgs(size_Ql, out, baby_elts, baby_keys, giant_elts, giant_keys, diagonals, scheme)
+    return out
+
+
 def matvec_row_blocks_sharded(ctx, size_Ql, ct, galois_elts, galois_keys, blocks, scheme, rank=None, world=None):
     """Config 5 on this rank: `blocks` is a list of row blocks of the matrix, each a list of encoded diagonals
     (one output ciphertext per block); blocks are split contiguously over the ranks.  Returns (index range,

@@ -181,3 +181,80 @@ def test_config5_128_diagonals_at_the_c3_parameter_set(gpu):
     okeys = [None] + [[key_pool[k % 3][i] for i in range(tool.beta)] for k in range(1, n_diag)]
     want = tool.hoisting_weighted(ct, elts, okeys, [w_pool[k % 4] for k in range(n_diag)], O.CKKS)
     assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("name,scheme,ql,nb,ng,ident", [("hyb12_a2", O.CKKS, 5, 4, 3, True), ("hyb12_a2", O.BGV, 6, 3, 2, True),
+                                                        ("hyb13_a3", O.CKKS, 7, 4, 2, False), ("hyb13_a3", O.CKKS, 9, 2, 9, True),
+                                                        ("c1_bfv4096", O.CKKS, 2, 3, 2, True)])
+def test_config5_bsgs_matches_the_composition_of_reference_steps(name, scheme, ql, nb, ng, ident, gpu):
+    """pha_hoisting_weighted_bsgs (baby-step / giant-step, double-hoisted) against the oracle's composition of the restated
+    reference steps (Tool.hoisting_weighted_bsgs): identity steps with and without keys around them, a missing term,
+    short digits, alpha = 1, bgv."""
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    if scheme == O.BGV:
+        ctx.set_plain_modulus(65537)
+        tool.set_plain_modulus(65537)
+    r = rng_for(950 + nb * 10 + ng)
+    first = 0 if ident else 1
+    baby = [int(pow(5, k, 2 * n)) for k in range(first, first + nb)]              # ident: element 1 first
+    giant = [int(pow(5, nb * k, 2 * n)) for k in range(first, first + ng)]
+    dnum = size_q // size_p
+    bkeys = [None if e == 1 else _keys(r, primes, n, dnum) for e in baby]
+    gkeys = [None if e == 1 else _keys(r, primes, n, dnum) for e in giant]
+    qlp_primes = [primes[i] for i in list(range(ql)) + [size_q + j for j in range(size_p)]]
+    ws = [[uniform_poly(r, qlp_primes, n) for _ in baby] for _ in giant]
+    ws[ng - 1][nb - 1] = None                                                     # one missing diagonal
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    d_bkeys = [None if k is None else P.PhantomRelinKey.from_numpy(k, gpu) for k in bkeys]
+    d_gkeys = [None if k is None else P.PhantomRelinKey.from_numpy(k, gpu) for k in gkeys]
+    d_ws = [[None if w is None else P.to_device(w, gpu) for w in row] for row in ws]
+    d_ct = P.to_device(ct, gpu)
+    out = P.to_host(W.diag_matvec_bsgs(ctx, ql, d_ct, baby, d_bkeys, giant, d_gkeys, d_ws, scheme))
+    assert np.array_equal(P.to_host(d_ct), ct)
+    okb = [None if k is None else [k[i] for i in range(tool.beta)] for k in bkeys]
+    okg = [None if k is None else [k[i] for i in range(tool.beta)] for k in gkeys]
+    want = tool.hoisting_weighted_bsgs(ct, baby, okb, giant, okg, ws, scheme)
+    assert np.array_equal(out, want)
+    # one giant step with element 1 is the flat form
+    flat = P.to_host(W.diag_matvec_bsgs(ctx, ql, d_ct, baby, d_bkeys, [1], [None], [[w if w is not None else d_ws[0][0] for w in d_ws[0]]], scheme))
+    assert np.array_equal(flat, P.to_host(W.diag_matvec(ctx, ql, d_ct, baby, d_bkeys, d_ws[0], scheme)))
+    with pytest.raises(ArithmeticError):         # std::logic_error: a rotation without its key (evaluate.cu:1783)
+        ctx.hoisting_weighted_bsgs(ql, d_ct.clone(), baby, [None] * nb, giant, d_gkeys, d_ws, scheme)
+
+
+def test_config5_bsgs_16_by_8_at_the_c3_parameter_set(gpu):
+    """BASELINE config 5 at its stated size in baby-step / giant-step form: 128 diagonals = 16 baby x 8 giant steps at the CKKS set
+    N = 2^16, 45 + 15 limbs (15 + 7 Galois keys instead of 127), against the oracle's composition.  Keys cycle over 3 buffers and
+    diagonals over 4 plaintexts as in the flat test (the launches, pointer tables and accumulations are the real ones)."""
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    name, ql, nb, ng = "c3_ckks16", 45, 16, 8
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(5129)
+    baby = [int(pow(5, k, 2 * n)) for k in range(nb)]
+    giant = [int(pow(5, nb * k, 2 * n)) for k in range(ng)]
+    key_pool = [_keys(r, primes, n, size_q // size_p) for _ in range(3)]
+    qlp_primes = [primes[i] for i in list(range(ql)) + [size_q + j for j in range(size_p)]]
+    w_pool = [uniform_poly(r, qlp_primes, n) for _ in range(4)]
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    d_key_pool = [P.PhantomRelinKey.from_numpy(k, gpu) for k in key_pool]
+    d_w_pool = [P.to_device(w, gpu) for w in w_pool]
+    d_bk = [None] + [d_key_pool[k % 3] for k in range(1, nb)]
+    d_gk = [None] + [d_key_pool[(k + 1) % 3] for k in range(1, ng)]
+    d_ws = [[d_w_pool[(i * nb + j) % 4] for j in range(nb)] for i in range(ng)]
+    out = P.to_host(W.diag_matvec_bsgs(ctx, ql, P.to_device(ct, gpu), baby, d_bk, giant, d_gk, d_ws, O.CKKS))
+    okb = [None] + [[key_pool[k % 3][i] for i in range(tool.beta)] for k in range(1, nb)]
+    okg = [None] + [[key_pool[(k + 1) % 3][i] for i in range(tool.beta)] for k in range(1, ng)]
+    ows = [[w_pool[(i * nb + j) % 4] for j in range(nb)] for i in range(ng)]
+    want = tool.hoisting_weighted_bsgs(ct, baby, okb, giant, okg, ows, O.CKKS)
+    assert np.array_equal(out, want)
