@@ -23,6 +23,10 @@ int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t coeff_modulu
  * the nominal 8 TB/s that the roofline object quotes beside it. */
 int pha_time_stream_copy(uint64_t *dst, const uint64_t *src, size_t bytes, int iters, void *stream, double *bytes_per_s);
 
+/* number of scratch arenas the context currently holds (one per explicit stream, one per live host thread for the per-thread and
+ * null streams; a thread's arenas are released when it exits) */
+int pha_context_arena_count(pha_context_t ctx, size_t *count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,14 @@ int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t cms, int ite
     PHA_API_END
 }
 
+int pha_context_arena_count(pha_context_t ctx, size_t *count) {
+    PHA_CTX_BEGIN(ctx)
+    need(count);
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    *count = ctx->c.arenas.size() + ctx->c.outer_arenas.size();
+    PHA_API_END
+}
+
 int pha_time_stream_copy(uint64_t *dst, const uint64_t *src, size_t bytes, int iters, void *stream, double *bytes_per_s) {
     PHA_API_BEGIN
     need(dst); need(src); need(bytes_per_s);

@@ -7,6 +7,7 @@
 // two can check each other.  Each prime's tables are computed once and shared by every level
 // (the reference recomputes them per ContextData).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <thread>
 
@@ -891,9 +892,50 @@ Tool &Context::tool(uint32_t size_ql) {
     return ref;
 }
 
+// ---- per-thread arenas of the sentinel streams ---------------------------------------------------------------------------------
+// hipStreamPerThread and the null stream name a different real stream in every host thread, so those two handles get one arena
+// per calling thread, keyed by a process-wide thread number (never reused: no two live threads share an arena).  A thread that
+// exits gives its arenas back: a thread_local reaper walks the live contexts at thread exit (a pool of short-lived threads no
+// longer grows one scratch arena -- hundreds of MB at N = 2^16 -- per thread for the life of the context).
+namespace {
+std::mutex g_live_mu;
+std::vector<Context *> g_live_contexts;
+std::atomic<size_t> g_thread_counter{0};
+
+struct ThreadReaper {
+    size_t id = 0;
+    ~ThreadReaper() {
+        if (!id) return;
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (Context *c : g_live_contexts) c->release_thread_arenas(id);
+    }
+};
+thread_local ThreadReaper t_reaper;
+
+size_t this_thread_number() {
+    if (!t_reaper.id) t_reaper.id = ++g_thread_counter;
+    return t_reaper.id;
+}
+}  // namespace
+
+void register_context(Context *c, bool alive) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (alive) g_live_contexts.push_back(c);
+    else g_live_contexts.erase(std::remove(g_live_contexts.begin(), g_live_contexts.end(), c), g_live_contexts.end());
+}
+
+void Context::release_thread_arenas(size_t thread_number) {
+    std::lock_guard<std::mutex> lk(mu);
+    DeviceGuard on_device(device);
+    // (DevBuf's hipFree waits for the device, so nothing the exiting thread enqueued can still be using the block)
+    for (auto *m : {&arenas, &outer_arenas})
+        for (auto it = m->begin(); it != m->end();)
+            it = it->first.second == thread_number ? m->erase(it) : std::next(it);
+}
+
 Context::ArenaKey Context::arena_key(void *stream) {
     const bool sentinel = stream == nullptr || as_stream(stream) == hipStreamPerThread;
-    return ArenaKey{stream, sentinel ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0};
+    return ArenaKey{stream, sentinel ? this_thread_number() : 0};
 }
 
 u64 *Context::scratch(void *stream, size_t words) {
@@ -985,12 +1027,14 @@ int pha_context_create(pha_context_t *out, uint32_t log_n, const uint64_t *prime
     if (!out || !primes_qp) throw std::invalid_argument("null argument");
     auto h = std::make_unique<pha_context>();
     context_init(h->c, log_n, primes_qp, size_qp, size_p, device_id);
+    register_context(&h->c, true);
     *out = h.release();
     PHA_API_END
 }
 
 void pha_context_destroy(pha_context_t ctx) {
     if (!ctx) return;
+    register_context(&ctx->c, false);
     (void)hipSetDevice(ctx->c.device);
     (void)hipDeviceSynchronize();
     delete ctx;

@@ -245,6 +245,7 @@ struct Context {
     // real stream (or none) in every host thread, so those two handles get one arena per calling thread
     typedef std::pair<void *, size_t> ArenaKey;
     static ArenaKey arena_key(void *stream);
+    void release_thread_arenas(size_t thread_number);   // called when a host thread exits (pha_context.hip: ThreadReaper)
     std::map<ArenaKey, std::unique_ptr<Arena>> arenas;
     std::map<ArenaKey, std::unique_ptr<Arena>> outer_arenas;   // for entry points that call other entry points (which use `arenas`)
     u64 *scratch_outer(void *stream, size_t words);
@@ -342,6 +343,8 @@ void describe_conv(const BConv &b, DevBuf<BConvDev> &out);
 void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,
                    hipStream_t s, size_t poly_limbs = 0);
 void launch_add(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, hipStream_t s);
+
+void register_context(Context *c, bool alive);   // live-context list walked by the per-thread arena reaper
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline void check_launch() { PHA_HIP(hipGetLastError()); }

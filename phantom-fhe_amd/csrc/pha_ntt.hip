@@ -400,6 +400,9 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
             raised.fetch_or(bit, std::memory_order_release);
         }
     }
+    // (r03: a two-tiles-per-wavefront, software-pipelined form of the one-wavefront contiguous pass for small launches was
+    //  measured and dropped -- half as many wavefronts with twice the work each lose more latency hiding than the overlap of
+    //  one tile's stores with the next tile's butterflies gains: 45 limbs 17.3 -> 19.2 us, 32 limbs 15.0 -> 16.5 us)
     hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, kk);
     check_launch();
 }
@@ -592,6 +595,12 @@ static void check_sel(Context &c, const LimbSel &sel) {
 //     config 4 at N = 2^15 and on the 2- / 3-polynomial launches of a key switch, hence the size rule);
 //   * other launches of >= 1024 tiles (the memory-bound throughput regime) form the last round's twiddles on the fly; small ones
 //     are latency-bound and keep the table-driven last round (r01c).
+#ifndef PHA_EPT4_MAX_LIMBS
+#define PHA_EPT4_MAX_LIMBS 64
+#endif
+#ifndef PHA_SMALL_PLAN
+#define PHA_SMALL_PLAN 5     // NttPlan variant of small launches (5: four coefficients per thread in the contiguous pass; 6 / 7: r03 experiments)
+#endif
 struct NttChoice {
     int v;            // NttPlan variant of the two-pass form (product: 3 or 4)
     int whole;        // 0: two passes; 12 / 13 / 14: the one-workgroup plan of that degree
@@ -606,6 +615,9 @@ static NttChoice choose_plan(Context &c, const LimbSel &sel, const NttExtra &x) 
     const bool shared_tables = has(vv, 2048) && batch >= 8 && tiles >= 8192;
     const bool ot = has(vv, 16) || (has(vv, 32) && has(vv, 1) && tiles >= 1024 && !shared_tables), wave = has(vv, 64) && has(vv, 1);
     NttChoice ch{ot ? (wave ? 4 : 2) : wave ? 3 : has(vv, 1), 0, shared_tables, nullptr};
+    // launches of a few dozen limbs (one co-resident generation of wavefronts): four coefficients per thread in the contiguous
+    // pass, i.e. twice the wavefronts with half the serial work each (r03; N = 2^14 .. 2^16)
+    if (ch.v == 3 && c.log_n >= 14 && c.log_n <= 16 && limb_polys <= (size_t)PHA_EPT4_MAX_LIMBS) ch.v = 5;
     if (c.log_n == 12 && !has(vv, 128)) ch.whole = 12;
     if (c.log_n == 13 && !has(vv, 128) && (has(vv, 256) || limb_polys >= 64)) ch.whole = 13;
 #if defined(PHA_EXPERIMENTS)
@@ -625,6 +637,7 @@ template <int LOGN>
 static void forward_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream_t s) {
 #if defined(PHA_EXPERIMENTS)
     switch (ch.v) {
+        case 5: if constexpr (LOGN >= 14 && LOGN <= 16) { forward_impl<LOGN, 5>(k, epi, s); return; }
         case 4: forward_impl<LOGN, 4>(k, epi, s, ch.fused); return;
         case 3: forward_impl<LOGN, 3>(k, epi, s, ch.fused); return;
         case 2: forward_impl<LOGN, 2>(k, epi, s); return;
@@ -635,13 +648,16 @@ static void forward_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream
     if constexpr (LOGN == 12) throw std::logic_error("N = 4096 has no two-pass plan in the product library");
     else if constexpr (LOGN == 13) forward_impl<LOGN, 3>(k, epi, s);   // (below 64 limb-polynomials: never 1024 tiles)
     else if (ch.v == 4) forward_impl<LOGN, 4>(k, epi, s);
-    else forward_impl<LOGN, 3>(k, epi, s);
+    else if (ch.v == 5) {
+        if constexpr (LOGN >= 14 && LOGN <= 16) forward_impl<LOGN, PHA_SMALL_PLAN>(k, epi, s);
+    } else forward_impl<LOGN, 3>(k, epi, s);
 #endif
 }
 template <int LOGN>
 static void inverse_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream_t s) {
 #if defined(PHA_EXPERIMENTS)
     switch (ch.v) {
+        case 5: if constexpr (LOGN >= 14 && LOGN <= 16) { inverse_impl<LOGN, 5>(k, epi, s); return; }
         case 4: inverse_impl<LOGN, 4>(k, epi, s, ch.fused); return;
         case 3: inverse_impl<LOGN, 3>(k, epi, s, ch.fused); return;
         case 2: inverse_impl<LOGN, 2>(k, epi, s); return;
@@ -652,7 +668,9 @@ static void inverse_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream
     if constexpr (LOGN == 12) throw std::logic_error("N = 4096 has no two-pass plan in the product library");
     else if constexpr (LOGN == 13) inverse_impl<LOGN, 3>(k, epi, s);
     else if (ch.v == 4) inverse_impl<LOGN, 4>(k, epi, s);
-    else inverse_impl<LOGN, 3>(k, epi, s);
+    else if (ch.v == 5) {
+        if constexpr (LOGN >= 14 && LOGN <= 16) inverse_impl<LOGN, PHA_SMALL_PLAN>(k, epi, s);
+    } else inverse_impl<LOGN, 3>(k, epi, s);
 #endif
 }
 

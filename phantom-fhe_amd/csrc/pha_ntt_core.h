@@ -716,6 +716,20 @@ template <> struct NttPlan<14, 4> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  us
 template <> struct NttPlan<15, 4> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true, 9>; };
 template <> struct NttPlan<16, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 3, 3, 2, 8, true, 9>; };
 template <> struct NttPlan<17, 4> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, true, 9>; };
+// VARIANT 5 (r03): variant 3 with FOUR coefficients per thread in the contiguous pass -- one T2-point row per wavefront, four
+// radix-4 (or 4-4-4-2) rounds: twice the wavefronts of variant 3 with half the serial work each, for launches of a few dozen
+// limbs (one co-resident generation: the passes want more, shorter wavefronts).  T2 <= 256 only (four rounds of <= 2 stages).
+template <> struct NttPlan<14, 5> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<7, false, 2, 2, 2, 4, false, 8, false, 1>; };
+template <> struct NttPlan<15, 5> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<8, false, 2, 2, 2, 4, false, 8, false, 2>; };
+template <> struct NttPlan<16, 5> { using P1 = PassCfg<8, true, 3, 3, 2, 8>;  using P2 = PassCfg<8, false, 2, 2, 2, 4, false, 8, false, 2>; };
+// VARIANTS 6 / 7 (r03 experiments): variant 5 with four coefficients per thread in the STRIDED pass too -- 6: 2048-coefficient
+// tiles (T1 rows x 8 or 16 columns, 512 threads), 7: 4096-coefficient tiles with 1024 threads
+template <> struct NttPlan<14, 6> { using P1 = PassCfg<7, true, 2, 2, 2, 4, false, 11, false, 1>;  using P2 = NttPlan<14, 5>::P2; };
+template <> struct NttPlan<15, 6> { using P1 = PassCfg<7, true, 2, 2, 2, 4, false, 11, false, 1>;  using P2 = NttPlan<15, 5>::P2; };
+template <> struct NttPlan<16, 6> { using P1 = PassCfg<8, true, 2, 2, 2, 4, false, 11, false, 2>;  using P2 = NttPlan<16, 5>::P2; };
+template <> struct NttPlan<14, 7> { using P1 = PassCfg<7, true, 2, 2, 2, 4, false, 12, false, 1>;  using P2 = NttPlan<14, 5>::P2; };
+template <> struct NttPlan<15, 7> { using P1 = PassCfg<7, true, 2, 2, 2, 4, false, 12, false, 1>;  using P2 = NttPlan<15, 5>::P2; };
+template <> struct NttPlan<16, 7> { using P1 = PassCfg<8, true, 2, 2, 2, 4, false, 12, false, 2>;  using P2 = NttPlan<16, 5>::P2; };
 // N = 4096: the whole transform in one 4096-coefficient tile (three radix-16 rounds, one launch, no intermediate)
 using WholePlan12 = PassCfg<12, false, 4, 4, 4, 16, false, 12, true>;
 // N = 8192: the same with a fourth (radix-2) round: one 8192-coefficient tile, 512 threads, 72 KiB of LDS

@@ -1120,6 +1120,7 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
     if (scheme == PHA_SCHEME_BGV && !t.bgv_ready)
         throw std::invalid_argument("bgv needs a plain modulus (pha_context_set_plain_modulus)");
     const size_t d_stride = (size_t)ql * n;
+    bool bfv_epilogue_fused = false;
     if (t.alpha == 1) {
         for (uint32_t z = 0; z < polys; z++) {
             SinglePArgs k{delta + z * d_stride, nullptr, cx + z * cx_stride + (size_t)ql * n, c.d_mod.p,
@@ -1128,10 +1129,12 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
             check_launch();
         }
     } else {
-        // BFV: (cx - delta) * P^-1 (+ add_to_ct) rides on the conversion's output loop, delta is never stored
+        // BFV: (cx - delta) * P^-1 (+ add_to_ct) rides on the conversion's output loop, delta is never stored -- for the
+        // register-resident converter (alpha <= 32); a wider P takes the conversion into delta and the element-wise kernel below
         BConvEpilogue e{cx, ct, t.pinv2.p, cx_stride, ct_stride, accumulate};
+        bfv_epilogue_fused = scheme == PHA_SCHEME_BFV && t.alpha <= 32;
         launch_bconv(c, t.d_p_to_ql_conv.p, 0, polys, t.alpha, ql, t.split_ok, delta, d_stride, cx, cx_stride,
-                     nullptr, !prescaled, s, 0, 0, scheme == PHA_SCHEME_BFV ? &e : nullptr);
+                     nullptr, !prescaled, s, 0, 0, bfv_epilogue_fused ? &e : nullptr);
     }
     if (scheme == PHA_SCHEME_BGV) {
         // [cx_P]_t lands in the first P limb of each polynomial, then the t-corrected division and the NTT
@@ -1166,9 +1169,9 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         x.out_stride = ct_stride;
         x.aux_stride = cx_stride;
         ntt_forward(c, delta, delta, ct, plain_sel(0, ql), accumulate ? EPI_FWD_MODDOWN_ADD : EPI_FWD_MODDOWN, x, s);
-    } else if (t.alpha == 1) {
-        // BFV, alpha = 1 (moddown_kernel rns_bconv.cu:680-689): every polynomial in ONE launch, ct (+)= (cx - delta) * P^-1
-        // (for alpha > 1 this already happened inside the base conversion above)
+    } else if (!bfv_epilogue_fused) {
+        // BFV, alpha = 1 or alpha > 32 (moddown_kernel rns_bconv.cu:680-689): every polynomial in ONE launch,
+        // ct (+)= (cx - delta) * P^-1 (for 1 < alpha <= 32 this already happened inside the base conversion above)
         SubMulArgs k{ct, cx, delta, t.pinv2.p, c.d_mod.p, (uint32_t)n};
         k.dst_stride = ct_stride;
         k.cx_stride = cx_stride;

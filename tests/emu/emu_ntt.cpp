@@ -88,6 +88,7 @@ static int check_wave_local() {
     std::vector<int> owner(C::LDS_WORDS, -1);
     int bad = check_round_owner<C, 0>(owner) + check_round_owner<C, 1>(owner);
     if constexpr (C::NR >= 3) bad += check_round_owner<C, 2>(owner);
+    if constexpr (C::NR >= 4) bad += check_round_owner<C, 3>(owner);
     int used = 0;
     for (int o : owner) used += o >= 0;
     if (used != C::TILE) bad += 1000000;   // every coefficient of the tile has exactly one slot
@@ -99,11 +100,13 @@ static int check_plan() {
 }
 extern "C" int emu_check_wave_local(int log_n, int variant) {
 #define CHK(N) case N: return variant == 4 ? check_plan<N, 4>() : variant == 3 ? check_plan<N, 3>() : 0;
+    if (variant == 5) return log_n == 14 ? check_plan<14, 5>() : log_n == 15 ? check_plan<15, 5>() : log_n == 16 ? check_plan<16, 5>() : -1;
     switch (log_n) { CHK(12) CHK(13) CHK(14) CHK(15) CHK(16) CHK(17) default: return -1; }
 }
 extern "C" int emu_plan_is_wave_local(int log_n, int variant) {   // bit 0: pass 1, bit 1: pass 2
 #define WL(N, V) ((NttPlan<N, V>::P1::WAVE_LOCAL ? 1 : 0) | (NttPlan<N, V>::P2::WAVE_LOCAL ? 2 : 0))
 #define WLC(N) case N: return variant == 4 ? WL(N, 4) : variant == 3 ? WL(N, 3) : variant == 2 ? WL(N, 2) : variant == 1 ? WL(N, 1) : WL(N, 0);
+    if (variant == 5) return log_n == 14 ? WL(14, 5) : log_n == 15 ? WL(15, 5) : log_n == 16 ? WL(16, 5) : -1;
     switch (log_n) { WLC(12) WLC(13) WLC(14) WLC(15) WLC(16) WLC(17) default: return -1; }
 }
 
@@ -141,6 +144,13 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
         else if (log_n == 13) emu_whole<WholePlan13>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
         else if (log_n == 14) emu_whole<WholePlan14>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
         else return -2;
+        return 0;
+    }
+    if (variant == 5 || variant == 7 || variant == 8) {   // four coefficients per thread (N = 2^14 .. 2^16); 7 / 8 = plans 6 / 7
+#define EMU4(V) do { if (log_n == 14) emu<14, V>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (log_n == 15) emu<15, V>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (log_n == 16) emu<16, V>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else return -2; } while (0)
+        if (variant == 5) EMU4(5);
+        else if (variant == 7) EMU4(6);
+        else EMU4(7);
         return 0;
     }
 #define EMU_CASE(N) case N: if (variant == 4) emu<N, 4>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 3) emu<N, 3>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 2) emu<N, 2>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;

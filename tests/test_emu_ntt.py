@@ -34,10 +34,12 @@ def pair(v, q):
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("bits", [40, 42, 43, 47, 48, 50, 60, 61])   # 42 / 47: just under the light-butterfly thresholds
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])   # 6: one-launch plans; 5 / 7 / 8: NttPlan variants 5 / 6 / 7
 def test_thread_program_matches_oracle(emu, log_n, bits, variant):
     if variant == 6 and log_n not in (12, 13, 14):
         pytest.skip("the one-launch plans exist for N = 4096, 8192 and 16384 only")
+    if variant in (5, 7, 8) and log_n not in (14, 15, 16):
+        pytest.skip("the four-coefficients-per-thread contiguous pass exists for N = 2^14 .. 2^16")
     n = 1 << log_n
     code = log_n | (variant << 8)   # variant 1 = 8 coefficients per thread (512-thread workgroups); 2 = 1 + on-the-fly twiddles
     q = int(O.get_primes(n, bits, 1)[0])
@@ -108,3 +110,5 @@ def test_barrier_free_plans_are_wave_local(emu, log_n):
     assert emu.emu_plan_is_wave_local(log_n, 3) == 2 and emu.emu_plan_is_wave_local(log_n, 4) == 2
     for variant in (3, 4):
         assert emu.emu_check_wave_local(log_n, variant) == 0
+    if log_n in (14, 15, 16):      # the four-coefficients-per-thread contiguous pass: one row per wavefront
+        assert emu.emu_plan_is_wave_local(log_n, 5) == 2 and emu.emu_check_wave_local(log_n, 5) == 0

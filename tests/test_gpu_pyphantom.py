@@ -59,6 +59,9 @@ def test_ckks_flow(gpu):
     assert np.array_equal(prod.to_numpy(), ref) and prod.scale() == 2.0 ** 80
     res = ph.rescale_to_next(ctx, prod)
     assert np.array_equal(res.to_numpy(), tool.rescale_ntt(ref, 2)) and res.chain_index() == 2
+    fused = ph.multiply_relin_rescale(ctx, a, b, rlk)           # extension: the same ciphertext from one fused call
+    assert np.array_equal(fused.to_numpy(), res.to_numpy()) and fused.chain_index() == 2 and fused.scale() == res.scale()
+    assert np.array_equal(ph.relinearize_rescale(ctx, ph.multiply(ctx, a, b), rlk).to_numpy(), res.to_numpy())
     rot = ph.rotate(ctx, a, 1, glk)
     tab = O.galois_ntt_table(log_n, e1)
     c0 = O.apply_galois_ntt(h1[0], tab, n, size_q)

@@ -60,7 +60,7 @@ def test_dyadic(name, gpu):
 
 def _keys(oc, rng, primes, n, size_q, size_p):
     """Uniform synthetic evaluation keys [dnum][2][QP][N] (arithmetic is data-independent)."""
-    dnum = size_q // size_p
+    dnum = -(-size_q // size_p)     # (a special base wider than Q still needs one digit)
     return np.stack([np.stack([uniform_poly(rng, primes, n), uniform_poly(rng, primes, n)]) for _ in range(dnum)])
 
 
@@ -76,6 +76,8 @@ KS_CASES = [
     ("hyb12_a2", O.BGV, [6, 5, 1]),      # t-corrected mod-down (bgv_moddown_kernel rns_bconv.cu:636-652)
     ("hyb13_a3", O.BGV, [9, 7]),
     ("c1_bfv4096", O.BGV, [2]),
+    ("wide_p33", O.BFV, [6, 4]),         # alpha = 33 > 32: the generic converter, mod-down through the element-wise kernel
+    ("wide_p33", O.CKKS, [6]),
 ]
 BGV_T = 65537
 
@@ -836,6 +838,42 @@ def test_concurrent_host_threads_on_their_own_streams(gpu):
     assert not errors, errors
     for i, (_, _, _, want) in enumerate(jobs):
         assert np.array_equal(results[i], want)
+
+
+def test_short_lived_threads_on_the_default_stream_give_their_arenas_back(gpu):
+    """The null / per-thread stream handles name a different stream in every host thread, so each such thread gets its own
+    scratch arena -- and returns it when it exits (a thread pool must not grow one arena per thread for the life of the context)."""
+    import threading
+    import phantom_fhe_amd as P
+    name = "hyb12_a2"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(161)
+    evk = _keys(oc, r, primes, n, size_q, size_p)
+    rlk = P.PhantomRelinKey.from_numpy(evk, gpu)
+    tool = O.Tool(oc, size_q)
+    ct = np.stack([uniform_poly(r, primes[:size_q], n) for _ in range(2)])
+    c2 = uniform_poly(r, primes[:size_q], n)
+    want = tool.keyswitch_inplace(ct, c2, [evk[k] for k in range(tool.beta)], O.CKKS)
+    errors, counts = [], []
+
+    def work():
+        try:
+            d_ct, d_c2 = P.to_device(ct, gpu), P.to_device(c2, gpu)        # torch's default stream = the null stream
+            ctx.keyswitch_inplace(size_q, d_ct, d_c2, rlk.public_keys_ptr, O.CKKS)
+            assert np.array_equal(P.to_host(d_ct), want)
+            counts.append(ctx.arena_count())
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    for _ in range(6):             # one after the other: each thread is gone before the next starts
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+    assert not errors, errors
+    assert max(counts) <= 2 and ctx.arena_count() <= 1, (counts, ctx.arena_count())
 
 
 def test_key_switch_and_rescale_replay_from_a_hip_graph(gpu):

@@ -18,6 +18,7 @@ CONFIGS = {
     "c4_bfv15": (15, [60] + [50] * 29 + [60] * 15, 15),   # benchmark/keyswitch_bench.cu:25-34
     "c2_ckks14": (14, [60] + [40] * 7 + [60], 1),         # benchmark/ckks_bench.cu:255 (8 data limbs + 1 special)
     "hyb14_a4": (14, [60] + [50] * 7 + [60] * 4, 4),      # 8 data limbs in 2 digits of 4
+    "wide_p33": (12, [36] * 6 + [37] * 33, 33),            # special base wider than the register-resident converters (alpha > 32)
     "bfv13_50": (13, [50] * 4 + [60, 60], 2),             # uniform data primes: what the HPS variant of BFV multiply needs
 }
 
