@@ -595,8 +595,8 @@ static void check_sel(Context &c, const LimbSel &sel) {
 //     config 4 at N = 2^15 and on the 2- / 3-polynomial launches of a key switch, hence the size rule);
 //   * other launches of >= 1024 tiles (the memory-bound throughput regime) form the last round's twiddles on the fly; small ones
 //     are latency-bound and keep the table-driven last round (r01c).
-#ifndef PHA_EPT4_MAX_LIMBS
-#define PHA_EPT4_MAX_LIMBS 64
+#ifndef PHA_EPT4_MAX_WAVES
+#define PHA_EPT4_MAX_WAVES 8192   // = 8 wavefronts per SIMD: 32 limb-polynomials at N = 2^16, 64 at 2^15, 128 at 2^14 (0 = never)
 #endif
 #ifndef PHA_SMALL_PLAN
 #define PHA_SMALL_PLAN 5     // NttPlan variant of small launches (5: four coefficients per thread in the contiguous pass; 6 / 7: r03 experiments)
@@ -615,9 +615,11 @@ static NttChoice choose_plan(Context &c, const LimbSel &sel, const NttExtra &x) 
     const bool shared_tables = has(vv, 2048) && batch >= 8 && tiles >= 8192;
     const bool ot = has(vv, 16) || (has(vv, 32) && has(vv, 1) && tiles >= 1024 && !shared_tables), wave = has(vv, 64) && has(vv, 1);
     NttChoice ch{ot ? (wave ? 4 : 2) : wave ? 3 : has(vv, 1), 0, shared_tables, nullptr};
-    // launches of a few dozen limbs (one co-resident generation of wavefronts): four coefficients per thread in the contiguous
-    // pass, i.e. twice the wavefronts with half the serial work each (r03; N = 2^14 .. 2^16)
-    if (ch.v == 3 && c.log_n >= 14 && c.log_n <= 16 && limb_polys <= (size_t)PHA_EPT4_MAX_LIMBS) ch.v = 5;
+    // launches that fit ONE co-resident generation of 256-coefficient wavefronts: four coefficients per thread in the contiguous
+    // pass, i.e. twice the wavefronts with half the serial work each (r03; N = 2^14 .. 2^16).  Same-box A/B (tools/time_small_ntt.py,
+    // tools/ks_trace.sh): a win of 0.4-1.1 us per launch pair up to 8 wavefronts per SIMD (2^16: 1-24 limbs, the 2 x 16-limb
+    // inverse of key switch + rescale 14.9 -> 13.6 us; 2^15: every size up to 60 limbs), a loss of 1-2.5 us beyond (2^16: 40-60 limbs)
+    if (ch.v == 3 && c.log_n >= 14 && c.log_n <= 16 && limb_polys * (c.n >> 8) <= (size_t)PHA_EPT4_MAX_WAVES) ch.v = 5;
     if (c.log_n == 12 && !has(vv, 128)) ch.whole = 12;
     if (c.log_n == 13 && !has(vv, 128) && (has(vv, 256) || limb_polys >= 64)) ch.whole = 13;
 #if defined(PHA_EXPERIMENTS)
