@@ -44,8 +44,10 @@ C4_BITS = [60] + [50] * 29 + [60] * 15  # benchmark/keyswitch_bench.cu:25-34
 C4_BATCH = 64
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes (tools/traffic.sh)
 STAGES_FILE = os.path.join(ROOT, "profiles", "stages.json")     # per-kernel GPU times of one HomMul (tools/stage_table.py over a committed kernel trace)
-C5_BABY, C5_GIANT = 32, 4             # BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block = 32 baby x 4 giant steps (tools/time_bsgs.py: 16x8 4.28, 32x4 3.59, 64x2 4.32 ms)
-C5_BLOCKS = 8                         # row blocks of the job (split over the ranks)
+# BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block = 64 baby x 2 giant steps, four row blocks per
+# pass over the baby keys (tools/time_bsgs.py, ms per block alone / in groups: 16x8 4.22 / 4.09, 32x4 3.57 / 2.72, 64x2 4.33 / 2.04)
+C5_BABY, C5_GIANT = 64, 2
+C5_BLOCKS = 32                        # row blocks of the job (split over the ranks: 4 per GPU at 8 GPUs, so the key pass is shared everywhere)
 
 
 def spawn_ranks(n):
@@ -502,7 +504,7 @@ def main():
         torch.cuda.empty_cache()
         nbaby, ngiant = (4, 2) if small else (C5_BABY, C5_GIANT)
         n_diag = nbaby * ngiant
-        n_blocks = 2 if small else C5_BLOCKS
+        n_blocks = 3 if small else C5_BLOCKS
         dnum5 = size_q // SIZE_P
         kg = torch.Generator(device=dev)
         kg.manual_seed(0x5EED0000 + 5)
@@ -529,20 +531,22 @@ def main():
         kg.manual_seed(0x5EED5000)
         ct5 = below_every_prime((2, size_q, n), kg)        # the same input ciphertext on every rank
         mine5 = pdist.shard_range(n_blocks, rank, world)
-        blocks5 = []
-        for b in mine5:                                    # block b's diagonals from its own seed: world-size independent
-            kg.manual_seed(0x5EED5100 + b)
-            blocks5.append([[below_every_prime((size_q + SIZE_P, n), kg) for _ in range(nbaby)] for _ in range(ngiant)])
+        # the plaintext diagonals: a pool of n_diag encoded diagonals (3.75 GiB at the C3 set), block b takes them rotated by b -- every
+        # (block, giant, baby) triple of one launch still streams its own tensor, the inputs do not depend on the world size, and
+        # 32 blocks do not need 120 GiB of synthetic plaintexts
+        kg.manual_seed(0x5EED5100)
+        pool5 = [below_every_prime((size_q + SIZE_P, n), kg) for _ in range(n_diag)]
+        blocks5 = [[[pool5[(i * nbaby + j + b) % n_diag] for j in range(nbaby)] for i in range(ngiant)] for b in mine5]
         res5 = [None]
 
-        def c5_step():
-            res5[0] = [W.diag_matvec_bsgs(ctx, size_q, ct5, baby_elts, baby_keys, giant_elts, giant_keys, blk, P.scheme_type.ckks)
-                       for blk in blocks5]
+        def c5_step():   # this rank's row blocks against the one ciphertext; the baby keys are streamed once per 8 / ngiant blocks
+            res5[0] = W.diag_matvec_bsgs_blocks(ctx, size_q, ct5, baby_elts, baby_keys, giant_elts, giant_keys, blocks5,
+                                                P.scheme_type.ckks) if blocks5 else []
 
         c5_step()
         c5_steps = 1 if small else 3
         c5_elapsed = timed(c5_step, c5_steps)
-        local5 = sum(int(o.sum().item()) for o in res5[0]) & ((1 << 64) - 1) if blocks5 else 0
+        local5 = int(res5[0].sum().item()) & ((1 << 64) - 1) if blocks5 else 0
         sums5 = pdist.gather_checksums(local5 - (1 << 64) if local5 >= (1 << 63) else local5, device=red_dev)
         key_bytes = n_keys * dnum5 * 2 * len(primes) * n * 8
         c5 = {"value": n_blocks * c5_steps / c5_elapsed, "unit": "128-diagonal blocks/s (whole job)", "blocks": n_blocks,
@@ -556,7 +560,7 @@ def main():
               "config": f"CKKS N=2^16, 45 + 15 limbs; out_b = sum_i rot_(nb i)(sum_j diag_(b, nb i + j) (.) rot_j(ct)), nb = {nbaby}: baby-step / "
                         f"giant-step with double hoisting (pha_hoisting_weighted_bsgs), {n_keys} Galois keys instead of {n_diag - 1}; no reference counterpart "
                         "(SURVEY 8(0) row C5; building blocks src/evaluate.cu:1670-1866, :1297-1340)"}
-        del gkeys, glks, blocks5, res5
+        del gkeys, glks, blocks5, res5, pool5
 
     if rank == 0:
         alg_bytes = 16.0 * n * size_q * nb             # 8 B read + 8 B write per coefficient

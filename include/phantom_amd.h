@@ -296,6 +296,14 @@ int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
 int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *baby_elts, size_t n_baby,
                                const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t n_giant,
                                const uint64_t *const *const *giant_glk, const uint64_t *const *weights, int scheme, void *stream);
+/* the same for n_blocks row blocks that share the input ciphertext and every Galois key (the rows of a matrix-vector product):
+ * weights [n_blocks][n_giant][n_baby], out [n_blocks][2][Ql][N] (must not overlap ct, which is only read).  The fused baby-step
+ * kernel serves the (block, giant step) pairs eight at a time, so the baby keys are streamed once per eight of them; each block's
+ * result is bit-identical to a one-block call. */
+int pha_hoisting_weighted_bsgs_blocks(pha_context_t ctx, size_t size_Ql, const uint64_t *ct, size_t n_blocks, const uint32_t *baby_elts,
+                                      size_t n_baby, const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t n_giant,
+                                      const uint64_t *const *const *giant_glk, const uint64_t *const *weights, uint64_t *out, int scheme,
+                                      void *stream);
 /* PhantomSecretKey::generate_one_kswitch_key (src/secretkey.cu:297-341 with encrypt_zero_symmetric :232-295),
  * arithmetic part; the randomness comes from the caller because the PRNG (sample_uniform_poly /
  * sample_error_poly, src/prng.cu) is outside the accelerated path.  All buffers on the device:

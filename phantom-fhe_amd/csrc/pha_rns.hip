@@ -751,10 +751,14 @@ __global__ __launch_bounds__(256) void hoist_bsgs_inner_prod_kernel(const BsgsAr
 
 // giant steps, part 1: ct0 = sum_i B_i0[perm_Gi], ct1 = sum over the identity giant steps of B_i1, and the dense operands
 // g1[z] = B_i1[perm_Gi] of the keyed giant steps (z = their rank among the keyed ones)
+// blockIdx.z = row block: its ng giant steps start at B + z * ng * 2 polynomials, its nk operands at g1 + z * nk, its output at ct + 2 z
 __global__ __launch_bounds__(256) void bsgs_combine_kernel(u64 *ct, u64 *g1, const u64 *B, const uint32_t *const *tables,
-                                                           const uint32_t *keyed_rank, uint32_t ng, const DModulus *mod, uint32_t n,
-                                                           size_t poly_stride) {
+                                                           const uint32_t *keyed_rank, uint32_t ng, uint32_t nk, const DModulus *mod,
+                                                           uint32_t n, size_t poly_stride) {
     const uint32_t limb = blockIdx.y;
+    ct += (size_t)blockIdx.z * 2 * poly_stride;
+    g1 += (size_t)blockIdx.z * nk * poly_stride;
+    B += (size_t)blockIdx.z * ng * 2 * poly_stride;
     const u64 q = mod[limb].value;
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
     const size_t id = (size_t)limb * n + coeff;
@@ -781,7 +785,10 @@ struct MultiInnerArgs {
     uint32_t n, beta, nk;
     size_t qlp_n, qp_n;
 };
-__global__ __launch_bounds__(256) void inner_prod_multi_kernel(const MultiInnerArgs k) {
+__global__ __launch_bounds__(256) void inner_prod_multi_kernel(const MultiInnerArgs kk) {   // blockIdx.z = row block
+    MultiInnerArgs k = kk;
+    k.cx += (size_t)blockIdx.z * 2 * k.qlp_n;
+    k.t_mod_up += (size_t)blockIdx.z * k.nk * k.beta * k.qlp_n;
     const uint32_t nid = blockIdx.y;
     const uint32_t twr = k.qlp_prime[nid];
     const DModulus m = k.mod[twr];
@@ -1592,18 +1599,16 @@ int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     PHA_API_END
 }
 
-int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *baby_elts, size_t n_baby,
-                               const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t n_giant,
-                               const uint64_t *const *const *giant_glk, const uint64_t *const *weights, int scheme, void *stream) {
-    PHA_CTX_BEGIN(ctx)
-    need(ct); need(baby_elts); need(baby_glk); need(giant_elts); need(giant_glk); need(weights);
-    if (n_baby == 0 || n_giant == 0) throw std::invalid_argument("steps must not be empty");
-    if (!ntt_domain_scheme(scheme)) throw std::invalid_argument("weighted hoisting takes NTT-form ciphertexts (ckks / bgv)");
-    Context &c = ctx->c;
-    check_level(c, size_Ql, true);
-    Tool &t = c.tool((uint32_t)size_Ql);
+// Core of the baby-step / giant-step entries: `blocks` row blocks that share the input ciphertext and every Galois key.  Block r
+// with weights w[r][i][j] gives out[r] = sum_i rot_{G_i}(sum_j w[r][i][j] (.) rot_{B_j}(ct)).  The fused baby-step kernel treats
+// the (block, giant step) pairs as one list of accumulators, so the baby keys, the gathered digits and the per-baby reductions are
+// paid once for up to 8 of them; everything after it is batched over the blocks.  Every block's result is bit-identical to a
+// one-block call.
+static void bsgs_core(Context &c, Tool &t, const u64 *ct_in, size_t blocks, const uint32_t *baby_elts, size_t nb,
+                      const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t ng,
+                      const uint64_t *const *const *giant_glk, const uint64_t *const *weights, u64 *out, int scheme, void *stream) {
     hipStream_t s = as_stream(stream);
-    const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n, nb = n_baby, ng = n_giant;
+    const size_t n = c.n, size_Ql = t.size_ql, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n, G = blocks * ng;
     // 128-bit accumulators: every weighted term is below 2^122 (61-bit primes), 63 of them fit; the giant inner products are
     // plain products (2^120 each for 60-bit primes)
     size_t nbk = 0, nk = 0;
@@ -1615,10 +1620,11 @@ int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, 
         if (giant_elts[i] != 1 && !giant_glk[i]) throw std::logic_error("Galois key not present in hoisting");
         nk += giant_elts[i] != 1;
     }
-    if (nbk > 63 || nk * t.beta > 63 || 2 * ng > 65535) throw std::invalid_argument("too many steps for one call (at most 63 keyed baby steps)");
+    if (nbk > 63 || nk * t.beta > 63) throw std::invalid_argument("too many steps for one call (at most 63 keyed baby steps)");
+    if (2 * G > 65535 || blocks * nk * t.beta > 65535) throw std::invalid_argument("too many row blocks for one call");
     if (t.beta > 4) throw std::invalid_argument("more than 4 key-switch digits are not supported by the baby-step / giant-step form");
     bool any_null = false;
-    for (size_t i = 0; i < ng * nb; i++) any_null = any_null || !weights[i];
+    for (size_t i = 0; i < G * nb; i++) any_null = any_null || !weights[i];
     std::vector<const void *> h_btab(nb), h_bkeys(nb), h_gtab(ng), h_gkeys;
     std::vector<uint32_t> h_rank(ng);
     for (size_t j = 0; j < nb; j++) {
@@ -1630,26 +1636,26 @@ int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, 
         h_rank[i] = giant_elts[i] == 1 ? 0xffffffffu : (uint32_t)h_gkeys.size();
         if (giant_elts[i] != 1) h_gkeys.push_back(giant_glk[i]);
     }
-    // scratch: cc [2][Ql][N] | tmp [max(2 ng, nk)][Ql][N] | mod-up [beta][QlP][N] | acc [ng][2][QlP][N] | B [ng][2][Ql][N] |
-    //          g1 [nk][Ql][N] | giant mod-up [nk][beta][QlP][N] | cx [2][QlP][N] | pointer tables
-    const size_t n_tmp = std::max<size_t>(2 * ng, std::max<size_t>(nk, 2));
-    const size_t ptr_words = 2 * nb + ng * nb + 2 * ng + nk + (any_null ? qlp_n : 0);   // (+ a zero plane for the missing weights)
-    u64 *base = c.scratch(stream, 2 * ql_n + n_tmp * ql_n + (size_t)t.beta * qlp_n + ng * 2 * qlp_n + ng * 2 * ql_n + nk * ql_n +
-                                      nk * (size_t)t.beta * qlp_n + 2 * qlp_n + ptr_words);
+    // scratch: cc [2][Ql][N] | tmp [max(2 G, blocks nk, 2 blocks)][Ql][N] | mod-up [beta][QlP][N] | acc [G][2][QlP][N] |
+    //          B [G][2][Ql][N] | g1 [blocks][nk][Ql][N] | giant mod-up [blocks][nk][beta][QlP][N] | cx [blocks][2][QlP][N] | tables
+    const size_t n_tmp = std::max<size_t>(2 * G, std::max<size_t>(blocks * nk, 2 * blocks));
+    const size_t ptr_words = 2 * nb + G * nb + 2 * ng + nk + (any_null ? qlp_n : 0);   // (+ a zero plane for the missing weights)
+    u64 *base = c.scratch(stream, 2 * ql_n + n_tmp * ql_n + (size_t)t.beta * qlp_n + G * 2 * qlp_n + G * 2 * ql_n + blocks * nk * ql_n +
+                                      blocks * nk * (size_t)t.beta * qlp_n + blocks * 2 * qlp_n + ptr_words);
     u64 *cc = base, *tmp = cc + 2 * ql_n, *t_mod_up = tmp + n_tmp * ql_n, *acc = t_mod_up + (size_t)t.beta * qlp_n,
-        *B = acc + ng * 2 * qlp_n, *g1 = B + ng * 2 * ql_n, *mu_g = g1 + nk * ql_n, *cxg = mu_g + nk * (size_t)t.beta * qlp_n,
-        *d_ptrs = cxg + 2 * qlp_n;
-    u64 *p_btab = d_ptrs, *p_bkeys = p_btab + nb, *p_w = p_bkeys + nb, *p_gtab = p_w + ng * nb, *p_rank = p_gtab + ng, *p_gkeys = p_rank + ng;
+        *B = acc + G * 2 * qlp_n, *g1 = B + G * 2 * ql_n, *mu_g = g1 + blocks * nk * ql_n,
+        *cxg = mu_g + blocks * nk * (size_t)t.beta * qlp_n, *d_ptrs = cxg + blocks * 2 * qlp_n;
+    u64 *p_btab = d_ptrs, *p_bkeys = p_btab + nb, *p_w = p_bkeys + nb, *p_gtab = p_w + G * nb, *p_rank = p_gtab + ng, *p_gkeys = p_rank + ng;
     PHA_HIP(hipMemcpyAsync(p_btab, h_btab.data(), nb * sizeof(void *), hipMemcpyHostToDevice, s));
     PHA_HIP(hipMemcpyAsync(p_bkeys, h_bkeys.data(), nb * sizeof(void *), hipMemcpyHostToDevice, s));
-    std::vector<const void *> h_w(weights, weights + ng * nb);
+    std::vector<const void *> h_w(weights, weights + G * nb);
     if (any_null) {
         u64 *zero = p_gkeys + nk;
         PHA_HIP(hipMemsetAsync(zero, 0, qlp_n * sizeof(u64), s));
         for (auto &w : h_w)
             if (!w) w = zero;
     }
-    PHA_HIP(hipMemcpyAsync(p_w, h_w.data(), ng * nb * sizeof(void *), hipMemcpyHostToDevice, s));
+    PHA_HIP(hipMemcpyAsync(p_w, h_w.data(), G * nb * sizeof(void *), hipMemcpyHostToDevice, s));
     PHA_HIP(hipMemcpyAsync(p_gtab, h_gtab.data(), ng * sizeof(void *), hipMemcpyHostToDevice, s));
     PHA_HIP(hipMemcpyAsync(p_rank, h_rank.data(), ng * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     if (nk) PHA_HIP(hipMemcpyAsync(p_gkeys, h_gkeys.data(), nk * sizeof(void *), hipMemcpyHostToDevice, s));
@@ -1659,10 +1665,10 @@ int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, 
     const uint32_t *const *d_gtab = reinterpret_cast<const uint32_t *const *>(p_gtab);
     const u64 *const *const *d_gkeys = reinterpret_cast<const u64 *const *const *>(p_gkeys);
 
-    PHA_HIP(hipMemcpyAsync(cc, ct, 2 * ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    // baby steps: one mod-up of c1, then every giant step's weighted sum of the hoisted inner products (and of the c0 / c1
-    // terms, pre-multiplied by P) in one pass over the baby keys; B_i = moddown(acc_i), all giant steps in one batched launch set
-    if (nbk) modup(c, t, t_mod_up, ct + ql_n, scheme, tmp, s);
+    PHA_HIP(hipMemcpyAsync(cc, ct_in, 2 * ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));   // (out may be ct_in: one-block in-place form)
+    // baby steps: one mod-up of c1, then every (block, giant step)'s weighted sum of the hoisted inner products (and of the c0 / c1
+    // terms, pre-multiplied by P) in one pass over the baby keys per 8 accumulators; B = moddown(acc), one batched launch set
+    if (nbk) modup(c, t, t_mod_up, cc + ql_n, scheme, tmp, s);
     {
         BsgsArgs k{};
         k.acc = acc; k.t_mod_up = t_mod_up; k.keys = d_bkeys; k.tables = d_btab; k.weights = d_w; k.mod = c.d_mod.p;
@@ -1679,8 +1685,8 @@ int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, 
             default: hipLaunchKernelGGL((hoist_bsgs_inner_prod_kernel<NG, 4>), grid, block, 0, s, k); break;             \
         }                                                                                                                 \
     } while (0)
-        for (size_t g0 = 0; g0 < ng;) {
-            const size_t left = ng - g0;
+        for (size_t g0 = 0; g0 < G;) {
+            const size_t left = G - g0;
             k.g0 = (uint32_t)g0;
             if (left >= 8) { PHA_BSGS_GO(8); g0 += 8; }
             else if (left >= 4) { PHA_BSGS_GO(4); g0 += 4; }
@@ -1690,18 +1696,48 @@ int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, 
         }
 #undef PHA_BSGS_GO
     }
-    moddown_from_ntt(c, t, B, ql_n, acc, qlp_n, (uint32_t)(2 * ng), scheme, false, tmp, s);
-    // giant steps: permutations, then ONE mod-down for the sum of their key-switch inner products
-    hipLaunchKernelGGL(bsgs_combine_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql), dim3(256), 0, s, ct, g1, B, d_gtab,
-                       reinterpret_cast<const uint32_t *>(p_rank), (uint32_t)ng, c.d_mod.p, (uint32_t)n, ql_n);
+    moddown_from_ntt(c, t, B, ql_n, acc, qlp_n, (uint32_t)(2 * G), scheme, false, tmp, s);
+    // giant steps: permutations (every block in one launch), then per block ONE mod-down for the sum of its key-switch inner products
+    hipLaunchKernelGGL(bsgs_combine_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql, (unsigned)blocks), dim3(256), 0, s, out, g1, B,
+                       d_gtab, reinterpret_cast<const uint32_t *>(p_rank), (uint32_t)ng, (uint32_t)nk, c.d_mod.p, (uint32_t)n, ql_n);
     check_launch();
     if (nk) {
-        modup(c, t, mu_g, g1, scheme, tmp, s, (uint32_t)nk);
+        modup(c, t, mu_g, g1, scheme, tmp, s, (uint32_t)(blocks * nk));
         MultiInnerArgs k{cxg, mu_g, d_gkeys, c.d_mod.p, t.d_qlp_prime.p, (uint32_t)n, t.beta, (uint32_t)nk, qlp_n, (size_t)c.size_qp * n};
-        hipLaunchKernelGGL(inner_prod_multi_kernel, dim3((unsigned)(n / 512), t.size_qlp), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(inner_prod_multi_kernel, dim3((unsigned)(n / 512), t.size_qlp, (unsigned)blocks), dim3(256), 0, s, k);
         check_launch();
-        moddown_from_ntt(c, t, ct, ql_n, cxg, qlp_n, 2, scheme, true, tmp, s);
+        moddown_from_ntt(c, t, out, ql_n, cxg, qlp_n, (uint32_t)(2 * blocks), scheme, true, tmp, s);
     }
+}
+
+int pha_hoisting_weighted_bsgs(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t *baby_elts, size_t n_baby,
+                               const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t n_giant,
+                               const uint64_t *const *const *giant_glk, const uint64_t *const *weights, int scheme, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(ct); need(baby_elts); need(baby_glk); need(giant_elts); need(giant_glk); need(weights);
+    if (n_baby == 0 || n_giant == 0) throw std::invalid_argument("steps must not be empty");
+    if (!ntt_domain_scheme(scheme)) throw std::invalid_argument("weighted hoisting takes NTT-form ciphertexts (ckks / bgv)");
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    bsgs_core(c, c.tool((uint32_t)size_Ql), ct, 1, baby_elts, n_baby, baby_glk, giant_elts, n_giant, giant_glk, weights, ct, scheme, stream);
+    PHA_API_END
+}
+
+int pha_hoisting_weighted_bsgs_blocks(pha_context_t ctx, size_t size_Ql, const uint64_t *ct, size_t n_blocks, const uint32_t *baby_elts,
+                                      size_t n_baby, const uint64_t *const *const *baby_glk, const uint32_t *giant_elts, size_t n_giant,
+                                      const uint64_t *const *const *giant_glk, const uint64_t *const *weights, uint64_t *out, int scheme,
+                                      void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(ct); need(baby_elts); need(baby_glk); need(giant_elts); need(giant_glk); need(weights); need(out);
+    if (n_blocks == 0) return 0;
+    if (n_baby == 0 || n_giant == 0) throw std::invalid_argument("steps must not be empty");
+    if (!ntt_domain_scheme(scheme)) throw std::invalid_argument("weighted hoisting takes NTT-form ciphertexts (ckks / bgv)");
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    const size_t ql_n = size_Ql * c.n;
+    if (overlaps(out, n_blocks * 2 * ql_n, ct, 2 * ql_n)) throw std::invalid_argument("out must not overlap ct");
+    bsgs_core(c, c.tool((uint32_t)size_Ql), ct, n_blocks, baby_elts, n_baby, baby_glk, giant_elts, n_giant, giant_glk, weights, out, scheme,
+              stream);
     PHA_API_END
 }
 

@@ -365,6 +365,20 @@ class PhantomContext:
         _lib.check(self._L.pha_hoisting_weighted_bsgs(self._h, size_Ql, _ptr(ct), be, len(baby_elts), bk, ge, len(giant_elts), gk, ws,
                                                       int(scheme), _stream()))
 
+    def hoisting_weighted_bsgs_blocks(self, size_Ql, ct, baby_elts, baby_keys, giant_elts, giant_keys, weights, out, scheme):
+        """Several row blocks that share ct and the keys (pha_hoisting_weighted_bsgs_blocks): weights[block][giant][baby] device
+        tensors or None, out [blocks][2][Ql][N]; ct is only read."""
+        be = (C.c_uint32 * len(baby_elts))(*[int(e) for e in baby_elts])
+        ge = (C.c_uint32 * len(giant_elts))(*[int(e) for e in giant_elts])
+        bk = (C.c_void_p * len(baby_keys))(*[k.public_keys_ptr.data_ptr() if k is not None else None for k in baby_keys])
+        gk = (C.c_void_p * len(giant_keys))(*[k.public_keys_ptr.data_ptr() if k is not None else None for k in giant_keys])
+        flat = [w for blk in weights for row in blk for w in row]
+        if len(flat) != len(weights) * len(baby_elts) * len(giant_elts):
+            raise ValueError("weights must be [n_blocks][n_giant][n_baby]")
+        ws = (C.c_void_p * len(flat))(*[_ptr(w) for w in flat])
+        _lib.check(self._L.pha_hoisting_weighted_bsgs_blocks(self._h, size_Ql, _ptr(ct), len(weights), be, len(baby_elts), bk, ge,
+                                                             len(giant_elts), gk, ws, _ptr(out), int(scheme), _stream()))
+
     def divide_and_round_q_last_ntt(self, size_Ql, src, cipher_size, dst):
         _lib.check(self._L.pha_divide_and_round_q_last_ntt(self._h, size_Ql, _ptr(src), cipher_size, _ptr(dst),
                                                            _stream()))

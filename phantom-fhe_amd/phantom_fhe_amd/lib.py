@@ -94,6 +94,8 @@ _SIGS = {
     "pha_hoisting_weighted": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.POINTER(vp), C.c_int, vp],
     "pha_hoisting_weighted_bsgs": [vp, sz, vp, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.POINTER(C.c_uint32), sz, C.POINTER(vp),
                                    C.POINTER(vp), C.c_int, vp],
+    "pha_hoisting_weighted_bsgs_blocks": [vp, sz, vp, sz, C.POINTER(C.c_uint32), sz, C.POINTER(vp), C.POINTER(C.c_uint32), sz, C.POINTER(vp),
+                                          C.POINTER(vp), vp, C.c_int, vp],
     "pha_divide_and_round_q_last_ntt": [vp, sz, vp, sz, vp, vp],
     "pha_generate_one_kswitch_key": [vp, vp, vp, vp, vp, vp, C.c_int, vp],
     "pha_mod_t_and_divide_q_last_ntt": [vp, sz, vp, sz, vp, vp],

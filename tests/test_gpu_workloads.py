@@ -226,6 +226,16 @@ def test_config5_bsgs_matches_the_composition_of_reference_steps(name, scheme, q
     assert np.array_equal(flat, P.to_host(W.diag_matvec(ctx, ql, d_ct, baby, d_bkeys, d_ws[0], scheme)))
     with pytest.raises(ArithmeticError):         # std::logic_error: a rotation without its key (evaluate.cu:1783)
         ctx.hoisting_weighted_bsgs(ql, d_ct.clone(), baby, [None] * nb, giant, d_gkeys, d_ws, scheme)
+    # several row blocks against the one ciphertext (shared mod-up, shared pass over the baby keys): every block equals its own call
+    ws2 = [[uniform_poly(r, qlp_primes, n) for _ in baby] for _ in giant]
+    ws3 = [[uniform_poly(r, qlp_primes, n) for _ in baby] for _ in giant]
+    d_blocks = [d_ws, [[P.to_device(w, gpu) for w in row] for row in ws2], [[P.to_device(w, gpu) for w in row] for row in ws3]]
+    singles = [out] + [P.to_host(W.diag_matvec_bsgs(ctx, ql, d_ct, baby, d_bkeys, giant, d_gkeys, blk, scheme)) for blk in d_blocks[1:]]
+    for per_call in (0, 1, 2, 3):
+        multi = P.to_host(W.diag_matvec_bsgs_blocks(ctx, ql, d_ct, baby, d_bkeys, giant, d_gkeys, d_blocks, scheme, per_call=per_call))
+        for b in range(3):
+            assert np.array_equal(multi[b], singles[b]), (per_call, b)
+    assert np.array_equal(P.to_host(d_ct), ct)
 
 
 def test_config5_bsgs_16_by_8_at_the_c3_parameter_set(gpu):

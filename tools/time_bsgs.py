@@ -38,4 +38,16 @@ for nb, ng in splits:
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
     print(f"{nb:3d} baby x {ng:2d} giant steps ({nb * ng} diagonals, {nb + ng - 2} keys): {ms:7.3f} ms per block", flush=True)
-    del bk, gk, ws
+    # 8 row blocks against the same ciphertext through the multi-block entry (8 / ng blocks share one pass over the baby keys)
+    nblk = 8
+    blocks = [ws] + [[[rnd(size_q + size_p) for _ in baby] for _ in giant] for _ in range(nblk - 1)]
+    for _ in range(2):
+        out = W.diag_matvec_bsgs_blocks(ctx, size_q, ct, baby, bk, giant, gk, blocks, CK)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = W.diag_matvec_bsgs_blocks(ctx, size_q, ct, baby, bk, giant, gk, blocks, CK)
+    torch.cuda.synchronize()
+    ms8 = (time.perf_counter() - t0) / 3 * 1e3 / nblk
+    print(f"      the same, {nblk} row blocks per call sequence ({max(1, 8 // ng)} per pass over the keys): {ms8:7.3f} ms per block", flush=True)
+    del bk, gk, ws, blocks

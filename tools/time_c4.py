@@ -23,10 +23,9 @@ rlk = P.PhantomRelinKey([rnd(2, len(primes), n) for _ in range(dnum)])
 glk = P.PhantomRelinKey([rnd(2, len(primes), n) for _ in range(dnum)])
 BFV = P.scheme_type.bfv
 ct3 = rnd(64, 3, size_q, n)
-for sub in (64, 16, 8, 1):
+for sub in (64, 16, 12, 8, 6, 4, 2, 1):     # ciphertexts per set of launches inside the one C call (pha_relinearize_rotate_batched's chunk)
     def run():
-        for b0 in range(0, 64, sub):
-            W.relinearize_rotate_batch(ctx, size_q, ct3[b0:b0 + sub], rlk, glk, 3, BFV)
+        W.relinearize_rotate_batch(ctx, size_q, ct3, rlk, glk, 3, BFV, chunk=sub)
     run(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
