@@ -69,9 +69,44 @@ def test_random_parameter_sets(case, gpu):
             assert np.array_equal(P.to_host(dst), tool.divide_and_round_q_last(ref, 2))
     elts = [5, 2 * n - 1]
     glk = [np.stack([np.stack([uniform_poly(rng, primes, n), uniform_poly(rng, primes, n)]) for _ in range(dnum)]) for _ in elts]
+    d_glk = [P.PhantomRelinKey.from_numpy(k, gpu) for k in glk]
+    o_glk = [[k[i] for i in range(tool.beta)] for k in glk]
     d_h = P.to_device(ct, gpu)
-    ctx.hoisting(ql, d_h, elts, [P.PhantomRelinKey.from_numpy(k, gpu) for k in glk], scheme)
-    assert np.array_equal(P.to_host(d_h), tool.hoisting(ct, elts, [[k[i] for i in range(tool.beta)] for k in glk], scheme))
+    ctx.hoisting(ql, d_h, elts, d_glk, scheme)
+    assert np.array_equal(P.to_host(d_h), tool.hoisting(ct, elts, o_glk, scheme))
+    keys = [evk[i] for i in range(tool.beta)]
+    # r03 entries.  key switch + rescale in one call (ckks): the two reference steps, bit for bit, alone and as a batch of two
+    if scheme == O.CKKS and ql > 1:
+        want = tool.rescale_ntt(ref, 2)
+        fused = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+        ctx.keyswitch_rescale(ql, P.to_device(ct, gpu), P.to_device(c2, gpu), rlk.public_keys_ptr, fused)
+        assert np.array_equal(P.to_host(fused), want), f"keyswitch_rescale {primes} alpha={alpha} ql={ql}"
+        fused2 = P.to_device(np.zeros((2, 2, ql - 1, n), dtype=np.uint64), gpu)
+        ctx.keyswitch_rescale_batched(ql, P.to_device(np.stack([ct, ref]), gpu), P.to_device(np.stack([c2, ct[0]]), gpu), 2,
+                                      rlk.public_keys_ptr, fused2)
+        got2 = P.to_host(fused2)
+        assert np.array_equal(got2[0], want)
+        assert np.array_equal(got2[1], tool.rescale_ntt(tool.keyswitch_inplace(ref, ct[0], keys, scheme), 2))
+    # relinearize + rotate of a batch in one call (BASELINE config 4's composition) against the oracle's three steps
+    from phantom_fhe_amd import workloads as W
+    ct3 = np.stack([np.concatenate([ct, c2[None]]), np.concatenate([ref, ct[1][None]])])
+    rr = P.to_host(W.relinearize_rotate_batch(ctx, ql, P.to_device(ct3, gpu), rlk, d_glk[0], elts[0], scheme))
+    table = O.galois_ntt_table(log_n, elts[0])
+    for b in range(2):
+        x = tool.keyswitch_inplace(ct3[b, :2], ct3[b, 2], keys, scheme)
+        if scheme == O.BFV:
+            g = [oc.apply_galois_coeff(x[p], elts[0], ql) for p in range(2)]
+        else:
+            g = [O.apply_galois_ntt(x[p], table, n, ql) for p in range(2)]
+        assert np.array_equal(rr[b], tool.keyswitch_inplace(np.stack([g[0], np.zeros_like(g[0])]), g[1], o_glk[0], scheme)), b
+    # baby-step / giant-step weighted hoisting (BASELINE config 5's composition), NTT-domain schemes
+    if scheme != O.BFV:
+        qlp_primes = [primes[i] for i in list(range(ql)) + [size_q + j for j in range(alpha)]]
+        ws = [[uniform_poly(rng, qlp_primes, n) for _ in range(2)] for _ in range(2)]
+        d_ws = [[P.to_device(w, gpu) for w in row] for row in ws]
+        bs = P.to_host(W.diag_matvec_bsgs(ctx, ql, P.to_device(ct, gpu), [1, elts[0]], [None, d_glk[0]], [1, elts[1]], [None, d_glk[1]],
+                                          d_ws, scheme))
+        assert np.array_equal(bs, tool.hoisting_weighted_bsgs(ct, [1, elts[0]], [None, o_glk[0]], [1, elts[1]], [None, o_glk[1]], ws, scheme))
 
 
 @pytest.mark.parametrize("case", list(range(6)) + [100 + i for i in range(int(os.environ.get("PHA_FUZZ_EXTRA", "0")) // 4)])
