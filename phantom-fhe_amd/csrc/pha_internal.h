@@ -311,6 +311,7 @@ struct NttExtra {
     size_t poly_stride = 0;                              // elements between consecutive polynomials of in / mid
     size_t out_stride = 0, aux_stride = 0;               // same for out and aux (0 = poly_stride)
     size_t in_stride = 0;                                // polynomials of `in` when it is strided differently from mid (0 = poly_stride)
+    bool first_pass_only = false;                        // forward: stop after the strided pass (the caller runs a fused second pass)
     const u64 *pro_src = nullptr;                        // forward only: every limb of polynomial z transforms
     size_t pro_stride = 0;                               //   (pro_src + z * pro_stride) mod its own prime; `in` unused
     uint32_t excl_step = 0;                              // polynomial z skips [excl_start + z*step, min(+len, limit))
@@ -321,6 +322,22 @@ void ntt_forward(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
                  hipStream_t s);
 void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &sel, int epi, const NttExtra &x,
                  hipStream_t s);
+// The mod-up's forward transform with the key inner product as the epilogue of its contiguous pass (pha_ntt.hip): digits
+// [beta][QlP][N] hold the converted limbs in coefficient form (own limbs untouched); cx [2][QlP][N] = sum_b NTT(digit_b) * key_b,
+// with digit b's own limbs taken from `own` (the NTT-form input) instead.  Returns false when the shape has no fused form (the
+// caller then runs the transform and the inner product separately).
+struct ModupIpArgs {
+    u64 *cx;
+    const u64 *own;                   // c2 in NTT form [Ql][N], or null: no digit has untransformed own limbs (coefficient-form input)
+    const u64 *const *evks;           // device array [beta] of keys [2][QP][N]
+    size_t qlp_n, qp_n;
+    uint32_t fix_limb;                // pha_keyswitch_rescale: limb whose cx receives ct + cx * P^-1 (0xffffffff = off)
+    u64x2 fix_cst;
+    const u64 *fix_ct;
+    size_t fix_ct_stride;
+};
+bool modup_ntt_inner_prod(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, uint32_t beta, const ModupIpArgs &ip,
+                          hipStream_t s);
 
 // shared launchers (pha_rns.hip / pha_poly.hip)
 // optional epilogue of a conversion: store dst_j (+)= (cx_j - converted_j) * cst_j instead of converted_j (BFV mod-down)

@@ -66,6 +66,7 @@ struct NttKArgs {
     uint32_t batch;          // polynomials per launch (blockIdx.z)
     size_t poly_stride, out_stride, aux_stride;
     size_t in_stride;        // elements between the polynomials of `in` (first pass; the second pass reads mid at poly_stride)
+    bool first_pass_only;    // forward: the caller runs its own (fused) second pass
     uint32_t excl_step, excl_limit, excl_mod;
     const u64 *pro_src;      // rescale prologue: every limb of polynomial z reads pro_src + z * pro_stride instead
     size_t pro_stride;
@@ -495,6 +496,7 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     (void)fused;
 #endif
     launch_pass<P1, true, EPI_NONE, false>(k1, s);
+    if (k.first_pass_only) return;
     // pass 1 ran in -> mid with the input stride; pass 2 reads mid and writes out with the output stride
     if (epi == EPI_FWD_MODDOWN) launch_pass<P2, true, EPI_FWD_MODDOWN, false>(k, s);
     else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<P2, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
@@ -560,6 +562,7 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.batch = x.batch ? x.batch : 1;
     k.poly_stride = x.poly_stride;
     k.in_stride = x.in_stride ? x.in_stride : x.poly_stride;
+    k.first_pass_only = fwd && x.first_pass_only;
     k.out_stride = x.out_stride ? x.out_stride : x.poly_stride;
     k.aux_stride = x.aux_stride ? x.aux_stride : x.poly_stride;
     k.excl_step = x.excl_step;
@@ -583,6 +586,172 @@ static void check_sel(Context &c, const LimbSel &sel) {
     const uint32_t last = sel.start + sel.count - 1;
     const uint32_t prime_last = last >= sel.remap_from ? last + sel.remap_add : last;
     if (prime_last >= c.rows) throw std::invalid_argument("modulus index out of range of the NTT tables");
+}
+
+
+// ---- the key inner product as the epilogue of the mod-up's contiguous pass (r03) ------------------------------------------------
+// keyswitch_inplace runs, per digit b, the forward NTT of the converted limbs and then key_switch_inner_prod over all digits
+// (src/rns_bconv.cu:530-627, src/eval_key_switch.cu:14-92): the transformed digits (beta x (l + alpha) limbs) are written and read
+// back once, and the digit's own limbs are copied verbatim first.  Here ONE wavefront owns a 512-coefficient tile of limb j for
+// ALL digits: it runs the contiguous pass on digit 0's tile, multiplies the outputs -- still in registers -- by the two key words,
+// does the same for digit 1, ... and stores only the two sums.  A digit's own limb is not transformed at all: its NTT-form value
+// is the input c2 itself, read where it lies (so the conversion need not copy it).  Per key switch at C3 that removes 67.5 MiB of
+// transformed-digit stores, 90 MiB of digit loads, the 45 MiB own-limb copy and one launch.
+// Accumulation: limbs on the FP64 back end add centred residues as doubles (fp_mulmod of the lazy transform output with the key
+// word as a double: |sum| <= beta (q/2 + 1)); integer limbs add Barrett-reduced products modulo q.  Both equal
+// (sum_b x_b k_b) mod q, the value the 128-bit accumulate + Barrett of inner_prod_kernel stores.
+template <class C, int BETA, bool FP>
+__device__ __forceinline__ void modup_ip_body(const NttKArgs &k, const ModupIpArgs &ip, uint32_t twr, uint32_t prime, uint32_t tile,
+                                              u64 *lds, int tid) {
+    constexpr int RL = C::NR - 1, r = C::r(RL), K = 1 << r, G = C::EPT >> r;
+    static_assert(C::LOGT - C::s0(RL) - r == 0, "the last round holds runs of K consecutive coefficients");
+    using Prog = PassProgram<C, true, EPI_NONE, false, 0, false>;
+    const size_t n = (size_t)1 << k.log_n;
+    const DModulus m = k.mod[prime];
+    const u64 q = m.value;
+    FpMod fm{};
+    u64 accb[C::EPT], acca[C::EPT];      // FP: doubles (bit patterns); integer: residues
+#pragma unroll
+    for (int i = 0; i < C::EPT; i++) accb[i] = acca[i] = FP ? as_u64(0.0) : 0;
+    size_t g0[G];                        // first coefficient of each run inside the limb
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        int v, hi, lo;
+        decode_group<C, RL>(tid + C::THREADS * gi, v, hi, lo);
+        g0[gi] = ((size_t)tile * C::V + v) * C::T + ((size_t)hi << r);
+    }
+#if defined(PHA_IP_UNROLLED)   // (r03 A/B: the unrolled digit loop overlaps consecutive digits, needs 210 VGPRs = two wavefronts per
+#pragma unroll                 //  SIMD, and is 3 % slower per key switch than the rolled one at 164 VGPRs = three)
+#else
+#pragma unroll 1
+#endif
+    for (int b = 0; b < BETA; b++) {
+        PassArgs a;
+        full_tile_args<C, true, EPI_NONE, false>(k, twr, (uint32_t)b, tile, a);
+        a.fp = FP;
+        fm = a.fpm;
+        u64 reg[C::EPT];
+        if (ip.own && limb_excluded(k, twr, (uint32_t)b)) {   // (uniform) digit b's own limb: the NTT-form input itself
+#pragma unroll
+            for (int gi = 0; gi < G; gi++)
+#pragma unroll
+                for (int kk = 0; kk < K; kk += 2) {
+                    const u64x2 w = *reinterpret_cast<const u64x2 *>(ip.own + (size_t)twr * n + g0[gi] + kk);
+                    reg[gi * K + kk] = FP ? as_u64(fp_from_canon(w.x)) : w.x;
+                    reg[gi * K + kk + 1] = FP ? as_u64(fp_from_canon(w.y)) : w.y;
+                }
+        } else {
+            u64x2 twreg[C::TW_TOTAL];
+            Prog::load_twiddles(a, tid, twreg);
+            Prog::template run<0>(a, lds, tid, reg, twreg);
+            tile_sync<C>();
+            if constexpr (Prog::NSEG >= 3) {
+                Prog::template run<1>(a, lds, tid, reg, twreg);
+                tile_sync<C>();
+                Prog::template run_keep<2>(a, lds, tid, reg, twreg);
+            } else {
+                Prog::template run_keep<1>(a, lds, tid, reg, twreg);
+            }
+            tile_sync<C>();   // the next digit reuses the LDS words
+            if (!FP) {
+#pragma unroll
+                for (int i = 0; i < C::EPT; i++) reg[i] = csub(csub(csub(reg[i], q << 2), q << 1), q);
+            }
+        }
+        const u64 *key = ip.evks[b];
+#pragma unroll
+        for (int gi = 0; gi < G; gi++)
+#pragma unroll
+            for (int kk = 0; kk < K; kk += 2) {
+                const size_t id = (size_t)prime * n + g0[gi] + kk;
+                const u64x2 kb = *reinterpret_cast<const u64x2 *>(key + id);
+                const u64x2 ka = *reinterpret_cast<const u64x2 *>(key + id + ip.qp_n);
+                const int i0 = gi * K + kk;
+                if (FP) {
+                    const double x0 = as_f64(reg[i0]), x1 = as_f64(reg[i0 + 1]);
+                    accb[i0] = as_u64(as_f64(accb[i0]) + fp_mulmod(x0, fp_from_canon(kb.x), fm));
+                    accb[i0 + 1] = as_u64(as_f64(accb[i0 + 1]) + fp_mulmod(x1, fp_from_canon(kb.y), fm));
+                    acca[i0] = as_u64(as_f64(acca[i0]) + fp_mulmod(x0, fp_from_canon(ka.x), fm));
+                    acca[i0 + 1] = as_u64(as_f64(acca[i0 + 1]) + fp_mulmod(x1, fp_from_canon(ka.y), fm));
+                } else {
+                    // (128-bit accumulators with one Barrett at the end, as inner_prod_kernel has them, cost 32 more VGPRs across the
+                    //  transforms: 256+ registers, one wavefront per SIMD; measured r03)
+                    accb[i0] = add_mod(accb[i0], mul_mod(reg[i0], kb.x, m), q);
+                    accb[i0 + 1] = add_mod(accb[i0 + 1], mul_mod(reg[i0 + 1], kb.y, m), q);
+                    acca[i0] = add_mod(acca[i0], mul_mod(reg[i0], ka.x, m), q);
+                    acca[i0 + 1] = add_mod(acca[i0 + 1], mul_mod(reg[i0 + 1], ka.y, m), q);
+                }
+            }
+    }
+    const bool fix = twr == ip.fix_limb;   // (uniform) pha_keyswitch_rescale: ct_last + cx_last * P^-1
+#pragma unroll
+    for (int gi = 0; gi < G; gi++)
+#pragma unroll
+        for (int kk = 0; kk < K; kk += 2) {
+            const int i0 = gi * K + kk;
+            u64x2 rb, ra;
+            if (FP) {
+                rb = u64x2{fp_to_canon(as_f64(accb[i0]), fm), fp_to_canon(as_f64(accb[i0 + 1]), fm)};
+                ra = u64x2{fp_to_canon(as_f64(acca[i0]), fm), fp_to_canon(as_f64(acca[i0 + 1]), fm)};
+            } else {
+                rb = u64x2{accb[i0], accb[i0 + 1]};
+                ra = u64x2{acca[i0], acca[i0 + 1]};
+            }
+            const size_t id = (size_t)twr * n + g0[gi] + kk;
+            if (fix) {
+                const u64x2 c0 = *reinterpret_cast<const u64x2 *>(ip.fix_ct + id);
+                const u64x2 c1 = *reinterpret_cast<const u64x2 *>(ip.fix_ct + ip.fix_ct_stride + id);
+                rb.x = add_mod(c0.x, shoup(rb.x, ip.fix_cst, q), q);
+                rb.y = add_mod(c0.y, shoup(rb.y, ip.fix_cst, q), q);
+                ra.x = add_mod(c1.x, shoup(ra.x, ip.fix_cst, q), q);
+                ra.y = add_mod(c1.y, shoup(ra.y, ip.fix_cst, q), q);
+            }
+            *reinterpret_cast<u64x2 *>(ip.cx + id) = rb;
+            *reinterpret_cast<u64x2 *>(ip.cx + ip.qlp_n + id) = ra;
+        }
+}
+
+// Limb order: blockIdx.y walks the special (P) limbs first -- 60-bit primes on the integer back end, the longest wavefronts of
+// the launch -- then the data limbs, so that the long poles start at once and the FP64 limbs fill in behind them.
+#if defined(PHA_IP_WAVES)
+#define PHA_IP_BOUNDS __launch_bounds__(C::THREADS, PHA_IP_WAVES)
+#else
+#define PHA_IP_BOUNDS __launch_bounds__(C::THREADS)
+#endif
+template <class C, int BETA>
+__global__ PHA_IP_BOUNDS void modup_ip_kernel(const NttKArgs k, const ModupIpArgs ip) {
+    static_assert(C::WAVE_LOCAL && !C::STRIDED && !C::WHOLE, "the fused inner product rides on the one-wavefront contiguous pass");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *lds = reinterpret_cast<u64 *>(smem);
+    const uint32_t tile = blockIdx.x;
+    const uint32_t n_special = k.sel.remap_from <= k.sel.start + k.sel.count ? k.sel.start + k.sel.count - k.sel.remap_from : 0;
+    const uint32_t y = blockIdx.y < n_special ? k.sel.count - n_special + blockIdx.y : blockIdx.y - n_special;
+    const uint32_t twr = k.sel.start + y;
+    const uint32_t prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
+    const bool fp = k.fpinfo && k.fpinfo[prime].ok;   // uniform
+    if (fp) modup_ip_body<C, BETA, true>(k, ip, twr, prime, tile, lds, threadIdx.x);
+    else modup_ip_body<C, BETA, false>(k, ip, twr, prime, tile, lds, threadIdx.x);
+}
+
+template <int LOGN>
+static void launch_modup_ip(NttKArgs k, uint32_t beta, const ModupIpArgs &ip, hipStream_t s) {
+    using P1 = typename NttPlan<LOGN, 3>::P1;
+    using P2 = typename NttPlan<LOGN, 3>::P2;
+    k.t1 = P1::T;
+    k.t2 = P2::T;
+    k.in = k.mid;                 // the contiguous pass reads what the strided pass left in the digits
+    k.in_stride = k.poly_stride;
+    k.pro_src = nullptr;
+    k.zfast_tiles = 0;
+    const dim3 grid((unsigned)(((size_t)1 << LOGN) >> P2::LOGTILE), k.sel.count, 1), block(P2::THREADS);
+    const size_t lds_bytes = (size_t)P2::LDS_WORDS * sizeof(u64);
+    switch (beta) {
+        case 1: hipLaunchKernelGGL((modup_ip_kernel<P2, 1>), grid, block, lds_bytes, s, k, ip); break;
+        case 2: hipLaunchKernelGGL((modup_ip_kernel<P2, 2>), grid, block, lds_bytes, s, k, ip); break;
+        case 3: hipLaunchKernelGGL((modup_ip_kernel<P2, 3>), grid, block, lds_bytes, s, k, ip); break;
+        default: hipLaunchKernelGGL((modup_ip_kernel<P2, 4>), grid, block, lds_bytes, s, k, ip); break;
+    }
+    check_launch();
 }
 
 // What a launch of `count` limbs x `batch` polynomials takes (measured rules):
@@ -720,6 +889,24 @@ void ntt_inverse(Context &c, const u64 *in, u64 *mid, u64 *out, const LimbSel &s
         case 17: inverse_two_pass<17>(k, epi, ch, s); break;
         default: throw std::invalid_argument("unsupported polynomial degree");
     }
+}
+
+bool modup_ntt_inner_prod(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, uint32_t beta, const ModupIpArgs &ip,
+                          hipStream_t s) {
+    if (c.log_n < 14 || c.log_n > 17 || beta < 1 || beta > 4 || sel.count == 0) return false;   // (N <= 8192 takes the one-launch plans)
+    if (choose_plan(c, sel, x).whole) return false;
+    check_sel(c, sel);
+    NttExtra x1 = x;
+    x1.first_pass_only = true;
+    ntt_forward(c, digits, digits, digits, sel, EPI_FWD_CANON, x1, s);   // strided pass of every digit, in place
+    NttKArgs k = make_args(c, digits, digits, digits, sel, x, true);
+    switch (c.log_n) {
+        case 14: launch_modup_ip<14>(k, beta, ip, s); break;
+        case 15: launch_modup_ip<15>(k, beta, ip, s); break;
+        case 16: launch_modup_ip<16>(k, beta, ip, s); break;
+        default: launch_modup_ip<17>(k, beta, ip, s); break;
+    }
+    return true;
 }
 
 }  // namespace pha

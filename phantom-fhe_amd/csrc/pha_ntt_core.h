@@ -659,6 +659,18 @@ struct PassProgram {
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
     }
 
+    // Last segment WITHOUT its store: the registers keep the transform's outputs in the last round's layout (group gi of the
+    // thread = K consecutive coefficients starting at global_index(e0, v), see round_out), lazy integers or lazy doubles -- what a
+    // fused consumer (the key inner product as the epilogue of the mod-up's contiguous pass) takes over.
+    template <int SEG>
+    PHA_HD static void run_keep(const PassArgs &a, u64 *lds, int tid, u64 *reg, u64x2 *twreg) {
+        constexpr int RI = FWD ? SEG : C::NR - 1 - SEG;
+        static_assert(SEG == C::NR - 1 && SEG > 0, "run_keep is the last segment of a multi-round pass");
+        segment_twiddles<SEG>(a, tid, twreg);
+        round_load<C, RI, false, COH>(a, lds, tid, reg);
+        round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
+    }
+
     // Pieces for the software-pipelined (persistent) kernel: the first round's global load is issued
     // one tile ahead of its computation.
     static constexpr int RI_FIRST = FWD ? 0 : C::NR - 1;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         ylo[i] = (u32)y[i] & 0x3fffffffu;
         yhi[i] = (u32)(y[i] >> 30);
     }
-    if (d.copy_own && blockIdx.y == 0) {  // modup_copy_partQl_kernel rns_bconv.cu:522-528
+    if (d.copy_own && L.own && blockIdx.y == 0) {  // modup_copy_partQl_kernel rns_bconv.cu:522-528 (null own: the caller reads c2 itself)
         for (uint32_t i = 0; i < isz; i++)
             dst[(size_t)(d.src_limb + i) * n + coeff] = own[(size_t)(d.src_limb + i) * n + coeff];
     }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
     const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)who.grp * L.src_group_stride + (size_t)d.src_limb * n;
     const u64 *own = L.own + (size_t)who.grp * L.own_group_stride;
     u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
-    if (d.copy_own && blockIdx.y == 0) {
+    if (d.copy_own && L.own && blockIdx.y == 0) {
         for (uint32_t i = 0; i < d.isz; i++)
             dst[(size_t)(d.src_limb + i) * n + coeff] = own[(size_t)(d.src_limb + i) * n + coeff];
     }
@@ -1004,8 +1004,13 @@ static bool ntt_domain_scheme(int scheme) {
 // forward-NTT launch pair (blockIdx.z = digit; digit z skips its own limbs, ntt_modup.cu:422).
 // `batch` ciphertexts at once: cks / t_cks are [batch][Ql][N], dst is [batch][beta][QlP][N].
 // cks_stride: elements between the c2 polynomials of consecutive ciphertexts (0 = dense, Ql * N)
+// fused_ip != null (one ciphertext): the forward transform's contiguous pass carries the key inner product
+// (modup_ntt_inner_prod): cx is produced here, the digits' own limbs are neither copied nor transformed, and the function
+// returns true; on false (shape without a fused form) nothing but the conversion has happened... the caller must not rely on
+// that: it passes fused_ip only when fusable_ip() says so.
+static bool fusable_ip(Context &c, Tool &t) { return t.alpha > 1 && c.log_n >= 14 && c.log_n <= 17 && t.beta <= 4; }
 static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64 *t_cks, hipStream_t s,
-                  uint32_t batch = 1, size_t cks_stride = 0) {
+                  uint32_t batch = 1, size_t cks_stride = 0, const ModupIpArgs *fused_ip = nullptr) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp, alpha = t.alpha;
     const bool ntt_dom = ntt_domain_scheme(scheme);
@@ -1040,9 +1045,10 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         for (const BConv &b : t.digit) max_osz = b.osz > max_osz ? b.osz : max_osz;
         // (coefficient-form input: the conversion reads c2 itself, at its own stride; NTT form: the dense t_cks, and c2 only
         //  for the verbatim copy of the digit's own limbs)
+        // (fused inner product, NTT-form input: the own limbs are read from c2 by the fused pass, no copy)
         launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.split_ok, dst, (size_t)qlp * n,
-                     ntt_dom ? t_cks : cks, 0, cks, !ntt_dom, s, batch > 1 ? t.beta : 0, ntt_dom ? (size_t)ql * n : cks_stride,
-                     nullptr, cks_stride);
+                     ntt_dom ? t_cks : cks, 0, (fused_ip && ntt_dom) ? nullptr : cks, !ntt_dom, s, batch > 1 ? t.beta : 0,
+                     ntt_dom ? (size_t)ql * n : cks_stride, nullptr, cks_stride);
     }
     LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);
     NttExtra x;
@@ -1055,6 +1061,12 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         x.excl_limit = ql;
         x.excl_mod = batch > 1 ? t.beta : 0;
     }
+    if (fused_ip) {
+        ModupIpArgs ip = *fused_ip;
+        ip.own = ntt_dom ? cks : nullptr;
+        if (!modup_ntt_inner_prod(c, dst, sel, x, t.beta, ip, s)) throw std::logic_error("fused inner product requested for a shape without one");
+        return;
+    }
     ntt_forward(c, dst, dst, dst, sel, EPI_FWD_CANON, x, s);
 }
 
@@ -1066,10 +1078,33 @@ static u64 h_invmod_p(Context &c, uint32_t limb) {
     return h_invmod(p, q);
 }
 
+// mod-up + inner product of ONE ciphertext: the fused form where the shape has one, else the two steps.  fix_ct as in inner_prod.
+static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s, uint32_t batch = 1,
+                       const u64 *fix_ct = nullptr);
+static void modup_inner_prod(Context &c, Tool &t, u64 *cx, u64 *t_mod_up, const u64 *c2, const u64 *const *rlk, int scheme, u64 *tmp,
+                             hipStream_t s, const u64 *fix_ct = nullptr) {
+    if (!fusable_ip(c, t)) {
+        modup(c, t, t_mod_up, c2, scheme, tmp, s);
+        inner_prod(c, t, cx, t_mod_up, rlk, s, 1, fix_ct);
+        return;
+    }
+    ModupIpArgs ip{};
+    ip.cx = cx; ip.evks = rlk; ip.qlp_n = (size_t)t.size_qlp * c.n; ip.qp_n = (size_t)c.size_qp * c.n;
+    ip.fix_limb = 0xffffffffu;
+    if (fix_ct) {
+        const u64 pinv_last = h_invmod_p(c, t.size_ql - 1);
+        ip.fix_limb = t.size_ql - 1;
+        ip.fix_cst = u64x2{pinv_last, h_shoup(pinv_last, c.primes[t.size_ql - 1])};
+        ip.fix_ct = fix_ct;
+        ip.fix_ct_stride = (size_t)t.size_ql * c.n;
+    }
+    modup(c, t, t_mod_up, c2, scheme, tmp, s, 1, 0, &ip);
+}
+
 // phantom::key_switch_inner_prod eval_key_switch.cu:71-92
 // fix_ct != null (pha_keyswitch_rescale): cx's last data limb receives ct_last + cx_last * P^-1 (see InnerArgs)
 static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s,
-                       uint32_t batch = 1, const u64 *fix_ct = nullptr) {
+                       uint32_t batch, const u64 *fix_ct) {
     InnerArgs k{};
     k.cx = cx; k.t_mod_up = t_mod_up; k.evks = rlk; k.mod = c.d_mod.p; k.qlp_prime = t.d_qlp_prime.p;
     k.n = (uint32_t)c.n; k.beta = t.beta; k.qlp_n = (size_t)t.size_qlp * c.n; k.qp_n = (size_t)c.size_qp * c.n;
@@ -1225,8 +1260,12 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
                               u64 *base, hipStream_t s) {
     const size_t n = c.n, ql = t.size_ql, ql_n = ql * n, qlp_n = (size_t)t.size_qlp * n, nl = ql - 1;
     u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n;
-    modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B);
-    inner_prod(c, t, cx, t_mod_up, rlk, s, B, ct);          // cx_last <- ct_last + cx_last * P^-1
+    if (B == 1) {
+        modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, PHA_SCHEME_CKKS, tmp, s, ct);   // cx_last <- ct_last + cx_last * P^-1
+    } else {
+        modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B);
+        inner_prod(c, t, cx, t_mod_up, rlk, s, B, ct);
+    }
     {   // coefficient form of the P limbs (x phat_i^-1, bconv phase 1) and of the last data limb, both polynomials, one launch pair
         NttExtra xb;
         xb.batch = 2 * B;
@@ -1336,8 +1375,7 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     // scratch: t_cks / delta [2][Ql][N] | t_mod_up [beta][QlP][N] | cx [2][QlP][N]  (eval_key_switch.cu:151,155)
     u64 *base = c.scratch(stream, 2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n);
     u64 *tmp = base, *t_mod_up = base + 2 * ql_n, *cx = t_mod_up + (size_t)t.beta * qlp_n;
-    modup(c, t, t_mod_up, c2, scheme, tmp, s);
-    inner_prod(c, t, cx, t_mod_up, rlk, s);
+    modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, scheme, tmp, s);
     // both polynomials at once; ct += moddown(cx) with the add fused into the NTT epilogue
     moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2, scheme, true, tmp, s);
     PHA_API_END

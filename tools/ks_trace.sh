@@ -6,5 +6,5 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -o trace -- python $R/tools/ckks_ops_bench.py > $OUT/ks_trace.log 2>&1
 python $R/tools/summarize_prof.py $OUT ${TAG:-ks} > /dev/null 2>&1
-grep -E "bconv|inner_prod|ntt_pass|ew_kernel" $OUT/${TAG:-ks}_kernel_by_grid.csv | cut -c1-150
+grep -E "bconv|inner_prod|ntt_pass|ew_kernel|modup_ip" $OUT/${TAG:-ks}_kernel_by_grid.csv | cut -c1-150
 rm -rf $OUT/prof_trace

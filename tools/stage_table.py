@@ -12,8 +12,9 @@ STAGES = [
     ("tensor product (multiply)", ["ew_kernel<6>"], 7 * QL * W),                                   # 4 reads + 3 writes per limb
     ("mod-up: inverse NTT x partQlHatInv", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * QL * W),
     ("mod-up: base conversion, 3 digits", ["bconv_kernel"], BETA * (ALPHA + QL) * W),             # in 15 + out 30 + 15 per digit
-    ("mod-up: forward NTT of the converted limbs", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * BETA * QL * W),
-    ("key inner product", ["inner_prod_kernel"], QLP * (3 * BETA + 2) * W),
+    # r03: the inner product is the epilogue of the forward transform's contiguous pass (modup_ip_kernel); algorithmic bytes of both
+    ("mod-up: forward NTT of the converted limbs + key inner product (fused)", ["ntt_pass_kernel", "modup_ip_kernel"],
+     2 * BETA * QL * W + QLP * (3 * BETA + 2) * W),
     ("mod-down + rescale: inverse NTT of P and last limb, 2 polys", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * 2 * (ALPHA + 1) * W),
     ("mod-down + rescale: conversion + last-limb fold", ["bconv_rescale_kernel"], 2 * (ALPHA + 1 + QL - 1) * W),
     ("mod-down + rescale: ONE forward NTT, epilogue (ct + cx/P - .)/q_last", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * (QL - 1) * (2 + 2) * W),
@@ -24,7 +25,7 @@ rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-lib = [r for r in rows if any(k in r["Kernel_Name"] for k in ("ntt_pass_kernel", "bconv", "inner_prod", "ew_kernel"))]
+lib = [r for r in rows if any(k in r["Kernel_Name"] for k in ("ntt_pass_kernel", "bconv", "inner_prod", "ew_kernel", "modup_ip"))]
 ops = len(lib) // PER_OP
 assert ops >= 2, f"{len(lib)} library kernels in the trace, {PER_OP} per op expected"
 lib = lib[-(ops - 1) * PER_OP:]          # drop the first op (cold)

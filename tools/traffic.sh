@@ -25,7 +25,7 @@ for mode, div in (("ntt", NTT_STEPS), ("hommul", HM_OPS)):
         for f in glob.glob(f"{out}/tr_{mode}_{c}/**/*counter_collection*.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"]
-                if not any(k in name for k in ("pha::", "pha_", "ntt_", "bconv", "inner_prod", "ew_kernel")):
+                if not any(k in name for k in ("pha::", "pha_", "ntt_", "bconv", "inner_prod", "ew_kernel", "modup_ip")):
                     continue      # torch's RNG / copy kernels of the setup are not part of the op (the op's own copy_ is counted below)
                 s += float(r["Counter_Value"])
                 per[name.split("(")[0][:60]] += float(r["Counter_Value"])
