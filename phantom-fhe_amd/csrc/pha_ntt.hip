@@ -645,7 +645,13 @@ __device__ __forceinline__ void modup_ip_body(const NttKArgs &k, const ModupIpAr
             Prog::load_twiddles(a, tid, twreg);
             Prog::template run<0>(a, lds, tid, reg, twreg);
             tile_sync<C>();
-            if constexpr (Prog::NSEG >= 3) {
+            if constexpr (Prog::NSEG == 4) {
+                Prog::template run<1>(a, lds, tid, reg, twreg);
+                tile_sync<C>();
+                Prog::template run<2>(a, lds, tid, reg, twreg);
+                tile_sync<C>();
+                Prog::template run_keep<3>(a, lds, tid, reg, twreg);
+            } else if constexpr (Prog::NSEG == 3) {
                 Prog::template run<1>(a, lds, tid, reg, twreg);
                 tile_sync<C>();
                 Prog::template run_keep<2>(a, lds, tid, reg, twreg);
@@ -733,10 +739,14 @@ __global__ PHA_IP_BOUNDS void modup_ip_kernel(const NttKArgs k, const ModupIpArg
     else modup_ip_body<C, BETA, false>(k, ip, twr, prime, tile, lds, threadIdx.x);
 }
 
+#ifndef PHA_IP_PLAN
+#define PHA_IP_PLAN 3    // NttPlan variant whose contiguous pass carries the inner product (3: 8 coefficients per thread; 5: 4)
+#endif
 template <int LOGN>
 static void launch_modup_ip(NttKArgs k, uint32_t beta, const ModupIpArgs &ip, hipStream_t s) {
-    using P1 = typename NttPlan<LOGN, 3>::P1;
-    using P2 = typename NttPlan<LOGN, 3>::P2;
+    constexpr int V = (LOGN >= 14 && LOGN <= 16) ? PHA_IP_PLAN : 3;
+    using P1 = typename NttPlan<LOGN, V>::P1;
+    using P2 = typename NttPlan<LOGN, V>::P2;
     k.t1 = P1::T;
     k.t2 = P2::T;
     k.in = k.mid;                 // the contiguous pass reads what the strided pass left in the digits

@@ -4,7 +4,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
 timeout 900 python -m pytest tests/test_gpu_rns.py -x -q -m gpu -k "keyswitch or rescale or hommul" 2>&1 | grep -E "passed|failed" | tail -1
-for v in "" w4; do
+for v in "" ip5; do
   echo "=== ${v:-w4 (product)}"
   if [ -n "$v" ]; then export PHA_LIB_OVERRIDE=$R/phantom-fhe_amd/phantom_fhe_amd/libphantom_amd_$v.so; else unset PHA_LIB_OVERRIDE; fi
   timeout 300 python tools/ckks_ops_bench.py 2>&1 | grep -E "relinearize|multiply \+"
