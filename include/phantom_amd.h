@@ -348,7 +348,10 @@ int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_Ql, uint64_
                                       const uint64_t *const *rlk, void *stream);
 /* Batched modular GEMM (benchmark/matmul_bench.cu:215-541): for z in [0, batch): C[z] = A[z] * B[z] mod q, q = the
  * context prime mod_start_idx + z; row-major A [batch][m][lda], B [batch][k][ldb], C [batch][m][ldc], inputs
- * canonical.  Exact (the reference's benchmark kernels lose the carries of the low product word, :231-232). */
+ * canonical (below q; q <= 60 bits).  Exact (the reference's benchmark kernels lose the carries of the low product word,
+ * :231-232).  Runs on the matrix cores (i8 digit planes, csrc/pha_gemm.hip).  Limits: k <= 16384, batch <= 65535, leading
+ * dimensions below 2^23; moduli above 2^50 anywhere in the batch take the 8-digit path for all of it (k in runs of 128,
+ * one launch per run). */
 int pha_batched_modular_gemm(pha_context_t ctx, uint64_t *C, size_t ldc, const uint64_t *A, size_t lda, const uint64_t *B,
                              size_t ldb, size_t m, size_t n, size_t k, size_t batch, size_t mod_start_idx, void *stream);
 /* DRNSTool::mod_t_and_divide_q_last_ntt (rns.cu:1210-1236), the BGV modulus switch: src [cipher][Ql][N]

@@ -11,12 +11,21 @@
 // D x D digit-plane products go through v_mfma_i32_32x32x32_i8 into 2 D - 1 int32 accumulators (one per digit weight
 // 256^(i+j)), and the exact 128-bit sum is put back together and Barrett-reduced once per output (once per 128 of k for the
 // wide moduli, where k q^2 can pass 2^128).  One wavefront owns a 32 x 32 tile of C: 13 (15) accumulators x 16 registers,
-// one wavefront per SIMD.  B fragments (a lane = a column, 16 consecutive k) come straight from coalesced loads; A
-// (a lane = a row) is loaded coalesced along k, cut into digits, and transposed through 7-8 KB of LDS.  The integer
-// multiply-add version this replaced (carry-free v_mad_u64_u32 on 25/30-bit halves, LDS-tiled) ran at 68 % of the
-// v_mad_u64_u32 peak and is kept below under PHA_GEMM_VALU for comparison builds (profiles/r03_experiments.md).
+// one wavefront per SIMD; four of them form a workgroup that shares the loads and the digit cutting of a 64 x 64 tile through
+// LDS (layouts and pipeline at the kernel).  Algorithmic work: 49 (64) i8 multiply-adds per modular one, so 30 x 256^3 is
+// 24.7 G i8 MACs = 11 us at the measured 4.4 POP/s i8 rate; the kernel runs at about 30 % of that (profiles/r03_experiments.md
+// has the phase stamps: MFMA issue is 63 % of the main loop, the reduction of the accumulators a quarter of a tile's time).
+// The integer multiply-add version this replaced (carry-free v_mad_u64_u32 on 25/30-bit halves, LDS-tiled) ran at 68 % of
+// the v_mad_u64_u32 peak (101 us) and is kept below under PHA_GEMM_VALU for comparison builds.
 #include "../../include/phantom_amd.h"
 #include "pha_internal.h"
+
+#ifndef PHA_GEMM_VALU_PER_MFMA
+#define PHA_GEMM_VALU_PER_MFMA 4      // vector instructions the scheduler places after each MFMA (3: slower, 4-5: same, 8: slower)
+#endif
+#ifndef PHA_GEMM_X
+#define PHA_GEMM_X 0      // 5: phase stamps instead of the result (tools/gemm_stamps.py)
+#endif
 
 namespace pha {
 
@@ -180,29 +189,82 @@ __device__ __forceinline__ void planes_of4(const u64 (&x)[4], u32 (&pl)[8]) {
     byte_transpose4((u32)(y[0] >> 32), (u32)(y[1] >> 32), (u32)(y[2] >> 32), (u32)(y[3] >> 32), pl[4], pl[5], pl[6], pl[7]);
 }
 
-// exact value of sum_s acc_s 256^s (acc_s signed 32-bit, the total is non-negative) as a 128-bit number
-template <int NACC>
-__device__ __forceinline__ void recombine(const int (&a)[NACC], u64 &lo, u64 &hi) {
-    unsigned __int128 tot = 0;
-#pragma unroll
-    for (int g = 0; g * 4 < NACC; g++) {
-        long long part = 0;      // four digit weights at a time: |part| < 2^31 * 2^24 * 2
-#pragma unroll
-        for (int s = 3; s >= 0; s--)
-            if (g * 4 + s < NACC) part = part * 256 + (long long)a[g * 4 + s];
-        tot += (unsigned __int128)(__int128)part << (32 * g);
-    }
-    lo = (u64)tot;
-    hi = (u64)(tot >> 64);
+// a * b + c on signed operands: one v_mad_i64_i32 (b uniform: the digit weights 2^8, 2^16, 2^24)
+__device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
+    long long d;
+    u64 carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
+    return d;
 }
 
-// One wavefront = one 32 x 32 tile of C for one modulus.  FULL: m, n, k multiples of 32 (no bounds checks).
-// ACCUM: add to what C holds (the launcher cuts k into runs of 224 for the wide moduli, where 256 q^2 can pass 2^128).
+// exact value of sum_s acc_s 256^s (acc_s signed 32-bit, the total is non-negative and below 2^128) as a 128-bit number:
+// four digit weights at a time into a signed 64-bit group g_i (|g_i| < 2^56), total = g0 + g1 2^32 + g2 2^64 + g3 2^96
+template <int NACC>
+__device__ __forceinline__ void recombine(const int (&a)[NACC], u64 &lo, u64 &hi) {
+    long long grp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        long long v = i * 4 < NACC ? (long long)a[i * 4] : 0;
+        if (i * 4 + 1 < NACC) v = mad_i64_i32(a[i * 4 + 1], 1 << 8, v);
+        if (i * 4 + 2 < NACC) v = mad_i64_i32(a[i * 4 + 2], 1 << 16, v);
+        if (i * 4 + 3 < NACC) v = mad_i64_i32(a[i * 4 + 3], 1 << 24, v);
+        grp[i] = v;
+    }
+    lo = (u64)grp[0] + ((u64)grp[1] << 32);
+    const long long carry = lo < (u64)grp[0] ? 1 : 0;
+    hi = (u64)((grp[0] >> 63) + (grp[1] >> 32) + carry) + (u64)grp[2] + ((u64)grp[3] << 32);
+}
+
+// 32 x 32 -> 64 product, b uniform (an SGPR: no copy of the modulus constants into vector registers)
+__device__ __forceinline__ u64 mul_u64_u32_s(u32 a, u32 b) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    return d;
+}
+// floor(a b / 2^64) or one less (the a0 b0 product is left out), b uniform
+__device__ __forceinline__ u64 mulhi64_near(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p01 = mul_u64_u32_s(a0, b1), p10 = mul_u64_u32_s(a1, b0), p11 = mul_u64_u32_s(a1, b1);
+    const u64 mid = (u64)(u32)p01 + (u32)p10;
+    return p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+__device__ __forceinline__ u64 mullo64_s(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    return mul_u64_u32_s(a0, b0) + ((u64)(u32)(a0 * b1 + a1 * b0) << 32);
+}
+// (hi : lo) mod q for q < 2^60 with ratio = floor(2^128 / q): the quotient estimate hi r1 + hi(hi r0) + hi(lo r1) is at most 6
+// short (three dropped fractions, the floor in ratio, two near-products), so the remainder is below 7 q < 2^63
+__device__ __forceinline__ u64 reduce128_uniform(u64 lo, u64 hi, const DModulus &m) {
+    const u64 quo = mullo64_s(hi, m.ratio1) + mulhi64_near(hi, m.ratio0) + mulhi64_near(lo, m.ratio1);
+    u64 r = lo - mullo64_s(quo, m.value);
+    r -= r >= 4 * m.value ? 4 * m.value : 0;
+    r -= r >= 2 * m.value ? 2 * m.value : 0;
+    r -= r >= m.value ? m.value : 0;
+    return r;
+}
+
+// One workgroup of four wavefronts (one per SIMD) = one 64 x 64 tile of C for one modulus, each wavefront a 32 x 32 quarter.
+// FULL: m, n multiples of 64 and k of 64 (no bounds checks, an even number of 32-deep blocks).
+// ACCUM: add to what C holds (the launcher cuts k into runs of 128 for the wide moduli, where 256 q^2 can pass 2^128).
+//
+// Per 32-deep block of k the workgroup loads 64 x 32 of A and 32 x 64 of B once (8 + 8 operands per thread, coalesced), cuts them
+// into digit planes and leaves those in LDS:
+//   A plane d: [row 0..63][32 bytes of k]               -> a fragment (row = lane & 31, 16 k) is one ds_read_b128
+//   B plane d: [k octet 0..3][column 0..63][8 bytes of k] -> a fragment (column = lane & 31, octets 2 g, 2 g + 1) is two ds_read_b64;
+//   a thread holds eight consecutive k of one row / column, so every plane is one ds_write_b64 at 8 * thread: no bank conflicts
+// Two LDS buffers and two operand register sets: in step kb the loads of block kb + 2 go out, the vector ALU cuts block kb + 1
+// (loaded during step kb - 1) into the other LDS buffer while the D^2 MFMAs of block kb run on the matrix pipe, then one
+// barrier and the fragments of block kb + 1 are read.  Measured and not kept (profiles/r03_experiments.md): the fragment reads
+// under the MFMAs as well (a second fragment set), loads three steps ahead (four operand sets).
+constexpr int kGemmWg = 256;
+
 template <int D, bool FULL, bool ACCUM>
-__global__ __launch_bounds__(64, 1) void gemm_mfma_kernel(const GemmArgs g, uint32_t tiles_m, uint32_t tiles_n) {
+__global__ __launch_bounds__(kGemmWg, 1) void gemm_mfma_kernel(const GemmArgs g, uint32_t tiles_m, uint32_t tiles_n) {
     constexpr int NACC = 2 * D - 1;
-    __shared__ u32 lds[D * 256];          // D planes x 32 rows x 32 bytes of k
-    const uint32_t lane = threadIdx.x;
+    constexpr int PLANE = 512;                           // 4-byte words per plane (2 KB)
+    __shared__ u32 lds[2][2][D * PLANE];                 // [buffer][A / B][plane][...]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wm = wave & 1, wn = wave >> 1;
     // workgroups are handed to the 8 XCDs in turn: give each XCD a contiguous run of tiles (neighbours share A rows / a modulus in its L2)
     const uint32_t total = gridDim.x, w = blockIdx.x;
     const uint32_t t = (total % 8 == 0) ? (w % 8) * (total / 8) + w / 8 : w;
@@ -211,9 +273,9 @@ __global__ __launch_bounds__(64, 1) void gemm_mfma_kernel(const GemmArgs g, uint
     const u64 *A = g.a + (size_t)z * g.a_batch_stride;
     const u64 *B = g.b + (size_t)z * g.b_batch_stride;
     u64 *C = g.c + (size_t)z * g.m * g.ldc;
-    const uint32_t row0 = mb * 32, col0 = nb * 32;
-    const uint32_t arow = lane >> 3, akq = (lane & 7) * 4;        // A loads: 8 lanes x 4 operands cover the 32 k of a row, 8 rows per pass
-    const uint32_t bj = lane & 31, bg = (lane >> 5) * 16;         // B loads = B fragment: column bj, k = bg .. bg + 15
+    const uint32_t row0 = mb * 64, col0 = nb * 64;
+    const uint32_t arow = tid >> 2, ak8 = (tid & 3) * 8;       // A loads: 4 threads x 8 operands cover the 32 k of a row
+    const uint32_t bj = tid & 63, bk8 = (tid >> 6) * 8;         // B loads: column bj, k = bk8 .. bk8 + 7
 
     v16i acc[NACC];
 #pragma unroll
@@ -222,57 +284,90 @@ __global__ __launch_bounds__(64, 1) void gemm_mfma_kernel(const GemmArgs g, uint
         for (int r = 0; r < 16; r++) acc[s][r] = 0;
     u64 out[16];
 
-    u64 ra[4][4], rb[16];
-    auto load_raw = [&](uint32_t k0) {
+    // loads: uniform (scalar) tile bases + loop-invariant 32-bit byte offsets per thread (the launcher bounds lda, ldb)
+    const char *Atile = reinterpret_cast<const char *>(A + (size_t)row0 * g.lda);
+    const char *Btile = reinterpret_cast<const char *>(B + col0);
+    const uint32_t aoff = (uint32_t)((arow * g.lda + ak8) * 8);
+    const uint32_t boff = (uint32_t)((bk8 * g.ldb + bj) * 8);
+    struct Raw {
+        u64 a[2][4], b[2][4];             // two runs of four consecutive k each
+    };
+    Raw r0, r1;                           // operands of two blocks in flight
+    auto load_raw = [&](Raw &raw, uint32_t k0) {
+        const char *ab = Atile + (size_t)k0 * 8;
+        const uint32_t gr = row0 + arow;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const uint32_t gr = row0 + p * 8 + arow;
-            const u64 *src = A + (size_t)gr * g.lda + k0 + akq;
+        for (int e = 0; e < 8; e++)
+            raw.a[e >> 2][e & 3] = (FULL || (gr < g.m && k0 + ak8 + e < g.k)) ? *reinterpret_cast<const u64 *>(ab + aoff + 8 * e) : 0;
 #pragma unroll
-            for (int e = 0; e < 4; e++) ra[p][e] = (FULL || (gr < g.m && k0 + akq + e < g.k)) ? src[e] : 0;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const uint32_t gk = k0 + bg + e, gc = col0 + bj;
-            rb[e] = (FULL || (gk < g.k && gc < g.n)) ? B[(size_t)gk * g.ldb + gc] : 0;
+        for (int e = 0; e < 8; e++) {
+            const char *bb = Btile + ((size_t)k0 + e) * g.ldb * 8;             // + bk8 rows through boff
+            raw.b[e >> 2][e & 3] = (FULL || (k0 + bk8 + e < g.k && col0 + bj < g.n)) ? *reinterpret_cast<const u64 *>(bb + boff) : 0;
         }
     };
+    // raw operands -> digit planes in LDS buffer `buf`: eight bytes (eight consecutive k) per thread and plane, one ds_write_b64
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    auto decompose = [&](const Raw &raw, uint32_t buf) {
+        u32 *la = lds[buf][0], *lb = lds[buf][1];
+        u32 p0[8], p1[8];
+        planes_of4<D>(raw.a[0], p0);
+        planes_of4<D>(raw.a[1], p1);
+#pragma unroll
+        for (int d = 0; d < D; d++) *reinterpret_cast<u32x2 *>(&la[d * PLANE + tid * 2]) = u32x2{p0[d], p1[d]};    // row arow, bytes ak8 .. ak8 + 7
+        planes_of4<D>(raw.b[0], p0);
+        planes_of4<D>(raw.b[1], p1);
+#pragma unroll
+        for (int d = 0; d < D; d++) *reinterpret_cast<u32x2 *>(&lb[d * PLANE + tid * 2]) = u32x2{p0[d], p1[d]};    // [k octet][column]
+    };
+    v4i afrag[D], bfrag[D];
+    auto take_frags = [&](uint32_t buf) {
+        __syncthreads();
+        const u32 *la = lds[buf][0] + (wm * 32 + (lane & 31)) * 8 + (lane >> 5) * 4;
+        const u32 *lb = lds[buf][1] + (lane >> 5) * 256 + (wn * 32 + (lane & 31)) * 2;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            afrag[d] = *reinterpret_cast<const v4i *>(la + d * PLANE);
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(lb + d * PLANE), hi = *reinterpret_cast<const u32x2 *>(lb + d * PLANE + 128);
+            bfrag[d] = v4i{(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+        }
+    };
+    // FULL means an even number of blocks; otherwise a block past the end loads zeros and adds nothing.
     const uint32_t nkb = (g.k + 31) / 32;
-    auto block = [&](uint32_t kb) {
-        // digits of A -> LDS (plane d, row, 4 bytes of k per lane); digits of B stay in registers as the B fragments
-        v4i bfrag[D];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            u32 pl[8];
-            planes_of4<D>(ra[p], pl);
-#pragma unroll
-            for (int d = 0; d < D; d++) lds[d * 256 + p * 64 + lane] = pl[d];      // (p * 8 + arow) * 8 + (lane & 7) = p * 64 + lane
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const u64 x4[4] = {rb[q * 4], rb[q * 4 + 1], rb[q * 4 + 2], rb[q * 4 + 3]};
-            u32 pl[8];
-            planes_of4<D>(x4, pl);
-#pragma unroll
-            for (int d = 0; d < D; d++) bfrag[d][q] = (int)pl[d];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kb + 1 < nkb) load_raw((kb + 1) * 32);      // in flight under the MFMAs of this block
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        v4i afrag[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) afrag[d] = *reinterpret_cast<const v4i *>(&lds[d * 256 + (lane & 31) * 8 + (lane >> 5) * 4]);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
+    auto block_k0 = [&](uint32_t b) { return (FULL ? min(b, nkb - 1) : b) * 32; };
+    auto step = [&](Raw &ld, const Raw &dc, uint32_t kb, uint32_t nextbuf) {
+        load_raw(ld, block_k0(kb + 2));
+        decompose(dc, nextbuf);
 #pragma unroll
         for (int i = 0; i < D; i++)
 #pragma unroll
             for (int j = 0; j < D; j++) acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[i], bfrag[j], acc[i + j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 12, 0);          // issue order: the loads,
+#pragma unroll
+        for (int i = 0; i < D * D; i++) {                            // then one MFMA and the vector work that hides under it
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, PHA_GEMM_VALU_PER_MFMA, 0);
+        }
+        take_frags(nextbuf);
+        __builtin_amdgcn_sched_barrier(0);                           // the two steps of a pair are scheduled separately
     };
-    load_raw(0);
-    for (uint32_t kb = 0; kb < nkb; kb++) block(kb);
+#if PHA_GEMM_X == 5      // phase stamps (tools/gemm_stamps.py): s_memtime over C instead of the result
+    u64 stamp[8];
+    int ns = 0;
+#define PHA_STAMP() do { __builtin_amdgcn_sched_barrier(0); if (ns < 8) stamp[ns++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PHA_STAMP() do { } while (0)
+#endif
+    PHA_STAMP();
+    load_raw(r0, 0);
+    decompose(r0, 0);
+    load_raw(r1, block_k0(1));
+    take_frags(0);
+    PHA_STAMP();
+    for (uint32_t kb = 0; kb < nkb; kb += 2) {
+        step(r0, r1, kb, 1);
+        step(r1, r0, kb + 1, 0);
+        PHA_STAMP();
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         int a[NACC];
@@ -280,13 +375,23 @@ __global__ __launch_bounds__(64, 1) void gemm_mfma_kernel(const GemmArgs g, uint
         for (int s = 0; s < NACC; s++) a[s] = acc[s][r];
         u64 lo, hi;
         recombine<NACC>(a, lo, hi);
-        out[r] = barrett128(lo, hi, mo);
+        out[r] = reduce128_uniform(lo, hi, mo);
         __builtin_amdgcn_sched_barrier(0);      // one output at a time: keeps the 13-15 accumulator reads of the others out of the VGPRs
     }
+#if PHA_GEMM_X == 5
+    u64 sink = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) sink ^= out[r];
+    asm volatile("" :: "v"(sink));
+    PHA_STAMP();
+    if (tid == 0)
+        for (int i = 0; i < 8; i++) g.c[(size_t)t * 8 + i] = stamp[i];
+    return;
+#endif
     // C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const uint32_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gc = col0 + (lane & 31);
+        const uint32_t gr = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gc = col0 + wn * 32 + (lane & 31);
         if (FULL || (gr < g.m && gc < g.n)) {
             u64 v = out[r];
             if (ACCUM) {
@@ -311,6 +416,7 @@ extern "C" int pha_batched_modular_gemm(pha_context_t ctx, uint64_t *C, size_t l
     if (batch == 0 || m == 0 || n == 0) return 0;
     if (mod_start_idx + batch > c.rows) throw std::invalid_argument("modulus index out of range");
     if (batch > 65535 || k == 0 || k > 16384 || lda < k || ldb < n || ldc < n) throw std::invalid_argument("gemm shape is not valid");
+    if ((lda | ldb | ldc) >> 23) throw std::invalid_argument("gemm leading dimension exceeds 2^23");     // 32-bit lane offsets in the kernel
     bool narrow = true;   // every modulus below 2^50: 25-bit halves, no folding inside the k loop
     for (size_t z = 0; z < batch; z++) {
         const u64 q = c.primes[mod_start_idx + z];
@@ -323,23 +429,23 @@ extern "C" int pha_batched_modular_gemm(pha_context_t ctx, uint64_t *C, size_t l
     if (narrow) hipLaunchKernelGGL((gemm_mod_kernel<25, false>), grid, dim3(kGemmThreads), 0, as_stream(stream), g);
     else hipLaunchKernelGGL((gemm_mod_kernel<30, true>), grid, dim3(kGemmThreads), 0, as_stream(stream), g);
 #else
-    const uint32_t tm = (uint32_t)((m + 31) / 32), tn = (uint32_t)((n + 31) / 32);
+    const uint32_t tm = (uint32_t)((m + 63) / 64), tn = (uint32_t)((n + 63) / 64);
     const size_t tiles = (size_t)tm * tn * batch;
     if (tiles > 0x7fffffffull) throw std::invalid_argument("gemm shape is not valid");
-    const bool full = m % 32 == 0 && n % 32 == 0 && k % 32 == 0;
-    const dim3 grid((unsigned)tiles), block(64);
+    const bool full = m % 64 == 0 && n % 64 == 0 && k % 64 == 0;      // whole tiles and an even number of 32-deep blocks
+    const dim3 grid((unsigned)tiles), block(kGemmWg);
     // narrow moduli: 7 digits, the int32 accumulators hold k <= 16384 (7 * 16384 * 2^14 < 2^31) and the 128-bit total k q^2 < 2^114;
-    // wide: 8 digits, k in runs of 224 (224 q^2 < 2^128), every run after the first added to C
+    // wide: 8 digits, k in runs of 128 (128 q^2 < 2^127; four blocks), every run after the first added to C
     auto launch = [&](auto kernel, const GemmArgs &ga) { hipLaunchKernelGGL(kernel, grid, block, 0, as_stream(stream), ga, tm, tn); };
     if (narrow) {
         if (full) launch(gemm_mfma_kernel<7, true, false>, g);
         else launch(gemm_mfma_kernel<7, false, false>, g);
     } else {
-        for (size_t k0 = 0; k0 < k; k0 += 224) {
+        for (size_t k0 = 0; k0 < k; k0 += 128) {
             GemmArgs ga = g;
             ga.a = A + k0;
             ga.b = B + k0 * ldb;
-            ga.k = (uint32_t)std::min<size_t>(224, k - k0);
+            ga.k = (uint32_t)std::min<size_t>(128, k - k0);
             ga.a_batch_stride = m * lda;
             ga.b_batch_stride = k * ldb;
             if (k0 == 0) {

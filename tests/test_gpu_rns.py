@@ -717,7 +717,8 @@ def test_bfv_hps_overq_leveled(name, plain_t, ql, gpu):
 
 
 @pytest.mark.parametrize("bits,m,n,k,batch", [(50, 256, 256, 256, 3), (50, 96, 40, 72, 2), (60, 128, 64, 100, 2), (36, 64, 32, 16, 1),
-                                                 (60, 64, 32, 1200, 2)])
+                                                 (60, 64, 32, 1200, 2), (50, 128, 64, 64, 9), (50, 64, 192, 96, 2), (60, 64, 64, 256, 3),
+                                                 (50, 1, 1, 1, 1), (50, 65, 33, 33, 2), (49, 64, 64, 4096, 1)])
 def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
     """matmul_bench shape (256^3 per 50-bit modulus) and ragged shapes, wide (60-bit) and narrow paths, vs the oracle;
     the benchmark's all-ones input gives k everywhere."""
@@ -740,6 +741,25 @@ def test_batched_modular_gemm(bits, m, n, k, batch, gpu):
     ones_a, ones_b = np.ones_like(A), np.ones_like(B)
     ctx.batched_modular_gemm(dC, P.to_device(ones_a, gpu), P.to_device(ones_b, gpu), m, n, k, batch)
     assert (P.to_host(dC) == k).all()
+
+
+@pytest.mark.parametrize("bits,x", [(50, 0x808080808080), (50, 0x7f7f7f7f7f7f), (60, 0x0080808080808080), (60, 0x007f7f7f7f7f7f7f)])
+def test_batched_modular_gemm_largest_digits_longest_k(bits, x, gpu):
+    """Headroom of the int32 digit-plane accumulators: every operand has the extreme signed bytes (-128 / +127 in all but the top
+    digit) and k is the largest the entry accepts (16384), so each accumulator holds 7 (8) x 16384 products of magnitude 2^14; the
+    exact answer is k x^2 mod q everywhere."""
+    import phantom_fhe_amd as P
+    primes = [int(p) for p in O.get_primes(4096, bits, 2)]
+    assert all(x < q for q in primes)
+    ctx = P.PhantomContext(12, primes, 0, device=gpu)
+    m, n, k = 64, 96, 16384
+    A = P.to_device(np.full((2, m, k), x, dtype=np.uint64), gpu)
+    B = P.to_device(np.full((2, k, n), x, dtype=np.uint64), gpu)
+    dC = P.to_device(np.zeros((2, m, n), dtype=np.uint64), gpu)
+    ctx.batched_modular_gemm(dC, A, B, m, n, k, 2)
+    got = P.to_host(dC)
+    for z, q in enumerate(primes):
+        assert (got[z] == np.uint64(k * x * x % q)).all(), f"modulus {z}"
 
 
 @pytest.mark.parametrize("name,ibase,obase", [
