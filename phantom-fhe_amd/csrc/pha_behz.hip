@@ -109,7 +109,7 @@ static void behz_lift(Context &c, Behz &b, const u64 *ct, u64 *out_q, u64 *out_b
     ScaleArgs sa{y, ct, c.d_mod.p, b.mt_qhatinv.p, n};
     hipLaunchKernelGGL(scale_limbs_kernel, dim3(n / 256, sq, 2), dim3(256), 0, s, sa);
     check_launch();
-    launch_bconv(c, b.d_q_to_bskmt.p, 0, 2, sq, sk + 1, false, lift, (size_t)(sk + 1) * n, y, qn, nullptr, false, s);
+    launch_bconv(c, b.d_q_to_bskmt.p, 0, 2, sq, sk + 1, b.q_to_bskmt.split_kind, lift, (size_t)(sk + 1) * n, y, qn, nullptr, false, s);
     // (2) small Montgomery reduction modulo q, switching to base Bsk
     MrqArgs ma{out_bsk, lift, c.d_mod.p, b.prod_q_mod_bsk.p, b.inv_mt_mod_bsk.p, b.neg_inv_prod_q_mod_mt, b.aux0, sk, n};
     hipLaunchKernelGGL(sm_mrq_kernel, dim3(n / 256, sk, 2), dim3(256), 0, s, ma);
@@ -250,7 +250,7 @@ void launch_bconv_phase1(Context &c, const BConv &conv, u64 *dst, const u64 *src
 static void bconv_hps(Context &c, const BConv &conv, const BConvDev *d_conv, const double *inv, const u64 *alpha_mod,
                       u64 *dst, const u64 *src, u64 *y, hipStream_t s) {
     const uint32_t n = (uint32_t)c.n;
-    launch_bconv(c, d_conv, 0, 1, conv.isz, conv.osz, false, dst, 0, src, 0, nullptr, true, s);
+    launch_bconv(c, d_conv, 0, 1, conv.isz, conv.osz, conv.split_kind, dst, 0, src, 0, nullptr, true, s);
     launch_bconv_phase1(c, conv, y, src, s);   // the fix-up needs the phase-1 values themselves
     HpsFixArgs fa{dst, y, inv, alpha_mod, c.d_mod.p, conv.d_oprime.p, conv.isz, conv.osz, n};
     hipLaunchKernelGGL(hps_fix_kernel, dim3(n / 256), dim3(256), 0, s, fa);
@@ -385,7 +385,7 @@ static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *c
     if (!square) {
         for (uint32_t p = 0; p < 2; p++) {   // second operand: Q -> Rl by bConv_BEHZ_var1, then Rl -> Ql exactly (:745-751)
             u64 *xr = x2 + p * qrn + qn;
-            launch_bconv(c, h.d_q_to_r_var1.p, 0, 1, h.q_to_r_var1.isz, sr, false, xr, 0, ct2 + p * qfn, 0, nullptr, true, s);
+            launch_bconv(c, h.d_q_to_r_var1.p, 0, 1, h.q_to_r_var1.isz, sr, h.q_to_r_var1.split_kind, xr, 0, ct2 + p * qfn, 0, nullptr, true, s);
             bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, x2 + p * qrn, xr, y, s);
         }
     }
@@ -537,13 +537,13 @@ extern "C" int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, con
     for (uint32_t p = 0; p < 3; p++) {
         u64 *xq_p = q1 + p * qn, *xb_p = b1 + p * bn, *out = dst + p * qn;
         // step 7 fast_floor (rns.cu:1394-1419)
-        launch_bconv(c, b.d_q_to_bsk.p, 0, 1, sq, sk, false, conv, 0, xq_p, 0, nullptr, true, s);
+        launch_bconv(c, b.d_q_to_bsk.p, 0, 1, sq, sk, b.q_to_bsk.split_kind, conv, 0, xq_p, 0, nullptr, true, s);
         FloorArgs fa{fl, xb_p, conv, c.d_mod.p, b.inv_prod_q_mod_bsk.p, b.aux0, n};
         hipLaunchKernelGGL(fast_floor_kernel, dim3(n / 256, sk), dim3(256), 0, s, fa);
         check_launch();
         // step 8 fastbconv_sk (rns.cu:1470-1510)
-        launch_bconv(c, b.d_b_to_msk.p, 0, 1, sb, 1, false, conv, 0, fl, 0, nullptr, true, s);   // conv[0..N) = B -> m_sk
-        launch_bconv(c, b.d_b_to_q.p, 0, 1, sb, sq, false, out, 0, fl, 0, nullptr, true, s);
+        launch_bconv(c, b.d_b_to_msk.p, 0, 1, sb, 1, b.b_to_msk.split_kind, conv, 0, fl, 0, nullptr, true, s);   // conv[0..N) = B -> m_sk
+        launch_bconv(c, b.d_b_to_q.p, 0, 1, sb, sq, b.b_to_q.split_kind, out, 0, fl, 0, nullptr, true, s);
         SkArgs ka{out, conv, fl + (size_t)sb * n, c.d_mod.p, b.prod_b_mod_q.p, b.inv_prod_b_mod_msk, b.m_sk, n};
         hipLaunchKernelGGL(sk_fix_kernel, dim3(n / 256, sq), dim3(256), 0, s, ka);
         check_launch();
@@ -613,7 +613,7 @@ int pha_bConv_BEHZ(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src
     PHA_API_BEGIN
     if (!conv || !dst || !src) throw std::invalid_argument("null pointer");
     Context &c = conv->ctx->c;
-    launch_bconv(c, conv->d_conv.p, 0, 1, conv->conv.isz, conv->conv.osz, conv->split_ok, dst, 0, src, 0, nullptr, true,
+    launch_bconv(c, conv->d_conv.p, 0, 1, conv->conv.isz, conv->conv.osz, conv->conv.split_kind, dst, 0, src, 0, nullptr, true,
                  as_stream(stream));
     PHA_API_END
 }

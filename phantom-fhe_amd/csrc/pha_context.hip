@@ -336,7 +336,7 @@ uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_l
 }
 
 void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
-    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz, 0xffffffffu, 0, 0, 0}});
+    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz, 0xffffffffu, 0, 0, 0, b.row_pad}});
 }
 
 // DRNSTool constructor, HPS multiply part (src/rns.cu:687-790; converters src/host/rns.cu:282-337,438-466).
@@ -661,9 +661,24 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
     b.osz = (uint32_t)op.size();
     b.iprime = ip;
     b.oprime = op;
+    // which carry-free split the kernel may use with these constants (BConv::split_kind)
+    auto bits_of = [](u64 v) { int n = 0; while (v) { n++; v >>= 1; } return n; };
+    int by = 0, bm = 0;       // residues of the input primes are below 2^by, matrix entries (residues of the output moduli) below 2^bm
+    for (uint32_t row : ip) by = std::max(by, bits_of(c.primes[row] - 1));
+    for (uint32_t row : op) bm = std::max(bm, bits_of(c.primes[row] - 1));
+    uint32_t sm = 30;         // the matrix entries are cut at this bit
+    b.split_kind = 0;
+    b.row_pad = kBcRowPad;
+    if (b.isz <= (uint32_t)kBcRowPad && by <= 60 && bm <= 60) b.split_kind = 1;
+    else if (b.isz <= 32 && by <= 60 && bm <= 62) { b.split_kind = 2; sm = 31; }
+    else if (b.isz <= 32 && by <= 62 && bm <= 60) { b.split_kind = 3; sm = 30; }
+    if (b.split_kind >= 2 && b.isz > (uint32_t)kBcRowPad) b.row_pad = 32;
     // Montgomery form for the split-accumulator kernel: rows hold qhat_i * 2^64 mod p_j, so that REDC of the accumulated
     // sum gives sum_i y_i * qhat_i mod p_j directly (valid for odd p_j; the BEHZ converter with m_tilde = 2^32 keeps Barrett)
-    b.mont = true;
+    // and for sum_i y_i * entry < 2^64 p_j: 16 inputs of 60 bits, or in general sum_i q_i < 2^64
+    unsigned __int128 sum_q = 0;
+    for (uint32_t row : ip) sum_q += c.primes[row];
+    b.mont = b.split_kind == 1 || (b.split_kind != 0 && (sum_q >> 64) == 0);
     for (uint32_t j = 0; j < b.osz; j++) b.mont = b.mont && (c.primes[op[j]] & 1);
     std::vector<u64> oninv(b.osz, 0);
     if (b.mont)
@@ -673,8 +688,8 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
             for (int it = 0; it < 6; it++) inv *= 2 - pj * inv;
             oninv[j] = 0 - inv;
         }
-    std::vector<uint32_t> mat30((size_t)b.osz * kBcRowPad * 2, 0u);
-    if (b.isz <= (uint32_t)kBcRowPad)
+    std::vector<uint32_t> mat30((size_t)b.osz * b.row_pad * 2, 0u);
+    if (b.isz <= b.row_pad)
         for (uint32_t j = 0; j < b.osz; j++)
             for (uint32_t i = 0; i < b.isz; i++) {
                 u64 m = mat[(size_t)j * b.isz + i];
@@ -682,8 +697,8 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
                     const u64 pj = c.primes[op[j]];
                     m = (u64)((((unsigned __int128)m) << 64) % pj);
                 }
-                mat30[((size_t)j * kBcRowPad + i) * 2] = (uint32_t)(m & 0x3fffffffu);
-                mat30[((size_t)j * kBcRowPad + i) * 2 + 1] = (uint32_t)(m >> 30);
+                mat30[((size_t)j * b.row_pad + i) * 2] = (uint32_t)(m & ((1u << sm) - 1));
+                mat30[((size_t)j * b.row_pad + i) * 2 + 1] = (uint32_t)(m >> sm);
             }
     b.hat_inv.upload(hat_inv);
     b.mat.upload(mat);
@@ -828,7 +843,7 @@ Tool &Context::tool(uint32_t size_ql) {
         // device descriptors for the batched launches
         auto describe = [](const BConv &b, uint32_t pad_start, uint32_t pad_len, uint32_t src_limb, uint32_t copy_own) {
             return BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz,
-                            pad_start, pad_len, src_limb, copy_own};
+                            pad_start, pad_len, src_limb, copy_own, b.row_pad};
         };
         std::vector<BConvDev> dd;
         for (uint32_t b = 0; b < t->beta; b++) {

@@ -119,6 +119,7 @@ struct BConvDev {
     uint32_t pad_start, pad_len; // output j goes to limb j + (j >= pad_start ? pad_len : 0)
     uint32_t src_limb;           // first input limb inside the source polynomial
     uint32_t copy_own;           // mod-up: also copy the digit's own limbs [src_limb, src_limb+isz) verbatim
+    uint32_t row_pad;            // row pitch (entries) of mat30: kBcRowPad, or 32 for 17..32 inputs (split kinds 2, 3)
 };
 
 
@@ -130,6 +131,11 @@ struct BConv {
     DevBuf<uint32_t> mat30;                // [osz][kBcRowPad][2] 30-bit halves of mat (Montgomery form when mont), zero-padded rows
     DevBuf<u64> oninv;                     // [osz] -p_j^-1 mod 2^64
     bool mont = false;                     // every output modulus is odd: the split kernel reduces with Montgomery
+    // which carry-free split the constants in mat30 were cut for (0: none): 1 = inputs and matrix entries in 30-bit halves
+    // (<= 16 inputs, every prime <= 60 bits); 2 = inputs cut at 30 bits, entries at 31 (<= 32 inputs of <= 60 bits, outputs
+    // <= 62 bits: Q -> Bsk / Q -> R of the BFV multiply, whose auxiliary primes are 61 bits wide); 3 = the mirror (31, 30)
+    int split_kind = 0;
+    uint32_t row_pad = kBcRowPad;
     DevBuf<uint32_t> d_iprime, d_oprime;
 };
 
@@ -349,7 +355,7 @@ struct BConvEpilogue {
     bool accumulate;
 };
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
-                  uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
+                  uint32_t max_osz, int split_kind, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
                   const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0,
                   const BConvEpilogue *epi = nullptr, size_t own_group_stride = 0);
 // converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)

@@ -64,11 +64,14 @@ __device__ __forceinline__ BConvWho bconv_who(const BConvLaunch &L) {
 }
 
 // bconv_mult (+) bconv_matmul (src/rns_bconv.cu:22-60,109-170; padded variant :455-485).
-// SPLIT: carry-free MAC -- inputs and matrix entries are cut into 30-bit halves, the four partial
-// products (< 2^60 each, <= 16 of them) accumulate in plain 64-bit registers with one
-// v_mad_u64_u32 each and are recombined once per output; valid for primes <= 60 bits, isz <= 16.
-template <int ISZ_PAD, bool SCALE_IN, bool SPLIT>
+// SPLIT: carry-free MAC -- inputs are cut at bit SY and matrix entries at bit SM, the four partial
+// products accumulate in plain 64-bit registers with one v_mad_u64_u32 each and are recombined once per
+// output.  (SY, SM) = (30, 30): primes <= 60 bits, isz <= 16 (products < 2^60, 16 of them).  (30, 31) / (31, 30): isz <= 32,
+// residues up to 60 bits on one side and up to 62 on the other (products < 2^61, recombined every 8 terms) -- the Q -> Bsk,
+// Q -> R and back conversions of the BFV multiply, whose auxiliary primes are 61 bits wide (BConv::split_kind).
+template <int ISZ_PAD, bool SCALE_IN, bool SPLIT, int SY = 30, int SM = 30>
 __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) {
+    constexpr int ROWPAD = ISZ_PAD > kBcRowPad ? 32 : kBcRowPad;
     const BConvWho who = bconv_who(L);
     const BConvDev &d = L.convs[who.ci * L.conv_step];
     const uint32_t coeff = blockIdx.x * kBcThreads + threadIdx.x;
@@ -84,15 +87,16 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     // out_per_block x 16 entries of two dwords, read back as broadcast ds_read_b64) and the prime's constants and
     // destination limb.  (r02: the loop used to fetch oprime[j] and then mod[oprime[j]] from global memory for every
     // output -- two dependent vector loads per iteration, which made the kernel latency-bound at 2.3x its VALU time.)
-    __shared__ uint2 s_rows[kBcMaxOutPerBlock * kBcRowPad];
+    __shared__ uint2 s_rows[kBcMaxOutPerBlock * ROWPAD];
     __shared__ u64 s_p[kBcMaxOutPerBlock], s_c0[kBcMaxOutPerBlock], s_c1[kBcMaxOutPerBlock];
     __shared__ uint32_t s_jo[kBcMaxOutPerBlock];
     __shared__ u64x2 s_e[kBcMaxOutPerBlock];
     if (SPLIT) {
-        const uint32_t limit = osz * kBcRowPad;
-        for (uint32_t e = threadIdx.x; e < L.out_per_block * kBcRowPad; e += kBcThreads) {
-            const uint32_t base = j0 * kBcRowPad + e;
-            s_rows[e] = base < limit ? reinterpret_cast<const uint2 *>(d.mat30)[base] : uint2{0u, 0u};
+        // the converter's own row pitch may be smaller than this instantiation's (a short last digit next to full ones)
+        const uint32_t pitch = d.row_pad;
+        for (uint32_t e = threadIdx.x; e < L.out_per_block * ROWPAD; e += kBcThreads) {
+            const uint32_t j = j0 + e / ROWPAD, i = e % ROWPAD;
+            s_rows[e] = (j < osz && i < pitch) ? reinterpret_cast<const uint2 *>(d.mat30)[j * pitch + i] : uint2{0u, 0u};
         }
     }
     if (threadIdx.x < L.out_per_block && j0 + threadIdx.x < osz) {
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
             if (SCALE_IN) x = shoup(x, d.hat_inv[i], L.mod[d.iprime[i]].value);
             y[i] = x;
         }
-        ylo[i] = (u32)y[i] & 0x3fffffffu;
-        yhi[i] = (u32)(y[i] >> 30);
+        ylo[i] = (u32)y[i] & ((1u << SY) - 1);
+        yhi[i] = (u32)(y[i] >> SY);
     }
     if (d.copy_own && L.own && blockIdx.y == 0) {  // modup_copy_partQl_kernel rns_bconv.cu:522-528 (null own: the caller reads c2 itself)
         for (uint32_t i = 0; i < isz; i++)
@@ -128,30 +132,62 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     for (uint32_t e = 0; e < count; e++) {
         u64 lo, hi;
         if (SPLIT) {
-            // rows are zero-padded to kBcRowPad entries, and y[i] = 0 beyond isz: no per-term branch
-            const uint2 *row = s_rows + e * kBcRowPad;
-            u64 ll = 0, lh = 0, hl = 0, hh = 0;
+            // rows are zero-padded to ROWPAD entries, and y[i] = 0 beyond isz: no per-term branch
+            const uint2 *row = s_rows + e * ROWPAD;
+            if (SY == 30 && SM == 30) {
+                u64 ll = 0, lh = 0, hl = 0, hh = 0;
 #pragma unroll
-            for (int i = 0; i < ISZ_PAD; i++) {
-                const u32 y0 = ylo[i], y1 = yhi[i];
-                const uint2 mm = row[i];
-                const u32 m0 = mm.x, m1 = mm.y;
-                ll = (u64)y0 * m0 + ll;
-                lh = (u64)y0 * m1 + lh;
-                hl = (u64)y1 * m0 + hl;
-                hh = (u64)y1 * m1 + hh;
+                for (int i = 0; i < ISZ_PAD; i++) {
+                    const u32 y0 = ylo[i], y1 = yhi[i];
+                    const uint2 mm = row[i];
+                    const u32 m0 = mm.x, m1 = mm.y;
+                    ll = (u64)y0 * m0 + ll;
+                    lh = (u64)y0 * m1 + lh;
+                    hl = (u64)y1 * m0 + hl;
+                    hh = (u64)y1 * m1 + hh;
+                }
+                // value = ll + (lh + hl) * 2^30 + hh * 2^60   (mid < 2^65: keep its carry)
+                const u64 mid = lh + hl;
+                const u64 mid_c = mid < lh ? 1 : 0;
+                lo = ll;
+                hi = 0;
+                const u64 t1 = mid << 30;
+                lo += t1;
+                hi += (lo < t1) + (mid >> 34) + (mid_c << 30);
+                const u64 t2 = hh << 60;
+                lo += t2;
+                hi += (lo < t2) + (hh >> 4);
+            } else {
+                // halves of up to 30 / 31 bits: partial products below 2^61, so the four sums are folded into the 128-bit
+                // total every 8 terms: value += ll + lh * 2^SM + hl * 2^SY + hh * 2^(SY + SM)
+                lo = 0;
+                hi = 0;
+#pragma unroll
+                for (int base = 0; base < ISZ_PAD; base += 8) {
+                    u64 ll = 0, lh = 0, hl = 0, hh = 0;
+#pragma unroll
+                    for (int i = base; i < base + 8 && i < ISZ_PAD; i++) {
+                        const u32 y0 = ylo[i], y1 = yhi[i];
+                        const uint2 mm = row[i];
+                        const u32 m0 = mm.x, m1 = mm.y;
+                        ll = (u64)y0 * m0 + ll;
+                        lh = (u64)y0 * m1 + lh;
+                        hl = (u64)y1 * m0 + hl;
+                        hh = (u64)y1 * m1 + hh;
+                    }
+                    lo += ll;
+                    hi += lo < ll;
+                    u64 t = lh << SM;
+                    lo += t;
+                    hi += (lo < t) + (lh >> (64 - SM));
+                    t = hl << SY;
+                    lo += t;
+                    hi += (lo < t) + (hl >> (64 - SY));
+                    t = hh << (SY + SM);
+                    lo += t;
+                    hi += (lo < t) + (hh >> (64 - SY - SM));
+                }
             }
-            // value = ll + (lh + hl) * 2^30 + hh * 2^60   (mid < 2^65: keep its carry)
-            const u64 mid = lh + hl;
-            const u64 mid_c = mid < lh ? 1 : 0;
-            lo = ll;
-            hi = 0;
-            const u64 t1 = mid << 30;
-            lo += t1;
-            hi += (lo < t1) + (mid >> 34) + (mid_c << 30);
-            const u64 t2 = hh << 60;
-            lo += t2;
-            hi += (lo < t2) + (hh >> 4);
         } else {
             const u64 *row = d.mat + (size_t)(j0 + e) * isz;
             lo = 0;
@@ -209,9 +245,10 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
     }
 }
 
-// convs: device array; max_isz / max_osz over the converters used; split_ok: all primes <= 60 bits
+// convs: device array; max_isz / max_osz over the converters used; split_kind: BConv::split_kind of the converters (0: none;
+// a Tool passes its split_ok: 1 = every prime <= 60 bits)
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
-                         uint32_t max_osz, bool split_ok, u64 *dst, size_t dst_stride, const u64 *src,
+                         uint32_t max_osz, int split_kind, u64 *dst, size_t dst_stride, const u64 *src,
                          size_t src_stride, const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count,
                          size_t group_stride, const BConvEpilogue *epi, size_t own_group_stride) {
     BConvLaunch L{};
@@ -228,8 +265,25 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
     L.out_per_block = (max_osz + groups - 1) / groups;
     dim3 grid((unsigned)(c.n / kBcThreads), groups, batch);
     dim3 block(kBcThreads);
-    // the carry-free split accumulators hold at most 16 terms; wider bases take the 128-bit accumulate
-    const bool split = split_ok && max_isz <= 16 && bconv_split_on();
+    // the 30 / 30 split accumulators hold at most 16 terms; wider bases or wider primes take the 30 / 31 cuts or the 128-bit accumulate
+    if (split_kind >= 2 && max_isz <= 32 && bconv_split_on()) {
+#define PHA_BCW(P, SY, SM)                                                                                       \
+    do {                                                                                                         \
+        if (scale_in) hipLaunchKernelGGL((bconv_kernel<P, true, true, SY, SM>), grid, block, 0, s, L);            \
+        else hipLaunchKernelGGL((bconv_kernel<P, false, true, SY, SM>), grid, block, 0, s, L);                    \
+    } while (0)
+        if (split_kind == 2) {
+            if (max_isz <= 16) PHA_BCW(16, 30, 31);
+            else PHA_BCW(32, 30, 31);
+        } else {
+            if (max_isz <= 16) PHA_BCW(16, 31, 30);
+            else PHA_BCW(32, 31, 30);
+        }
+#undef PHA_BCW
+        check_launch();
+        return;
+    }
+    const bool split = split_kind == 1 && max_isz <= 16 && bconv_split_on();
 #define PHA_BC(P)                                                                                        \
     do {                                                                                                 \
         if (scale_in && split) hipLaunchKernelGGL((bconv_kernel<P, true, true>), grid, block, 0, s, L);   \
