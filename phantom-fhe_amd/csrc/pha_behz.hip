@@ -145,6 +145,38 @@ __global__ __launch_bounds__(256) void hps_fix_kernel(const HpsFixArgs k) {
     }
 }
 
+// sum_i x_i * tab[i] (i < count <= PAD) as a 128-bit number, carry-free: x_i arrives cut at bit SX (x0, x1), the uniform table
+// entries are cut at bit SM on the way, partial products stay below 2^61 (halves of at most 31 and 30 bits) and the four partial
+// sums are folded into the total every 8 terms -- four v_mad_u64_u32 per term instead of the nine of a 128-bit multiply-add.
+template <int PAD, int SX, int SM>
+__device__ __forceinline__ void split_dot(const u32 (&x0)[PAD], const u32 (&x1)[PAD], const u64 *tab, uint32_t count, u64 &lo, u64 &hi) {
+    static_assert(SX + SM == 61, "halves of 30 and 31 bits");
+#pragma unroll
+    for (int base = 0; base < PAD; base += 8) {
+        u64 ll = 0, lh = 0, hl = 0, hh = 0;
+#pragma unroll
+        for (int i = base; i < base + 8 && i < PAD; i++) {
+            const u64 m = i < (int)count ? tab[i] : 0;
+            const u32 m0 = (u32)m & ((1u << SM) - 1), m1 = (u32)(m >> SM);
+            ll = (u64)x0[i] * m0 + ll;
+            lh = (u64)x0[i] * m1 + lh;
+            hl = (u64)x1[i] * m0 + hl;
+            hh = (u64)x1[i] * m1 + hh;
+        }
+        lo += ll;
+        hi += lo < ll;
+        u64 t = lh << SM;
+        lo += t;
+        hi += (lo < t) + (lh >> (64 - SM));
+        t = hl << SX;
+        lo += t;
+        hi += (lo < t) + (hl >> (64 - SX));
+        t = hh << (SX + SM);
+        lo += t;
+        hi += (lo < t) + (hh >> (64 - SX - SM));
+    }
+}
+
 struct ScaleRoundArgs {
     u64 *dst;                // [R][N]
     const u64 *src;          // [Q + R][N] coefficient form
@@ -153,17 +185,26 @@ struct ScaleRoundArgs {
     const DModulus *mod;
     uint32_t size_q, size_r, aux0, n;
 };
-template <int QPAD>   // QPAD >= size_q: the Q residues of the coefficient stay in registers across the R limbs
+// QPAD >= size_q: the Q residues of the coefficient stay in registers across the R limbs.  SPLIT: Q primes <= 60 bits and R
+// primes <= 62: the carry-free dot product (residues cut at 30 bits, table entries at 31)
+template <int QPAD, bool SPLIT>
 __global__ __launch_bounds__(256) void hps_scale_round_kernel(const ScaleRoundArgs k) {
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
-    u64 x[QPAD];
+    u64 x[SPLIT ? 1 : QPAD];
+    u32 x0[SPLIT ? QPAD : 1], x1[SPLIT ? QPAD : 1];
     double nu = 0.5;
 #pragma unroll
     for (int i = 0; i < QPAD; i++) {
-        x[i] = 0;
+        u64 v = 0;
         if (i < (int)k.size_q) {
-            x[i] = k.src[(size_t)i * k.n + coeff];
-            nu = __builtin_fma((double)x[i], k.frac[i], nu);
+            v = k.src[(size_t)i * k.n + coeff];
+            nu = __builtin_fma((double)v, k.frac[i], nu);
+        }
+        if (SPLIT) {
+            x0[i] = (u32)v & 0x3fffffffu;
+            x1[i] = (u32)(v >> 30);
+        } else {
+            x[i] = v;
         }
     }
     u64 alpha = (u64)nu;
@@ -171,9 +212,13 @@ __global__ __launch_bounds__(256) void hps_scale_round_kernel(const ScaleRoundAr
         const DModulus m = k.mod[k.aux0 + j];
         const u64 *tab = k.tab + (size_t)j * (k.size_q + 1);
         u64 lo = 0, hi = 0;
+        if constexpr (SPLIT) {
+            split_dot<QPAD, 30, 31>(x0, x1, tab, k.size_q, lo, hi);
+        } else {
 #pragma unroll
-        for (int i = 0; i < QPAD; i++)
-            if (i < (int)k.size_q) mac128(x[i], tab[i], lo, hi);
+            for (int i = 0; i < QPAD; i++)
+                if (i < (int)k.size_q) mac128(x[i], tab[i], lo, hi);
+        }
         mac128(k.src[(size_t)(k.size_q + j) * k.n + coeff], tab[k.size_q], lo, hi);
         const u64 v = barrett128(lo, hi, m);
         alpha = barrett64(alpha, m.value, m.ratio1);   // reduced IN PLACE across the R limbs, as rns.cu:1733 does
@@ -207,19 +252,28 @@ struct ScaleRoundQArgs {
     const DModulus *mod;
     uint32_t size_q, size_r, n;
 };
-template <int RPAD>   // RPAD >= size_r: the Rl residues of the coefficient stay in registers across the Q limbs (0 = re-read)
+// RPAD >= size_r: the Rl residues of the coefficient stay in registers across the Q limbs (0 = re-read).  SPLIT (RPAD > 0): R
+// primes <= 62 bits and Q primes <= 60: the carry-free dot product (residues cut at 31 bits, table entries at 30)
+template <int RPAD, bool SPLIT>
 __global__ __launch_bounds__(256) void hps_scale_round_q_kernel(const ScaleRoundQArgs k) {
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
     const u64 *src_r = k.src + (size_t)k.size_q * k.n + coeff;
-    u64 x[RPAD ? RPAD : 1];
+    u64 x[RPAD && !SPLIT ? RPAD : 1];
+    u32 x0[SPLIT ? RPAD : 1], x1[SPLIT ? RPAD : 1];
     double nu = 0.5;
     if (RPAD) {
 #pragma unroll
         for (int j = 0; j < RPAD; j++) {
-            x[j] = 0;
+            u64 v = 0;
             if (j < (int)k.size_r) {
-                x[j] = src_r[(size_t)j * k.n];
-                nu = __builtin_fma((double)x[j], k.frac[j], nu);
+                v = src_r[(size_t)j * k.n];
+                nu = __builtin_fma((double)v, k.frac[j], nu);
+            }
+            if (SPLIT) {
+                x0[j] = (u32)v & 0x7fffffffu;
+                x1[j] = (u32)(v >> 31);
+            } else {
+                x[j] = v;
             }
         }
     } else {
@@ -230,7 +284,9 @@ __global__ __launch_bounds__(256) void hps_scale_round_q_kernel(const ScaleRound
         const DModulus m = k.mod[i];
         const u64 *tab = k.tab + (size_t)i * (k.size_r + 1);
         u64 lo = 0, hi = 0;
-        if (RPAD) {
+        if constexpr (SPLIT) {
+            split_dot<RPAD, 31, 30>(x0, x1, tab, k.size_r, lo, hi);
+        } else if (RPAD) {
 #pragma unroll
             for (int j = 0; j < RPAD; j++)
                 if (j < (int)k.size_r) mac128(x[j], tab[j], lo, hi);
@@ -242,6 +298,25 @@ __global__ __launch_bounds__(256) void hps_scale_round_q_kernel(const ScaleRound
         alpha = barrett64(alpha, m.value, m.ratio1);
         k.dst[(size_t)i * k.n + coeff] = add_mod(v, alpha, m.value);
     }
+}
+
+static void launch_scale_round(Context &c, const ScaleRoundArgs &ka, hipStream_t s) {
+    // the carry-free dot product needs the residues (Q primes) below 2^60 and the table entries (R primes) below 2^62
+    bool split = true;
+    for (uint32_t i = 0; i < ka.size_q; i++) split = split && !(c.primes[i] >> 60);
+    for (uint32_t j = 0; j < ka.size_r; j++) split = split && !(c.primes[ka.aux0 + j] >> 62);
+    const dim3 grid(ka.n / 256), block(256);
+#define PHA_SR(P)                                                                                    \
+    do {                                                                                             \
+        if (split) hipLaunchKernelGGL((hps_scale_round_kernel<P, true>), grid, block, 0, s, ka);      \
+        else hipLaunchKernelGGL((hps_scale_round_kernel<P, false>), grid, block, 0, s, ka);           \
+    } while (0)
+    if (ka.size_q <= 8) PHA_SR(8);
+    else if (ka.size_q <= 16) PHA_SR(16);
+    else if (ka.size_q <= 32) PHA_SR(32);
+    else hipLaunchKernelGGL(hps_scale_round_wide_kernel, grid, block, 0, s, ka);
+#undef PHA_SR
+    check_launch();
 }
 
 void launch_bconv_phase1(Context &c, const BConv &conv, u64 *dst, const u64 *src, hipStream_t s);
@@ -325,11 +400,7 @@ extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, cons
     for (uint32_t p = 0; p < 3; p++) {
         // scale by t/Q and round into base R, then R -> Q (evaluate.cu:800-808)
         ScaleRoundArgs ka{tmp, x1 + p * qrn, h.frac.p, h.div_mod_r.p, c.d_mod.p, sq, sr, h.aux0, n};
-        if (sq <= 8) hipLaunchKernelGGL(hps_scale_round_kernel<8>, dim3(n / 256), dim3(256), 0, s, ka);
-        else if (sq <= 16) hipLaunchKernelGGL(hps_scale_round_kernel<16>, dim3(n / 256), dim3(256), 0, s, ka);
-        else if (sq <= 32) hipLaunchKernelGGL(hps_scale_round_kernel<32>, dim3(n / 256), dim3(256), 0, s, ka);
-        else hipLaunchKernelGGL(hps_scale_round_wide_kernel, dim3(n / 256), dim3(256), 0, s, ka);
-        check_launch();
+        launch_scale_round(c, ka, s);
         bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, dst + p * qn, tmp, y, s);
     }
     PHA_API_END
@@ -353,10 +424,21 @@ static void launch_scale_round_q(Context &c, u64 *dst, const u64 *src, const dou
                                  uint32_t extra, hipStream_t s) {
     const uint32_t n = (uint32_t)c.n;
     ScaleRoundQArgs ka{dst, src, frac, tab, c.d_mod.p, size_ql, extra, n};
-    if (extra <= 8) hipLaunchKernelGGL(hps_scale_round_q_kernel<8>, dim3(n / 256), dim3(256), 0, s, ka);
-    else if (extra <= 16) hipLaunchKernelGGL(hps_scale_round_q_kernel<16>, dim3(n / 256), dim3(256), 0, s, ka);
-    else if (extra <= 32) hipLaunchKernelGGL(hps_scale_round_q_kernel<32>, dim3(n / 256), dim3(256), 0, s, ka);
-    else hipLaunchKernelGGL(hps_scale_round_q_kernel<0>, dim3(n / 256), dim3(256), 0, s, ka);
+    // the carry-free dot product needs the residues (primes size_ql .. size_ql + extra) below 2^62 and the table (Ql primes) below 2^60
+    bool split = true;
+    for (uint32_t i = 0; i < size_ql; i++) split = split && !(c.primes[i] >> 60);
+    for (uint32_t j = 0; j < extra; j++) split = split && !(c.primes[size_ql + j] >> 62);
+    const dim3 grid(n / 256), block(256);
+#define PHA_SRQ(P)                                                                                     \
+    do {                                                                                               \
+        if (split) hipLaunchKernelGGL((hps_scale_round_q_kernel<P, true>), grid, block, 0, s, ka);      \
+        else hipLaunchKernelGGL((hps_scale_round_q_kernel<P, false>), grid, block, 0, s, ka);           \
+    } while (0)
+    if (extra <= 8) PHA_SRQ(8);
+    else if (extra <= 16) PHA_SRQ(16);
+    else if (extra <= 32) PHA_SRQ(32);
+    else hipLaunchKernelGGL((hps_scale_round_q_kernel<0, false>), grid, block, 0, s, ka);
+#undef PHA_SRQ
     check_launch();
 }
 static void launch_expand(Context &c, HpsQ &h, u64 *dst, const u64 *src, hipStream_t s) {
