@@ -184,12 +184,15 @@ struct ScaleRoundArgs {
     const u64 *tab;          // [R][Q + 1]
     const DModulus *mod;
     uint32_t size_q, size_r, aux0, n;
+    size_t dst_stride = 0, src_stride = 0;   // polynomial blockIdx.y
 };
 // QPAD >= size_q: the Q residues of the coefficient stay in registers across the R limbs.  SPLIT: Q primes <= 60 bits and R
 // primes <= 62: the carry-free dot product (residues cut at 30 bits, table entries at 31)
 template <int QPAD, bool SPLIT>
-__global__ __launch_bounds__(256) void hps_scale_round_kernel(const ScaleRoundArgs k) {
+__global__ __launch_bounds__(256) void hps_scale_round_kernel(ScaleRoundArgs k) {
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    k.src += blockIdx.y * k.src_stride;
+    k.dst += blockIdx.y * k.dst_stride;
     u64 x[SPLIT ? 1 : QPAD];
     u32 x0[SPLIT ? QPAD : 1], x1[SPLIT ? QPAD : 1];
     double nu = 0.5;
@@ -225,8 +228,10 @@ __global__ __launch_bounds__(256) void hps_scale_round_kernel(const ScaleRoundAr
         k.dst[(size_t)j * k.n + coeff] = add_mod(v, alpha, m.value);
     }
 }
-__global__ __launch_bounds__(256) void hps_scale_round_wide_kernel(const ScaleRoundArgs k) {  // size_q > 32
+__global__ __launch_bounds__(256) void hps_scale_round_wide_kernel(ScaleRoundArgs k) {  // size_q > 32
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    k.src += blockIdx.y * k.src_stride;
+    k.dst += blockIdx.y * k.dst_stride;
     double nu = 0.5;
     for (uint32_t i = 0; i < k.size_q; i++) nu = __builtin_fma((double)k.src[(size_t)i * k.n + coeff], k.frac[i], nu);
     u64 alpha = (u64)nu;
@@ -251,12 +256,15 @@ struct ScaleRoundQArgs {
     const u64 *tab;          // [Q][Rl + 1]
     const DModulus *mod;
     uint32_t size_q, size_r, n;
+    size_t dst_stride = 0, src_stride = 0;   // polynomial blockIdx.y
 };
 // RPAD >= size_r: the Rl residues of the coefficient stay in registers across the Q limbs (0 = re-read).  SPLIT (RPAD > 0): R
 // primes <= 62 bits and Q primes <= 60: the carry-free dot product (residues cut at 31 bits, table entries at 30)
 template <int RPAD, bool SPLIT>
-__global__ __launch_bounds__(256) void hps_scale_round_q_kernel(const ScaleRoundQArgs k) {
+__global__ __launch_bounds__(256) void hps_scale_round_q_kernel(ScaleRoundQArgs k) {
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    k.src += blockIdx.y * k.src_stride;
+    k.dst += blockIdx.y * k.dst_stride;
     const u64 *src_r = k.src + (size_t)k.size_q * k.n + coeff;
     u64 x[RPAD && !SPLIT ? RPAD : 1];
     u32 x0[SPLIT ? RPAD : 1], x1[SPLIT ? RPAD : 1];
@@ -300,12 +308,12 @@ __global__ __launch_bounds__(256) void hps_scale_round_q_kernel(const ScaleRound
     }
 }
 
-static void launch_scale_round(Context &c, const ScaleRoundArgs &ka, hipStream_t s) {
+static void launch_scale_round(Context &c, const ScaleRoundArgs &ka, hipStream_t s, uint32_t batch = 1) {
     // the carry-free dot product needs the residues (Q primes) below 2^60 and the table entries (R primes) below 2^62
     bool split = true;
     for (uint32_t i = 0; i < ka.size_q; i++) split = split && !(c.primes[i] >> 60);
     for (uint32_t j = 0; j < ka.size_r; j++) split = split && !(c.primes[ka.aux0 + j] >> 62);
-    const dim3 grid(ka.n / 256), block(256);
+    const dim3 grid(ka.n / 256, batch), block(256);
 #define PHA_SR(P)                                                                                    \
     do {                                                                                             \
         if (split) hipLaunchKernelGGL((hps_scale_round_kernel<P, true>), grid, block, 0, s, ka);      \
@@ -321,10 +329,22 @@ static void launch_scale_round(Context &c, const ScaleRoundArgs &ka, hipStream_t
 
 void launch_bconv_phase1(Context &c, const BConv &conv, u64 *dst, const u64 *src, hipStream_t s);
 
-// DBaseConverter::bConv_HPS on one polynomial: dst [osz][N] <- src [isz][N]
+// DBaseConverter::bConv_HPS on `batch` polynomials (strides in words): dst [osz][N] <- src [isz][N].  Up to 32 inputs the
+// correction term rides in the conversion kernel (one launch for all the polynomials); wider bases: conversion, phase 1 and
+// fix-up per polynomial, y [isz][N] scratch.
 static void bconv_hps(Context &c, const BConv &conv, const BConvDev *d_conv, const double *inv, const u64 *alpha_mod,
-                      u64 *dst, const u64 *src, u64 *y, hipStream_t s) {
+                      u64 *dst, const u64 *src, u64 *y, hipStream_t s, uint32_t batch = 1, size_t dst_stride = 0,
+                      size_t src_stride = 0) {
     const uint32_t n = (uint32_t)c.n;
+    if (conv.isz <= 32) {
+        BConvEpilogue e{};
+        e.hps_inv = inv;
+        e.hps_alpha = alpha_mod;
+        launch_bconv(c, d_conv, 0, batch, conv.isz, conv.osz, conv.split_kind, dst, dst_stride, src, src_stride, nullptr, true, s, 0,
+                     0, &e);
+        return;
+    }
+    for (uint32_t b = 1; b < batch; b++) bconv_hps(c, conv, d_conv, inv, alpha_mod, dst + b * dst_stride, src + b * src_stride, y, s);
     launch_bconv(c, d_conv, 0, 1, conv.isz, conv.osz, conv.split_kind, dst, 0, src, 0, nullptr, true, s);
     launch_bconv_phase1(c, conv, y, src, s);   // the fix-up needs the phase-1 values themselves
     HpsFixArgs fa{dst, y, inv, alpha_mod, c.d_mod.p, conv.d_oprime.p, conv.isz, conv.osz, n};
@@ -373,17 +393,16 @@ extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, cons
     const uint32_t n = (uint32_t)c.n, sq = h.size_q, sr = h.size_r, sqr = sq + sr;
     const size_t qn = (size_t)sq * n, rn = (size_t)sr * n, qrn = (size_t)sqr * n;
     const bool square = ct1 == ct2;
-    // scratch: x1 [3][Q+R] | x2 [2][Q+R] | y [R] | tmp [R]
-    u64 *base = c.scratch(stream, 5 * qrn + 2 * rn);
-    u64 *x1 = base, *x2 = x1 + 3 * qrn, *y = x2 + 2 * qrn, *tmp = y + rn;
+    // scratch: x1 [3][Q+R] | x2 [2][Q+R] | y [max(Q, R)] | tmp [3][R]
+    u64 *base = c.scratch(stream, 5 * qrn + std::max(qn, rn) + 3 * rn);
+    u64 *x1 = base, *x2 = x1 + 3 * qrn, *y = x2 + 2 * qrn, *tmp = y + std::max(qn, rn);
     // lift every input polynomial from base Q to Q || R (evaluate.cu:702-716, :733-748)
     for (int w = 0; w < (square ? 1 : 2); w++) {
         const u64 *ct = w ? ct2 : ct1;
         u64 *x = w ? x2 : x1;
-        for (uint32_t p = 0; p < 2; p++) {
+        for (uint32_t p = 0; p < 2; p++)
             PHA_HIP(hipMemcpyAsync(x + p * qrn, ct + p * qn, qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
-            bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x + p * qrn + qn, ct + p * qn, y, s);
-        }
+        bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x + qn, ct, y, s, 2, qrn, qn);   // both polynomials
         NttExtra xf;
         xf.batch = 2;
         xf.poly_stride = qrn;
@@ -397,12 +416,10 @@ extern "C" int pha_bfv_multiply_hps(pha_context_t ctx, const uint64_t *ct1, cons
     xi.batch = 3;
     xi.poly_stride = qrn;
     ntt_inverse(c, x1, x1, x1, qr_sel(sq, sr, h.aux0), EPI_INV_CANON, xi, s);
-    for (uint32_t p = 0; p < 3; p++) {
-        // scale by t/Q and round into base R, then R -> Q (evaluate.cu:800-808)
-        ScaleRoundArgs ka{tmp, x1 + p * qrn, h.frac.p, h.div_mod_r.p, c.d_mod.p, sq, sr, h.aux0, n};
-        launch_scale_round(c, ka, s);
-        bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, dst + p * qn, tmp, y, s);
-    }
+    // scale by t/Q and round into base R, then R -> Q (evaluate.cu:800-808): the three polynomials in one launch each
+    ScaleRoundArgs ka{tmp, x1, h.frac.p, h.div_mod_r.p, c.d_mod.p, sq, sr, h.aux0, n, rn, qrn};
+    launch_scale_round(c, ka, s, 3);
+    bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, dst, tmp, y, s, 3, qn, rn);
     PHA_API_END
 }
 
@@ -421,14 +438,14 @@ __global__ __launch_bounds__(256) void hps_expand_kernel(const ExpandArgs k) {
     k.dst[id] = i < k.size_ql ? shoup(k.src[id], u64x2{k.c[i], k.c_shoup[i]}, k.mod[i].value) : 0;
 }
 static void launch_scale_round_q(Context &c, u64 *dst, const u64 *src, const double *frac, const u64 *tab, uint32_t size_ql,
-                                 uint32_t extra, hipStream_t s) {
+                                 uint32_t extra, hipStream_t s, uint32_t batch = 1, size_t dst_stride = 0, size_t src_stride = 0) {
     const uint32_t n = (uint32_t)c.n;
-    ScaleRoundQArgs ka{dst, src, frac, tab, c.d_mod.p, size_ql, extra, n};
+    ScaleRoundQArgs ka{dst, src, frac, tab, c.d_mod.p, size_ql, extra, n, dst_stride, src_stride};
     // the carry-free dot product needs the residues (primes size_ql .. size_ql + extra) below 2^62 and the table (Ql primes) below 2^60
     bool split = true;
     for (uint32_t i = 0; i < size_ql; i++) split = split && !(c.primes[i] >> 60);
     for (uint32_t j = 0; j < extra; j++) split = split && !(c.primes[size_ql + j] >> 62);
-    const dim3 grid(n / 256), block(256);
+    const dim3 grid(n / 256, batch), block(256);
 #define PHA_SRQ(P)                                                                                     \
     do {                                                                                               \
         if (split) hipLaunchKernelGGL((hps_scale_round_q_kernel<P, true>), grid, block, 0, s, ka);      \
@@ -462,14 +479,11 @@ static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *c
     for (uint32_t p = 0; p < 2; p++) {   // first operand: (scaled down to Ql when levels are dropped, :709-710) exact lift to Ql || Rl
         if (h.drop) launch_scale_round_q(c, x1 + p * qrn, ct1 + p * qfn, h.frac_drop.p, h.div_mod_q_drop.p, sq, h.drop, s);
         else PHA_HIP(hipMemcpyAsync(x1 + p * qrn, ct1 + p * qfn, qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
-        bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x1 + p * qrn + qn, x1 + p * qrn, y, s);
     }
-    if (!square) {
-        for (uint32_t p = 0; p < 2; p++) {   // second operand: Q -> Rl by bConv_BEHZ_var1, then Rl -> Ql exactly (:745-751)
-            u64 *xr = x2 + p * qrn + qn;
-            launch_bconv(c, h.d_q_to_r_var1.p, 0, 1, h.q_to_r_var1.isz, sr, h.q_to_r_var1.split_kind, xr, 0, ct2 + p * qfn, 0, nullptr, true, s);
-            bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, x2 + p * qrn, xr, y, s);
-        }
+    bconv_hps(c, h.q_to_r, h.d_q_to_r.p, h.q_inv.p, h.alpha_q_mod_r.p, x1 + qn, x1, y, s, 2, qrn, qrn);
+    if (!square) {   // second operand: Q -> Rl by bConv_BEHZ_var1, then Rl -> Ql exactly (:745-751); both polynomials per launch
+        launch_bconv(c, h.d_q_to_r_var1.p, 0, 2, h.q_to_r_var1.isz, sr, h.q_to_r_var1.split_kind, x2 + qn, qrn, ct2, qfn, nullptr, true, s);
+        bconv_hps(c, h.r_to_q, h.d_r_to_q.p, h.r_inv.p, h.alpha_r_mod_q.p, x2, x2 + qn, y, s, 2, qrn, qrn);
     }
     NttExtra xf;
     xf.batch = 2;
@@ -483,10 +497,10 @@ static void hps_overq_multiply(Context &c, HpsQ &h, const u64 *ct1, const u64 *c
     xi.batch = 3;
     xi.poly_stride = qrn;
     ntt_inverse(c, x1, x1, x1, qr_sel(sq, sr, h.aux0), EPI_INV_CANON, xi, s);
-    for (uint32_t p = 0; p < 3; p++) {   // scale by t / Rl and round straight into base Ql (:790-792), expand to Q (:794-795)
-        launch_scale_round_q(c, dst + p * qfn, x1 + p * qrn, h.frac.p, h.div_mod_q.p, sq, sr, s);
+    // scale by t / Rl and round straight into base Ql (:790-792; the three polynomials in one launch), expand to Q (:794-795)
+    launch_scale_round_q(c, dst, x1, h.frac.p, h.div_mod_q.p, sq, sr, s, 3, qfn, qrn);
+    for (uint32_t p = 0; p < 3; p++)
         if (h.drop && !(keep_c2_low && p == 2)) launch_expand(c, h, dst + p * qfn, dst + p * qfn, s);   // (:957-958: c2 stays at level l)
-    }
 }
 
 extern "C" int pha_bfv_multiply_hps_overq(pha_context_t ctx, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst,

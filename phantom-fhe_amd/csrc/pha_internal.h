@@ -348,11 +348,15 @@ bool modup_ntt_inner_prod(Context &c, u64 *digits, const LimbSel &sel, const Ntt
 // shared launchers (pha_rns.hip / pha_poly.hip)
 // optional epilogue of a conversion: store dst_j (+)= (cx_j - converted_j) * cst_j instead of converted_j (BFV mod-down)
 struct BConvEpilogue {
-    const u64 *cx;
+    const u64 *cx;            // BFV mod-down: dst (+)= (cx - converted) * cst; null = off
     u64 *dst;
     const u64x2 *cst;
     size_t cx_stride, dst_stride;
     bool accumulate;
+    // bConv_HPS (rns_bconv.cu:248-372): converted_j -= alpha_mod[v][j], v = round(sum_i y_i / q_i) from the scaled inputs the
+    // kernel already holds; null = off
+    const double *hps_inv = nullptr;      // [isz] 1 / q_i
+    const u64 *hps_alpha = nullptr;       // [isz + 1][osz]
 };
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                   uint32_t max_osz, int split_kind, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,

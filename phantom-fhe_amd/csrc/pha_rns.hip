@@ -54,6 +54,9 @@ struct BConvLaunch {
     const u64x2 *epi_cst;        // [limb] constant with its Shoup quotient (P^-1 mod q_j)
     size_t epi_cx_stride, epi_dst_stride;
     uint32_t epi_acc;
+    // optional bConv_HPS correction (BConvEpilogue::hps_inv / hps_alpha)
+    const double *hps_inv;
+    const u64 *hps_alpha;
 };
 struct BConvWho {
     uint32_t ci, grp;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     if (j0 >= osz) return;  // (after the barrier) nothing to produce for this group
     u64 y[ISZ_PAD];
     u32 ylo[ISZ_PAD], yhi[ISZ_PAD];  // SPLIT: 30-bit halves, cut once per input
+    double hps_frac = 0.0;           // bConv_HPS: sum_i y_i / q_i in the reference's order (hps_fix_kernel)
 #pragma unroll
     for (int i = 0; i < ISZ_PAD; i++) {
         y[i] = 0;
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
             u64 x = src[(size_t)i * n + coeff];
             if (SCALE_IN) x = shoup(x, d.hat_inv[i], L.mod[d.iprime[i]].value);
             y[i] = x;
+            if (L.hps_inv) hps_frac = __builtin_fma((double)x, L.hps_inv[i], hps_frac);
         }
         ylo[i] = (u32)y[i] & ((1u << SY) - 1);
         yhi[i] = (u32)(y[i] >> SY);
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
             dst[(size_t)(d.src_limb + i) * n + coeff] = own[(size_t)(d.src_limb + i) * n + coeff];
     }
     const uint32_t count = j1 - j0;
+    const u64 *hps_row = L.hps_inv ? L.hps_alpha + (size_t)llround(hps_frac) * osz + j0 : nullptr;
     for (uint32_t e = 0; e < count; e++) {
         u64 lo, hi;
         if (SPLIT) {
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         u64 r;
         if (mont) r = mont_redc128(lo, hi, p, s_c0[e]);
         else r = barrett128(lo, hi, DModulus{p, s_c0[e], s_c1[e]});
+        if (hps_row) r = sub_mod(r, hps_row[e], p);
         const size_t id = (size_t)s_jo[e] * n + coeff;
         if (L.epi_cx) {
             const u64 t = sub_mod(L.epi_cx[(size_t)blockIdx.z * L.epi_cx_stride + id], r, p);
@@ -253,9 +260,10 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
                          size_t group_stride, const BConvEpilogue *epi, size_t own_group_stride) {
     BConvLaunch L{};
     if (epi) {
-        if (max_isz > 32) throw std::logic_error("the fused mod-down epilogue needs the register-resident converter");
+        if (max_isz > 32) throw std::logic_error("the fused conversion epilogues need the register-resident converter");
         L.epi_cx = epi->cx; L.epi_dst = epi->dst; L.epi_cst = epi->cst;
         L.epi_cx_stride = epi->cx_stride; L.epi_dst_stride = epi->dst_stride; L.epi_acc = epi->accumulate ? 1 : 0;
+        L.hps_inv = epi->hps_inv; L.hps_alpha = epi->hps_alpha;
     }
     L.conv_count = conv_count; L.src_group_stride = group_stride; L.own_group_stride = own_group_stride ? own_group_stride : group_stride;
     L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;
