@@ -43,12 +43,14 @@ struct FloorArgs {
     const DModulus *mod;
     const u64x2 *scale;
     uint32_t aux0, n;
+    size_t dst_stride = 0, x_stride = 0, conv_stride = 0;   // polynomial blockIdx.z
 };
 __global__ __launch_bounds__(256) void fast_floor_kernel(const FloorArgs k) {
     const uint32_t j = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
     const u64 p = k.mod[k.aux0 + j].value;
-    const size_t id = (size_t)j * k.n + coeff;
-    k.dst[id] = shoup(k.x_bsk[id] + (p - k.conv[id]), k.scale[j], p);   // the sum is not reduced first (:1376-1378)
+    const size_t id = (size_t)j * k.n + coeff, z = blockIdx.z;
+    // the sum is not reduced first (:1376-1378)
+    k.dst[z * k.dst_stride + id] = shoup(k.x_bsk[z * k.x_stride + id] + (p - k.conv[z * k.conv_stride + id]), k.scale[j], p);
 }
 
 // alpha_sk (bconv_fuse_sub_mul_single_unroll2_kernel rns.cu:1421-1464) and the Shenoy-Kumaresan correction
@@ -62,9 +64,13 @@ struct SkArgs {
     u64x2 inv_prod_b_mod_msk;
     u64 m_sk;
     uint32_t n;
+    size_t out_stride = 0, conv_stride = 0, x_stride = 0;   // polynomial blockIdx.z
 };
-__global__ __launch_bounds__(256) void sk_fix_kernel(const SkArgs k) {
+__global__ __launch_bounds__(256) void sk_fix_kernel(SkArgs k) {
     const uint32_t i = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
+    k.out_q += blockIdx.z * k.out_stride;
+    k.conv_msk += blockIdx.z * k.conv_stride;
+    k.x_msk += blockIdx.z * k.x_stride;
     const DModulus m = k.mod[i];
     u64 a = shoup(k.conv_msk[coeff] + (k.m_sk - k.x_msk[coeff]), k.inv_prod_b_mod_msk, k.m_sk);
     u64 pb = k.prod_b_mod_q[i];
@@ -608,7 +614,7 @@ extern "C" int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, con
     const size_t qn = (size_t)sq * n, bn = (size_t)sk * n;
     const bool square = ct1 == ct2;
     // scratch: q1 [3][Q] | b1 [3][Bsk] | q2 [2][Q] | b2 [2][Bsk] | tmp (y [2][Q] + lift [2][Bsk+1], later conv / floor)
-    const size_t tmp_words = 2 * qn + 2 * (bn + n) + 3 * bn;
+    const size_t tmp_words = std::max(2 * qn + 2 * (bn + n), 6 * bn + 3 * (size_t)n);
     u64 *base = c.scratch(stream, 3 * qn + 3 * bn + 2 * qn + 2 * bn + tmp_words);
     u64 *q1 = base, *b1 = q1 + 3 * qn, *q2 = b1 + 3 * bn, *b2 = q2 + 2 * qn, *tmp = b2 + 2 * bn;
     behz_lift(c, b, ct1, q1, b1, tmp, s);
@@ -629,21 +635,19 @@ extern "C" int pha_bfv_multiply_behz(pha_context_t ctx, const uint64_t *ct1, con
     xb.scale = b.t_bsk.p;
     xb.scale_shoup = b.t_bsk_shoup.p;
     ntt_inverse(c, b1, b1, b1, aux_sel(sk, b.aux0), EPI_INV_SCALE, xb, s);
-    u64 *conv = tmp, *fl = tmp + 3 * bn;  // conv [3][Bsk][N] (re-used per polynomial), fl [Bsk][N]
-    for (uint32_t p = 0; p < 3; p++) {
-        u64 *xq_p = q1 + p * qn, *xb_p = b1 + p * bn, *out = dst + p * qn;
-        // step 7 fast_floor (rns.cu:1394-1419)
-        launch_bconv(c, b.d_q_to_bsk.p, 0, 1, sq, sk, b.q_to_bsk.split_kind, conv, 0, xq_p, 0, nullptr, true, s);
-        FloorArgs fa{fl, xb_p, conv, c.d_mod.p, b.inv_prod_q_mod_bsk.p, b.aux0, n};
-        hipLaunchKernelGGL(fast_floor_kernel, dim3(n / 256, sk), dim3(256), 0, s, fa);
-        check_launch();
-        // step 8 fastbconv_sk (rns.cu:1470-1510)
-        launch_bconv(c, b.d_b_to_msk.p, 0, 1, sb, 1, b.b_to_msk.split_kind, conv, 0, fl, 0, nullptr, true, s);   // conv[0..N) = B -> m_sk
-        launch_bconv(c, b.d_b_to_q.p, 0, 1, sb, sq, b.b_to_q.split_kind, out, 0, fl, 0, nullptr, true, s);
-        SkArgs ka{out, conv, fl + (size_t)sb * n, c.d_mod.p, b.prod_b_mod_q.p, b.inv_prod_b_mod_msk, b.m_sk, n};
-        hipLaunchKernelGGL(sk_fix_kernel, dim3(n / 256, sq), dim3(256), 0, s, ka);
-        check_launch();
-    }
+    // steps 7-8 for the three polynomials in one launch each
+    u64 *conv = tmp, *fl = tmp + 3 * bn, *msk = fl + 3 * bn;  // conv [3][Bsk][N], fl [3][Bsk][N], msk [3][N]
+    // step 7 fast_floor (rns.cu:1394-1419)
+    launch_bconv(c, b.d_q_to_bsk.p, 0, 3, sq, sk, b.q_to_bsk.split_kind, conv, bn, q1, qn, nullptr, true, s);
+    FloorArgs fa{fl, b1, conv, c.d_mod.p, b.inv_prod_q_mod_bsk.p, b.aux0, n, bn, bn, bn};
+    hipLaunchKernelGGL(fast_floor_kernel, dim3(n / 256, sk, 3), dim3(256), 0, s, fa);
+    check_launch();
+    // step 8 fastbconv_sk (rns.cu:1470-1510)
+    launch_bconv(c, b.d_b_to_msk.p, 0, 3, sb, 1, b.b_to_msk.split_kind, msk, n, fl, bn, nullptr, true, s);   // B -> m_sk
+    launch_bconv(c, b.d_b_to_q.p, 0, 3, sb, sq, b.b_to_q.split_kind, dst, qn, fl, bn, nullptr, true, s);
+    SkArgs ka{dst, msk, fl + (size_t)sb * n, c.d_mod.p, b.prod_b_mod_q.p, b.inv_prod_b_mod_msk, b.m_sk, n, qn, n, bn};
+    hipLaunchKernelGGL(sk_fix_kernel, dim3(n / 256, sq, 3), dim3(256), 0, s, ka);
+    check_launch();
     PHA_API_END
 }
 
