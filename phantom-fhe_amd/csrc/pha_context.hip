@@ -656,7 +656,7 @@ Behz &Context::behz() {
 // q-hat_i^-1 mod q_i and q-hat_i mod p_j for an (ibase -> obase) converter: src/host/rns.cu:282-337,438-457
 // upload converter constants: hat_inv [isz] (value, Shoup), mat [osz][isz]
 static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
-                         const std::vector<u64x2> &hat_inv, const std::vector<u64> &mat) {
+                         const std::vector<u64x2> &hat_inv, const std::vector<u64> &mat, uint32_t family_isz = 0) {
     b.isz = (uint32_t)ip.size();
     b.osz = (uint32_t)op.size();
     b.iprime = ip;
@@ -669,9 +669,10 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
     uint32_t sm = 30;         // the matrix entries are cut at this bit
     b.split_kind = 0;
     b.row_pad = kBcRowPad;
-    if (b.isz <= (uint32_t)kBcRowPad && by <= 60 && bm <= 60) b.split_kind = 1;
-    else if (b.isz <= 32 && by <= 60 && bm <= 62) { b.split_kind = 2; sm = 31; }
-    else if (b.isz <= 32 && by <= 62 && bm <= 60) { b.split_kind = 3; sm = 30; }
+    const uint32_t widest = std::max(b.isz, family_isz);   // converters launched together (mod-up digits) take one kind
+    if (widest <= (uint32_t)kBcRowPad && by <= 60 && bm <= 60) b.split_kind = 1;
+    else if (widest <= 32 && by <= 60 && bm <= 62) { b.split_kind = 2; sm = 31; }
+    else if (widest <= 32 && by <= 62 && bm <= 60) { b.split_kind = 3; sm = 30; }
     if (b.split_kind >= 2 && b.isz > (uint32_t)kBcRowPad) b.row_pad = 32;
     // Montgomery form for the split-accumulator kernel: rows hold qhat_i * 2^64 mod p_j, so that REDC of the accumulated
     // sum gives sum_i y_i * qhat_i mod p_j directly (valid for odd p_j; the BEHZ converter with m_tilde = 2^32 keeps Barrett)
@@ -711,7 +712,7 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
 // out_scale (optional, [osz]): row j of the matrix is multiplied by out_scale[j] mod p_j, i.e. the converter delivers
 // out_scale[j] * (converted value) mod p_j at no extra cost (pha_keyswitch_rescale: P^-1 mod q_j)
 void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
-                 const std::vector<u64> *out_scale) {
+                 const std::vector<u64> *out_scale, uint32_t family_isz) {
     const uint32_t isz = (uint32_t)ip.size(), osz = (uint32_t)op.size();
     std::vector<u64x2> hat_inv(isz);
     for (uint32_t i = 0; i < isz; i++) {
@@ -732,7 +733,7 @@ void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const st
             mat[(size_t)j * isz + i] = h;
         }
     }
-    upload_bconv(c, b, ip, op, hat_inv, mat);
+    upload_bconv(c, b, ip, op, hat_inv, mat, family_isz);
 }
 
 // bConv_BEHZ_var1 (src/rns_bconv.cu:231-246, constants src/host/rns.cu:469-496): the quotient-style conversion
@@ -818,7 +819,7 @@ Tool &Context::tool(uint32_t size_ql) {
                 if (j >= s && j < s + len) ip.push_back(t->qlp_prime[j]);
                 else op.push_back(t->qlp_prime[j]);
             }
-            build_bconv(*this, t->digit[b], ip, op);
+            build_bconv(*this, t->digit[b], ip, op, nullptr, t->alpha);
             std::vector<u64x2> hi(len);
             PHA_HIP(hipMemcpy(hi.data(), t->digit[b].hat_inv.p, len * sizeof(u64x2), hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < len; i++) { phi[s + i] = hi[i].x; phis[s + i] = hi[i].y; }
@@ -856,6 +857,12 @@ Tool &Context::tool(uint32_t size_ql) {
         t->split_ok = true;
         for (uint32_t i = 0; i < t->size_qlp; i++)
             if (primes[t->qlp_prime[i]] >> 60) t->split_ok = false;
+        // the carry-free form the conversion launches may use: the digits' common kind (1 = the 30 / 30 split of the headline
+        // sets; 2 / 3 = special bases of 17..32 primes or 61-bit primes, BConv::split_kind), 0 if they differ
+        t->modup_split = t->digit[0].split_kind;
+        for (uint32_t b = 1; b < t->beta; b++)
+            if (t->digit[b].split_kind != t->modup_split) t->modup_split = 0;
+        t->moddown_split = t->p_to_ql.split_kind;
     }
     if (plain_t) {
         // rns.cu:200-212 (q_last, q_last^-1 mod t), :270-284 (P, P^-1 mod t; P -> {t} converter row)

@@ -150,6 +150,7 @@ struct Tool {
     BConv p_to_ql_pinv;                            // the same with every output row pre-multiplied by P^-1 mod q_j
     DevBuf<BConvDev> d_digit_convs, d_p_to_ql_conv, d_p_to_ql_pinv_conv; // device descriptors used by the batched launches
     bool split_ok = false;                         // every prime <= 60 bits: carry-free split MAC is valid
+    int modup_split = 0, moddown_split = 0;        // BConv::split_kind of the digit converters (if common) and of P -> Ql
     DevBuf<u64> pinv, pinv_shoup;                  // bigPInv_mod_q (rns.cu:110-123)
     DevBuf<u64> inv_q_last, inv_q_last_shoup;      // rns.cu:66-80
     DevBuf<u64x2> inv_q_last2;                     // same, interleaved
@@ -364,7 +365,7 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
                   const BConvEpilogue *epi = nullptr, size_t own_group_stride = 0);
 // converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)
 void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
-                 const std::vector<u64> *out_scale = nullptr);
+                 const std::vector<u64> *out_scale = nullptr, uint32_t family_isz = 0);
 void build_bconv_var1(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op);
 void describe_conv(const BConv &b, DevBuf<BConvDev> &out);
 void launch_tensor(Context &c, const u64 *a, const u64 *b, u64 *r, size_t limbs, size_t mod_start, bool square,

@@ -1108,7 +1108,7 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         // (coefficient-form input: the conversion reads c2 itself, at its own stride; NTT form: the dense t_cks, and c2 only
         //  for the verbatim copy of the digit's own limbs)
         // (fused inner product, NTT-form input: the own limbs are read from c2 by the fused pass, no copy)
-        launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.split_ok, dst, (size_t)qlp * n,
+        launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.modup_split, dst, (size_t)qlp * n,
                      ntt_dom ? t_cks : cks, 0, (fused_ip && ntt_dom) ? nullptr : cks, !ntt_dom, s, batch > 1 ? t.beta : 0,
                      ntt_dom ? (size_t)ql * n : cks_stride, nullptr, cks_stride);
     }
@@ -1237,7 +1237,7 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         // register-resident converter (alpha <= 32); a wider P takes the conversion into delta and the element-wise kernel below
         BConvEpilogue e{cx, ct, t.pinv2.p, cx_stride, ct_stride, accumulate};
         bfv_epilogue_fused = scheme == PHA_SCHEME_BFV && t.alpha <= 32;
-        launch_bconv(c, t.d_p_to_ql_conv.p, 0, polys, t.alpha, ql, t.split_ok, delta, d_stride, cx, cx_stride,
+        launch_bconv(c, t.d_p_to_ql_conv.p, 0, polys, t.alpha, ql, t.moddown_split, delta, d_stride, cx, cx_stride,
                      nullptr, !prescaled, s, 0, 0, bfv_epilogue_fused ? &e : nullptr);
     }
     if (scheme == PHA_SCHEME_BGV) {
@@ -1387,7 +1387,7 @@ int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const ui
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
     // src is the bare [P][N] block: the converter's src_limb offset (Ql) must not be applied
-    launch_bconv(c, t.d_p_to_ql_conv.p, 0, 1, t.alpha, (uint32_t)size_Ql, t.split_ok, dst, 0,
+    launch_bconv(c, t.d_p_to_ql_conv.p, 0, 1, t.alpha, (uint32_t)size_Ql, t.moddown_split, dst, 0,
                  src - (size_t)size_Ql * c.n, 0, nullptr, true, as_stream(stream));
     PHA_API_END
 }

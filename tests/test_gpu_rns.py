@@ -78,6 +78,11 @@ KS_CASES = [
     ("c1_bfv4096", O.BGV, [2]),
     ("wide_p33", O.BFV, [6, 4]),         # alpha = 33 > 32: the generic converter, mod-down through the element-wise kernel
     ("wide_p33", O.CKKS, [6]),
+    ("wide_p20", O.CKKS, [24, 21]),      # 17..32 special primes: split_kind 2 with a 32-entry row pitch next to a short last digit
+    ("wide_p20", O.BFV, [24]),           # (+ the fused BFV mod-down epilogue on that kernel)
+    ("wide_p20", O.BGV, [20]),
+    ("p61_a2", O.CKKS, [6, 3]),          # 61-bit special primes: split_kind 2 (mod-up) and 3 (mod-down)
+    ("p61_a2", O.BFV, [6]),
 ]
 BGV_T = 65537
 
