@@ -336,7 +336,7 @@ uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_l
 }
 
 void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
-    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz, 0xffffffffu, 0, 0, 0, b.row_pad, b.split_kind == 1 ? b.wfrag.p : nullptr}});
+    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz, 0xffffffffu, 0, 0, 0, b.row_pad}});
 }
 
 // DRNSTool constructor, HPS multiply part (src/rns.cu:687-790; converters src/host/rns.cu:282-337,438-466).
@@ -701,27 +701,6 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
                 mat30[((size_t)j * b.row_pad + i) * 2] = (uint32_t)(m & ((1u << sm) - 1));
                 mat30[((size_t)j * b.row_pad + i) * 2 + 1] = (uint32_t)(m >> sm);
             }
-    if (b.split_kind == 1) {
-        const uint32_t tiles = (b.osz + 31) / 32;
-        std::vector<uint8_t> wf((size_t)tiles * 4 * 8 * 64 * 16, 0);
-        for (uint32_t j = 0; j < b.osz; j++) {
-            const u64 pj = c.primes[op[j]];
-            for (uint32_t i = 0; i < b.isz; i++) {
-                u64 w = mat[(size_t)j * b.isz + i] % pj;
-                if (b.mont) w = (u64)((((unsigned __int128)w) << 64) % pj);
-                for (uint32_t di = 0; di < 8; di++) {
-                    const u64 digits = (w + 0x0080808080808080ull) ^ 0x0080808080808080ull;      // 8 signed bytes of w
-                    const uint32_t k = i * 8 + di, kb = k / 32, g = (k % 32) / 16, t = k % 16, lane = (j % 32) + 32 * g;
-                    for (uint32_t dj = 0; dj < 8; dj++)
-                        wf[(((((size_t)(j / 32) * 4 + kb) * 8 + dj) * 64 + lane) * 16) + t] = (uint8_t)(digits >> (8 * dj));
-                    w = (u64)(((unsigned __int128)w << 8) % pj);                                 // next digit weight of the input
-                }
-            }
-        }
-        std::vector<uint32_t> wf32(wf.size() / 4);
-        std::memcpy(wf32.data(), wf.data(), wf.size());
-        b.wfrag.upload(wf32);
-    }
     b.hat_inv.upload(hat_inv);
     b.mat.upload(mat);
     b.mat30.upload(mat30);
@@ -865,7 +844,7 @@ Tool &Context::tool(uint32_t size_ql) {
         // device descriptors for the batched launches
         auto describe = [](const BConv &b, uint32_t pad_start, uint32_t pad_len, uint32_t src_limb, uint32_t copy_own) {
             return BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz,
-                            pad_start, pad_len, src_limb, copy_own, b.row_pad, b.split_kind == 1 ? b.wfrag.p : nullptr};
+                            pad_start, pad_len, src_limb, copy_own, b.row_pad};
         };
         std::vector<BConvDev> dd;
         for (uint32_t b = 0; b < t->beta; b++) {

@@ -120,7 +120,6 @@ struct BConvDev {
     uint32_t src_limb;           // first input limb inside the source polynomial
     uint32_t copy_own;           // mod-up: also copy the digit's own limbs [src_limb, src_limb+isz) verbatim
     uint32_t row_pad;            // row pitch (entries) of mat30: kBcRowPad, or 32 for 17..32 inputs (split kinds 2, 3)
-    const uint32_t *wfrag;       // MFMA form of the matrix (BConv::wfrag), or null
 };
 
 
@@ -137,10 +136,6 @@ struct BConv {
     // <= 62 bits: Q -> Bsk / Q -> R of the BFV multiply, whose auxiliary primes are 61 bits wide); 3 = the mirror (31, 30)
     int split_kind = 0;
     uint32_t row_pad = kBcRowPad;
-    // split_kind 1 only: the matrix as i8 digit planes in MFMA A-fragment order, [output tile of 32][k block 0..3][plane 0..7]
-    // [lane 0..63][16 bytes]: byte t of lane (row, g) = signed digit `plane` of 2^(8 di) * qhat_i (* 2^64 when mont) mod p_j, with
-    // j = 32 tile + row and (i, di) = divmod(32 kblock + 16 g + t, 8) -- bconv_mfma_kernel (pha_rns.hip)
-    DevBuf<uint32_t> wfrag;
     DevBuf<uint32_t> d_iprime, d_oprime;
 };
 
@@ -367,7 +362,7 @@ struct BConvEpilogue {
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                   uint32_t max_osz, int split_kind, u64 *dst, size_t dst_stride, const u64 *src, size_t src_stride,
                   const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count = 0, size_t group_stride = 0,
-                  const BConvEpilogue *epi = nullptr, size_t own_group_stride = 0, bool mfma_ok = false);
+                  const BConvEpilogue *epi = nullptr, size_t own_group_stride = 0);
 // converter constants for arbitrary bases given as rows of the context's prime table (pha_context.hip)
 void build_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, const std::vector<uint32_t> &op,
                  const std::vector<u64> *out_scale = nullptr, uint32_t family_isz = 0);

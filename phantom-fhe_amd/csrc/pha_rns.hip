@@ -30,9 +30,6 @@ static inline bool bconv_split_on() { return g_bconv_split.load(std::memory_orde
 static constexpr bool bconv_split_on() { return true; }
 #endif
 
-#ifndef PHA_BCONV_MFMA
-#define PHA_BCONV_MFMA 1      // 0: comparison builds without the matrix-core conversion
-#endif
 constexpr int kBcThreads = 256;
 constexpr int kBcMaxOutPerBlock = 24;  // output primes per workgroup (upper bound; the launch balances the groups)
 
@@ -255,151 +252,12 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
     }
 }
 
-// ---- base conversion on the matrix cores --------------------------------------------------------------------------------
-// The conversion IS a matrix product (the reference calls its kernel bconv_matmul): out[j][c] = sum_i y_i[c] * qhat_ij mod p_j.
-// Every y_i is cut into 8 signed bytes s_(i,di) (balanced base-256 digits), so out = sum_(i,di) s_(i,di)[c] * W_(i,di),j with
-// W_(i,di),j = 2^(8 di) qhat_ij mod p_j precomputed and itself cut into 8 signed-byte planes (BConv::wfrag).  One
-// v_mfma_i32_32x32x32_i8 multiplies a 32-output x 32-k slice of a W plane with 32 k x 32 coefficients of digits; 4 k blocks (16
-// inputs x 8 digits) x 8 planes = 32 MFMAs per 32 x 32 tile, into 8 int32 accumulators (|.| < 2^21).  The W fragments of the
-// workgroup's output tile (128 VGPRs) stay in registers for all its coefficients; the digit fragment of a lane is just the two
-// 64-bit inputs it loaded (input 4 kb + 2 g + {0, 1}: their 8 + 8 bytes are the 16 k of the lane).  Outputs land with lanes along
-// coefficients (rows of the accumulator tile = outputs): coalesced stores, no LDS.  Per output the eight planes are recombined
-// (two v_mad_i64_i32 chains), a multiple of p_j makes the sum positive (digits are signed, W is a residue: |sum| < 2^14 p_j)
-// and one REDC (W carries the factor 2^64) or Barrett finishes.  VALU work per output: about 45 instructions against the 80
-// multiply-adds of the split kernel; the MFMAs (33 cycles each) hide behind them.
-typedef int bc_v4i __attribute__((ext_vector_type(4)));
-typedef int bc_v16i __attribute__((ext_vector_type(16)));
-constexpr int kBcMfmaThreads = 256;
-
-__device__ __forceinline__ long long bc_mad_i64_i32(int a, int b, long long c) {
-    long long d;
-    u64 carry;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
-    return d;
-}
-
-template <bool SCALE_IN>
-__global__ __launch_bounds__(kBcMfmaThreads, 1) void bconv_mfma_kernel(const BConvLaunch L, uint32_t coeffs_per_wg) {
-    const BConvWho who = bconv_who(L);
-    const BConvDev &d = L.convs[who.ci * L.conv_step];
-    const uint32_t n = L.n, isz = d.isz, osz = d.osz, tile = blockIdx.y;
-    if (tile * 32 >= osz) return;   // (a shorter converter in a family launch)
-    const u64 *src = L.src + (size_t)blockIdx.z * L.src_stride + (size_t)who.grp * L.src_group_stride + (size_t)d.src_limb * n;
-    const u64 *own = L.own + (size_t)who.grp * L.own_group_stride;
-    u64 *dst = L.dst + (size_t)blockIdx.z * L.dst_stride;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5;
-    const bool mont = d.oninv != nullptr;
-    // per-output constants of this tile
-    __shared__ u64 s_p[32], s_c0[32], s_c1[32], s_bias_lo[32], s_bias_hi[32];
-    __shared__ uint32_t s_jo[32];
-    if (threadIdx.x < 32) {
-        const uint32_t j = tile * 32 + threadIdx.x;
-        u64 p = 0, c0 = 0, c1 = 0;
-        uint32_t jo = 0xffffffffu;
-        if (j < osz) {
-            const DModulus m = L.mod[d.oprime[j]];
-            p = m.value;
-            c0 = mont ? d.oninv[j] : m.ratio0;
-            c1 = m.ratio1;
-            jo = j + (j >= d.pad_start ? d.pad_len : 0);
-        }
-        s_p[threadIdx.x] = p;
-        s_c0[threadIdx.x] = c0;
-        s_c1[threadIdx.x] = c1;
-        s_bias_lo[threadIdx.x] = p << 15;           // 2^15 p: above the most negative digit sum (128 terms x 128 x p)
-        s_bias_hi[threadIdx.x] = p >> 49;
-        s_jo[threadIdx.x] = jo;
-    }
-    // W fragments of this output tile: [k block][plane]
-    bc_v4i wf[4][8];
-    {
-        const bc_v4i *w = reinterpret_cast<const bc_v4i *>(d.wfrag) + (size_t)tile * 4 * 8 * 64 + lane;
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++)
-#pragma unroll
-            for (int dj = 0; dj < 8; dj++) wf[kb][dj] = w[(kb * 8 + dj) * 64];
-    }
-    __syncthreads();
-    const uint32_t c_begin = blockIdx.x * coeffs_per_wg;
-    if (d.copy_own && L.own && tile == 0) {  // modup_copy_partQl_kernel rns_bconv.cu:522-528
-        for (uint32_t e = threadIdx.x; e < isz * coeffs_per_wg; e += kBcMfmaThreads) {
-            const size_t id = (size_t)(d.src_limb + e / coeffs_per_wg) * n + c_begin + e % coeffs_per_wg;
-            dst[id] = own[id];
-        }
-    }
-    // this lane's eight inputs (4 kb + 2 g + e) of a block of 32 coefficients; the next block's are in flight under the work
-    u64 raw[8];
-    auto load_block = [&](uint32_t c0) {
-        const uint32_t coeff = c0 + (lane & 31);
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++)
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const uint32_t i = 4 * kb + 2 * g + e;
-                raw[kb * 2 + e] = (i < isz && c0 < c_begin + coeffs_per_wg) ? src[(size_t)i * n + coeff] : 0;
-            }
-    };
-    constexpr uint32_t kStep = (kBcMfmaThreads / 64) * 32;
-    load_block(c_begin + wave * 32);
-    for (uint32_t c0 = c_begin + wave * 32; c0 < c_begin + coeffs_per_wg; c0 += kStep) {
-        const uint32_t coeff = c0 + (lane & 31);
-        // digits: the bytes of (y + 0x80..80) ^ 0x80..80 are the signed digits
-        bc_v4i yf[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++) {
-            u64 y2[2];
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const uint32_t i = 4 * kb + 2 * g + e;
-                u64 x = raw[kb * 2 + e];
-                if (SCALE_IN && i < isz) x = shoup(x, d.hat_inv[i], L.mod[d.iprime[i]].value);
-                y2[e] = (x + 0x0080808080808080ull) ^ 0x0080808080808080ull;
-            }
-            yf[kb] = bc_v4i{(int)(u32)y2[0], (int)(u32)(y2[0] >> 32), (int)(u32)y2[1], (int)(u32)(y2[1] >> 32)};
-        }
-        load_block(c0 + kStep);
-        bc_v16i acc[8];
-        const bc_v16i zero = {};
-#pragma unroll
-        for (int dj = 0; dj < 8; dj++) acc[dj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][dj], yf[0], zero, 0, 0, 0);
-#pragma unroll
-        for (int kb = 1; kb < 4; kb++)
-#pragma unroll
-            for (int dj = 0; dj < 8; dj++) acc[dj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kb][dj], yf[kb], acc[dj], 0, 0, 0);
-        // accumulator tile: column = lane & 31 = coefficient, row = (r & 3) + 8 (r >> 2) + 4 g = output within the tile
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * g;
-            const uint32_t jo = s_jo[row];
-            long long g0 = acc[0][r], g1 = acc[4][r];
-            g0 = bc_mad_i64_i32(acc[1][r], 1 << 8, g0);
-            g0 = bc_mad_i64_i32(acc[2][r], 1 << 16, g0);
-            g0 = bc_mad_i64_i32(acc[3][r], 1 << 24, g0);
-            g1 = bc_mad_i64_i32(acc[5][r], 1 << 8, g1);
-            g1 = bc_mad_i64_i32(acc[6][r], 1 << 16, g1);
-            g1 = bc_mad_i64_i32(acc[7][r], 1 << 24, g1);
-            // sum = g0 + g1 2^32 (signed, |.| < 2^14 p) + 2^15 p
-            u64 lo = (u64)g0 + ((u64)g1 << 32);
-            u64 hi = (u64)((g0 >> 63) + (g1 >> 32)) + (lo < (u64)g0 ? 1 : 0);
-            const u64 bl = s_bias_lo[row];
-            lo += bl;
-            hi += s_bias_hi[row] + (lo < bl ? 1 : 0);
-            const u64 p = s_p[row];
-            u64 v;
-            if (mont) v = mont_redc128(lo, hi, p, s_c0[row]);
-            else v = barrett128(lo, hi, DModulus{p, s_c0[row], s_c1[row]});
-            if (jo != 0xffffffffu) dst[(size_t)jo * n + coeff] = v;
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four outputs in flight: their chains interleave, registers stay bounded
-        }
-    }
-}
-
 // convs: device array; max_isz / max_osz over the converters used; split_kind: BConv::split_kind of the converters (0: none;
 // a Tool passes its split_ok: 1 = every prime <= 60 bits)
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
                          uint32_t max_osz, int split_kind, u64 *dst, size_t dst_stride, const u64 *src,
                          size_t src_stride, const u64 *own, bool scale_in, hipStream_t s, uint32_t conv_count,
-                         size_t group_stride, const BConvEpilogue *epi, size_t own_group_stride, bool mfma_ok) {
+                         size_t group_stride, const BConvEpilogue *epi, size_t own_group_stride) {
     BConvLaunch L{};
     if (epi) {
         if (max_isz > 32) throw std::logic_error("the fused conversion epilogues need the register-resident converter");
@@ -415,22 +273,6 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
     L.out_per_block = (max_osz + groups - 1) / groups;
     dim3 grid((unsigned)(c.n / kBcThreads), groups, batch);
     dim3 block(kBcThreads);
-#if PHA_BCONV_MFMA
-    // register-resident bases of <= 60-bit primes without a fused epilogue: the matrix-core form (every converter of the launch
-    // carries its W planes: BConv::split_kind 1)
-    if (split_kind == 1 && max_isz <= 16 && !epi && mfma_ok && c.n >= 2048 && bconv_split_on()) {
-        const uint32_t tiles = (max_osz + 31) / 32;
-        // enough workgroups for three per CU, at least 128 coefficients each (one 32-coefficient block per wavefront)
-        uint32_t gx = (uint32_t)(c.n / 128);
-        while (gx > 1 && (size_t)(gx / 2) * tiles * batch >= 768) gx /= 2;
-        const dim3 mgrid(gx, tiles, batch), mblock(kBcMfmaThreads);
-        const uint32_t per_wg = (uint32_t)(c.n / gx);
-        if (scale_in) hipLaunchKernelGGL(bconv_mfma_kernel<true>, mgrid, mblock, 0, s, L, per_wg);
-        else hipLaunchKernelGGL(bconv_mfma_kernel<false>, mgrid, mblock, 0, s, L, per_wg);
-        check_launch();
-        return;
-    }
-#endif
     // the 30 / 30 split accumulators hold at most 16 terms; wider bases or wider primes take the 30 / 31 cuts or the 128-bit accumulate
     if (split_kind >= 2 && max_isz <= 32 && bconv_split_on()) {
 #define PHA_BCW(P, SY, SM)                                                                                       \
@@ -1268,7 +1110,7 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         // (fused inner product, NTT-form input: the own limbs are read from c2 by the fused pass, no copy)
         launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.modup_split, dst, (size_t)qlp * n,
                      ntt_dom ? t_cks : cks, 0, (fused_ip && ntt_dom) ? nullptr : cks, !ntt_dom, s, batch > 1 ? t.beta : 0,
-                     ntt_dom ? (size_t)ql * n : cks_stride, nullptr, cks_stride, t.modup_split == 1);
+                     ntt_dom ? (size_t)ql * n : cks_stride, nullptr, cks_stride);
     }
     LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);
     NttExtra x;

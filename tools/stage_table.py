@@ -11,7 +11,7 @@ W = 8 * N   # bytes of one limb
 STAGES = [
     ("tensor product (multiply)", ["ew_kernel<6>"], 7 * QL * W),                                   # 4 reads + 3 writes per limb
     ("mod-up: inverse NTT x partQlHatInv", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * QL * W),
-    ("mod-up: base conversion, 3 digits", ["bconv_"], BETA * (ALPHA + QL) * W),             # in 15 + out 30 + 15 per digit
+    ("mod-up: base conversion, 3 digits", ["bconv_kernel"], BETA * (ALPHA + QL) * W),             # in 15 + out 30 + 15 per digit
     # r03: the inner product is the epilogue of the forward transform's contiguous pass (modup_ip_kernel); algorithmic bytes of both
     ("mod-up: forward NTT of the converted limbs + key inner product (fused)", ["ntt_pass_kernel", "modup_ip_kernel"],
      2 * BETA * QL * W + QLP * (3 * BETA + 2) * W),
