@@ -495,6 +495,63 @@ def main():
               "checksum_note": "sum mod 2^64 of all output words of the 64 ciphertexts; identical for every --gpus",
               "config": "BFV N=2^15, 30 data + 15 special limbs (keyswitch_bench.cu:25-34), keys broadcast from rank 0"}
 
+    extras = None
+    if not args.only_ntt:
+        # ---- SURVEY 8(f) rows measured beside the headline (this rank's GPU only; no collectives): BFV multiply at the config-4 chain
+        #      and the reference's matmul_bench shape (30 x 256^3 modular GEMM, 50-bit moduli) ----
+        def local_ms(fn, reps):
+            fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / reps
+
+        xg = torch.Generator(device=dev)
+        xg.manual_seed(0x5EED0000 + 6)
+        ctx4.set_plain_modulus(1032193)
+        m1 = torch.stack([uniform_residues(primes4[:q4], n4, dev, xg) for _ in range(2)])
+        m2 = torch.stack([uniform_residues(primes4[:q4], n4, dev, xg) for _ in range(2)])
+        prod = torch.zeros((3, q4, n4), dtype=torch.int64, device=dev)
+        reps = 3 if small else 20
+        bfv = {}
+        for name, fn in (("behz", ctx4.bfv_multiply_behz), ("hps", ctx4.bfv_multiply_hps)):
+            mul = local_ms(lambda: fn(m1, m2, prod), reps)
+
+            def mul_relin():
+                fn(m1, m2, prod)
+                ctx4.keyswitch_inplace(q4, prod[:2], prod[2], rlk4.public_keys_ptr, P.scheme_type.bfv)
+            bfv[name + "_multiply_ms"] = mul
+            bfv[name + "_multiply_relinearize_ms"] = local_ms(mul_relin, reps)
+        bfv["config"] = ("BFV N=2^15, 30 data limbs (+15 special for the relinearization), 61-bit auxiliary bases; bfv_multiply_behz / "
+                         "bfv_multiply_hps, src/evaluate.cu:447-548, :674-818")
+        gm = gn = gk = 256
+        gbatch = 4 if small else 30
+        gprimes = [int(p) for p in P.coeff_modulus_create(4096, [50] * gbatch)]
+        gctx = P.PhantomContext(12, gprimes, 0, device=dev)
+        ga = torch.stack([torch.randint(0, q, (gm, gk), generator=xg, device=dev, dtype=torch.int64) for q in gprimes])
+        gb = torch.stack([torch.randint(0, q, (gk, gn), generator=xg, device=dev, dtype=torch.int64) for q in gprimes])
+        gc = torch.zeros((gbatch, gm, gn), dtype=torch.int64, device=dev)
+        gemm_ms = local_ms(lambda: gctx.batched_modular_gemm(gc, ga, gb, gm, gn, gk, gbatch), 5 if small else 50)
+        z, r_, c_ = gbatch - 1, 17, 203                    # one entry against Python integers
+        want = sum(int(x) * int(y) for x, y in zip(ga[z, r_].tolist(), gb[z, :, c_].tolist())) % gprimes[z]
+        if int(gc[z, r_, c_].item()) != want:
+            raise RuntimeError("modular GEMM: the checked entry differs from the integer dot product")
+        i8_macs = gbatch * gm * gn * gk * 49.0             # 7 x 7 signed-byte digit products per modular multiply-add
+        extras = {"bfv_multiply": bfv,
+                  "modular_gemm": {"us_per_batch": 1e3 * gemm_ms, "batch": gbatch, "m": gm, "n": gn, "k": gk, "modulus_bits": 50,
+                                   "modular_mac_per_s": gbatch * gm * gn * gk / (gemm_ms * 1e-3),
+                                   "i8_mac_per_s": i8_macs / (gemm_ms * 1e-3),
+                                   "frac_of_i8_mfma_peak": 2.0 * i8_macs / (gemm_ms * 1e-3) / 5.0e15,
+                                   "peak_note": "5.0 PF/s dense i8 MFMA (MI355X_MICROARCH.md; 4.4 measured); one entry checked against "
+                                                "Python integers in this run",
+                                   "config": "benchmark/matmul_bench.cu:545-673 shape: 256^3 per modulus, 50-bit moduli; operands as "
+                                             "signed-byte digit planes through v_mfma_i32_32x32x32_i8 (DESIGN 4.9)"}}
+        del gctx, ga, gb, gc, m1, m2, prod
+
     c5 = None
     if not args.only_ntt and not args.no_c5:
         # ---- BASELINE config 5: encrypted 128-slot matrix-vector product in diagonal form at the C3 set: C5_BLOCKS row blocks
@@ -609,6 +666,7 @@ def main():
             "hommul_relin_rescale": hm,
             "keyswitch_c4": c4,
             "matvec_c5": c5,
+            "next_rows": extras,
             "rccl": comm,
             "collectives": ("RCCL (torch.distributed backend nccl)" if (world > 1 or force_dist) and not share else
                             "gloo (PHA_BENCH_SHARE_GPU)" if share and world > 1 else "none (one rank, no process group)"),
