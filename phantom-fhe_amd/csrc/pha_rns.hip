@@ -31,7 +31,7 @@ static constexpr bool bconv_split_on() { return true; }
 #endif
 
 constexpr int kBcThreads = 256;
-constexpr int kBcMaxOutPerBlock = 24;  // output primes per workgroup (upper bound; the launch balances the groups)
+constexpr int kBcMaxOutPerBlock = 32;  // output primes per workgroup (upper bound; the launch balances the groups)
 
 struct BConvLaunch {
     const BConvDev *convs;       // device array
@@ -252,6 +252,15 @@ __global__ __launch_bounds__(kBcThreads) void bconv_wide_kernel(const BConvLaunc
     }
 }
 
+// Output groups (blockIdx.y) of a conversion launch: up to 32 outputs per workgroup (the inputs are loaded and scaled once per
+// group: config 4's 30-output mod-down in one group, +4 % on that job) when that still leaves four workgroups per CU, 24 otherwise
+// (a single polynomial at N = 2^15); balanced: 45 outputs -> 2 groups of 23
+static uint32_t bconv_groups(const Context &c, uint32_t osz, uint32_t polys) {
+    const uint32_t few = (osz + kBcMaxOutPerBlock - 1) / kBcMaxOutPerBlock;
+    const uint32_t cap = (c.n / kBcThreads) * few * polys >= 1024 ? kBcMaxOutPerBlock : 24;
+    return (osz + cap - 1) / cap;
+}
+
 // convs: device array; max_isz / max_osz over the converters used; split_kind: BConv::split_kind of the converters (0: none;
 // a Tool passes its split_ok: 1 = every prime <= 60 bits)
 void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_t batch, uint32_t max_isz,
@@ -268,8 +277,7 @@ void launch_bconv(Context &c, const BConvDev *convs, uint32_t conv_step, uint32_
     L.conv_count = conv_count; L.src_group_stride = group_stride; L.own_group_stride = own_group_stride ? own_group_stride : group_stride;
     L.convs = convs; L.conv_step = conv_step; L.dst = dst; L.src = src; L.own = own;
     L.dst_stride = dst_stride; L.src_stride = src_stride; L.mod = c.d_mod.p; L.n = (uint32_t)c.n;
-    // balanced output groups: 45 outputs -> 2 groups of 23 (6 wavefronts per SIMD at C3 mod-up: one resident round)
-    const uint32_t groups = (max_osz + kBcMaxOutPerBlock - 1) / kBcMaxOutPerBlock;
+    const uint32_t groups = bconv_groups(c, max_osz, batch);
     L.out_per_block = (max_osz + groups - 1) / groups;
     dim3 grid((unsigned)(c.n / kBcThreads), groups, batch);
     dim3 block(kBcThreads);
@@ -1340,7 +1348,7 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
         BConvRescaleLaunch L{};
         L.conv = t.d_p_to_ql_pinv_conv.p; L.dst = tmp; L.cx = cx; L.dst_stride = ql_n; L.cx_stride = qlp_n;
         L.mod = c.d_mod.p; L.n = (uint32_t)n; L.ql = (uint32_t)ql;
-        const uint32_t groups = ((uint32_t)nl + kBcMaxOutPerBlock - 1) / kBcMaxOutPerBlock;
+        const uint32_t groups = bconv_groups(c, (uint32_t)nl, 2 * (uint32_t)B);
         L.out_per_block = ((uint32_t)nl + groups - 1) / groups;
         const dim3 grid((unsigned)(n / kBcThreads), groups, 2 * B), block(kBcThreads);
         if (t.alpha <= 2) hipLaunchKernelGGL(bconv_rescale_kernel<2>, grid, block, 0, s, L);
