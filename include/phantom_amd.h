@@ -401,7 +401,9 @@ int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint6
  * apply_galois_inplace :1567-1624 over a batch, no reference launcher): out [batch][2][Ql][N] =
  * rotate_{galois_elt}(relinearize(ct3 [batch][3][Ql][N])), i.e. per ciphertext keyswitch_inplace with rlk, the automorphism, and
  * keyswitch_inplace with glk -- bit-identical to those calls.  ct3 is only read (out must not overlap it); the batch runs
- * `chunk` ciphertexts per set of launches (0 = sized so that a set's mod-up digits stay within the 256 MiB MALL); no copies. */
+ * `chunk` ciphertexts per set of launches (0 = sized so that a set's mod-up digits stay within the 256 MiB MALL, and the sets
+ * alternate between two streams the context owns, forked from and joined back into `stream` with events: warm the call up once
+ * before capturing it into a graph); no copies. */
 int pha_relinearize_rotate_batched(pha_context_t ctx, size_t size_Ql, const uint64_t *ct3, size_t batch,
                                    const uint64_t *const *rlk, const uint64_t *const *glk, uint32_t galois_elt, int scheme,
                                    uint64_t *out, size_t chunk, void *stream);

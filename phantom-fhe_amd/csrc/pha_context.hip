@@ -960,6 +960,22 @@ Context::ArenaKey Context::arena_key(void *stream) {
     return ArenaKey{stream, sentinel ? this_thread_number() : 0};
 }
 
+void Lanes::ensure() {
+    if (s[0]) return;
+    for (int l = 0; l < 2; l++) {
+        PHA_HIP(hipStreamCreateWithFlags(&s[l], hipStreamNonBlocking));
+        PHA_HIP(hipEventCreateWithFlags(&join[l], hipEventDisableTiming));
+    }
+    PHA_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+}
+Lanes::~Lanes() {
+    for (int l = 0; l < 2; l++) {
+        if (join[l]) (void)hipEventDestroy(join[l]);
+        if (s[l]) (void)hipStreamDestroy(s[l]);
+    }
+    if (fork) (void)hipEventDestroy(fork);
+}
+
 u64 *Context::scratch(void *stream, size_t words) {
     std::lock_guard<std::mutex> lk(mu);
     auto &a = arenas[arena_key(stream)];

@@ -222,6 +222,16 @@ struct Arena {
     }
 };
 
+// two internal streams that a batched entry point may spread independent sub-batches over (forked from and joined back into the
+// caller's stream with events; created on first use)
+struct Lanes {
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    std::mutex mu;                                 // one batched call at a time enqueues on them
+    void ensure();
+    ~Lanes();
+};
+
 struct Context {
     int device = 0;
     int num_cus = 256;
@@ -257,6 +267,7 @@ struct Context {
     std::map<ArenaKey, std::unique_ptr<Arena>> outer_arenas;   // for entry points that call other entry points (which use `arenas`)
     u64 *scratch_outer(void *stream, size_t words);
     std::map<uint32_t, DevBuf<uint32_t>> galois_tables;  // NTT-domain permutation per galois_elt
+    Lanes lanes;
 
     Tool &tool(uint32_t size_ql);
     Behz &behz();                                             // built on first use; needs the plain modulus

@@ -1534,31 +1534,53 @@ int pha_relinearize_rotate_batched(pha_context_t ctx, size_t size_Ql, const uint
     const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
     if (overlaps(out, batch * 2 * ql_n, ct3, batch * 3 * ql_n)) throw std::invalid_argument("out must not overlap ct3");
     // ciphertexts per set of launches: the mod-up digits of a set (beta x (l + alpha) limbs each) should stay within the MALL
-    // (measured at N = 2^15 / 30 + 15 limbs: 8 per set 233 us per ciphertext, all 64 at once 268, one by one 334)
+    // (measured at N = 2^15 / 30 + 15 limbs: 8 per set 233 us per ciphertext, all 64 at once 268, one by one 334).
+    // chunk = 0 also spreads the sets over two internal streams, half a set each: the short kernels of one set fill the tails of
+    // the other's (same process, alternating: 6045-6086 against 5909-5920 ciphertexts/s; four streams or two full sets: no better).
+    const bool auto_chunk = chunk == 0;
     if (chunk == 0) chunk = std::max<size_t>(1, ((size_t)192 << 20) / ((size_t)t.beta * qlp_n * sizeof(u64)));
     chunk = std::min<size_t>(std::min<size_t>(chunk, batch), 1024);
     while ((size_t)t.beta * chunk > 65535 || 2 * chunk > 65535) chunk /= 2;
+    const bool two_lanes = auto_chunk && chunk >= 2 && batch >= 2 * chunk;
+    if (two_lanes) chunk /= 2;
     const uint32_t *tab = ntt_dom ? c.galois_table(galois_elt) : nullptr;
-    // scratch: tmp [C][2][Ql][N] | t_mod_up [C][beta][QlP][N] | cx [C][2][QlP][N] | ks [C][2][Ql][N] | g1 [C][Ql][N]
     const size_t C = chunk;
-    u64 *base = c.scratch(stream, C * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n + 3 * ql_n));
-    u64 *tmp = base, *t_mod_up = base + C * 2 * ql_n, *cx = t_mod_up + C * (size_t)t.beta * qlp_n, *ks = cx + C * 2 * qlp_n,
-        *g1 = ks + C * 2 * ql_n;
-    for (size_t b0 = 0; b0 < batch; b0 += C) {
+    const size_t words = C * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n + 3 * ql_n);
+    // one set of B ciphertexts from b0 on stream ls, scratch base: tmp [C][2][Ql][N] | t_mod_up [C][beta][QlP][N] | cx [C][2][QlP][N] |
+    // ks [C][2][Ql][N] | g1 [C][Ql][N]
+    auto one_set = [&](hipStream_t ls, u64 *base, size_t b0) {
+        u64 *tmp = base, *t_mod_up = base + C * 2 * ql_n, *cx = t_mod_up + C * (size_t)t.beta * qlp_n, *ks = cx + C * 2 * qlp_n,
+            *g1 = ks + C * 2 * ql_n;
         const uint32_t B = (uint32_t)std::min(C, batch - b0);
         const u64 *in = ct3 + b0 * 3 * ql_n;
         u64 *o = out + b0 * 2 * ql_n;
         // relinearize: ks = keyswitch(c2), c2 read where it lies (every third polynomial)
-        modup(c, t, t_mod_up, in + 2 * ql_n, scheme, tmp, s, B, 3 * ql_n);
-        inner_prod(c, t, cx, t_mod_up, rlk, s, B);
-        moddown_from_ntt(c, t, ks, ql_n, cx, qlp_n, 2 * B, scheme, false, tmp, s);
+        modup(c, t, t_mod_up, in + 2 * ql_n, scheme, tmp, ls, B, 3 * ql_n);
+        inner_prod(c, t, cx, t_mod_up, rlk, ls, B);
+        moddown_from_ntt(c, t, ks, ql_n, cx, qlp_n, 2 * B, scheme, false, tmp, ls);
         // rotate: (galois(c0 + ks0), 0) and galois(c1 + ks1) in the layout of the second key switch (apply_galois_inplace)
-        hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql, 2 * B), dim3(256), 0, s, o, g1, ks, tab,
+        hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql, 2 * B), dim3(256), 0, ls, o, g1, ks, tab,
                            c.d_mod.p, galois_elt, (uint32_t)n, (uint32_t)size_Ql, in, 3u);
         check_launch();
-        modup(c, t, t_mod_up, g1, scheme, tmp, s, B);
-        inner_prod(c, t, cx, t_mod_up, glk, s, B);
-        moddown_from_ntt(c, t, o, ql_n, cx, qlp_n, 2 * B, scheme, true, tmp, s);
+        modup(c, t, t_mod_up, g1, scheme, tmp, ls, B);
+        inner_prod(c, t, cx, t_mod_up, glk, ls, B);
+        moddown_from_ntt(c, t, o, ql_n, cx, qlp_n, 2 * B, scheme, true, tmp, ls);
+    };
+    if (!two_lanes) {
+        u64 *base = c.scratch(stream, words);
+        for (size_t b0 = 0; b0 < batch; b0 += C) one_set(s, base, b0);
+    } else {
+        std::lock_guard<std::mutex> lk(c.lanes.mu);
+        c.lanes.ensure();
+        u64 *base[2] = {c.scratch(c.lanes.s[0], words), c.scratch(c.lanes.s[1], words)};
+        PHA_HIP(hipEventRecord(c.lanes.fork, s));
+        for (int l = 0; l < 2; l++) PHA_HIP(hipStreamWaitEvent(c.lanes.s[l], c.lanes.fork, 0));
+        size_t set = 0;
+        for (size_t b0 = 0; b0 < batch; b0 += C, set++) one_set(c.lanes.s[set & 1], base[set & 1], b0);
+        for (int l = 0; l < 2; l++) {
+            PHA_HIP(hipEventRecord(c.lanes.join[l], c.lanes.s[l]));
+            PHA_HIP(hipStreamWaitEvent(s, c.lanes.join[l], 0));
+        }
     }
     PHA_API_END
 }

@@ -23,7 +23,7 @@ rlk = P.PhantomRelinKey([rnd(2, len(primes), n) for _ in range(dnum)])
 glk = P.PhantomRelinKey([rnd(2, len(primes), n) for _ in range(dnum)])
 BFV = P.scheme_type.bfv
 ct3 = rnd(64, 3, size_q, n)
-for sub in (64, 16, 12, 8, 6, 4, 2, 1):     # ciphertexts per set of launches inside the one C call (pha_relinearize_rotate_batched's chunk)
+for sub in (0, 8, 0, 8, 4, 16):     # 0 = the library's own choice (two internal streams, half a set each)     # ciphertexts per set of launches inside the one C call (pha_relinearize_rotate_batched's chunk)
     def run():
         W.relinearize_rotate_batch(ctx, size_q, ct3, rlk, glk, 3, BFV, chunk=sub)
     run(); torch.cuda.synchronize()
