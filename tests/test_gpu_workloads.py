@@ -108,6 +108,45 @@ def _gpu_uniform(primes, n, gpu, gen):
     return out
 
 
+def test_config4_two_internal_streams_replay_from_a_hip_graph(gpu):
+    """With its own chunking pha_relinearize_rotate_batched alternates the sets between two streams the context owns (forked from
+    and joined back into the caller's stream by events): the result equals the one-stream form, and the whole call -- fork, both
+    lanes, join -- can be captured into a hipGraph on a side stream (after one warm-up call) and replayed."""
+    import torch
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    name, ql, batch, elt = "c4_bfv15", 30, 16, 3          # 16 ciphertexts: two sets of four per lane at this shape
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    ctx = _ctx(name, gpu)
+    r = rng_for(4016)
+    rlk, glk = _keys(r, primes, n, size_q // size_p), _keys(r, primes, n, size_q // size_p)
+    d_rlk, d_glk = P.PhantomRelinKey.from_numpy(rlk, gpu), P.PhantomRelinKey.from_numpy(glk, gpu)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(0x5EED4016)
+    ct3 = torch.stack([torch.stack([_gpu_uniform(primes[:ql], n, gpu, gen) for _ in range(3)]) for _ in range(batch)])
+    one_stream = W.relinearize_rotate_batch(ctx, ql, ct3, d_rlk, d_glk, elt, O.BFV, chunk=8)
+    assert torch.equal(W.relinearize_rotate_batch(ctx, ql, ct3, d_rlk, d_glk, elt, O.BFV), one_stream)    # chunk = 0: two lanes
+    out = torch.empty_like(ct3[:, :2])
+    side = torch.cuda.Stream(device=gpu)
+
+    def call():
+        ctx.relinearize_rotate_batched(ql, ct3, batch, d_rlk.public_keys_ptr, d_glk.public_keys_ptr, elt, O.BFV, out, 0)
+
+    with torch.cuda.stream(side):
+        call()                                            # warm-up: the lanes and their arenas exist from here on
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        call()
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, one_stream)
+
+
 def test_config4_batch_64_at_its_stated_shape(gpu):
     """BASELINE config 4 as written: BFV relinearize + Galois rotate at N = 2^15, 30 + 15 limbs, a batch of 64
     ciphertexts.  Four sampled ciphertexts are checked against the oracle's composition of the reference steps; the
