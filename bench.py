@@ -477,12 +477,17 @@ def main():
             for p_ in range(3):
                 ct3[i, p_] = uniform_residues(primes4[:q4], n4, dev, kgen)
         elt = 3
-        res = [None]
+        # the output buffer exists before the clock starts (W.relinearize_rotate_batch would allocate 1 GiB per call: a fresh
+        # block inside the timed region, which on some boxes of the pool halves the figure)
+        out4 = torch.empty((len(mine), 2, q4, n4), dtype=torch.int64, device=dev)
+        res = [out4]
 
         def c4_step():
             if len(mine):
-                res[0] = W.relinearize_rotate_batch(ctx4, q4, ct3, rlk4, glk4, elt, P.scheme_type.bfv)
+                ctx4.relinearize_rotate_batched(q4, ct3, len(mine), rlk4.public_keys_ptr, glk4.public_keys_ptr, elt, P.scheme_type.bfv,
+                                                out4, 0)
 
+        c4_step()
         c4_step()
         c4_steps = 1 if small else 3
         c4_elapsed = timed(c4_step, c4_steps)
@@ -601,6 +606,7 @@ def main():
                                                 P.scheme_type.ckks) if blocks5 else []
 
         c5_step()
+        c5_step()     # twice: the wrapper allocates its 1.5 GiB output while the previous one is still held -- both blocks exist now
         c5_steps = 1 if small else 3
         c5_elapsed = timed(c5_step, c5_steps)
         local5 = int(res5[0].sum().item()) & ((1 << 64) - 1) if blocks5 else 0
