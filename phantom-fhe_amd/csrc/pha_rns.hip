@@ -1013,6 +1013,12 @@ __global__ __launch_bounds__(256) void scale_by_t_kernel(u64 *e, const DModulus 
 }
 
 // ---- Galois (src/galois.cu:11-39) ----------------------------------------------------------------
+// elt^-1 mod 2n for an odd elt (Newton: x <- x (2 - elt x) doubles the correct low bits)
+static uint32_t inv_mod_2n(uint32_t elt, size_t n) {
+    uint32_t x = elt;                      // correct to 3 bits: elt^2 = 1 mod 8
+    for (int i = 0; i < 5; i++) x *= 2 - elt * x;
+    return x & (uint32_t)(2 * n - 1);
+}
 __global__ __launch_bounds__(256) void galois_ntt_kernel(u64 *dst, const u64 *src, const uint32_t *table, uint32_t n) {
     const uint32_t limb = blockIdx.y;
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
@@ -1020,21 +1026,24 @@ __global__ __launch_bounds__(256) void galois_ntt_kernel(u64 *dst, const u64 *sr
 }
 // blockIdx.z = polynomial of a batch (stride = gridDim.y limbs)
 __global__ __launch_bounds__(256) void galois_coeff_kernel(u64 *dst, const u64 *src, const DModulus *mod,
-                                                           uint32_t mod_start, uint32_t elt, uint32_t n) {
+                                                           uint32_t mod_start, uint32_t elt_inv, uint32_t n) {
     const uint32_t limb = blockIdx.z * gridDim.y + blockIdx.y;
     const u64 q = mod[mod_start + blockIdx.y].value;
     const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
-    // index_raw = coeff * galois_elt mod 2n (include/galois.cuh:115-130)
-    const uint32_t raw = (uint32_t)(((u64)coeff * elt) & (2 * (u64)n - 1));
-    u64 v = src[(size_t)limb * n + coeff];
-    if (raw >= n) v = neg_mod(v, q);
-    dst[(size_t)limb * n + (raw & (n - 1))] = v;
+    // index_raw = c * galois_elt mod 2n sends coefficient c to position index_raw mod n, negated when index_raw >= n
+    // (include/galois.cuh:115-130).  As a gather (contiguous stores): position `coeff` comes from c = coeff * elt^-1 mod 2n, from
+    // c - n and negated when c >= n; `elt_inv` = elt^-1 mod 2n (inv_mod_2n below)
+    const uint32_t c = (uint32_t)(((u64)coeff * elt_inv) & (2 * (u64)n - 1));
+    u64 v = src[(size_t)limb * n + (c & (n - 1))];
+    if (c >= n) v = neg_mod(v, q);
+    dst[(size_t)limb * n + coeff] = v;
 }
 
 // Galois automorphism of a batch of size-2 ciphertexts laid out for the key switch that follows it (rotate_internal /
 // apply_galois_inplace, src/evaluate.cu:1567-1624): polynomial 0 goes to dst_ct[b][0], dst_ct[b][1] is zeroed and polynomial 1
 // goes to the dense key-switch operand dst_c2[b] -- one kernel instead of permutation + memset + two strided copies.
 // blockIdx.z = 2 b + p.  `table` != null: NTT-domain gather; null: coefficient-domain scatter with sign (galois.cu:11-39).
+// (`elt` is the element for the table form and its inverse mod 2n for the coefficient form: see the gather below.)
 // `add` != null: the automorphism is applied to src + add (mod q), add being polynomial p of ciphertext b at add + (b * add_ct_polys
 // + p) * Ql * N -- the sum ct + keyswitch(c2) of a relinearization that was never stored (pha_relinearize_rotate_batched).
 __global__ __launch_bounds__(256) void galois_split_kernel(u64 *dst_ct, u64 *dst_c2, const u64 *src, const uint32_t *table,
@@ -1053,13 +1062,19 @@ __global__ __launch_bounds__(256) void galois_split_kernel(u64 *dst_ct, u64 *dst
         if (in2) v = add_mod(v, in2[from], q);
         out[coeff] = v;
     } else {
-        const uint32_t raw = (uint32_t)(((u64)coeff * elt) & (2 * (u64)n - 1));
-        u64 v = in[coeff];
-        if (in2) v = add_mod(v, in2[coeff], q);
-        if (raw >= n) v = neg_mod(v, q);
-        out[raw & (n - 1)] = v;
+        // X -> X^elt sends coefficient c to position c elt mod n with the sign of (c elt mod 2n) >= n (galois.cu:11-39).  Written
+        // as a gather: output `coeff` comes from c = coeff elt^-1 mod 2n (c >= n: from c - n, negated), so the stores of a
+        // wavefront are one contiguous run and the scattered side is the loads, which the limb's 256-512 KB in L2 absorb;
+        // `elt` holds elt^-1 mod 2n here (the launcher inverts it)
+        const uint32_t c = (uint32_t)(((u64)coeff * elt) & (2 * (u64)n - 1));
+        const uint32_t from = c & (n - 1);
+        u64 v = in[from];
+        if (in2) v = add_mod(v, in2[from], q);
+        if (c >= n) v = neg_mod(v, q);
+        out[coeff] = v;
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // drivers
@@ -1560,7 +1575,7 @@ int pha_relinearize_rotate_batched(pha_context_t ctx, size_t size_Ql, const uint
         moddown_from_ntt(c, t, ks, ql_n, cx, qlp_n, 2 * B, scheme, false, tmp, ls);
         // rotate: (galois(c0 + ks0), 0) and galois(c1 + ks1) in the layout of the second key switch (apply_galois_inplace)
         hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql, 2 * B), dim3(256), 0, ls, o, g1, ks, tab,
-                           c.d_mod.p, galois_elt, (uint32_t)n, (uint32_t)size_Ql, in, 3u);
+                           c.d_mod.p, tab ? galois_elt : inv_mod_2n(galois_elt, n), (uint32_t)n, (uint32_t)size_Ql, in, 3u);
         check_launch();
         modup(c, t, t_mod_up, g1, scheme, tmp, ls, B);
         inner_prod(c, t, cx, t_mod_up, glk, ls, B);
@@ -1648,7 +1663,7 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
         PHA_HIP(hipMemsetAsync(ct, 0, ql_n * sizeof(u64), s));
         for (size_t e = 0; e < n_elts; e++) {  // coefficient-domain automorphism (src/galois.cu:20-39)
             hipLaunchKernelGGL(galois_coeff_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql), dim3(256), 0, s,
-                               tmp, c0, c.d_mod.p, 0u, galois_elts[e], (uint32_t)n);
+                               tmp, c0, c.d_mod.p, 0u, inv_mod_2n(galois_elts[e], n), (uint32_t)n);
             check_launch();
             launch_add(c, ct, tmp, ct, size_Ql, 0, s);
         }
@@ -1995,7 +2010,7 @@ int pha_apply_galois_batched(pha_context_t ctx, const uint64_t *src, uint64_t *d
         }
     } else {
         hipLaunchKernelGGL(galois_coeff_kernel, dim3((unsigned)(c.n / 256), (unsigned)cms, (unsigned)polys), dim3(256), 0,
-                           as_stream(stream), dst, src, c.d_mod.p, 0u, galois_elt, (uint32_t)c.n);
+                           as_stream(stream), dst, src, c.d_mod.p, 0u, inv_mod_2n(galois_elt, c.n), (uint32_t)c.n);
     }
     check_launch();
     PHA_API_END
@@ -2013,8 +2028,8 @@ int pha_apply_galois_for_keyswitch(pha_context_t ctx, const uint64_t *src, uint6
     if (2 * batch > 65535) throw std::invalid_argument("batch out of range");
     const uint32_t *tab = ntt_form ? c.galois_table(galois_elt) : nullptr;
     hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(c.n / 256), (unsigned)size_Ql, (unsigned)(2 * batch)), dim3(256), 0,
-                       as_stream(stream), dst_ct, dst_c2, src, tab, c.d_mod.p, galois_elt, (uint32_t)c.n, (uint32_t)size_Ql,
-                       (const u64 *)nullptr, 0u);
+                       as_stream(stream), dst_ct, dst_c2, src, tab, c.d_mod.p, tab ? galois_elt : inv_mod_2n(galois_elt, c.n), (uint32_t)c.n,
+                       (uint32_t)size_Ql, (const u64 *)nullptr, 0u);
     check_launch();
     PHA_API_END
 }
@@ -2028,7 +2043,7 @@ int pha_apply_galois(pha_context_t ctx, const uint64_t *src, uint64_t *dst, uint
     if (!(galois_elt & 1) || galois_elt >= 2 * c.n) throw std::invalid_argument("Galois element is not valid");
     if (mod_start + cms > c.size_qp) throw std::invalid_argument("modulus index out of range");
     hipLaunchKernelGGL(galois_coeff_kernel, dim3((unsigned)(c.n / 256), (unsigned)cms), dim3(256), 0,
-                       as_stream(stream), dst, src, c.d_mod.p, (uint32_t)mod_start, galois_elt, (uint32_t)c.n);
+                       as_stream(stream), dst, src, c.d_mod.p, (uint32_t)mod_start, inv_mod_2n(galois_elt, c.n), (uint32_t)c.n);
     check_launch();
     PHA_API_END
 }
