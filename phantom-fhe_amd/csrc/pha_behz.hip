@@ -80,19 +80,6 @@ __global__ __launch_bounds__(256) void sk_fix_kernel(SkArgs k) {
     k.out_q[id] = add_mod(k.out_q[id], mul_mod(a, pb, m), m.value);
 }
 
-// x * c_i mod q_i per limb (bconv_mult_kernel with the m_tilde-scaled factors, rns.cu:1259-1262)
-struct ScaleArgs {
-    u64 *dst;
-    const u64 *src;
-    const DModulus *mod;
-    const u64x2 *c;
-    uint32_t n;
-};
-__global__ __launch_bounds__(256) void scale_limbs_kernel(const ScaleArgs k) {
-    const uint32_t i = blockIdx.y, coeff = blockIdx.x * 256 + threadIdx.x;
-    const size_t id = ((size_t)blockIdx.z * gridDim.y + i) * k.n + coeff;
-    k.dst[id] = shoup(k.src[id], k.c[i], k.mod[i].value);
-}
 
 static LimbSel aux_sel(uint32_t count, uint32_t aux0) {  // a buffer of `count` limbs whose table rows start at aux0
     LimbSel s = plain_sel(0, count);
@@ -105,17 +92,14 @@ static LimbSel aux_sel(uint32_t count, uint32_t aux0) {  // a buffer of `count` 
 static void behz_lift(Context &c, Behz &b, const u64 *ct, u64 *out_q, u64 *out_bsk, u64 *tmp, hipStream_t s) {
     const uint32_t n = (uint32_t)c.n, sq = b.size_q, sk = b.size_bsk;
     const size_t qn = (size_t)sq * n;
-    PHA_HIP(hipMemcpyAsync(out_q, ct, 2 * qn * sizeof(u64), hipMemcpyDeviceToDevice, s));
     NttExtra xq;
     xq.batch = 2;
     xq.poly_stride = qn;
-    ntt_forward(c, out_q, out_q, out_q, plain_sel(0, sq), EPI_FWD_CANON, xq, s);
-    // (1) q -> Bsk u {m_tilde}: phase 1 with m_tilde * qhat^-1, then one conversion for all Bsk + 1 outputs
-    u64 *y = tmp, *lift = tmp + 2 * qn;  // y [2][Q][N], lift [2][Bsk + 1][N]
-    ScaleArgs sa{y, ct, c.d_mod.p, b.mt_qhatinv.p, n};
-    hipLaunchKernelGGL(scale_limbs_kernel, dim3(n / 256, sq, 2), dim3(256), 0, s, sa);
-    check_launch();
-    launch_bconv(c, b.d_q_to_bskmt.p, 0, 2, sq, sk + 1, b.q_to_bskmt.split_kind, lift, (size_t)(sk + 1) * n, y, qn, nullptr, false, s);
+    ntt_forward(c, ct, out_q, out_q, plain_sel(0, sq), EPI_FWD_CANON, xq, s);      // out of place: no copy of ct first
+    // (1) q -> Bsk u {m_tilde}: phase 1 with m_tilde * qhat^-1 (the converter's own scale-in factors, Context::behz), one
+    // conversion for all Bsk + 1 outputs
+    u64 *lift = tmp + 2 * qn;  // lift [2][Bsk + 1][N]
+    launch_bconv(c, b.d_q_to_bskmt.p, 0, 2, sq, sk + 1, b.q_to_bskmt.split_kind, lift, (size_t)(sk + 1) * n, ct, qn, nullptr, true, s);
     // (2) small Montgomery reduction modulo q, switching to base Bsk
     MrqArgs ma{out_bsk, lift, c.d_mod.p, b.prod_q_mod_bsk.p, b.inv_mt_mod_bsk.p, b.neg_inv_prod_q_mod_mt, b.aux0, sk, n};
     hipLaunchKernelGGL(sm_mrq_kernel, dim3(n / 256, sk, 2), dim3(256), 0, s, ma);

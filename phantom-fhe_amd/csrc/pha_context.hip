@@ -617,6 +617,9 @@ Behz &Context::behz() {
         PHA_HIP(hipMemcpy(hi.data(), b->q_to_bsk.hat_inv.p, size_q * sizeof(u64x2), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < size_q; i++) v[i] = pair(h_mulmod(m_tilde % primes[i], hi[i].x, primes[i]), primes[i]);
         b->mt_qhatinv.upload(v);
+        // the Q -> Bsk u {m_tilde} converter is only ever fed m_tilde * x (BEHZ_mul_1): its phase-1 factors carry the m_tilde, so
+        // the conversion kernel scales on load and no scaled copy of the input is written (describe_conv keeps this pointer)
+        b->q_to_bskmt.hat_inv.upload(v);
     }
     {
         std::vector<u64x2> ipq(b->size_bsk), imt(b->size_bsk);
