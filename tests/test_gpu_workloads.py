@@ -147,6 +147,49 @@ def test_config4_two_internal_streams_replay_from_a_hip_graph(gpu):
         assert torch.equal(out, one_stream)
 
 
+def test_config4_two_internal_streams_from_concurrent_host_threads(gpu):
+    """Two host threads, each on its own stream, go through the context's two internal streams at the same time (the enqueue is
+    serialised inside the entry, the fork / join events are re-recorded per call): both get the one-stream result, every time."""
+    import threading
+    import torch
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    name, ql, batch, elt = "c4_bfv15", 30, 16, 3
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    ctx = _ctx(name, gpu)
+    r = rng_for(4017)
+    rlk, glk = _keys(r, primes, n, size_q // size_p), _keys(r, primes, n, size_q // size_p)
+    d_rlk, d_glk = P.PhantomRelinKey.from_numpy(rlk, gpu), P.PhantomRelinKey.from_numpy(glk, gpu)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(0x5EED4017)
+    inputs = [torch.stack([torch.stack([_gpu_uniform(primes[:ql], n, gpu, gen) for _ in range(3)]) for _ in range(batch)]) for _ in range(2)]
+    want = [W.relinearize_rotate_batch(ctx, ql, x, d_rlk, d_glk, elt, O.BFV, chunk=8) for x in inputs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(gpu)
+            st = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    got = W.relinearize_rotate_batch(ctx, ql, inputs[i], d_rlk, d_glk, elt, O.BFV)
+                    st.synchronize()
+                    if not torch.equal(got, want[i]):
+                        errors.append(f"thread {i}: result differs")
+        except Exception as e:   # noqa: BLE001
+            errors.append(f"thread {i}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_config4_batch_64_at_its_stated_shape(gpu):
     """BASELINE config 4 as written: BFV relinearize + Galois rotate at N = 2^15, 30 + 15 limbs, a batch of 64
     ciphertexts.  Four sampled ciphertexts are checked against the oracle's composition of the reference steps; the
