@@ -152,7 +152,7 @@ def cpu_baseline(primes, n, seconds=12.0, gpu_forward=None):
     except (OSError, ValueError):
         pass
     threads = min(cores, 45)
-    reps_all, dt_all = run(threads, 4.0)
+    reps_all, dt_all = run(threads, 3.0)
     oc.L.orc_set_threads(1)
     return {"value": 45 * reps / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
             "sample": f"{reps} forward NTTs of 45 limbs at N=2^16 ({dt:.1f} s, oracle/oracle.c -O3 -march=native, 1 thread)",
@@ -264,14 +264,23 @@ def main():
         if world > 1 or force_dist:
             dist.barrier()
 
+    direct_bcast = os.environ.get("PHA_BCAST_DIRECT") == "1"   # pha_broadcast_keys on the process group's own RCCL communicator
+
+    def key_slab(count, shape):
+        """`count` key buffers of `shape` cut out of ONE allocation: the set travels as one flat buffer per collective call
+        (phantom_fhe_amd/dist.py merges back-to-back views), not as one call per [2][#QP][N] tensor."""
+        slab = torch.empty((count,) + tuple(shape), dtype=torch.int64, device=dev)
+        return [slab[i] for i in range(count)]
+
     def broadcast(keys):
+        """Returns the number of collective calls issued (0 without a process group)."""
         if share and world > 1:               # gloo moves host tensors
-            host = [k.cpu() for k in keys]
-            pdist.broadcast_keys(host, src=0)
+            host = torch.stack([k.cpu() for k in keys])
+            calls = pdist.broadcast_keys([host[i] for i in range(len(keys))], src=0)
             for k, h in zip(keys, host):
                 k.copy_(h)
-        else:
-            pdist.broadcast_keys(keys, src=0)  # one-time RCCL broadcast over xGMI; no collective on the data path
+            return calls
+        return pdist.broadcast_keys(keys, src=0, ctx=ctx, direct=direct_bcast)  # one-time RCCL broadcast over xGMI; no collective on the data path
 
     def timed(fn, steps):
         """K calls between barrier + synchronize on both sides; whole-job time = the slowest rank's."""
@@ -378,21 +387,27 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     copy_bps = 10 * 2 * cal_a.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3)
-    own_copy_bps = P.stream_copy_rate(cal_b, cal_a, 10)    # the library's own 16-byte-per-lane streaming kernel
+    own_copy_bps = P.stream_copy_rate(cal_b, cal_a, 10)    # the library's own 16-byte-per-lane streaming kernel (nontemporal copy)
+    # r04: the independent calibration (tools/stream_calib.hip in library form): read-only, write-only, copy and in-place
+    # read-modify-write over 512 MiB, default and nontemporal policy; the best of each kind is what a pass can be held against
+    cal = {}
+    for name, mode in (("copy", 0), ("read", 1), ("write", 2), ("rmw", 3)):
+        cal[name + "_GBps"] = max(P.stream_rate(cal_b, cal_a, mode, nt, 10) for nt in (False, True)) / 1e9
     del cal_a, cal_b
     del polys
 
     hm = None
     c4 = None
+    bcast_calls = {}
     if not args.only_ntt:
         # ---- evaluation key: generated on rank 0, broadcast once over RCCL/xGMI --------
         dnum = size_q // SIZE_P
-        evk = [torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum)]
+        evk = key_slab(dnum, (2, len(primes), n))
         if rank == 0:
             for k in evk:
                 k[0] = uniform_residues(primes, n, dev, gen)
                 k[1] = uniform_residues(primes, n, dev, gen)
-        broadcast(evk)
+        bcast_calls["evk_c3"] = broadcast(evk)
         rlk = P.PhantomRelinKey(evk)
 
         # ---- HomMul + relinearize + rescale (secondary figure, same parameter set) -------------------------
@@ -424,21 +439,30 @@ def main():
 
         # the same operation on a batch of B ciphertext pairs through the batched entry points (one set of launches:
         # key limbs read once, NTT / base-conversion launches B times larger).
-        B = 2 if small else int(os.environ.get("PHA_BENCH_BATCH", "8"))
-        bt1 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
-        bt2 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(B)])
+        # r04: a sweep over B; the best batch is the figure quoted as sustained HomMul + relinearize + rescale / s
+        sweep_B = [2] if small else [int(b) for b in os.environ.get("PHA_BENCH_BATCHES", "1,2,4,8,16,32").split(",")]
+        Bmax = max(sweep_B)
+        bt1 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(min(Bmax, 8))])
+        bt2 = torch.stack([torch.stack([uniform_residues(primes[:size_q], n, dev, gen) for _ in range(2)]) for _ in range(min(Bmax, 8))])
+        if Bmax > 8:   # the arithmetic is data-independent: the larger batches repeat the 8 seeded pairs
+            bt1 = bt1.repeat((Bmax + 7) // 8, 1, 1, 1)[:Bmax].contiguous()
+            bt2 = bt2.repeat((Bmax + 7) // 8, 1, 1, 1)[:Bmax].contiguous()
         b01 = torch.zeros_like(bt1)
-        b2 = torch.zeros((B, size_q, n), dtype=torch.int64, device=dev)
-        bout = torch.zeros((B, 2, size_q - 1, n), dtype=torch.int64, device=dev)
+        b2 = torch.zeros((Bmax, size_q, n), dtype=torch.int64, device=dev)
+        bout = torch.zeros((Bmax, 2, size_q - 1, n), dtype=torch.int64, device=dev)
+        batch_sweep = []
+        for B in sweep_B:
+            def hommul_batched():
+                ctx.tensor_prod_2x2_batched(bt1, bt2, b01, b2, size_q, B)
+                ctx.keyswitch_rescale_batched(size_q, b01, b2, B, rlk.public_keys_ptr, bout)
 
-        def hommul_batched():
-            ctx.tensor_prod_2x2_batched(bt1, bt2, b01, b2, size_q, B)
-            ctx.keyswitch_rescale_batched(size_q, b01, b2, B, rlk.public_keys_ptr, bout)
-
-        hb_steps = 2 if small else max(5, args.steps // 10)
-        for _ in range(2):
-            hommul_batched()
-        hm_batched_elapsed = timed(hommul_batched, hb_steps)
+            hb_steps = 2 if small else max(3, min(10, 64 // B))
+            for _ in range(2):
+                hommul_batched()
+            el = timed(hommul_batched, hb_steps)
+            batch_sweep.append({"batch": B, "ms_per_op": 1e3 * el / (B * hb_steps), "ops_per_s": world * B * hb_steps / el})
+        best = min(batch_sweep, key=lambda e: e["ms_per_op"])
+        B, hb_steps, hm_batched_elapsed = best["batch"], 1, best["ms_per_op"] * 1e-3 * best["batch"]
         # minimal per-stage traffic of one HomMul + relinearize + rescale at C3: 929 MiB
         hm_alg_bytes = 929.0 * (1 << 20)
         hm = {"value": world * hm_steps / hm_elapsed, "unit": "ops/s", "ms_per_op": 1e3 * hm_elapsed / hm_steps,
@@ -450,7 +474,8 @@ def main():
               "batched": {"value": world * B * hb_steps / hm_batched_elapsed, "unit": "ops/s",
                           "ms_per_op": 1e3 * hm_batched_elapsed / (B * hb_steps), "batch": B,
                           "frac_of_peak": hm_alg_bytes / (hm_batched_elapsed / (B * hb_steps)) / PEAK_HBM,
-                          "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_rescale_batched"}}
+                          "sweep": batch_sweep,
+                          "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_rescale_batched; the best batch of the sweep"}}
         del ct1, ct2, buf, out, bt1, bt2, b01, b2, bout, rlk, evk
 
         # ---- BASELINE config 4: BFV relinearize + Galois rotate, N = 2^15, 30 + 15 limbs, batch 64 over the ranks ----
@@ -461,12 +486,12 @@ def main():
         batch4 = 6 if small else C4_BATCH
         kgen = torch.Generator(device=dev)
         kgen.manual_seed(0x5EED0000 + 4)
-        keys4 = [torch.empty((2, len(primes4), n4), dtype=torch.int64, device=dev) for _ in range(2 * (q4 // SIZE_P))]
+        keys4 = key_slab(2 * (q4 // SIZE_P), (2, len(primes4), n4))
         if rank == 0:
             for k in keys4:
                 k[0] = uniform_residues(primes4, n4, dev, kgen)
                 k[1] = uniform_residues(primes4, n4, dev, kgen)
-        broadcast(keys4)                                    # relin key + one Galois key, RCCL broadcast from rank 0
+        bcast_calls["keys_c4"] = broadcast(keys4)           # relin key + one Galois key, RCCL broadcast from rank 0
         rlk4 = P.PhantomRelinKey(keys4[: q4 // SIZE_P])
         glk4 = P.PhantomRelinKey(keys4[q4 // SIZE_P:])
         mine = pdist.shard_range(batch4, rank, world)
@@ -493,7 +518,32 @@ def main():
         c4_elapsed = timed(c4_step, c4_steps)
         local_sum = int(res[0].sum().item()) & ((1 << 64) - 1) if len(mine) else 0
         sums = pdist.gather_checksums(local_sum - (1 << 64) if local_sum >= (1 << 63) else local_sum, device=red_dev)
+        # r04: the leg proves its own parity -- two of this rank's ciphertexts (first and last of the shard) against the oracle's
+        # composition of the restated reference steps (relinearize: keyswitch of c2 into (c0, c1); rotate: automorphism in the
+        # coefficient domain, key switch of the rotated c1), outside the timed region; the oracle is the checker, never the path
+        c4_checked = None
+        if not args.no_cpu_baseline:
+            import numpy as np
+            from oracle import oracle as O
+            oc4 = O.Ctx(C4_LOG_N, primes4, SIZE_P)
+            tool4 = O.Tool(oc4, q4)
+            h_keys = [P.to_host(k) for k in keys4]
+            half4 = q4 // SIZE_P
+            n_checked = 0
+            for i in (sorted({0, len(mine) - 1}) if len(mine) else []):
+                x = P.to_host(ct3[i])
+                ctk = tool4.keyswitch_inplace(x[:2], x[2], [h_keys[j] for j in range(tool4.beta)], O.BFV)
+                g_ = [oc4.apply_galois_coeff(ctk[p_], elt, q4) for p_ in range(2)]
+                want4 = tool4.keyswitch_inplace(np.stack([g_[0], np.zeros_like(g_[0])]), g_[1],
+                                                [h_keys[half4 + j] for j in range(tool4.beta)], O.BFV)
+                if not np.array_equal(P.to_host(out4[i]), want4):
+                    raise SystemExit(f"bench: config-4 ciphertext {mine[i]} differs from the oracle's composition")
+                n_checked += 1
+            all_checked = pdist.gather_checksums(n_checked, device=red_dev)
+            c4_checked = f"{sum(all_checked)} ciphertexts == oracle (first and last of every rank's shard, bit for bit)"
+            del h_keys, oc4, tool4
         c4 = {"value": batch4 * c4_steps / c4_elapsed, "unit": "relinearize+rotate ciphertexts/s (whole job)",
+              "checked": c4_checked,
               "batch": batch4, "scaling": "strong", "ms_per_ciphertext": 1e3 * c4_elapsed / (batch4 * c4_steps),
               "per_rank_ciphertexts": [len(pdist.shard_range(batch4, r, world)) for r in range(world)],
               "checksum": f"{sum(sums) & ((1 << 64) - 1):016x}",
@@ -578,13 +628,14 @@ def main():
         baby_elts = [pow(5, j, 2 * n) for j in range(nbaby)]
         giant_elts = [pow(5, nbaby * i, 2 * n) for i in range(ngiant)]
         n_keys = nbaby - 1 + ngiant - 1
-        gkeys = [[torch.empty((2, len(primes), n), dtype=torch.int64, device=dev) for _ in range(dnum5)] for _ in range(n_keys)]
+        flat5 = key_slab(n_keys * dnum5, (2, len(primes), n))    # ONE allocation for the whole Galois key set
+        gkeys = [flat5[i * dnum5:(i + 1) * dnum5] for i in range(n_keys)]
         if rank == 0:
             for key in gkeys:
                 for d in key:
                     d.copy_(below_every_prime((2, len(primes), n), kg))
         t_b0 = time.perf_counter()
-        broadcast([d for key in gkeys for d in key])      # one-time RCCL broadcast of the Galois keys from rank 0
+        bcast_calls5 = broadcast([d for key in gkeys for d in key])   # one-time RCCL broadcast of the Galois keys from rank 0
         torch.cuda.synchronize()
         bcast_s = time.perf_counter() - t_b0
         glks = [P.PhantomRelinKey(key) for key in gkeys]
@@ -618,19 +669,22 @@ def main():
               "per_rank_blocks": [len(pdist.shard_range(n_blocks, r, world)) for r in range(world)],
               "galois_keys": n_keys, "galois_key_bytes": key_bytes,
               "key_broadcast_s": bcast_s if (world > 1 or force_dist) else None,
+              "key_broadcast_calls": bcast_calls5 if (world > 1 or force_dist) else None,
               "checksum": f"{sum(sums5) & ((1 << 64) - 1):016x}",
               "checksum_note": "sum mod 2^64 of all output words of the row blocks; identical for every --gpus",
               "config": f"CKKS N=2^16, 45 + 15 limbs; out_b = sum_i rot_(nb i)(sum_j diag_(b, nb i + j) (.) rot_j(ct)), nb = {nbaby}: baby-step / "
                         f"giant-step with double hoisting (pha_hoisting_weighted_bsgs), {n_keys} Galois keys instead of {n_diag - 1}; no reference counterpart "
                         "(SURVEY 8(0) row C5; building blocks src/evaluate.cu:1670-1866, :1297-1340)"}
-        del gkeys, glks, blocks5, res5, pool5
+        del gkeys, glks, blocks5, res5, pool5, flat5
 
     if rank == 0:
         alg_bytes = 16.0 * n * size_q * nb             # 8 B read + 8 B write per coefficient
         achieved = alg_bytes / (kernel_ms * 1e-3)
         one = 16.0 * n * size_q
         traffic = load_traffic()
-        ceiling = max(own_copy_bps, copy_bps) / 2.0 / PEAK_HBM   # two passes: every coefficient crosses the fabric twice each way
+        # two in-place passes: every coefficient is read and written twice, so the algorithmic rate cannot exceed half the rate of an
+        # in-place read-modify-write stream (r04: measured with the calibration kernels, not with the r01-r03 grid-stride copy)
+        ceiling = cal["rmw_GBps"] * 1e9 / 2.0 / PEAK_HBM
         line = {
             "metric": "forward NTT limb-transforms/s at N=2^16, 45 RNS moduli",
             "value": ntt_per_s, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -652,15 +706,25 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
                          "per_step_events": step_stats,
                          "calibrated_copy_GBps": own_copy_bps / 1e9,
-                         "calibrated_note": "512 MiB device-to-device copy by the library's own 16-byte-per-lane streaming kernel "
-                                            "(pha_time_stream_copy), read + write bytes / time, this run",
+                         "read_GBps": cal["read_GBps"], "write_GBps": cal["write_GBps"], "copy_GBps": cal["copy_GBps"],
+                         "rmw_GBps": cal["rmw_GBps"],
+                         "calibrated_note": "512 MiB per operand, one 16-byte word per lane, one trip per thread (pha_time_stream; the "
+                                            "form of tools/stream_calib.hip that reaches the guide's float4-copy rate), best of default / "
+                                            "nontemporal policy, (bytes read + bytes written) / time, this run; rmw = in-place "
+                                            "read-modify-write, what an in-place pass does",
+                         "kernel_memory_floor_ms": 0.245,
+                         "kernel_memory_floor_note": "the two pass kernels with their butterflies compiled out (r03 plan, "
+                                                     "profiles/r04_experiments.md): 245 us per step = 0.385 of 8 TB/s; the VALU "
+                                                     "side of the same kernels is 2 x ~123 us at the 1.85 GHz the part holds under "
+                                                     "this load, so the passes are issue- and memory-bound at once",
                          "torch_copy_GBps": copy_bps / 1e9, "guide_copy_GBps": 6290.0,
                          "ceiling_two_pass": ceiling, "frac_of_ceiling": achieved / PEAK_HBM / ceiling,
                          "ceiling_two_pass_guide": 6.29e12 / 2.0 / PEAK_HBM,
                          "frac_of_ceiling_guide": achieved / PEAK_HBM / (6.29e12 / 2.0 / PEAK_HBM),
                          "ceiling_note": "a two-pass transform moves every coefficient through the fabric twice in each "
-                                         "direction: algorithmic rate <= measured copy rate / 2; N = 2^16 (512 KiB per limb) "
-                                         "does not fit one CU's 160 KiB LDS, so no single-pass plan exists for it (DESIGN 4.1)"},
+                                         "direction: algorithmic rate <= measured in-place read-modify-write rate / 2; N = 2^16 (512 "
+                                         "KiB per limb) does not fit one CU's 160 KiB LDS, so no single-pass plan exists for it "
+                                         "(DESIGN 4.1)"},
             "single_polynomial": {
                 "mall_resident": dict(mall_stats, value=size_q / (mall_stats["mean_ms"] * 1e-3), unit="NTT/s (this rank)",
                                       frac_of_peak=one / (mall_stats["mean_ms"] * 1e-3) / PEAK_HBM,
@@ -674,6 +738,8 @@ def main():
             "matvec_c5": c5,
             "next_rows": extras,
             "rccl": comm,
+            "key_broadcast_calls": (bcast_calls if (world > 1 or force_dist) and not args.only_ntt else None),
+            "key_broadcast_path": pdist.LAST_BROADCAST_PATH,
             "collectives": ("RCCL (torch.distributed backend nccl)" if (world > 1 or force_dist) and not share else
                             "gloo (PHA_BENCH_SHARE_GPU)" if share and world > 1 else "none (one rank, no process group)"),
         }
@@ -683,16 +749,19 @@ def main():
         stages = load_stages()
         if hm is not None and stages:
             hm["stages"] = stages      # per-kernel us, algorithmic bytes and fraction of 8 TB/s from the committed kernel trace
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:      # rank 0 times it (for N > 1 the other ranks wait at the final barrier below)
             def gpu_forward(host_poly):   # the product path on the baseline's own input
                 d = P.to_device(host_poly, dev)
                 ctx.nwt_2d_radix8_forward_inplace(d, 45, 0)
                 return P.to_host(d)
-            line["cpu_baseline"] = cpu_baseline(primes, n, seconds=2.0 if small else 12.0, gpu_forward=gpu_forward)
+            line["cpu_baseline"] = cpu_baseline(primes, n, seconds=2.0 if small else 10.0, gpu_forward=gpu_forward)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
+        if not share:
+            torch.cuda.synchronize()
+        dist.barrier()                  # the other ranks leave only after rank 0 has printed the line (it times the CPU baseline last)
         dist.destroy_process_group()
 
 

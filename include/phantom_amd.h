@@ -13,6 +13,9 @@
  * All `uint64_t*` data arguments are DEVICE pointers owned by the caller, limb-major contiguous
  * `data[limb * N + coeff]`, values canonical in [0, q_limb).  No entry point
  * allocates caller-visible memory; scratch comes from a per-context, per-stream arena.
+ * Capturing calls into a hipGraph: warm the same call up once first (same level and batch: an arena grows on demand, and growth is
+ * an allocation), and capture on an EXPLICIT stream -- the arenas behind NULL / hipStreamPerThread belong to the calling host thread
+ * and are released when that thread exits, so a graph captured on them must not be replayed after the thread is gone.
  * Nothing here touches torch types.
  */
 #ifndef PHANTOM_AMD_H

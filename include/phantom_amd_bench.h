@@ -18,9 +18,14 @@ int pha_repeat_forward_ntt_batched(pha_context_t ctx, uint64_t *inout, size_t co
 int pha_time_forward_ntt(pha_context_t ctx, uint64_t *inout, size_t coeff_modulus_size, int iters,
                          void *stream, float *ms_out);
 
-/* device-to-device streaming copy of `bytes` bytes (a multiple of 16) with the library's own 16-byte-per-lane kernel, `iters`
- * times, timed with hipEvents on `stream`: bytes moved per second (read + write) in *bytes_per_s.  The calibrated counterpart of
- * the nominal 8 TB/s that the roofline object quotes beside it. */
+/* streaming calibration (r04; the in-library form of tools/stream_calib.hip): `iters` launches over `bytes` bytes (a multiple of 16),
+ * one 16-byte word per lane, one trip per thread, timed with hipEvents on `stream`.  mode 0 = copy src -> dst, 1 = read-only (src),
+ * 2 = write-only (dst), 3 = in-place read-modify-write of dst (what an in-place NTT pass does); nontemporal != 0 streams with the
+ * `nt` policy.  *bytes_per_s = bytes read + bytes written per second: the calibrated counterparts of the nominal 8 TB/s that the
+ * roofline object quotes beside them. */
+int pha_time_stream(uint64_t *dst, const uint64_t *src, size_t bytes, int mode, int nontemporal, int iters, void *stream,
+                    double *bytes_per_s);
+/* = pha_time_stream(dst, src, bytes, 0, 1, ...): the nontemporal copy */
 int pha_time_stream_copy(uint64_t *dst, const uint64_t *src, size_t bytes, int iters, void *stream, double *bytes_per_s);
 
 /* number of scratch arenas the context currently holds (one per explicit stream, one per live host thread for the per-thread and

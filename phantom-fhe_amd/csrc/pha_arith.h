@@ -16,6 +16,16 @@
 #define PHA_HD inline
 #endif
 
+// The FP64 residue arithmetic below (and every kernel that includes this header) relies on separately rounded
+// multiplies and adds: h = Y*W must round before fma(Y, W, -h) recovers its error term.  The rule is stated here, in
+// the source, so that it does not depend on the build's -ffp-contract flag (a CXXFLAGS override used to drop it):
+// at file scope the pragma holds to the end of the translation unit, i.e. for everything that includes this header.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+
 namespace pha {
 
 typedef uint64_t u64;

@@ -7,20 +7,24 @@ using namespace pha;
 
 namespace {
 
-// 16 bytes per lane, grid-stride, four loads in flight per lane: the plain streaming pattern of the guide's 6.29 TB/s float4 copy
+// Streaming kernels of the calibration (r04, tools/stream_calib.hip): ONE 16-byte word per lane, one trip per thread, a grid that
+// covers the buffer -- the form that reaches the guide's 6.29 TB/s float4 copy on this part.  (The r01-r03 kernel kept four loads in
+// flight per lane over a grid-stride loop and measured 4.8 TB/s on buffers beyond the MALL: more bytes in flight per lane run
+// slower, profiles/r04_stream_calibration.txt.)  MODE 0 copy, 1 read-only, 2 write-only, 3 in-place read-modify-write; NT = nontemporal.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void stream_copy_kernel(u32x4 *__restrict__ dst, const u32x4 *__restrict__ src, size_t words16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < words16; i += 4 * stride) {
-        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
-                    c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void stream_kernel(u32x4 *__restrict__ dst, const u32x4 *__restrict__ src, size_t words16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words16) return;
+    u32x4 v = {1u, 2u, 3u, 4u};
+    if (MODE != 2) v = NT ? __builtin_nontemporal_load((MODE == 3 ? (const u32x4 *)dst : src) + i) : (MODE == 3 ? (const u32x4 *)dst : src)[i];
+    if (MODE == 1) {
+        if (v.x + v.y + v.z + v.w == 0x12345678u && v.x == 0x9abcdef0u) dst[0] = v;   // keeps the load alive; practically never true
+        return;
     }
-    for (; i < words16; i += stride) dst[i] = src[i];
+    if (MODE == 3) v += 1u;
+    if (NT) __builtin_nontemporal_store(v, dst + i);
+    else dst[i] = v;
 }
 
 void need(const void *p) {
@@ -72,16 +76,28 @@ int pha_context_arena_count(pha_context_t ctx, size_t *count) {
     PHA_API_END
 }
 
-int pha_time_stream_copy(uint64_t *dst, const uint64_t *src, size_t bytes, int iters, void *stream, double *bytes_per_s) {
+int pha_time_stream(uint64_t *dst, const uint64_t *src, size_t bytes, int mode, int nontemporal, int iters, void *stream,
+                    double *bytes_per_s) {
     PHA_API_BEGIN
-    need(dst); need(src); need(bytes_per_s);
-    if (bytes == 0 || bytes % 16 || iters < 1) throw std::invalid_argument("bytes must be a positive multiple of 16, iters >= 1");
+    need(dst); need(bytes_per_s);
+    if (mode != 2 && mode != 3) need(src);
+    if (bytes == 0 || bytes % 16 || iters < 1 || mode < 0 || mode > 3) throw std::invalid_argument("bytes must be a positive multiple of 16, iters >= 1, mode 0..3");
     hipStream_t s = as_stream(stream);
     const size_t words16 = bytes / 16;
-    const unsigned blocks = (unsigned)std::min<size_t>((words16 + 255) / 256, 256 * 32);   // 32 workgroups per CU, grid-stride
+    const unsigned blocks = (unsigned)((words16 + 255) / 256);
+    u32x4 *d = reinterpret_cast<u32x4 *>(dst);
+    const u32x4 *sp = reinterpret_cast<const u32x4 *>(src);
     auto launch = [&]() {
-        hipLaunchKernelGGL(stream_copy_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<u32x4 *>(dst),
-                           reinterpret_cast<const u32x4 *>(src), words16);
+        switch (mode * 2 + (nontemporal ? 1 : 0)) {
+            case 0: hipLaunchKernelGGL((stream_kernel<0, false>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+            case 1: hipLaunchKernelGGL((stream_kernel<0, true>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+            case 2: hipLaunchKernelGGL((stream_kernel<1, false>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+            case 3: hipLaunchKernelGGL((stream_kernel<1, true>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+            case 4: hipLaunchKernelGGL((stream_kernel<2, false>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+            case 5: hipLaunchKernelGGL((stream_kernel<2, true>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+            case 6: hipLaunchKernelGGL((stream_kernel<3, false>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+            default: hipLaunchKernelGGL((stream_kernel<3, true>), dim3(blocks), dim3(256), 0, s, d, sp, words16); break;
+        }
         check_launch();
     };
     for (int i = 0; i < 3; i++) launch();
@@ -96,8 +112,12 @@ int pha_time_stream_copy(uint64_t *dst, const uint64_t *src, size_t bytes, int i
     PHA_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    *bytes_per_s = 2.0 * (double)bytes * iters / ((double)ms * 1e-3);
+    *bytes_per_s = ((mode == 0 || mode == 3) ? 2.0 : 1.0) * (double)bytes * iters / ((double)ms * 1e-3);
     PHA_API_END
+}
+
+int pha_time_stream_copy(uint64_t *dst, const uint64_t *src, size_t bytes, int iters, void *stream, double *bytes_per_s) {
+    return pha_time_stream(dst, src, bytes, 0, 1, iters, stream, bytes_per_s);
 }
 
 }  // extern "C"

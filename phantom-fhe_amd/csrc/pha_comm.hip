@@ -33,15 +33,25 @@ Rccl &rccl() {
     std::call_once(once, [] {
         const char *names[] = {std::getenv("PHA_RCCL_LIB"), "librccl.so", "librccl.so.1"};
         void *h = nullptr;
-        for (const char *name : names) {
-            if (!name || !*name) continue;
-            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);            // a copy this process already holds (e.g. PyTorch's)
-            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (h) {
-                r.origin = name;
-                break;
+        // two passes: first ANY copy this process already holds under one of the names (PyTorch's bundled librccl.so has the
+        // soname librccl.so.1 and lives outside the default search path) -- the caller's ncclComm_t was created by that copy and
+        // must go back into it; only when none is resident is a library loaded.  PHA_RCCL_LIB, when set, wins in both passes.
+        for (int pass = 0; pass < 2 && !h; pass++)
+            for (const char *name : names) {
+                if (!name || !*name) continue;
+                h = dlopen(name, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_GLOBAL));
+                if (h) {
+                    r.origin = name;
+                    break;
+                }
+                if (pass == 0 && name == names[0]) {   // an explicit override is loaded rather than passed over for a resident RCCL
+                    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                    if (h) {
+                        r.origin = name;
+                        break;
+                    }
+                }
             }
-        }
         if (!h) return;
         r.broadcast = reinterpret_cast<bcast_fn>(dlsym(h, "ncclBroadcast"));
         r.group_start = reinterpret_cast<void_fn>(dlsym(h, "ncclGroupStart"));

@@ -931,8 +931,17 @@ struct ThreadReaper {
     size_t id = 0;
     ~ThreadReaper() {
         if (!id) return;
-        std::lock_guard<std::mutex> lk(g_live_mu);
-        for (Context *c : g_live_contexts) c->release_thread_arenas(id);
+        // the blocks are unhooked under the locks and freed after them: hipFree waits for the device, and no other caller of any
+        // context should stall behind that wait (r03 advisor)
+        std::vector<std::unique_ptr<Arena>> dead;
+        {
+            std::lock_guard<std::mutex> lk(g_live_mu);
+            for (Context *c : g_live_contexts) c->release_thread_arenas(id, dead);
+        }
+        int dev = 0;
+        const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+        dead.clear();   // (~DevBuf: hipFree; device pointers are valid process-wide, the current device does not matter)
+        if (have_dev) (void)hipSetDevice(dev);
     }
 };
 thread_local ThreadReaper t_reaper;
@@ -949,13 +958,20 @@ void register_context(Context *c, bool alive) {
     else g_live_contexts.erase(std::remove(g_live_contexts.begin(), g_live_contexts.end(), c), g_live_contexts.end());
 }
 
-void Context::release_thread_arenas(size_t thread_number) {
+void Context::release_thread_arenas(size_t thread_number, std::vector<std::unique_ptr<Arena>> &dead) {
     std::lock_guard<std::mutex> lk(mu);
-    DeviceGuard on_device(device);
-    // (DevBuf's hipFree waits for the device, so nothing the exiting thread enqueued can still be using the block)
+    // (the caller frees `dead` outside the locks; DevBuf's hipFree waits for the device, so nothing the exiting thread enqueued can
+    //  still be using a block.  A hipGraph that the thread captured on hipStreamPerThread / the null stream has these pointers baked
+    //  in and must not be replayed after the thread has exited: capture on an explicit stream instead -- include/phantom_amd.h)
     for (auto *m : {&arenas, &outer_arenas})
-        for (auto it = m->begin(); it != m->end();)
-            it = it->first.second == thread_number ? m->erase(it) : std::next(it);
+        for (auto it = m->begin(); it != m->end();) {
+            if (it->first.second == thread_number) {
+                dead.push_back(std::move(it->second));
+                it = m->erase(it);
+            } else {
+                ++it;
+            }
+        }
 }
 
 Context::ArenaKey Context::arena_key(void *stream) {

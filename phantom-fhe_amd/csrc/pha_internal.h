@@ -262,7 +262,7 @@ struct Context {
     // real stream (or none) in every host thread, so those two handles get one arena per calling thread
     typedef std::pair<void *, size_t> ArenaKey;
     static ArenaKey arena_key(void *stream);
-    void release_thread_arenas(size_t thread_number);   // called when a host thread exits (pha_context.hip: ThreadReaper)
+    void release_thread_arenas(size_t thread_number, std::vector<std::unique_ptr<Arena>> &dead);   // a host thread exits (pha_context.hip: ThreadReaper)
     std::map<ArenaKey, std::unique_ptr<Arena>> arenas;
     std::map<ArenaKey, std::unique_ptr<Arena>> outer_arenas;   // for entry points that call other entry points (which use `arenas`)
     u64 *scratch_outer(void *stream, size_t words);

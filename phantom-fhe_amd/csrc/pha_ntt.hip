@@ -11,6 +11,7 @@
 #include "pha_ntt_core.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace pha {
 
@@ -24,8 +25,19 @@ namespace pha {
 // launches of >= 1024 tiles, bit 6 = one-wavefront workgroups in the contiguous pass (NttPlan variants 3 / 4), bit 7 = N = 4096
 // through the two-pass plans too, bit 8 = the one-workgroup plans of N = 8192 / 16384 for every launch size, bit 9 / 10 = always /
 // never both passes in one launch (L2 hand-off), bit 11 = polynomial-fastest, XCD-grouped block order in the contiguous pass of
-// batched launches.
-constexpr int kDefaultVariant = 1 | 32 | 64 | 2048;   // 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles of fewer than 8 polynomials, polynomial-fastest block order in large batched contiguous passes
+// batched launches, bit 12 (r04) = N = 2^16 as 64 x 1024 (NttPlan<16, 10>: strided tiles of 64 rows x 64 columns, i.e. 512-byte runs and
+// ONE exchange; 1024-point rows, two wavefronts each), bit 13 = the same with one wavefront x 16 coefficients per row (plan 12),
+// bit 14 = 2^16 as 128 x 512 (plan 8).  r04 (profiles/r04_experiments.md): 720 limbs 333 -> 317 us, one 45-limb polynomial 28.4 -> 26.5 us.
+#ifndef PHA_X_HOIST_C
+#define PHA_X_HOIST_C 0    // r04 experiment: twiddle request schedule of the contiguous pass (0 per round, 1 all up front, 2 one round ahead)
+#endif
+#ifndef PHA_X_HOIST_S
+#define PHA_X_HOIST_S 0
+#endif
+#ifndef PHA_X_VARIANT
+#define PHA_X_VARIANT (1 | 32 | 64 | 2048 | 4096)
+#endif
+constexpr int kDefaultVariant = PHA_X_VARIANT;   // 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles of fewer than 8 polynomials, polynomial-fastest block order in large batched contiguous passes, 2^16 = 64 x 1024   // 8 coefficients per thread, one-wavefront contiguous pass, on-the-fly twiddles for >= 1024 tiles of fewer than 8 polynomials, polynomial-fastest block order in large batched contiguous passes
 #if defined(PHA_EXPERIMENTS)
 std::atomic<int> g_ntt_variant{kDefaultVariant};
 static inline int ntt_variant() { return g_ntt_variant.load(std::memory_order_relaxed); }
@@ -73,6 +85,7 @@ struct NttKArgs {
     // batched launches, polynomial-fastest order: a 1-D grid in which the `batch` polynomials of one (tile, limb) run back to
     // back on ONE XCD (block b -> XCD b % 8), so that the twiddle rows they share are fetched into that L2 once
     uint32_t zfast_tiles;    // 0 = plain 3-D grid (tile, limb, polynomial); else tiles per limb of the 1-D form
+    uint32_t zfast_run;      // tiles of one polynomial that run back to back before the next polynomial's (a multiple of 8)
 };
 
 // Per-tile arguments of limb `twr` (absolute limb index in the buffer), tile `tile`.
@@ -196,16 +209,32 @@ __device__ __forceinline__ void exec_pass(const PassArgs &a, u64 *lds, int tid) 
     }
 }
 
+// r04 experiment hook: minimum wavefronts per SIMD asked of the compiler for the strided / contiguous pass (register budget 512 / n)
+#if defined(PHA_X_OCC_S) || defined(PHA_X_OCC_C)
+#ifndef PHA_X_OCC_S
+#define PHA_X_OCC_S 2
+#endif
+#ifndef PHA_X_OCC_C
+#define PHA_X_OCC_C 1
+#endif
+template <class C> constexpr int x_occ() { return C::WHOLE ? 1 : C::STRIDED ? (C::THREADS >= 512 ? PHA_X_OCC_S : 1) : (C::THREADS == 64 ? PHA_X_OCC_C : 1); }
+#define PHA_PASS_BOUNDS __launch_bounds__(C::THREADS, x_occ<C>())
+#else
+#define PHA_PASS_BOUNDS __launch_bounds__(C::THREADS)
+#endif
 template <class C, bool FWD, int EPI, bool FOLD, int HOIST>
-__global__ __launch_bounds__(C::THREADS) PHA_PASS_ATTR void ntt_pass_kernel(const NttKArgs k) {
+__global__ PHA_PASS_BOUNDS PHA_PASS_ATTR void ntt_pass_kernel(const NttKArgs k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *lds = reinterpret_cast<u64 *>(smem);
 
+    __builtin_amdgcn_s_setprio(3);   // until the first round's global loads are issued (PassProgram::run)
     uint32_t tile = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
     if (k.zfast_tiles) {
-        const uint32_t b = blockIdx.x, q = b >> 3;
-        z = q % k.batch;
-        const uint32_t group = (q / k.batch) * 8 + (b & 7u);
+        // block b = ((chunk * batch) + z) * run + i: the `run` adjacent (tile, limb) groups of a chunk for polynomial 0, then the same
+        // groups for polynomial 1, ...; run is a multiple of 8, so group i of every polynomial lands on XCD i % 8
+        const uint32_t b = blockIdx.x, per_chunk = k.zfast_run * k.batch, chunk = b / per_chunk, rem = b - chunk * per_chunk;
+        z = rem / k.zfast_run;
+        const uint32_t group = chunk * k.zfast_run + (rem - z * k.zfast_run);
         if (group >= k.zfast_tiles * k.sel.count) return;
         tile = group % k.zfast_tiles;
         y = group / k.zfast_tiles;
@@ -385,8 +414,13 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     kk.zfast_tiles = 0;   // (k.zfast_tiles is only the caller's request flag)
     if (!C::STRIDED && !C::WHOLE && k.zfast_tiles) {
         kk.zfast_tiles = tiles_per_limb;
+        kk.zfast_run = 8;
+#if defined(PHA_X_KNOBS)   // r04 experiment: longer runs of adjacent tiles per polynomial (env, read once; a multiple of 8)
+        static const unsigned run_x = std::getenv("PHA_X_ZRUN") ? (unsigned)std::atol(std::getenv("PHA_X_ZRUN")) : 8u;
+        kk.zfast_run = run_x;
+#endif
         const unsigned groups = tiles_per_limb * k.sel.count;
-        grid = dim3(((groups + 7) / 8) * 8 * k.batch, 1, 1);
+        grid = dim3(((groups + kk.zfast_run - 1) / kk.zfast_run) * kk.zfast_run * k.batch, 1, 1);
     }
     // (requesting all rounds' twiddles up front, HOIST 1, was measured again in r02 for the small launches of mod-down and
     //  rescale: no gain at any size)
@@ -396,7 +430,7 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
         PHA_HIP(hipGetDevice(&dev));
         const uint64_t bit = 1ull << (dev & 63);
         if (!(raised.load(std::memory_order_acquire) & bit)) {
-            PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<C, FWD, EPI, FOLD, 0>),
+            PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<C, FWD, EPI, FOLD, (C::WHOLE ? 0 : C::STRIDED ? PHA_X_HOIST_S : PHA_X_HOIST_C)>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             raised.fetch_or(bit, std::memory_order_release);
         }
@@ -404,7 +438,15 @@ static void launch_pass(const NttKArgs &k, hipStream_t s) {
     // (r03: a two-tiles-per-wavefront, software-pipelined form of the one-wavefront contiguous pass for small launches was
     //  measured and dropped -- half as many wavefronts with twice the work each lose more latency hiding than the overlap of
     //  one tile's stores with the next tile's butterflies gains: 45 limbs 17.3 -> 19.2 us, 32 limbs 15.0 -> 16.5 us)
-    hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, 0>), grid, dim3(C::THREADS), lds_bytes, s, kk);
+    constexpr int HX = C::WHOLE ? 0 : C::STRIDED ? PHA_X_HOIST_S : PHA_X_HOIST_C;
+#if defined(PHA_X_KNOBS)   // r04 experiment: cap the resident workgroups of a pass by padding its LDS request (bytes; env, read once)
+    static const size_t pad_s = std::getenv("PHA_X_LDS_S") ? (size_t)std::atol(std::getenv("PHA_X_LDS_S")) : 0;
+    static const size_t pad_c = std::getenv("PHA_X_LDS_C") ? (size_t)std::atol(std::getenv("PHA_X_LDS_C")) : 0;
+    const size_t lds_x = lds_bytes + (C::STRIDED ? pad_s : pad_c);
+    hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, HX>), grid, dim3(C::THREADS), lds_x, s, kk);
+#else
+    hipLaunchKernelGGL((ntt_pass_kernel<C, FWD, EPI, FOLD, HX>), grid, dim3(C::THREADS), lds_bytes, s, kk);
+#endif
     check_launch();
 }
 
@@ -799,6 +841,15 @@ static NttChoice choose_plan(Context &c, const LimbSel &sel, const NttExtra &x) 
     // tools/ks_trace.sh): a win of 0.4-1.1 us per launch pair up to 8 wavefronts per SIMD (2^16: 1-24 limbs, the 2 x 16-limb
     // inverse of key switch + rescale 14.9 -> 13.6 us; 2^15: every size up to 60 limbs), a loss of 1-2.5 us beyond (2^16: 40-60 limbs)
     if (ch.v == 3 && c.log_n >= 14 && c.log_n <= 16 && limb_polys * (c.n >> 8) <= (size_t)PHA_EPT4_MAX_WAVES) ch.v = 5;
+    // r04: N = 2^16 as 64 x 1024 for every launch that is not the first half of the fused mod-up (whose contiguous pass, with the key
+    // inner product as its epilogue, is the 256-point one-wavefront pass of plan 3)
+    if (c.log_n == 16 && (ch.v == 3 || ch.v == 4) && !x.first_pass_only) {
+        if (has(vv, 4096)) ch.v = 10;
+#if defined(PHA_EXPERIMENTS)
+        else if (has(vv, 8192)) ch.v = 12;
+        else if (has(vv, 16384)) ch.v = 8;
+#endif
+    }
     if (c.log_n == 12 && !has(vv, 128)) ch.whole = 12;
     if (c.log_n == 13 && !has(vv, 128) && (has(vv, 256) || limb_polys >= 64)) ch.whole = 13;
 #if defined(PHA_EXPERIMENTS)
@@ -818,6 +869,9 @@ template <int LOGN>
 static void forward_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream_t s) {
 #if defined(PHA_EXPERIMENTS)
     switch (ch.v) {
+        case 8: if constexpr (LOGN == 16) { forward_impl<16, 8>(k, epi, s); return; }
+        case 10: if constexpr (LOGN == 16) { forward_impl<16, 10>(k, epi, s); return; }
+        case 12: if constexpr (LOGN == 16) { forward_impl<16, 12>(k, epi, s); return; }
         case 5: if constexpr (LOGN >= 14 && LOGN <= 16) { forward_impl<LOGN, 5>(k, epi, s); return; }
         case 4: forward_impl<LOGN, 4>(k, epi, s, ch.fused); return;
         case 3: forward_impl<LOGN, 3>(k, epi, s, ch.fused); return;
@@ -828,6 +882,9 @@ static void forward_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream
 #else
     if constexpr (LOGN == 12) throw std::logic_error("N = 4096 has no two-pass plan in the product library");
     else if constexpr (LOGN == 13) forward_impl<LOGN, 3>(k, epi, s);   // (below 64 limb-polynomials: never 1024 tiles)
+    else if (ch.v == 10) {
+        if constexpr (LOGN == 16) forward_impl<16, 10>(k, epi, s);
+    }
     else if (ch.v == 4) forward_impl<LOGN, 4>(k, epi, s);
     else if (ch.v == 5) {
         if constexpr (LOGN >= 14 && LOGN <= 16) forward_impl<LOGN, PHA_SMALL_PLAN>(k, epi, s);
@@ -838,6 +895,9 @@ template <int LOGN>
 static void inverse_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream_t s) {
 #if defined(PHA_EXPERIMENTS)
     switch (ch.v) {
+        case 8: if constexpr (LOGN == 16) { inverse_impl<16, 8>(k, epi, s); return; }
+        case 10: if constexpr (LOGN == 16) { inverse_impl<16, 10>(k, epi, s); return; }
+        case 12: if constexpr (LOGN == 16) { inverse_impl<16, 12>(k, epi, s); return; }
         case 5: if constexpr (LOGN >= 14 && LOGN <= 16) { inverse_impl<LOGN, 5>(k, epi, s); return; }
         case 4: inverse_impl<LOGN, 4>(k, epi, s, ch.fused); return;
         case 3: inverse_impl<LOGN, 3>(k, epi, s, ch.fused); return;
@@ -848,6 +908,9 @@ static void inverse_two_pass(NttKArgs k, int epi, const NttChoice &ch, hipStream
 #else
     if constexpr (LOGN == 12) throw std::logic_error("N = 4096 has no two-pass plan in the product library");
     else if constexpr (LOGN == 13) inverse_impl<LOGN, 3>(k, epi, s);
+    else if (ch.v == 10) {
+        if constexpr (LOGN == 16) inverse_impl<16, 10>(k, epi, s);
+    }
     else if (ch.v == 4) inverse_impl<LOGN, 4>(k, epi, s);
     else if (ch.v == 5) {
         if constexpr (LOGN >= 14 && LOGN <= 16) inverse_impl<LOGN, PHA_SMALL_PLAN>(k, epi, s);

@@ -377,6 +377,56 @@ PHA_HD u64 coherent_load(const u64 *p) {
 #endif
 }
 
+// r04 experiment hook (compile-time, default off): cache policy of the coefficient traffic of a pass.  PHA_X_NT bits: 1 = strided pass
+// loads, 2 = strided pass stores, 4 = contiguous pass loads, 8 = contiguous pass stores are nontemporal (`nt`: streamed through the
+// L2 / MALL without displacing the twiddle rows).  tools/stream_calib.hip: an in-place read-modify-write stream runs at 5.9 TB/s with
+// the default policy and at 6.6 TB/s nontemporal on buffers beyond the MALL.
+#ifndef PHA_X_NT
+#define PHA_X_NT 0
+#endif
+template <class C, bool LOAD>
+constexpr bool x_nt() { return ((PHA_X_NT >> ((C::STRIDED ? 0 : 2) + (LOAD ? 0 : 1))) & 1) != 0; }
+#if defined(__clang__)
+typedef unsigned long long u64v2 __attribute__((ext_vector_type(2)));
+#endif
+template <bool NT>
+PHA_HD u64 gload(const u64 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
+template <bool NT>
+PHA_HD u64x2 gload2(const u64x2 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) {
+        const u64v2 t = __builtin_nontemporal_load(reinterpret_cast<const u64v2 *>(p));
+        return u64x2{t.x, t.y};
+    }
+#endif
+    return *p;
+}
+template <bool NT>
+PHA_HD void gstore(u64 *p, u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) {
+        __builtin_nontemporal_store(v, p);
+        return;
+    }
+#endif
+    *p = v;
+}
+template <bool NT>
+PHA_HD void gstore2(u64x2 *p, u64x2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) {
+        __builtin_nontemporal_store(u64v2{v.x, v.y}, reinterpret_cast<u64v2 *>(p));
+        return;
+    }
+#endif
+    *p = v;
+}
+
 // Load one round's registers: from global memory on the first round, else from LDS.
 // COH: the global input was produced by other workgroups of this launch (see coherent_load).
 template <class C, int RI, bool FROM_GLOBAL, bool COH = false>
@@ -427,13 +477,13 @@ PHA_HD void round_load(const PassArgs &a, const u64 *lds, int tid, u64 *reg) {
                 const u64x2 *p = reinterpret_cast<const u64x2 *>(a.in + global_index<C>(a, e0, v));
 #pragma unroll
                 for (int k = 0; k < K; k += 2) {
-                    u64x2 t = p[k >> 1];
+                    u64x2 t = gload2<x_nt<C, true>()>(p + (k >> 1));
                     rg[k] = t.x;
                     rg[k + 1] = t.y;
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < K; k++) rg[k] = a.in[global_index<C>(a, e0 + (k << LOGD), v)];
+                for (int k = 0; k < K; k++) rg[k] = gload<x_nt<C, true>()>(a.in + global_index<C>(a, e0 + (k << LOGD), v));
             }
         } else {
 #pragma unroll
@@ -555,13 +605,13 @@ PHA_HD void round_out(const PassArgs &a, u64 *lds, int tid, const u64 *reg) {
                     u64x2 t;
                     t.x = apply_epilogue_v<EPI>(rg[k], a, aux.x, acc.x);
                     t.y = apply_epilogue_v<EPI>(rg[k + 1], a, aux.y, acc.y);
-                    p[k >> 1] = t;
+                    gstore2<x_nt<C, false>()>(p + (k >> 1), t);
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     const size_t gidx = global_index<C>(a, e0 + (k << LOGD), v);
-                    a.out[gidx] = apply_epilogue<EPI>(rg[k], a, gidx);
+                    gstore<x_nt<C, false>()>(a.out + gidx, apply_epilogue<EPI>(rg[k], a, gidx));
                 }
             }
         } else {
@@ -620,6 +670,9 @@ struct PassProgram {
     // tile, more registers); otherwise each round requests its own when it starts (fewer registers).
     static constexpr int round_of(int seg) { return FWD ? seg : C::NR - 1 - seg; }
     PHA_HD static void load_twiddles(const PassArgs &a, int tid, u64x2 *twreg) {
+#if defined(PHA_X_NOCOMPUTE) && PHA_X_NOCOMPUTE >= 2
+        return;
+#endif
         if (HOIST == 1) {
             round_load_tw<C, 0>(a, tid, twreg);
             round_load_tw<C, 1>(a, tid, twreg);
@@ -631,6 +684,9 @@ struct PassProgram {
     }
     template <int SEG>
     PHA_HD static void segment_twiddles(const PassArgs &a, int tid, u64x2 *twreg) {
+#if defined(PHA_X_NOCOMPUTE) && PHA_X_NOCOMPUTE >= 2   // 2: no twiddle loads either
+        return;
+#endif
         if (HOIST == 0) round_load_tw<C, round_of(SEG)>(a, tid, twreg);
         if (HOIST == 2 && SEG + 1 < C::NR) round_load_tw<C, round_of(SEG + 1 < C::NR ? SEG + 1 : SEG)>(a, tid, twreg);
     }
@@ -641,6 +697,12 @@ struct PassProgram {
         constexpr bool first = SEG == 0, last = SEG == C::NR - 1;
         segment_twiddles<SEG>(a, tid, twreg);
         round_load<C, RI, first, COH>(a, lds, tid, reg);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // r04: ntt_pass_kernel starts every wavefront at raised priority, so that the ~100 scalar / address instructions in front of
+        // its global loads are not queued behind the butterflies of the older wavefronts of its SIMD (oldest-first issue): the loads
+        // go out at once, the butterflies then run at normal priority (720 limbs -2 %, tools/build_variant.sh prioA)
+        if (first) __builtin_amdgcn_s_setprio(0);
+#endif
         if (first && FWD && FIRST_PASS && a.pro_reduce) {  // uniform per workgroup
 #pragma unroll
             for (int i = 0; i < C::EPT; i++) reg[i] = barrett64(reg[i], a.q, a.pro_ratio1);
@@ -654,7 +716,9 @@ struct PassProgram {
 #pragma unroll
             for (int i = 0; i < C::EPT; i++) reg[i] = as_u64(fp_reduce(as_f64(reg[i]), a.fpm));
         }
+#if !defined(PHA_X_NOCOMPUTE)   // r04 timing experiment (wrong results): the pass without its butterflies = its memory + LDS floor
         round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
+#endif
         if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
     }
@@ -742,6 +806,16 @@ template <> struct NttPlan<16, 6> { using P1 = PassCfg<8, true, 2, 2, 2, 4, fals
 template <> struct NttPlan<14, 7> { using P1 = PassCfg<7, true, 2, 2, 2, 4, false, 12, false, 1>;  using P2 = NttPlan<14, 5>::P2; };
 template <> struct NttPlan<15, 7> { using P1 = PassCfg<7, true, 2, 2, 2, 4, false, 12, false, 1>;  using P2 = NttPlan<15, 5>::P2; };
 template <> struct NttPlan<16, 7> { using P1 = PassCfg<8, true, 2, 2, 2, 4, false, 12, false, 2>;  using P2 = NttPlan<16, 5>::P2; };
+// VARIANTS 8 / 9 (r04, experiments library, N = 2^16 only): 2^16 = 128 x 512 instead of 256 x 256 -- the strided pass's tile is 128 rows x 32
+// adjacent columns, so its global accesses are runs of 256 bytes instead of 128, and the contiguous pass transforms ONE 512-point
+// row per wavefront (three radix-8 rounds).  8: table-driven, 9: on-the-fly twiddles in the last round.
+template <> struct NttPlan<16, 8> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, false, 9>; };
+template <> struct NttPlan<16, 9> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  using P2 = PassCfg<9, false, 3, 3, 3, 8, true, 9>; };
+// VARIANTS 10 / 12 (r04; 10 is the product's plan for N = 2^16, 12 an experiment): 2^16 = 64 x 1024 -- strided tile = 64 rows x 64 adjacent columns (512-byte runs, two
+// radix-8 rounds, ONE exchange), contiguous pass = 1024-point rows: 10: two wavefronts per row (128 threads x 8, rounds 8-8-4-4),
+// 12: one wavefront per row with 16 coefficients per thread (rounds 16-8-8, no workgroup barrier).
+template <> struct NttPlan<16, 10> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<10, false, 3, 3, 2, 8, false, 10, false, 2>; };
+template <> struct NttPlan<16, 12> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<10, false, 4, 3, 3, 16, false, 10>; };
 // N = 4096: the whole transform in one 4096-coefficient tile (three radix-16 rounds, one launch, no intermediate)
 using WholePlan12 = PassCfg<12, false, 4, 4, 4, 16, false, 12, true>;
 // N = 8192: the same with a fourth (radix-2) round: one 8192-coefficient tile, 512 threads, 72 KiB of LDS

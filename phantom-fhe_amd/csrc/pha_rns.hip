@@ -1339,7 +1339,9 @@ static void rescale_ntt(Context &c, Tool &t, u64 *src, uint32_t polys, u64 *dst,
 // (their work rides on one inverse over the P limbs + the last data limb and ONE forward over 2 x (Ql - 1) limbs), and ct is
 // never written.  scratch `base` as laid out by the callers.
 static bool keyswitch_rescale_fusable(const Tool &t) {
-    return t.alpha > 1 && t.alpha <= (uint32_t)kBcRowPad && t.split_ok && t.p_to_ql_pinv.mont && t.size_ql >= 2;
+    // bconv_rescale_kernel hard-codes the 16-row padding and the 30 / 30 cuts of converter kind 1 (Montgomery entries)
+    return t.alpha > 1 && t.alpha <= (uint32_t)kBcRowPad && t.split_ok && t.p_to_ql_pinv.split_kind == 1 && t.p_to_ql_pinv.mont &&
+           t.p_to_ql_pinv.row_pad == (uint32_t)kBcRowPad && t.size_ql >= 2;
 }
 static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2, const u64 *const *rlk, u64 *dst, uint32_t B,
                               u64 *base, hipStream_t s) {
@@ -1588,10 +1590,20 @@ int pha_relinearize_rotate_batched(pha_context_t ctx, size_t size_Ql, const uint
         std::lock_guard<std::mutex> lk(c.lanes.mu);
         c.lanes.ensure();
         u64 *base[2] = {c.scratch(c.lanes.s[0], words), c.scratch(c.lanes.s[1], words)};
+        // (both lane arenas are reserved above, before the fork: nothing below allocates)
         PHA_HIP(hipEventRecord(c.lanes.fork, s));
         for (int l = 0; l < 2; l++) PHA_HIP(hipStreamWaitEvent(c.lanes.s[l], c.lanes.fork, 0));
-        size_t set = 0;
-        for (size_t b0 = 0; b0 < batch; b0 += C, set++) one_set(c.lanes.s[set & 1], base[set & 1], b0);
+        auto join = [&]() {   // whatever the lanes have been given so far is ordered before anything the caller enqueues on `stream` next
+            for (int l = 0; l < 2; l++)
+                if (hipEventRecord(c.lanes.join[l], c.lanes.s[l]) == hipSuccess) (void)hipStreamWaitEvent(s, c.lanes.join[l], 0);
+        };
+        try {
+            size_t set = 0;
+            for (size_t b0 = 0; b0 < batch; b0 += C, set++) one_set(c.lanes.s[set & 1], base[set & 1], b0);
+        } catch (...) {   // a failed launch must not leave work in flight on the internal streams behind an error code
+            join();
+            throw;
+        }
         for (int l = 0; l < 2; l++) {
             PHA_HIP(hipEventRecord(c.lanes.join[l], c.lanes.s[l]));
             PHA_HIP(hipStreamWaitEvent(s, c.lanes.join[l], 0));
@@ -1765,7 +1777,17 @@ static void bsgs_core(Context &c, Tool &t, const u64 *ct_in, size_t blocks, cons
         if (giant_elts[i] != 1 && !giant_glk[i]) throw std::logic_error("Galois key not present in hoisting");
         nk += giant_elts[i] != 1;
     }
-    if (nbk > 63 || nk * t.beta > 63) throw std::invalid_argument("too many steps for one call (at most 63 keyed baby steps)");
+    // what the unreduced 128-bit accumulators of the fused baby-step kernel hold: one s * w product per baby ENTRY (identity entries and
+    // repeated elements included) plus the P-scaled c0 / c1 term, each below q_max^2 -- floor(2^128 / q_max^2) - 1 terms (255 for
+    // primes up to 60 bits, 63 for the 61-bit primes the context also accepts); the giant steps' key products likewise
+    u64 qmax = 0;
+    for (uint32_t i = 0; i < c.size_qp; i++) qmax = std::max(qmax, c.primes[i]);
+    int qbits = 0;
+    while (qbits < 64 && (qmax >> qbits)) qbits++;
+    const size_t max_terms = qbits >= 64 ? 1 : ((size_t)1 << std::min(20, 128 - 2 * qbits)) - 1;
+    if (nb + 1 > max_terms || nk * t.beta > max_terms || nbk > 255)
+        throw std::invalid_argument("too many steps for one call: the 128-bit accumulators hold floor(2^128 / q_max^2) - 1 products (at most "
+                                    "254 baby entries for primes up to 60 bits, 62 for 61-bit primes)");
     if (2 * G > 65535 || blocks * nk * t.beta > 65535) throw std::invalid_argument("too many row blocks for one call");
     if (t.beta > 4) throw std::invalid_argument("more than 4 key-switch digits are not supported by the baby-step / giant-step form");
     bool any_null = false;

@@ -54,6 +54,16 @@ def stream_copy_rate(dst, src, iters=10):
     return rate.value
 
 
+def stream_rate(dst, src, mode, nontemporal=False, iters=10):
+    """bytes per second (read + written) of the library's streaming calibration kernels (phantom_amd_bench.h: pha_time_stream):
+    mode 0 copy src -> dst, 1 read-only, 2 write-only, 3 in-place read-modify-write of dst."""
+    rate = C.c_double()
+    nbytes = min(dst.numel() * dst.element_size(), src.numel() * src.element_size())
+    _lib.check(_lib.load().pha_time_stream(_ptr(dst), _ptr(src), nbytes - nbytes % 16, int(mode), int(bool(nontemporal)), iters, _stream(),
+                                           C.byref(rate)))
+    return rate.value
+
+
 def has_tuning():
     """True when the loaded library is the test-only experiments build (PHA_LIB_OVERRIDE=.../libphantom_amd_exp.so)."""
     return hasattr(_lib.load(), "pha_set_tuning")

@@ -29,13 +29,93 @@ def shard_range(batch, rank_, world_):
     return range(lo, lo + base + (1 if rank_ < rem else 0))
 
 
-def broadcast_keys(keys, src=0):
-    """Broadcast every key tensor ([2][#QP][N] int64) from src to all ranks, in place."""
-    if not _group():
-        return keys
+def _flat_runs(keys):
+    """Merge CONSECUTIVE key tensors of the list that lie back to back in one storage into flat 1-D views (slices of one
+    allocation per key set become ONE buffer); every other tensor stays as it is.  The list order is kept -- every rank must
+    issue the same sequence of collectives, so the result depends only on how the caller laid the keys out (which must be the
+    same on every rank: either one slab per key set everywhere, or separate tensors everywhere)."""
+    out, cur = [], None   # cur = [storage, first_byte, end_byte, dtype, device]
+    def flush():
+        nonlocal cur
+        if cur is not None:
+            st, lo, hi, dt, dev = cur
+            esz = torch.empty(0, dtype=dt).element_size()
+            out.append(torch.empty(0, dtype=dt, device=dev).set_(st, (lo - st.data_ptr()) // esz, ((hi - lo) // esz,)))
+            cur = None
     for k in keys:
-        dist.broadcast(k, src=src)
-    return keys
+        if not k.is_contiguous():
+            flush()
+            out.append(k)
+            continue
+        st = k.untyped_storage()
+        lo = k.data_ptr()
+        hi = lo + k.numel() * k.element_size()
+        if cur is not None and cur[0].data_ptr() == st.data_ptr() and cur[3] == k.dtype and lo == cur[2]:
+            cur[2] = hi
+        else:
+            flush()
+            cur = [st, lo, hi, k.dtype, k.device]
+    flush()
+    return out
+
+
+def _raw_nccl_comm(device):
+    """The default group's ncclComm_t (RCCL on ROCm) as an integer, or None (gloo, no group, torch without the accessor, or a
+    communicator that does not exist yet because no collective has run on `device`)."""
+    try:
+        pg = dist.distributed_c10d._get_default_group()
+        if dist.get_backend(pg) != "nccl":
+            return None
+        ptr = pg._get_backend(torch.device(device))._comm_ptr()
+        return int(ptr) or None
+    except Exception:
+        return None
+
+
+LAST_BROADCAST_PATH = None        # "pha_broadcast_keys" / "dist.broadcast": which form the last broadcast_keys call took
+BROADCAST_CHUNK_BYTES = 1 << 31   # one collective call moves at most 2 GiB (a C5 key set is 12 GiB per rank)
+
+
+def broadcast_keys(keys, src=0, ctx=None, direct=False):
+    """Broadcast every key tensor ([2][#QP][N] int64) from src to all ranks, in place, in as few collective calls as the
+    layout allows (192 per-tensor calls for the config-5 leg).
+
+    * default: tensors that lie back to back in one storage (slices of one allocation per key set) are merged into flat
+      views and each run is one `dist.broadcast`, split at BROADCAST_CHUNK_BYTES;
+    * `direct=True` with an RCCL group and `ctx` (a PhantomContext on this rank's device): all keys go through ONE
+      `pha_broadcast_keys` call per key size -- one ncclGroupStart / ncclGroupEnd around the set, on the process group's own
+      communicator (csrc/pha_comm.hip), the call a C / C++ job makes.  Opt-in: it has only ever run as a one-rank group
+      (no multi-GPU node was available to the build); falls back to the default when the communicator is not reachable.
+    Returns the number of collective calls issued (0 without a process group)."""
+    global LAST_BROADCAST_PATH
+    if not _group() or not keys:
+        return 0
+    calls = 0
+    if direct and ctx is not None and all(k.is_cuda and k.is_contiguous() for k in keys):
+        comm = _raw_nccl_comm(keys[0].device)
+        if comm is not None:
+            by_size = {}
+            for k in keys:
+                by_size.setdefault((k.numel(), k.element_size()), []).append(k)
+            if all(esz == 8 for _, esz in by_size):
+                torch.cuda.current_stream(keys[0].device).synchronize()   # the keys were written on torch's stream
+                for group in by_size.values():
+                    ctx.broadcast_keys(group, src, comm)
+                    calls += 1
+                torch.cuda.current_stream(keys[0].device).synchronize()   # one-time setup: hand the communicator back idle
+                LAST_BROADCAST_PATH = "pha_broadcast_keys"
+                return calls
+    LAST_BROADCAST_PATH = "dist.broadcast"
+    for t in _flat_runs(keys):
+        step = max(1, BROADCAST_CHUNK_BYTES // t.element_size()) if t.dim() == 1 and t.is_contiguous() else None
+        if step is None or t.numel() <= step:
+            dist.broadcast(t, src=src)
+            calls += 1
+        else:
+            for lo in range(0, t.numel(), step):
+                dist.broadcast(t[lo:lo + step], src=src)
+                calls += 1
+    return calls
 
 
 def max_over_ranks(seconds, device=None):

@@ -110,6 +110,7 @@ _SIGS = {
     "pha_time_forward_ntt": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)],
     "pha_repeat_forward_ntt_batched": [vp, vp, sz, sz, sz, sz, C.c_int, vp],
     "pha_time_stream_copy": [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_double)],
+    "pha_time_stream": [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_double)],
     "pha_context_arena_count": [vp, C.POINTER(C.c_size_t)],
 }
 # exported by the test-only experiments library alone (csrc/pha_experiments.h); bound when present

@@ -153,6 +153,14 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
         else EMU4(7);
         return 0;
     }
+    if (variant >= 9 && variant <= 12) {   // r04 experiment plans of N = 2^16: codes 9 / 10 -> plans 8 / 9 (128 x 512), 11 / 12 -> plans 10 / 12 (64 x 1024)
+        if (log_n != 16) return -2;
+        if (variant == 9) emu<16, 8>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else if (variant == 10) emu<16, 9>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else if (variant == 11) emu<16, 10>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else emu<16, 12>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        return 0;
+    }
 #define EMU_CASE(N) case N: if (variant == 4) emu<N, 4>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 3) emu<N, 3>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 2) emu<N, 2>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;
     switch (log_n) {
         EMU_CASE(12)

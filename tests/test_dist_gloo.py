@@ -28,8 +28,18 @@ def _worker(rank, world, port, batch, q):
         g = torch.Generator().manual_seed(1234)
         keys = [torch.randint(0, 1 << 50, (2, 3, 64), dtype=torch.int64, generator=g) if rank == 0
                 else torch.zeros((2, 3, 64), dtype=torch.int64) for _ in range(2)]
-        pd.broadcast_keys(keys, src=0)
+        assert pd.broadcast_keys(keys, src=0) == 2          # separately allocated tensors: one call each
         key_sum = int(sum(int(k.sum()) for k in keys))
+        # a key set cut out of ONE allocation (what bench.py does) travels as one flat buffer, split only at the chunk size
+        slab = torch.randint(0, 1 << 50, (5, 3, 2, 3, 64), dtype=torch.int64, generator=g) if rank == 0 \
+            else torch.zeros((5, 3, 2, 3, 64), dtype=torch.int64)
+        views = [slab[k][d] for k in range(5) for d in range(3)]
+        assert pd.broadcast_keys(views, src=0) == 1
+        key_sum += int(slab.sum())
+        slab2 = slab * 3 if rank == 0 else torch.zeros_like(slab)
+        pd.BROADCAST_CHUNK_BYTES = slab2[0].numel() * 8 * 2        # two keys per call: 5 keys -> 3 calls
+        assert pd.broadcast_keys([slab2[k][d] for k in range(5) for d in range(3)], src=0) == 3
+        key_sum += int(slab2.sum())
         mine = list(pd.shard_range(batch, rank, world))
         # "process" the shard: a per-ciphertext function of the index and the key only (no cross-rank data)
         local = sum((i * 2654435761 + key_sum) % (1 << 40) for i in mine)

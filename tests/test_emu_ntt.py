@@ -34,12 +34,14 @@ def pair(v, q):
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("bits", [40, 42, 43, 47, 48, 50, 60, 61])   # 42 / 47: just under the light-butterfly thresholds
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])   # 6: one-launch plans; 5 / 7 / 8: NttPlan variants 5 / 6 / 7
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12])   # 6: one-launch plans; 5 / 7 / 8: NttPlan variants 5 / 6 / 7; 9 / 11 / 12: the r04 splits of 2^16 (plans 8 / 10 / 12)
 def test_thread_program_matches_oracle(emu, log_n, bits, variant):
     if variant == 6 and log_n not in (12, 13, 14):
         pytest.skip("the one-launch plans exist for N = 4096, 8192 and 16384 only")
     if variant in (5, 7, 8) and log_n not in (14, 15, 16):
         pytest.skip("the four-coefficients-per-thread contiguous pass exists for N = 2^14 .. 2^16")
+    if variant in (9, 11, 12) and log_n != 16:
+        pytest.skip("the 128 x 512 and 64 x 1024 plans exist for N = 2^16")
     n = 1 << log_n
     code = log_n | (variant << 8)   # variant 1 = 8 coefficients per thread (512-thread workgroups); 2 = 1 + on-the-fly twiddles
     q = int(O.get_primes(n, bits, 1)[0])
@@ -112,3 +114,45 @@ def test_barrier_free_plans_are_wave_local(emu, log_n):
         assert emu.emu_check_wave_local(log_n, variant) == 0
     if log_n in (14, 15, 16):      # the four-coefficients-per-thread contiguous pass: one row per wavefront
         assert emu.emu_plan_is_wave_local(log_n, 5) == 2 and emu.emu_check_wave_local(log_n, 5) == 0
+
+
+def _has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+@pytest.mark.skipif(not _has_fma(), reason="host CPU has no FMA unit: contraction cannot happen")
+@pytest.mark.parametrize("cxx", ["g++", "/opt/rocm/lib/llvm/bin/clang++"])
+def test_fp64_path_does_not_depend_on_the_contract_flag(cxx, tmp_path):
+    """pha_arith.h states `fp contract(off)` itself: a build whose flags ask for contraction (-ffp-contract=fast with an
+    FMA unit to contract into) must still replay the FP64 butterflies bit-exactly for 40..50-bit primes, forward and
+    inverse, incl. the extreme-residue inputs."""
+    if not (os.path.exists(cxx) or cxx == "g++"):
+        pytest.skip(cxx + " not present")
+    out = str(tmp_path / "libemu_fast.so")
+    subprocess.check_call([cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-mfma", "-ffp-contract=fast", "-o", out,
+                           os.path.join(HERE, "emu", "emu_ntt.cpp")])
+    L = C.CDLL(out)
+    L.emu_ntt.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, C.c_uint64] + [u64p] * 5
+    z = np.zeros(2, dtype=np.uint64)
+    for log_n, variant in ((12, 6), (14, 4), (16, 4), (16, 5)):
+        n = 1 << log_n
+        for bits in (40, 43, 47, 50):
+            q = int(O.get_primes(n, bits, 1)[0])
+            tw, tws, itw, itws, ni, nis = O.ntt_tables(log_n, q)
+            c = O.Ctx(log_n, [q], 0)
+            r = rng_for(log_n * 1000 + bits)
+            itw_p = itw.copy()
+            itw_p[1] = int(itw[1]) * n % q
+            f = lambda w: np.ascontiguousarray(w.astype(np.float64)).view(np.uint64).copy()
+            f1 = lambda v: np.array([float(v), 0.0], dtype=np.float64).view(np.uint64).copy()
+            fcode = log_n | (variant << 8) | (1 << 16)
+            near_q = (q - 1 - r.integers(0, 1 << 16, n)).astype(np.uint64)
+            for x in (r.integers(0, q, n, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64), near_q):
+                got = np.zeros(n, dtype=np.uint64)
+                assert L.emu_ntt(fcode, 1, 1, p(x), p(got), q, p(f(tw)), p(z), p(z), p(z), p(z)) == 0
+                assert np.array_equal(got, c.nwt_forward(x.reshape(1, n), 1)[0])
+                assert L.emu_ntt(fcode, 0, 3, p(x), p(got), q, p(f(itw_p)), p(f1(ni)), p(f1(int(itw[1]))), p(z), p(z)) == 0
+                assert np.array_equal(got, c.nwt_backward(x.reshape(1, n), 1)[0])

@@ -24,7 +24,7 @@ def _run(extra_args, **extra_env):
 
 
 def test_bench_line_contract(gpu):
-    d = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline"], PHA_BENCH_BATCH="2")
+    d = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline"], PHA_BENCH_BATCHES="1,2")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -41,8 +41,15 @@ def test_bench_line_contract(gpu):
     assert d["config"]["polynomials_per_step"] * 45 * 65536 * 8 > 256 << 20
     assert r["per_step_events"]["steps"] >= 100 and r["per_step_events"]["median_ms"] > 0
     assert d["single_polynomial"]["mall_resident"]["value"] > 0 and d["single_polynomial"]["hbm_resident"]["value"] > 0
-    assert d["hommul_relin_rescale"]["value"] > 0 and d["hommul_relin_rescale"]["batched"]["batch"] == 2
+    hb = d["hommul_relin_rescale"]["batched"]
+    assert d["hommul_relin_rescale"]["value"] > 0 and [e["batch"] for e in hb["sweep"]] == [1, 2] and hb["batch"] in (1, 2)
+    assert abs(hb["ms_per_op"] - min(e["ms_per_op"] for e in hb["sweep"])) < 1e-9          # the quoted batch is the sweep's best
     assert d["keyswitch_c4"]["batch"] == 64 and d["keyswitch_c4"]["value"] > 0
+    assert d["keyswitch_c4"]["checked"] is None                                            # --no-cpu-baseline: the oracle is not touched
+    # r04 calibration: read-only / write-only / copy / in-place streams, each at a plausible fraction of the 8 TB/s line
+    for k in ("read_GBps", "write_GBps", "copy_GBps", "rmw_GBps"):
+        assert 2000.0 < r[k] < 8000.0, (k, r[k])
+    assert abs(r["ceiling_two_pass"] - r["rmw_GBps"] / 2 / 8000.0) < 1e-9
 
 
 def test_bench_two_ranks_self_spawned_reproduce_one_rank(gpu):
@@ -56,6 +63,23 @@ def test_bench_two_ranks_self_spawned_reproduce_one_rank(gpu):
     assert two["keyswitch_c4"]["per_rank_ciphertexts"] == [3, 3] and one["keyswitch_c4"]["per_rank_ciphertexts"] == [6]
     assert one["keyswitch_c4"]["checksum"] == two["keyswitch_c4"]["checksum"]
     assert two["value"] > 0 and two["hommul_relin_rescale"]["value"] > 0
+    # the key sets travel as one flat buffer each (one slab per set), not as one collective per [2][#QP][N] tensor
+    assert two["key_broadcast_calls"] == {"evk_c3": 1, "keys_c4": 1} and two["matvec_c5"]["key_broadcast_calls"] == 1
+    assert one["key_broadcast_calls"] is None
+    per_rank = two["rccl"]["per_rank"]
+    assert [p["rank"] for p in per_rank] == [0, 1]
+    import torch
+    if torch.cuda.device_count() >= 2:      # a multi-GPU box (ranks on their own devices): one PCI bus id per rank
+        assert len({p["pci_bus_id"] for p in per_rank}) == 2
+
+
+def test_bench_two_ranks_keep_the_cpu_baseline_and_check_config4(gpu):
+    """With the CPU baseline on (the default) a multi-rank line still carries `cpu_baseline` (rank 0 times it while the others
+    wait at the final barrier) and the config-4 leg states how many ciphertexts it compared with the oracle."""
+    two = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-graph", "--no-c5"], PHA_BENCH_SMALL="1", PHA_BENCH_SHARE_GPU="1")
+    assert two["n_gpus"] == 2 and two["cpu_baseline"]["value"] > 0 and two["cpu_baseline"]["kind"] == "port"
+    assert two["cpu_baseline"]["checked"].startswith("GPU forward NTT")
+    assert two["keyswitch_c4"]["checked"].startswith("4 ciphertexts == oracle")      # first and last of each rank's 3
 
 
 def test_bench_one_rank_through_rccl(gpu):
@@ -66,3 +90,10 @@ def test_bench_one_rank_through_rccl(gpu):
     rccl = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph"], PHA_BENCH_SMALL="1", PHA_BENCH_FORCE_DIST="1")
     assert rccl["collectives"].startswith("RCCL") and plain["collectives"].startswith("none")
     assert rccl["keyswitch_c4"]["checksum"] == plain["keyswitch_c4"]["checksum"] and rccl["n_gpus"] == 1
+    assert rccl["key_broadcast_calls"] == {"evk_c3": 1, "keys_c4": 1}
+    # the opt-in direct form: pha_broadcast_keys (one ncclGroupStart / End around the set) on the process group's OWN communicator
+    direct = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph"], PHA_BENCH_SMALL="1", PHA_BENCH_FORCE_DIST="1",
+                  PHA_BCAST_DIRECT="1")
+    assert direct["key_broadcast_path"] == "pha_broadcast_keys" and rccl["key_broadcast_path"] == "dist.broadcast"
+    assert direct["keyswitch_c4"]["checksum"] == plain["keyswitch_c4"]["checksum"]
+    assert direct["matvec_c5"]["checksum"] == plain["matvec_c5"]["checksum"]

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 # that loads it (PHA_LIB_OVERRIDE), which turns the variant sweep below on.
 EXPERIMENTS = os.path.basename(os.environ.get("PHA_LIB_OVERRIDE", "")) == "libphantom_amd_exp.so"
 needs_experiments = pytest.mark.skipif(not EXPERIMENTS, reason="needs libphantom_amd_exp.so (run by test_gpu_ntt_variants.py)")
-DEFAULT_VARIANT = 1 | 32 | 64 | 2048
+DEFAULT_VARIANT = 1 | 32 | 64 | 2048 | 4096
 
 
 def _ctx(name, gpu):
@@ -51,10 +51,11 @@ def test_forward_inverse_inplace(name, gpu, ntt_variant):
 # 353 / 361: bit 8 forces the one-launch plans of N = 8192 and N = 16384 for every launch size
 # 609 / 617 / 625: bit 9 sends every launch through the one-launch form (both passes in one kernel, L2 hand-off)
 # 2145: the default (bit 11: polynomial-fastest block order in batched contiguous passes)
-_VARIANTS = [0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361, 609, 617, 625, 1121, 2145]
+# 6241: the default (bit 12: N = 2^16 as 64 x 1024); 10337 / 18529: the one-wavefront 1024-point rows, 128 x 512
+_VARIANTS = [0, 1, 8, 9, 17, 25, 65, 73, 81, 225, 353, 361, 609, 617, 625, 1121, 2145, 6241, 10337, 18529]
 _VARIANT_IDS = ["ept16", "ept8", "ept16-int", "ept8-int", "ept8-ot", "ept8-ot-int", "ept8-wave", "ept8-wave-int", "ept8-ot-wave",
                 "two-pass-4096", "one-launch-8192-16384", "one-launch-8192-16384-int", "fused", "fused-int", "fused-ot", "never-fused",
-                "default"]
+                "r03-default", "default", "rows1024-one-wavefront", "split-128x512"]
 
 
 @pytest.fixture(params=_VARIANTS if EXPERIMENTS else [DEFAULT_VARIANT], ids=_VARIANT_IDS if EXPERIMENTS else ["product"])

@@ -350,3 +350,42 @@ def test_config5_bsgs_16_by_8_at_the_c3_parameter_set(gpu):
     ows = [[w_pool[(i * nb + j) % 4] for j in range(nb)] for i in range(ng)]
     want = tool.hoisting_weighted_bsgs(ct, baby, okb, giant, okg, ows, O.CKKS)
     assert np.array_equal(out, want)
+
+
+def test_config5_bench_shape_64_by_2_four_row_blocks_per_call(gpu):
+    """BASELINE config 5 at the shape bench.py's `matvec_c5` leg runs: 128 diagonals = 64 baby x 2 giant steps at
+    the CKKS set N = 2^16, 45 + 15 limbs, FOUR row blocks per call of pha_hoisting_weighted_bsgs_blocks (8 (block, giant step)
+    accumulators: the full width of the fused baby-step kernel, one pass over the 63 baby keys for the four blocks) -- every block
+    against the oracle's composition (Tool.hoisting_weighted_bsgs, src/evaluate.cu:1670-1866 steps).  Keys cycle over 3 buffers and
+    the diagonals over a pool of 5 plaintexts taken at a different offset in every block, as bench.py rotates its pool (the launches,
+    pointer tables and accumulations are the real ones; the oracle's cost stays at ~25 s per block)."""
+    import phantom_fhe_amd as P
+    from phantom_fhe_amd import workloads as W
+    name, ql, nb, ng, nblk = "c3_ckks16", 45, 64, 2, 4
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    tool = O.Tool(oc, ql)
+    r = rng_for(5130)
+    baby = [int(pow(5, k, 2 * n)) for k in range(nb)]
+    giant = [int(pow(5, nb * k, 2 * n)) for k in range(ng)]
+    key_pool = [_keys(r, primes, n, size_q // size_p) for _ in range(3)]
+    qlp_primes = [primes[i] for i in list(range(ql)) + [size_q + j for j in range(size_p)]]
+    w_pool = [uniform_poly(r, qlp_primes, n) for _ in range(5)]
+    ct = np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)])
+    d_key_pool = [P.PhantomRelinKey.from_numpy(k, gpu) for k in key_pool]
+    d_w_pool = [P.to_device(w, gpu) for w in w_pool]
+    d_bk = [None] + [d_key_pool[k % 3] for k in range(1, nb)]
+    d_gk = [None] + [d_key_pool[(k + 1) % 3] for k in range(1, ng)]
+    pick = lambda b, i, j: (i * nb + j + b) % 5          # block b takes the pool rotated by b
+    d_blocks = [[[d_w_pool[pick(b, i, j)] for j in range(nb)] for i in range(ng)] for b in range(nblk)]
+    d_ct = P.to_device(ct, gpu)
+    out = P.to_host(W.diag_matvec_bsgs_blocks(ctx, ql, d_ct, baby, d_bk, giant, d_gk, d_blocks, O.CKKS, per_call=4))
+    assert np.array_equal(P.to_host(d_ct), ct)                                  # the input ciphertext is only read
+    okb = [None] + [[key_pool[k % 3][i] for i in range(tool.beta)] for k in range(1, nb)]
+    okg = [None] + [[key_pool[(k + 1) % 3][i] for i in range(tool.beta)] for k in range(1, ng)]
+    for b in range(nblk):
+        ows = [[w_pool[pick(b, i, j)] for j in range(nb)] for i in range(ng)]
+        want = tool.hoisting_weighted_bsgs(ct, baby, okb, giant, okg, ows, O.CKKS)
+        assert np.array_equal(out[b], want), b

@@ -34,6 +34,44 @@ __device__ __forceinline__ void butterfly_step(u64 (&v)[8], bool b) {
     }
 }
 
+// r04: the same 8 x 8 transpose with the gfx950 VALU cross-lane instructions, which do NOT go through the LDS
+// pipe: register bit 2 <-> lane bit 5 by v_permlane32_swap (swaps the upper 32 lanes of one register with the lower 32 of another:
+// exactly one transposition step per register pair, one instruction per dword pair), register bit 1 <-> lane bit 4 by
+// v_permlane16_swap (odd rows of one register <-> even rows of the other), register bit 0 <-> lane bit 3 by DPP row_ror:8 moves
+// with a bank mask (lane i <- lane i ^ 8 inside a row of 16; two masked moves per dword pair).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int WHICH>
+__device__ __forceinline__ void swap_pair(unsigned &a, unsigned &b) {   // a = register with the bit clear, b = with the bit set
+    if (WHICH == 2) {
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r.x;
+        b = r.y;
+    } else if (WHICH == 1) {
+        const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r.x;
+        b = r.y;
+    } else {
+        // lanes with bit 3 clear (banks 0, 1 of each row) take b <- a of lane ^ 8; lanes with bit 3 set (banks 2, 3) take a <- b of lane ^ 8
+        const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x128 /* row_ror:8 */, 0xf, 0x3, false);
+        const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x128, 0xf, 0xc, false);
+        a = na;
+        b = nb;
+    }
+}
+template <int BIT>
+__device__ __forceinline__ void permlane_step(u64 (&v)[8]) {
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0++) {
+        if (r0 & (1 << BIT)) continue;
+        const int r1 = r0 | (1 << BIT);
+        unsigned a0 = (unsigned)v[r0], a1 = (unsigned)(v[r0] >> 32), b0 = (unsigned)v[r1], b1 = (unsigned)(v[r1] >> 32);
+        swap_pair<BIT>(a0, b0);
+        swap_pair<BIT>(a1, b1);
+        v[r0] = ((u64)a1 << 32) | a0;
+        v[r1] = ((u64)b1 << 32) | b0;
+    }
+}
+
 template <int MODE, int FILL>
 __global__ __launch_bounds__(64) void exch_kernel(u64 *out, int iters) {
     __shared__ u64 tile[2 * (256 + 32)];
@@ -64,6 +102,10 @@ __global__ __launch_bounds__(64) void exch_kernel(u64 *out, int iters) {
             butterfly_step<0>(v, (lane >> 2) & 1);
             butterfly_step<1>(v, (lane >> 3) & 1);
             butterfly_step<2>(v, (lane >> 4) & 1);
+        } else if (MODE == 3) {   // VALU cross-lane transposes over lane bits 3, 4, 5
+            permlane_step<0>(v);
+            permlane_step<1>(v);
+            permlane_step<2>(v);
         }
 #pragma unroll
         for (int f = 0; f < FILL; f++)   // VALU filler with the cost profile of the butterflies (v_fma_f64 rate)
@@ -104,12 +146,16 @@ int main() {
     for (int i = 0; i < 4; i++) printf(" %8.1f", run<0, 0>(w[i], 4096));
     printf("\n%-34s", "ds_swizzle butterflies, no filler");
     for (int i = 0; i < 4; i++) printf(" %8.1f", run<1, 0>(w[i], 4096));
+    printf("\n%-34s", "permlane swap + DPP, no filler");
+    for (int i = 0; i < 4; i++) printf(" %8.1f", run<3, 0>(w[i], 4096));
     printf("\n%-34s", "filler only (12 x 8 fma_f64)");
     for (int i = 0; i < 4; i++) printf(" %8.1f", run<2, 12>(w[i], 4096));
     printf("\n%-34s", "LDS round trip + filler");
     for (int i = 0; i < 4; i++) printf(" %8.1f", run<0, 12>(w[i], 4096));
     printf("\n%-34s", "ds_swizzle butterflies + filler");
     for (int i = 0; i < 4; i++) printf(" %8.1f", run<1, 12>(w[i], 4096));
+    printf("\n%-34s", "permlane swap + DPP + filler");
+    for (int i = 0; i < 4; i++) printf(" %8.1f", run<3, 12>(w[i], 4096));
     printf("\n");
     return 0;
 }
