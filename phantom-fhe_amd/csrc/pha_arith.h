@@ -218,6 +218,11 @@ struct FpMod {
     // 2^50.3), the full forward butterfly reaches q + 12 (q/2 + 1) < 7.1 q < 2^52.9 at q < 2^50 (integers below
     // 2^53 are exact and fp_mulmod's quotient stays within 3 there), and the inverse only runs light below 2^40
     // (round_compute in pha_ntt_core.h).
+    // r04: primes from 2^47 up to 2^50 run the forward transform on the light butterflies too, with the registers re-centred
+    // after the rounds PassProgram::fp_sched() (pha_ntt_core.h) names: with |values| <= M q entering a stage, |t| <= q (0.5 + 0.375 M)
+    // at q < 2^50, i.e. M -> 1.375 M + 0.5 per stage (1/2 -> 1.19 -> 2.13 -> 3.43 -> 5.22 from centred, 1 -> 1.88 -> 3.08 -> 4.73 ->
+    // 7.0 from canonical input); everything stays an exact integer while M < 8.  ct_light (below 2^47) marks the primes that
+    // need no re-centring inside a pass at all.
     bool ct_light, gs_light;
 };
 PHA_HD FpMod make_fpmod(u64 q) { return FpMod{(double)q, 1.0 / (double)q, (q >> 47) == 0, (q >> 42) == 0}; }

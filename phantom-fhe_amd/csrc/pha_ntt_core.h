@@ -531,7 +531,9 @@ PHA_HD void round_load_tw(const PassArgs &a, int tid, u64x2 *twreg) {
 }
 
 // Run one round's stages on the registers.
-template <class C, int RI, bool FWD, bool FOLD>
+// RECENTRE (forward FP64 path, primes of 47..50 bits): the round runs the LIGHT butterflies and ends by re-centring its registers
+// (PassProgram::fp_sched decides after which rounds; pha_arith.h has the magnitude argument).
+template <class C, int RI, bool FWD, bool FOLD, bool RECENTRE = false>
 PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twreg) {
     constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r;
     const u64 q4 = a.q << 2, nq = 0 - a.q;
@@ -556,8 +558,13 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
             u64 *rg = reg + gi * K;
             const u64x2 *t = twreg + C::tw_off(RI) + gi * (K - 1);
             if (FWD) {
-                if (a.fpm.ct_light) fp_ct_round<r, true>(rg, t, a.fpm);
-                else fp_ct_round<r, false>(rg, t, a.fpm);
+                // light butterflies for every prime below 2^50: below 2^47 a whole pass stays exact without any re-centring
+                // (ct_light); from 2^47 the registers are re-centred after the rounds fp_sched() names
+                fp_ct_round<r, true>(rg, t, a.fpm);
+                if (RECENTRE && !a.fpm.ct_light) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) rg[k] = as_u64(fp_reduce(as_f64(rg[k]), a.fpm));
+                }
             } else {
                 // stages of this pass already done (inverse order: rounds NR-1 .. 0), and whether it began canonical
                 constexpr int stage0 = C::LOGT - C::s0(RI) - r;
@@ -650,10 +657,55 @@ struct PassProgram {
     static constexpr bool FIRST_PASS = C::WHOLE || (FWD ? C::STRIDED : !C::STRIDED);
     static constexpr bool LAST_PASS = C::WHOLE || !(FWD ? C::STRIDED : !C::STRIDED);
 
-    // FP64 path: what just came from global memory becomes a small double.  First pass: canonical
-    // integers -> doubles; second pass: the lazy doubles of the first pass are centred again.
+    // Forward FP64 path for primes in [2^47, 2^50) (r04): LIGHT butterflies (8 operations instead of 11) plus a re-centring of the
+    // registers (3 operations per coefficient) after some rounds.  With |values| <= M q entering a stage, fp_mulmod_light returns
+    // |t| <= q (0.5 + 1.5 M q 2^-52) <= q (0.5 + 0.375 M) for q < 2^50, so a stage takes M to 1.375 M + 0.5 (pha_arith.h); every
+    // sum and every fma result stays an exact integer while M < 8 (2^53 / 2^50).  fp_sched() follows that bound through the pass
+    // in execution order, starting from 1 (canonical input, first pass) or 1/2 (centred input), and re-centres after a round when
+    // the next round would pass kFpLimit, and after the last round of a pass that is not the transform's last (so that the
+    // intermediate is stored centred and the next pass loads it as it is).  The last pass ends in fp_to_canon, which reduces
+    // anything below 2^53.  Rounds with on-the-fly twiddles keep the full butterflies (|t| <= q/2 + 1: M grows by 1/2 per stage).
+    static constexpr double kFpLimit = 7.5;
+    struct FpSched {
+        bool recentre[4];
+        double after[4];   // bound (units of q) of the registers when round i (execution order) has run, before any re-centring
+    };
+    static constexpr double fp_grow(double m, int stages, bool full) {
+        for (int i = 0; i < stages; i++) m = full ? m + 0.5 + 1e-6 : 1.375 * m + 0.5 + 1e-6;
+        return m;
+    }
+    static constexpr FpSched fp_sched() {
+        FpSched sc{};
+        double m = FIRST_PASS ? 1.0 : 0.5 + 1e-6;
+        for (int seg = 0; seg < C::NR; seg++) {
+            const int ri = FWD ? seg : C::NR - 1 - seg;
+            m = fp_grow(m, C::r(ri), C::ot_round(ri));
+            sc.after[seg] = m;
+            bool rc = false;
+            if (seg == C::NR - 1) rc = !LAST_PASS;
+            else {
+                const int rn = FWD ? seg + 1 : C::NR - 2 - seg;
+                rc = fp_grow(m, C::r(rn), C::ot_round(rn)) > kFpLimit;
+            }
+            sc.recentre[seg] = rc;
+            if (rc) m = 0.5 + 1e-6;
+        }
+        return sc;
+    }
+    static constexpr bool fp_sched_ok() {
+        const FpSched sc = fp_sched();
+        for (int seg = 0; seg < C::NR; seg++)
+            if (sc.after[seg] > kFpLimit) return false;
+        return true;
+    }
+    static_assert(!FWD || fp_sched_ok(), "forward FP64 path: a round would take the registers past 7.5 q (exactness needs < 8 q at 50 bits)");
+
+    // FP64 path: what just came from global memory becomes a small double.  First pass: canonical integers -> doubles; second
+    // pass: the doubles of the first pass -- centred already when the forward pass re-centred them before its store (primes from
+    // 2^47), lazy otherwise (the inverse, and the forward's never-re-centred path below 2^47) and then centred here.
     PHA_HD static void fp_after_global_load(const PassArgs &a, u64 *reg) {
         if (!PHA_FPSEL(a)) return;
+        if (!FIRST_PASS && FWD && !a.fpm.ct_light) return;   // (uniform)
 #pragma unroll
         for (int i = 0; i < C::EPT; i++)
             reg[i] = as_u64(FIRST_PASS ? fp_from_canon(reg[i]) : fp_reduce(as_f64(reg[i]), a.fpm));
@@ -717,7 +769,7 @@ struct PassProgram {
             for (int i = 0; i < C::EPT; i++) reg[i] = as_u64(fp_reduce(as_f64(reg[i]), a.fpm));
         }
 #if !defined(PHA_X_NOCOMPUTE)   // r04 timing experiment (wrong results): the pass without its butterflies = its memory + LDS floor
-        round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
+        round_compute<C, RI, FWD, FOLD && RI == 0, FWD && fp_sched().recentre[SEG]>(a, tid, reg, twreg);
 #endif
         if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
@@ -748,7 +800,7 @@ struct PassProgram {
         segment_twiddles<SEG>(a, tid, twreg);
         if (!first) round_load<C, RI, false>(a, lds, tid, reg);
         if (first) fp_after_global_load(a, reg);
-        round_compute<C, RI, FWD, FOLD && RI == 0>(a, tid, reg, twreg);
+        round_compute<C, RI, FWD, FOLD && RI == 0, FWD && fp_sched().recentre[SEG]>(a, tid, reg, twreg);
         if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
     }
