@@ -86,6 +86,7 @@ struct NttKArgs {
     // back on ONE XCD (block b -> XCD b % 8), so that the twiddle rows they share are fetched into that L2 once
     uint32_t zfast_tiles;    // 0 = plain 3-D grid (tile, limb, polynomial); else tiles per limb of the 1-D form
     uint32_t zfast_run;      // tiles of one polynomial that run back to back before the next polynomial's (a multiple of 8)
+    const u64 *h_primes;     // HOST copy of the context's primes (launchers only: which limbs run on the FP64 back end)
 };
 
 // Per-tile arguments of limb `twr` (absolute limb index in the buffer), tile `tile`.
@@ -206,6 +207,75 @@ __device__ __forceinline__ void exec_pass(const PassArgs &a, u64 *lds, int tid) 
         PassArgs b = a;
         b.fp = false;
         pass(b);
+    }
+}
+
+// ---- r04: the contiguous pass of BATCHED forward launches with the twiddles resident in registers ------------------------------
+// A tile of the contiguous pass (whole rows of limb j) needs the same twiddles for every polynomial of the batch.  ntt_pass_kernel
+// fetches them once per (tile, polynomial) -- 26 loads per thread with their address arithmetic, from the L2 when the
+// polynomial-fastest block order has kept the rows there.  Here one workgroup owns tile t of limb j for `zper` polynomials in a
+// row: on the FP64 back end it requests ALL rounds' twiddles once (8 bytes per entry: two registers each) and then walks its
+// polynomials -- 26 loads, their address arithmetic and their waits leave the loop, which is what an issue-bound pass is short of
+// (720 limbs at N = 2^16: 300 -> 274 us per step with 4 polynomials per workgroup; requesting the next polynomial's coefficients
+// during the current transform, a second register set, measured 1-2 % SLOWER and is not built).  Integer-back-end limbs (60-bit primes: 16-byte twiddle pairs would need 100+ registers) take the plain pass, one
+// (tile, polynomial) per workgroup, at the head of the same grid.
+// Work map of one launch: a 1-D grid, the integer-back-end limbs FIRST (their tiles are the longest: one polynomial per workgroup, so that
+// they run side by side from the start), then the FP64 limbs with zper polynomials per workgroup.
+struct ZloopMap {
+    uint32_t n_int, n_fp;      // limbs of each kind in the selection
+    uint32_t zper;             // polynomials per FP64 workgroup
+    uint32_t tiles;            // tiles per limb
+    uint32_t int_blocks;       // n_int * tiles * batch
+    uint8_t limb[128];         // selection-relative limb indices: the n_int integer limbs, then the n_fp FP64 limbs
+};
+template <class C, int EPI>
+__global__ __launch_bounds__(C::THREADS) void ntt_cpass_zloop_kernel(const NttKArgs k, const ZloopMap m) {
+    static_assert(!C::STRIDED && !C::WHOLE, "the batched form exists for the forward contiguous pass");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *lds = reinterpret_cast<u64 *>(smem);
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    uint32_t b = blockIdx.x;
+    PassArgs a;
+    if (b < m.int_blocks) {   // (uniform) integer back end: the plain pass on one (tile, limb, polynomial)
+        const uint32_t tile = b % m.tiles, rest = b / m.tiles, z = rest % k.batch, twr = k.sel.start + m.limb[rest / k.batch];
+        full_tile_args<C, true, EPI, false>(k, twr, z, tile, a);
+        exec_pass<C, true, EPI, false, 0, false>(a, lds, tid);
+        return;
+    }
+    b -= m.int_blocks;
+    const uint32_t tile = b % m.tiles, rest = b / m.tiles, zgroups = (k.batch + m.zper - 1) / m.zper;
+    const uint32_t twr = k.sel.start + m.limb[m.n_int + rest / zgroups];
+    const uint32_t z0 = (rest % zgroups) * m.zper, z1 = (z0 + m.zper < k.batch) ? z0 + m.zper : k.batch;
+    full_tile_args<C, true, EPI, false>(k, twr, z0, tile, a);
+    using Prog = PassProgram<C, true, EPI, false, 1, false>;   // HOIST 1: every round's twiddles before the loop
+    a.fp = true;
+    u64x2 twreg[C::TW_TOTAL];
+    Prog::load_twiddles(a, tid, twreg);
+    u64 reg[C::EPT];
+    for (uint32_t z = z0; z < z1; z++) {
+        PassArgs b = a;
+        if (k.batch > 1) {
+            const size_t dz = (size_t)(z - z0);
+            b.in += dz * k.in_stride;
+            b.out += dz * k.out_stride;
+            if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) b.aux += dz * k.aux_stride;
+            if (EPI == EPI_FWD_KSRESCALE) b.aux2 += dz * k.aux2_stride;
+        }
+        Prog::prefetch(b, tid, reg);             // (the first round's global loads)
+        __builtin_amdgcn_s_setprio(0);
+        Prog::template run_prefetched<0>(b, lds, tid, reg, twreg);
+        tile_sync<C>();
+        Prog::template run_prefetched<1>(b, lds, tid, reg, twreg);
+        if constexpr (Prog::NSEG >= 3) {
+            tile_sync<C>();
+            Prog::template run_prefetched<2>(b, lds, tid, reg, twreg);
+        }
+        if constexpr (Prog::NSEG == 4) {
+            tile_sync<C>();
+            Prog::template run_prefetched<3>(b, lds, tid, reg, twreg);
+        }
+        tile_sync<C>();   // the next polynomial's first round writes the same LDS words
     }
 }
 
@@ -509,6 +579,51 @@ static void inverse_whole(NttKArgs k, int epi, hipStream_t s) {
     else launch_pass<W, false, EPI_INV_CANON, true>(k, s);
 }
 
+// the batched, twiddle-resident contiguous pass (ntt_cpass_zloop_kernel): plain forward launches of >= 8 polynomials that fill the device
+// several times over (the headline step, the batched key switch's 2 B-polynomial transforms); zper polynomials per workgroup, chosen so
+// that the launch still holds >= 3 generations of wavefronts
+#ifndef PHA_ZLOOP_MIN_BATCH
+#define PHA_ZLOOP_MIN_BATCH 8
+#endif
+template <class C, int EPI>
+static bool launch_cpass_zloop(const NttKArgs &k, hipStream_t s) {
+    if (k.batch < (uint32_t)PHA_ZLOOP_MIN_BATCH || k.sel.excl_end > k.sel.excl_start || k.pro_src) return false;
+    const size_t n = (size_t)1 << k.log_n;
+    const unsigned tiles_per_limb = (unsigned)(n >> C::LOGTILE);
+    const size_t waves_per_poly = (size_t)tiles_per_limb * k.sel.count * (C::THREADS / 64);
+    // resident wavefront slots at this kernel's register budget (4 per SIMD) x 3 generations
+    const size_t want = (size_t)256 * 4 * 4 * 3;
+    uint32_t zper = k.batch;
+    while (zper > 4 && waves_per_poly * ((k.batch + zper - 1) / zper) < want) zper = (zper + 1) / 2;
+    if (waves_per_poly * ((k.batch + zper - 1) / zper) < want / 3) return false;   // too small a launch: the plain pass
+#if defined(PHA_X_KNOBS)
+    static const unsigned zper_x = std::getenv("PHA_X_ZPER") ? (unsigned)std::atol(std::getenv("PHA_X_ZPER")) : 0u;
+    if (zper_x) zper = zper_x;
+#endif
+    // which limbs of the selection run on the FP64 back end (the others: runs of consecutive limbs through the plain kernel)
+    auto is_fp = [&](uint32_t y) {
+        const uint32_t twr = k.sel.start + y, prime = twr >= k.sel.remap_from ? twr + k.sel.remap_add : twr;
+        return k.fpinfo != nullptr && (k.h_primes[prime] >> 50) == 0;
+    };
+    if (k.sel.count > 128) return false;
+    ZloopMap m{};
+    m.zper = zper;
+    m.tiles = tiles_per_limb;
+    for (uint32_t y = 0; y < k.sel.count; y++)
+        if (!is_fp(y)) m.limb[m.n_int++] = (uint8_t)y;
+    for (uint32_t y = 0; y < k.sel.count; y++)
+        if (is_fp(y)) m.limb[m.n_int + m.n_fp++] = (uint8_t)y;
+    if (m.n_fp * 2 < k.sel.count) return false;   // mostly wide primes: the plain pass for everything
+    m.int_blocks = m.n_int * tiles_per_limb * k.batch;
+    NttKArgs kk = k;
+    kk.zfast_tiles = 0;
+    const unsigned blocks = m.int_blocks + m.n_fp * tiles_per_limb * ((k.batch + zper - 1) / zper);
+    const size_t lds_bytes = (size_t)C::LDS_WORDS * sizeof(u64);
+    hipLaunchKernelGGL((ntt_cpass_zloop_kernel<C, EPI>), dim3(blocks), dim3(C::THREADS), lds_bytes, s, kk, m);
+    check_launch();
+    return true;
+}
+
 template <int LOGN, int VARIANT>
 static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nullptr) {
     using P1 = typename NttPlan<LOGN, VARIANT>::P1;
@@ -540,6 +655,15 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     launch_pass<P1, true, EPI_NONE, false>(k1, s);
     if (k.first_pass_only) return;
     // pass 1 ran in -> mid with the input stride; pass 2 reads mid and writes out with the output stride
+#if !defined(PHA_NO_ZLOOP)
+    if constexpr (VARIANT == 10) {   // the product's N = 2^16 plan: batched launches take the twiddle-resident contiguous pass
+        const bool done = epi == EPI_FWD_MODDOWN ? launch_cpass_zloop<P2, EPI_FWD_MODDOWN>(k, s)
+                          : epi == EPI_FWD_MODDOWN_ADD ? launch_cpass_zloop<P2, EPI_FWD_MODDOWN_ADD>(k, s)
+                          : epi == EPI_FWD_KSRESCALE ? launch_cpass_zloop<P2, EPI_FWD_KSRESCALE>(k, s)
+                                                     : launch_cpass_zloop<P2, EPI_FWD_CANON>(k, s);
+        if (done) return;
+    }
+#endif
     if (epi == EPI_FWD_MODDOWN) launch_pass<P2, true, EPI_FWD_MODDOWN, false>(k, s);
     else if (epi == EPI_FWD_MODDOWN_ADD) launch_pass<P2, true, EPI_FWD_MODDOWN_ADD, false>(k, s);
     else if (epi == EPI_FWD_KSRESCALE) launch_pass<P2, true, EPI_FWD_KSRESCALE, false>(k, s);
@@ -601,6 +725,7 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.aux2_stride = x.aux2_stride ? x.aux2_stride : x.poly_stride;
     k.sel = sel;
     k.log_n = c.log_n;
+    k.h_primes = c.primes.data();
     k.batch = x.batch ? x.batch : 1;
     k.poly_stride = x.poly_stride;
     k.in_stride = x.in_stride ? x.in_stride : x.poly_stride;

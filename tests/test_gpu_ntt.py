@@ -361,6 +361,34 @@ def test_one_launch_8192_takes_over_for_large_launches(gpu):
     assert np.array_equal(P.to_host(d), x)
 
 
+@pytest.mark.parametrize("batch", [8, 9, 16])
+def test_batched_forward_with_resident_twiddles_at_2_16(batch, gpu):
+    """r04: plain forward launches of >= 8 polynomials at N = 2^16 take the twiddle-resident contiguous pass (ntt_cpass_zloop_kernel:
+    the FP64 limbs walk `zper` polynomials per workgroup, the integer limbs run one (tile, polynomial) per workgroup at the head of
+    the same grid).  The C3 chain mixes both back ends (limb 0 is a 60-bit prime, limbs 1..44 are 50-bit); every polynomial against
+    the oracle, odd batch sizes included, plus a limb range that starts inside the chain."""
+    import phantom_fhe_amd as P
+    name = "c3_ckks16"
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    L = len(primes) - size_p
+    x = np.stack([uniform_poly(rng_for(700 + z), primes[:L], n) for z in range(batch)])
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_batched(d, L, 0, batch, L * n)
+    got = P.to_host(d)
+    for z in range(batch):
+        assert np.array_equal(got[z], oc.nwt_forward(x[z], L, 0)), z
+    ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
+    assert np.array_equal(P.to_host(d), x)
+    # limbs [0, 7) only (one integer limb + six FP64 limbs), the other limbs must stay untouched
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_batched(d, 7, 0, batch, L * n)
+    got = P.to_host(d)
+    for z in range(0, batch, 3):
+        assert np.array_equal(got[z, :7], oc.nwt_forward(x[z, :7], 7, 0)) and np.array_equal(got[z, 7:], x[z, 7:])
+
+
 @needs_experiments
 @pytest.mark.parametrize("lag", [0, 1, 2, 5])
 @pytest.mark.parametrize("name,batch", [("c2_ntt14", 3), ("c4_bfv15", 2), ("c3_ckks16", 2)])
@@ -386,7 +414,7 @@ def test_one_launch_transform_lags_and_batches(name, batch, lag, gpu):
             ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
             assert np.array_equal(P.to_host(d), x)
     finally:
-        P.set_tuning(0, 1 | 32 | 64 | 2048)
+        P.set_tuning(0, DEFAULT_VARIANT)
         P.set_tuning(3, 2)
 
 
@@ -411,7 +439,7 @@ def test_batched_launches_in_both_block_orders(name, batch, gpu):
             ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
             assert np.array_equal(P.to_host(d), x)
     finally:
-        P.set_tuning(0, 1 | 32 | 64 | 2048)
+        P.set_tuning(0, DEFAULT_VARIANT)
     assert np.array_equal(outs[0], outs[1])
     for z in range(batch):
         assert np.array_equal(outs[1][z], oc.nwt_forward(x[z], L, 0))

@@ -299,7 +299,8 @@ def test_hommul_relin_rescale_c3(gpu):
 
 # (config, live data limbs, batch): alpha = 2 / 3 / 15 incl. short last digits, the alpha = 1 fallback, both BASELINE sizes
 KSR_CASES = [("hyb12_a2", 6, 1), ("hyb12_a2", 5, 2), ("hyb12_a2", 2, 1), ("hyb13_a3", 9, 1), ("hyb13_a3", 7, 3), ("hyb13_a3", 4, 1),
-             ("c1_bfv4096", 2, 2), ("c2_ckks14", 8, 2), ("hyb14_a4", 8, 1), ("hyb14_a4", 5, 2), ("c4_bfv15", 30, 2), ("c4_bfv15", 17, 1), ("c3_ckks16", 45, 1), ("c3_ckks16", 31, 2)]
+             ("c1_bfv4096", 2, 2), ("c2_ckks14", 8, 2), ("hyb14_a4", 8, 1), ("hyb14_a4", 5, 2), ("c4_bfv15", 30, 2), ("c4_bfv15", 17, 1), ("c3_ckks16", 45, 1), ("c3_ckks16", 31, 2),
+             ("c3_ckks16", 45, 4)]   # 2 x 4 = 8 polynomials at N = 2^16: the twiddle-resident batched contiguous pass (r04) with the key switch + rescale epilogue
 
 
 @pytest.mark.parametrize("name,ql,batch", KSR_CASES)
@@ -473,7 +474,8 @@ def test_extreme_residues_and_empty_calls(gpu):
 
 @pytest.mark.parametrize("name,scheme,ql,batch", [("hyb12_a2", O.CKKS, 6, 3), ("hyb12_a2", O.CKKS, 5, 2), ("hyb13_a3", O.CKKS, 7, 4),
                                                   ("hyb12_a2", O.BFV, 6, 2), ("hyb12_a2", O.BGV, 6, 2), ("c1_bfv4096", O.CKKS, 2, 3),
-                                                  ("c4_bfv15", O.BFV, 30, 4), ("c3_ckks16", O.CKKS, 45, 2)])
+                                                  ("c4_bfv15", O.BFV, 30, 4), ("c3_ckks16", O.CKKS, 45, 2),
+                                                  ("c3_ckks16", O.CKKS, 45, 5)])   # 10 polynomials at N = 2^16: the r04 batched contiguous pass, mod-down epilogue
 def test_batched_keyswitch_and_tensor(name, scheme, ql, batch, gpu):
     """pha_keyswitch_inplace_batched / pha_tensor_prod_2x2_batched: every ciphertext of the batch must equal the
     single-ciphertext result (oracle), including short last digits and the alpha = 1 path."""

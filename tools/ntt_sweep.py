@@ -17,7 +17,7 @@ for log_n in LOGNS:
     n = 1 << log_n
     primes = [int(p) for p in P.coeff_modulus_create(n, [50] * 60)]
     ctx = P.PhantomContext(log_n, primes, 0, device=0)
-    for limbs, batch in ((1, 1), (10, 1), (60, 1), (60, 4), (60, 17), (60, 68)):
+    for limbs, batch in ((1, 1), (8, 1), (45, 1), (60, 1), (60, 4), (60, 17), (60, 68)):   # 1, 8, 45, 60, 240, 1020, 4080 limbs per launch
         total = limbs * batch
         if total * n * 8 > (2 << 30):
             continue

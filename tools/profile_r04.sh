@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-3 profile set, ONE command on the GPU box (TAG=r03x bash tools/profile_r03.sh): bench line, rocprofv3 kernel trace of the
+# Round-4 profile set (the r03 script under its new name), ONE command on the GPU box (TAG=r04x bash tools/profile_r04.sh): bench line, rocprofv3 kernel trace of the
 # same command (by kernel and by grid), the per-stage table of one HomMul (profiles/stages.json), PMC passes in their own runs
 # (SQ / LDS counters over the two small workloads, FETCH_SIZE / WRITE_SIZE traffic -> profiles/traffic.json).  Everything lands in
 # gpurun_out/ under the tag; copy the summaries into profiles/ (tools/collect_profiles.sh does that) and commit them WITH the
 # tree they were measured on -- bench.py prints the sha of traffic.json / stages.json so a stale file shows.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err

@@ -32,24 +32,26 @@ lib = lib[-(ops - 1) * PER_OP:]          # drop the first op (cold)
 ops -= 1
 table, pos = [], 0
 for label, frags, nbytes in STAGES:
-    us, grids = 0.0, []
+    us, grids, each = 0.0, [], []
     for j, frag in enumerate(frags):
         ks = [lib[o * PER_OP + pos + j] for o in range(ops)]
         assert all(frag in k["Kernel_Name"] for k in ks), (label, frag, ks[0]["Kernel_Name"])
-        us += sum(int(k["End_Timestamp"]) - int(k["Start_Timestamp"]) for k in ks) / ops / 1e3
+        one = sum(int(k["End_Timestamp"]) - int(k["Start_Timestamp"]) for k in ks) / ops / 1e3
+        each.append(round(one, 2))
+        us += one
         k0 = ks[0]
         grids.append(f'{int(k0["Grid_Size_X"]) // int(k0["Workgroup_Size_X"])}x{k0["Grid_Size_Y"]}x{k0["Grid_Size_Z"]}')
     pos += len(frags)
-    table.append({"stage": label, "grids": grids, "us": round(us, 2), "algorithmic_bytes": nbytes,
+    table.append({"stage": label, "grids": grids, "us": round(us, 2), "kernels_us": each, "algorithmic_bytes": nbytes,
                   "frac_of_8TBps": round(nbytes / (us * 1e-6) / 8e12, 4)})
 span = [(int(lib[o * PER_OP]["Start_Timestamp"]), int(lib[o * PER_OP + PER_OP - 1]["End_Timestamp"])) for o in range(ops)]
 worst = min(table, key=lambda t: t["frac_of_8TBps"])
 doc = {"per_op_us_sum_of_kernels": round(sum(t["us"] for t in table), 2),
        "per_op_us_first_start_to_last_end": round(sum(b - a for a, b in span) / ops / 1e3, 2),
        "furthest_below_roofline": worst["stage"], "stages": table, "ops_averaged": ops,
-       "source": "rocprofv3 --kernel-trace of tools/traffic_probe.py hommul (tools/profile_r03.sh)",
+       "source": "rocprofv3 --kernel-trace of tools/traffic_probe.py hommul (tools/profile_r04.sh)",
        "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}
 json.dump(doc, open(sys.argv[2], "w"), indent=1)
 for t in table:
-    print(f'{t["us"]:8.2f} us  {t["frac_of_8TBps"]:.3f}  {t["stage"]}  {t["grids"]}')
+    print(f'{t["us"]:8.2f} us  {t["frac_of_8TBps"]:.3f}  {t["stage"]}  {t["grids"]}  {t["kernels_us"]}')
 print("sum", doc["per_op_us_sum_of_kernels"], "span", doc["per_op_us_first_start_to_last_end"], "worst:", worst["stage"])
