@@ -228,9 +228,9 @@ struct ZloopMap {
     uint32_t int_blocks;       // n_int * tiles * batch
     uint8_t limb[128];         // selection-relative limb indices: the n_int integer limbs, then the n_fp FP64 limbs
 };
-template <class C, int EPI>
-__global__ __launch_bounds__(C::THREADS) void ntt_cpass_zloop_kernel(const NttKArgs k, const ZloopMap m) {
-    static_assert(!C::STRIDED && !C::WHOLE, "the batched form exists for the forward contiguous pass");
+template <class C, bool FWD, int EPI, bool FOLD>
+__global__ __launch_bounds__(C::THREADS) void ntt_zloop_kernel(const NttKArgs k, const ZloopMap m) {
+    static_assert(!C::WHOLE, "the batched form exists for the passes of the two-pass plans");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *lds = reinterpret_cast<u64 *>(smem);
     __builtin_amdgcn_s_setprio(3);
@@ -239,16 +239,16 @@ __global__ __launch_bounds__(C::THREADS) void ntt_cpass_zloop_kernel(const NttKA
     PassArgs a;
     if (b < m.int_blocks) {   // (uniform) integer back end: the plain pass on one (tile, limb, polynomial)
         const uint32_t tile = b % m.tiles, rest = b / m.tiles, z = rest % k.batch, twr = k.sel.start + m.limb[rest / k.batch];
-        full_tile_args<C, true, EPI, false>(k, twr, z, tile, a);
-        exec_pass<C, true, EPI, false, 0, false>(a, lds, tid);
+        full_tile_args<C, FWD, EPI, FOLD>(k, twr, z, tile, a);
+        exec_pass<C, FWD, EPI, FOLD, 0, false>(a, lds, tid);
         return;
     }
     b -= m.int_blocks;
     const uint32_t tile = b % m.tiles, rest = b / m.tiles, zgroups = (k.batch + m.zper - 1) / m.zper;
     const uint32_t twr = k.sel.start + m.limb[m.n_int + rest / zgroups];
     const uint32_t z0 = (rest % zgroups) * m.zper, z1 = (z0 + m.zper < k.batch) ? z0 + m.zper : k.batch;
-    full_tile_args<C, true, EPI, false>(k, twr, z0, tile, a);
-    using Prog = PassProgram<C, true, EPI, false, 1, false>;   // HOIST 1: every round's twiddles before the loop
+    full_tile_args<C, FWD, EPI, FOLD>(k, twr, z0, tile, a);
+    using Prog = PassProgram<C, FWD, EPI, FOLD, 1, false>;   // HOIST 1: every round's twiddles before the loop
     a.fp = true;
     u64x2 twreg[C::TW_TOTAL];
     Prog::load_twiddles(a, tid, twreg);
@@ -579,14 +579,14 @@ static void inverse_whole(NttKArgs k, int epi, hipStream_t s) {
     else launch_pass<W, false, EPI_INV_CANON, true>(k, s);
 }
 
-// the batched, twiddle-resident contiguous pass (ntt_cpass_zloop_kernel): plain forward launches of >= 8 polynomials that fill the device
+// the batched, twiddle-resident passes (ntt_zloop_kernel): plain launches of >= 8 polynomials that fill the device
 // several times over (the headline step, the batched key switch's 2 B-polynomial transforms); zper polynomials per workgroup, chosen so
 // that the launch still holds >= 3 generations of wavefronts
 #ifndef PHA_ZLOOP_MIN_BATCH
 #define PHA_ZLOOP_MIN_BATCH 8
 #endif
-template <class C, int EPI>
-static bool launch_cpass_zloop(const NttKArgs &k, hipStream_t s) {
+template <class C, bool FWD, int EPI, bool FOLD>
+static bool launch_zloop(const NttKArgs &k, hipStream_t s) {
     if (k.batch < (uint32_t)PHA_ZLOOP_MIN_BATCH || k.sel.excl_end > k.sel.excl_start || k.pro_src) return false;
     const size_t n = (size_t)1 << k.log_n;
     const unsigned tiles_per_limb = (unsigned)(n >> C::LOGTILE);
@@ -619,7 +619,7 @@ static bool launch_cpass_zloop(const NttKArgs &k, hipStream_t s) {
     kk.zfast_tiles = 0;
     const unsigned blocks = m.int_blocks + m.n_fp * tiles_per_limb * ((k.batch + zper - 1) / zper);
     const size_t lds_bytes = (size_t)C::LDS_WORDS * sizeof(u64);
-    hipLaunchKernelGGL((ntt_cpass_zloop_kernel<C, EPI>), dim3(blocks), dim3(C::THREADS), lds_bytes, s, kk, m);
+    hipLaunchKernelGGL((ntt_zloop_kernel<C, FWD, EPI, FOLD>), dim3(blocks), dim3(C::THREADS), lds_bytes, s, kk, m);
     check_launch();
     return true;
 }
@@ -652,15 +652,18 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
 #else
     (void)fused;
 #endif
+    // (the strided pass in the batched form measured SLOWER -- 720 limbs 282 -> 302 us: its twiddles are few and shared by a tile's columns,
+    //  and a 512-thread workgroup that walks several polynomials keeps its barrier schedule for all of them)
     launch_pass<P1, true, EPI_NONE, false>(k1, s);
     if (k.first_pass_only) return;
     // pass 1 ran in -> mid with the input stride; pass 2 reads mid and writes out with the output stride
 #if !defined(PHA_NO_ZLOOP)
-    if constexpr (VARIANT == 10) {   // the product's N = 2^16 plan: batched launches take the twiddle-resident contiguous pass
-        const bool done = epi == EPI_FWD_MODDOWN ? launch_cpass_zloop<P2, EPI_FWD_MODDOWN>(k, s)
-                          : epi == EPI_FWD_MODDOWN_ADD ? launch_cpass_zloop<P2, EPI_FWD_MODDOWN_ADD>(k, s)
-                          : epi == EPI_FWD_KSRESCALE ? launch_cpass_zloop<P2, EPI_FWD_KSRESCALE>(k, s)
-                                                     : launch_cpass_zloop<P2, EPI_FWD_CANON>(k, s);
+    if constexpr (VARIANT == 10 || VARIANT == 3 || VARIANT == 4) {   // the product's plans: batched launches take the twiddle-resident contiguous pass
+        using Z2 = typename NttPlan<LOGN, VARIANT == 4 ? 3 : VARIANT>::P2;   // (with the twiddles out of the loop there is nothing to form on the fly)
+        const bool done = epi == EPI_FWD_MODDOWN ? launch_zloop<Z2, true, EPI_FWD_MODDOWN, false>(k, s)
+                          : epi == EPI_FWD_MODDOWN_ADD ? launch_zloop<Z2, true, EPI_FWD_MODDOWN_ADD, false>(k, s)
+                          : epi == EPI_FWD_KSRESCALE ? launch_zloop<Z2, true, EPI_FWD_KSRESCALE, false>(k, s)
+                                                     : launch_zloop<Z2, true, EPI_FWD_CANON, false>(k, s);
         if (done) return;
     }
 #endif
@@ -695,6 +698,15 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     }
 #else
     (void)fused;
+#endif
+#if !defined(PHA_NO_ZLOOP)
+    if constexpr (VARIANT == 10 || VARIANT == 3 || VARIANT == 4) {   // batched launches: the contiguous pass with the twiddles resident (ntt_zloop_kernel)
+        using Z2 = typename NttPlan<LOGN, VARIANT == 4 ? 3 : VARIANT>::P2;
+        if (!launch_zloop<Z2, false, EPI_NONE, false>(k1, s)) launch_pass<P2, false, EPI_NONE, false>(k1, s);
+        if (epi == EPI_INV_SCALE) launch_pass<P1, false, EPI_INV_SCALE, true>(k, s);
+        else launch_pass<P1, false, EPI_INV_CANON, true>(k, s);
+        return;
+    }
 #endif
     launch_pass<P2, false, EPI_NONE, false>(k1, s);
     if (epi == EPI_INV_SCALE) launch_pass<P1, false, EPI_INV_SCALE, true>(k, s);
