@@ -702,7 +702,8 @@ def main():
                          "frac": achieved / PEAK_HBM,
                          "traffic": (traffic or {}).get("ntt_batched_bytes_per_launch"),
                          "traffic_source": traffic,
-                         "kernel": "ntt_pass_kernel pair (strided pass + contiguous pass)",
+                         "kernel": "ntt_pass_kernel (strided pass, 64 x 64 tiles) + ntt_zloop_kernel (contiguous pass, 1024-point rows, twiddles resident "
+                      "across the polynomials of the batch)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
                          "per_step_events": step_stats,
                          "calibrated_copy_GBps": own_copy_bps / 1e9,
@@ -712,11 +713,12 @@ def main():
                                             "form of tools/stream_calib.hip that reaches the guide's float4-copy rate), best of default / "
                                             "nontemporal policy, (bytes read + bytes written) / time, this run; rmw = in-place "
                                             "read-modify-write, what an in-place pass does",
-                         "kernel_memory_floor_ms": 0.245,
-                         "kernel_memory_floor_note": "the two pass kernels with their butterflies compiled out (r03 plan, "
-                                                     "profiles/r04_experiments.md): 245 us per step = 0.385 of 8 TB/s; the VALU "
-                                                     "side of the same kernels is 2 x ~123 us at the 1.85 GHz the part holds under "
-                                                     "this load, so the passes are issue- and memory-bound at once",
+                         "kernel_memory_floor_ms": 0.239,
+                         "kernel_memory_floor_note": "the two pass kernels with their butterflies compiled out (-DPHA_X_NOCOMPUTE build, "
+                                                     "profiles/r04j_bygrid_nocompute.csv): strided 110 + contiguous 129 us per step = "
+                                                     "0.395 of 8 TB/s; the FP64 work of the same step is ~84 operations per coefficient "
+                                                     "= 131 us of pure issue at the 1.85 GHz the part holds under this load, so the "
+                                                     "passes are issue- and memory-bound at once (profiles/r04_experiments.md)",
                          "torch_copy_GBps": copy_bps / 1e9, "guide_copy_GBps": 6290.0,
                          "ceiling_two_pass": ceiling, "frac_of_ceiling": achieved / PEAK_HBM / ceiling,
                          "ceiling_two_pass_guide": 6.29e12 / 2.0 / PEAK_HBM,

@@ -533,7 +533,9 @@ PHA_HD void round_load_tw(const PassArgs &a, int tid, u64x2 *twreg) {
 // Run one round's stages on the registers.
 // RECENTRE (forward FP64 path, primes of 47..50 bits): the round runs the LIGHT butterflies and ends by re-centring its registers
 // (PassProgram::fp_sched decides after which rounds; pha_arith.h has the magnitude argument).
-template <class C, int RI, bool FWD, bool FOLD, bool RECENTRE = false>
+// GSFULL (inverse FP64 path only): the round is too long for the light butterflies (sums double per stage: more than three stages
+// from centred input, more than two from canonical input) and runs the r01 butterflies, which re-centre the sums on their own schedule.
+template <class C, int RI, bool FWD, bool FOLD, bool RECENTRE = false, bool GSFULL = false>
 PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twreg) {
     constexpr int r = C::r(RI), K = 1 << r, G = C::EPT >> r;
     const u64 q4 = a.q << 2, nq = 0 - a.q;
@@ -565,15 +567,29 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
 #pragma unroll
                     for (int k = 0; k < K; k++) rg[k] = as_u64(fp_reduce(as_f64(rg[k]), a.fpm));
                 }
-            } else {
+            } else if (a.fpm.gs_light) {   // (uniform) primes below 2^42: the r01 rules, no re-centring schedule
                 // stages of this pass already done (inverse order: rounds NR-1 .. 0), and whether it began canonical
                 constexpr int stage0 = C::LOGT - C::s0(RI) - r;
                 constexpr bool canon_in = !C::STRIDED;  // the inverse's first pass is the contiguous one
                 // unreduced sums double every stage: a LOGT-stage pass reaches 2^LOGT q, so the whole-transform plans
                 // (12 / 13 stages) only run light while that stays within 2^52 (inputs just below q do reach it)
-                const bool light = a.fpm.gs_light && (C::LOGT <= 9 || a.fpm.q < (double)(1ull << (52 - C::LOGT)));
+                const bool light = C::LOGT <= 9 || a.fpm.q < (double)(1ull << (52 - C::LOGT));
                 if (light) fp_gs_round<r, FOLD, true>(rg, t, a.fpm, a.ninv, a.w1ninv);
                 else fp_gs_round<r, FOLD, false, stage0, canon_in>(rg, t, a.fpm, a.ninv, a.w1ninv);
+            } else {
+                // r04: primes from 2^42: light butterflies (unreduced sums, fp_mulmod_light products) and a re-centring of the registers
+                // after the rounds PassProgram::fp_sched() names -- sums double per stage, so at most three stages run between two
+                // re-centrings (1/2 -> 1 -> 2 -> 4 q; the product's input |X - Y| stays below 8 q)
+                if (GSFULL) {   // from a fresh start: centred input, or canonical input in the first round of the first pass
+                    constexpr bool canon = RI == C::NR - 1 && (!C::STRIDED || C::WHOLE);
+                    fp_gs_round<r, FOLD, false, 0, canon>(rg, t, a.fpm, a.ninv, a.w1ninv);
+                } else {
+                    fp_gs_round<r, FOLD, true>(rg, t, a.fpm, a.ninv, a.w1ninv);
+                }
+                if (RECENTRE) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) rg[k] = as_u64(fp_reduce(as_f64(rg[k]), a.fpm));
+                }
             }
         }
         return;
@@ -657,7 +673,7 @@ struct PassProgram {
     static constexpr bool FIRST_PASS = C::WHOLE || (FWD ? C::STRIDED : !C::STRIDED);
     static constexpr bool LAST_PASS = C::WHOLE || !(FWD ? C::STRIDED : !C::STRIDED);
 
-    // Forward FP64 path for primes in [2^47, 2^50) (r04): LIGHT butterflies (8 operations instead of 11) plus a re-centring of the
+    // FP64 path for primes in [2^47, 2^50) going forward and [2^42, 2^50) going backward (r04): LIGHT butterflies (8 operations instead of 11) plus a re-centring of the
     // registers (3 operations per coefficient) after some rounds.  With |values| <= M q entering a stage, fp_mulmod_light returns
     // |t| <= q (0.5 + 1.5 M q 2^-52) <= q (0.5 + 0.375 M) for q < 2^50, so a stage takes M to 1.375 M + 0.5 (pha_arith.h); every
     // sum and every fma result stays an exact integer while M < 8 (2^53 / 2^50).  fp_sched() follows that bound through the pass
@@ -665,12 +681,21 @@ struct PassProgram {
     // the next round would pass kFpLimit, and after the last round of a pass that is not the transform's last (so that the
     // intermediate is stored centred and the next pass loads it as it is).  The last pass ends in fp_to_canon, which reduces
     // anything below 2^53.  Rounds with on-the-fly twiddles keep the full butterflies (|t| <= q/2 + 1: M grows by 1/2 per stage).
+    // The inverse's sums X + Y double per stage while the products (X - Y) W stay below q (0.5 + 0.75 M): M -> 2 M, so at most three
+    // stages from centred input (4 q) or two from canonical input run before a re-centring.
     static constexpr double kFpLimit = 7.5;
     struct FpSched {
         bool recentre[4];
+        bool full[4];      // inverse only: the round runs the self-re-centring butterflies (see round_compute GSFULL)
         double after[4];   // bound (units of q) of the registers when round i (execution order) has run, before any re-centring
     };
     static constexpr double fp_grow(double m, int stages, bool full) {
+        if (!FWD) {   // inverse: the sum X + Y doubles per stage, the product (X - Y) W comes back below q (0.5 + 0.75 M); rounds with
+                      // on-the-fly twiddles and GSFULL rounds re-centre sums themselves and stay below 2 q
+            if (full) return 2.0;
+            for (int i = 0; i < stages; i++) m = 2.0 * m + 1e-6;
+            return m;
+        }
         for (int i = 0; i < stages; i++) m = full ? m + 0.5 + 1e-6 : 1.375 * m + 0.5 + 1e-6;
         return m;
     }
@@ -679,7 +704,10 @@ struct PassProgram {
         double m = FIRST_PASS ? 1.0 : 0.5 + 1e-6;
         for (int seg = 0; seg < C::NR; seg++) {
             const int ri = FWD ? seg : C::NR - 1 - seg;
-            m = fp_grow(m, C::r(ri), C::ot_round(ri));
+            // (a round that is too long for the light inverse butterflies always starts fresh: from the pass's input, or behind the
+            //  re-centring that the previous round's look-ahead asked for)
+            sc.full[seg] = !FWD && !C::ot_round(ri) && fp_grow(m, C::r(ri), false) > kFpLimit;
+            m = fp_grow(m, C::r(ri), C::ot_round(ri) || sc.full[seg]);
             sc.after[seg] = m;
             bool rc = false;
             if (seg == C::NR - 1) rc = !LAST_PASS;
@@ -698,14 +726,14 @@ struct PassProgram {
             if (sc.after[seg] > kFpLimit) return false;
         return true;
     }
-    static_assert(!FWD || fp_sched_ok(), "forward FP64 path: a round would take the registers past 7.5 q (exactness needs < 8 q at 50 bits)");
+    static_assert(fp_sched_ok(), "FP64 path: a round would take the registers past 7.5 q (exactness needs < 8 q at 50 bits)");
 
     // FP64 path: what just came from global memory becomes a small double.  First pass: canonical integers -> doubles; second
     // pass: the doubles of the first pass -- centred already when the forward pass re-centred them before its store (primes from
     // 2^47), lazy otherwise (the inverse, and the forward's never-re-centred path below 2^47) and then centred here.
     PHA_HD static void fp_after_global_load(const PassArgs &a, u64 *reg) {
         if (!PHA_FPSEL(a)) return;
-        if (!FIRST_PASS && FWD && !a.fpm.ct_light) return;   // (uniform)
+        if (!FIRST_PASS && !(FWD ? a.fpm.ct_light : a.fpm.gs_light)) return;   // (uniform) the first pass stored centred values
 #pragma unroll
         for (int i = 0; i < C::EPT; i++)
             reg[i] = as_u64(FIRST_PASS ? fp_from_canon(reg[i]) : fp_reduce(as_f64(reg[i]), a.fpm));
@@ -769,7 +797,7 @@ struct PassProgram {
             for (int i = 0; i < C::EPT; i++) reg[i] = as_u64(fp_reduce(as_f64(reg[i]), a.fpm));
         }
 #if !defined(PHA_X_NOCOMPUTE)   // r04 timing experiment (wrong results): the pass without its butterflies = its memory + LDS floor
-        round_compute<C, RI, FWD, FOLD && RI == 0, FWD && fp_sched().recentre[SEG]>(a, tid, reg, twreg);
+        round_compute<C, RI, FWD, FOLD && RI == 0, fp_sched().recentre[SEG], fp_sched().full[SEG]>(a, tid, reg, twreg);
 #endif
         if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
@@ -800,7 +828,7 @@ struct PassProgram {
         segment_twiddles<SEG>(a, tid, twreg);
         if (!first) round_load<C, RI, false>(a, lds, tid, reg);
         if (first) fp_after_global_load(a, reg);
-        round_compute<C, RI, FWD, FOLD && RI == 0, FWD && fp_sched().recentre[SEG]>(a, tid, reg, twreg);
+        round_compute<C, RI, FWD, FOLD && RI == 0, fp_sched().recentre[SEG], fp_sched().full[SEG]>(a, tid, reg, twreg);
         if (last) fp_before_global_store(a, reg);
         round_out<C, RI, last, last ? EPI : (int)EPI_NONE>(a, lds, tid, reg);
     }
