@@ -10,8 +10,8 @@ trace() {  # name
 import sys
 sys.path.insert(0, "$R/tools")
 import summarize_prof as S
-S.by_grid("/tmp/prof_$1", "$OUT/r04j_bygrid_$1.csv")
-print("== $1"); print("".join(l for l in open("$OUT/r04j_bygrid_$1.csv") if "ntt_pass" in l))
+S.by_grid("/tmp/prof_$1", "$OUT/${TAG:-r04j}_bygrid_$1.csv")
+print("== $1"); print("".join(l for l in open("$OUT/${TAG:-r04j}_bygrid_$1.csv") if "ntt_pass" in l))
 PY
 }
 trace product
@@ -25,6 +25,6 @@ import sys
 sys.path.insert(0, "$R/tools")
 import summarize_prof as S
 for n in "abc":
-    S.pmc("/tmp/pmc_" + n, "$OUT/r04j_pmc_" + n + ".csv")
+    S.pmc("/tmp/pmc_" + n, "$OUT/${TAG:-r04j}_pmc_" + n + ".csv")
 PY
-grep -h "ntt_pass" $OUT/r04j_pmc_*.csv | sed 's/void ntt_pass_kernel//; s/(NttKArgs)//' | cut -d, -f1,7,8,9- | sort
+grep -h "ntt_pass" $OUT/${TAG:-r04j}_pmc_*.csv | sed 's/void ntt_pass_kernel//; s/(NttKArgs)//' | cut -d, -f1,7,8,9- | sort
