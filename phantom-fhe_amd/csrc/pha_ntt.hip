@@ -175,7 +175,8 @@ __device__ __forceinline__ void full_tile_args(const NttKArgs &k, uint32_t twr, 
 // uniform per workgroup): each copy is then scheduled and register-allocated like a kernel that has only that butterfly
 // back end (sweep at 2^16, 60 / 240 / 1020 limbs: 36.3 / 118 / 505 us with one shared body, 32.8 / 107 / 458 us specialised).
 // COH: the pass reads what other workgroups of this launch wrote (one-launch transform).
-template <class C, bool FWD, int EPI, bool FOLD, int HOIST, bool COH>
+// ONLY: 0 = both back ends (a.fp decides), 2 = the caller knows the limb runs on the integer back end (one body: fewer registers).
+template <class C, bool FWD, int EPI, bool FOLD, int HOIST, bool COH, int ONLY = 0>
 __device__ __forceinline__ void exec_pass(const PassArgs &a, u64 *lds, int tid) {
     u64 reg[C::EPT];
     u64x2 twreg[C::TW_TOTAL];
@@ -199,7 +200,7 @@ __device__ __forceinline__ void exec_pass(const PassArgs &a, u64 *lds, int tid) 
             Prog::template run<3>(pa, lds, tid, reg, twreg);
         }
     };
-    if (a.fp) {
+    if (ONLY != 2 && a.fp) {
         PassArgs b = a;
         b.fp = true;
         pass(b);
@@ -239,8 +240,9 @@ __global__ __launch_bounds__(C::THREADS) void ntt_zloop_kernel(const NttKArgs k,
     PassArgs a;
     if (b < m.int_blocks) {   // (uniform) integer back end: the plain pass on one (tile, limb, polynomial)
         const uint32_t tile = b % m.tiles, rest = b / m.tiles, z = rest % k.batch, twr = k.sel.start + m.limb[rest / k.batch];
+        if (limb_excluded(k, twr, z)) return;    // (uniform) the mod-up's rule: digit z does not transform its own limbs
         full_tile_args<C, FWD, EPI, FOLD>(k, twr, z, tile, a);
-        exec_pass<C, FWD, EPI, FOLD, 0, false>(a, lds, tid);
+        exec_pass<C, FWD, EPI, FOLD, 0, false, 2>(a, lds, tid);   // (integer body only: the map put no FP64 limb here)
         return;
     }
     b -= m.int_blocks;
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(C::THREADS) void ntt_zloop_kernel(const NttKArgs k,
     Prog::load_twiddles(a, tid, twreg);
     u64 reg[C::EPT];
     for (uint32_t z = z0; z < z1; z++) {
+        if (limb_excluded(k, twr, z)) continue;   // (uniform)
         PassArgs b = a;
         if (k.batch > 1) {
             const size_t dz = (size_t)(z - z0);
@@ -587,7 +590,7 @@ static void inverse_whole(NttKArgs k, int epi, hipStream_t s) {
 #endif
 template <class C, bool FWD, int EPI, bool FOLD>
 static bool launch_zloop(const NttKArgs &k, hipStream_t s) {
-    if (k.batch < (uint32_t)PHA_ZLOOP_MIN_BATCH || k.sel.excl_end > k.sel.excl_start || k.pro_src) return false;
+    if (k.batch < (uint32_t)PHA_ZLOOP_MIN_BATCH || k.pro_src) return false;
     const size_t n = (size_t)1 << k.log_n;
     const unsigned tiles_per_limb = (unsigned)(n >> C::LOGTILE);
     const size_t waves_per_poly = (size_t)tiles_per_limb * k.sel.count * (C::THREADS / 64);
