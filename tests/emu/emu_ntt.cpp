@@ -25,6 +25,22 @@ static void run_segments(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
     }
 }
 
+// the batched kernel's form of a pass (ntt_zloop_kernel): every round's twiddles requested once (HOIST 1), then per polynomial
+// prefetch (the first round's global loads) + run_prefetched
+static bool g_zloop_form = false;
+template <class Prog, int SEG>
+static void run_segments_prefetched(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
+    if constexpr (SEG == 0)
+        for (int tid = 0; tid < Prog::THREADS; tid++) {
+            Prog::load_twiddles(a, tid, g_twregs[tid]);
+            Prog::prefetch(a, tid, regs[tid]);
+        }
+    if constexpr (SEG < Prog::NSEG) {
+        for (int tid = 0; tid < Prog::THREADS; tid++) Prog::template run_prefetched<SEG>(a, lds, tid, regs[tid], g_twregs[tid]);
+        run_segments_prefetched<Prog, SEG + 1>(a, lds, regs);
+    }
+}
+
 template <class C, bool FWD, int EPI, bool FOLD>
 static void run_pass(PassArgs a, size_t n) {
     std::vector<u64> lds(C::LDS_WORDS);
@@ -32,7 +48,8 @@ static void run_pass(PassArgs a, size_t n) {
     const u32 tiles = (u32)(n >> C::LOGTILE);
     for (u32 t = 0; t < tiles; t++) {
         a.tile = t;
-        run_segments<PassProgram<C, FWD, EPI, FOLD, 2>, 0>(a, lds.data(), regs);
+        if (g_zloop_form && !C::STRIDED) run_segments_prefetched<PassProgram<C, FWD, EPI, FOLD, 1>, 0>(a, lds.data(), regs);
+        else run_segments<PassProgram<C, FWD, EPI, FOLD, 2>, 0>(a, lds.data(), regs);
     }
 }
 
@@ -139,6 +156,7 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
     const u64 *ax = reinterpret_cast<const u64 *>(aux);
     const int log_n = log_n_and_variant & 0xff, variant = (log_n_and_variant >> 8) & 0xff;
     const bool fp = (log_n_and_variant >> 16) & 1;
+    g_zloop_form = (log_n_and_variant >> 17) & 1;   // bit 17: the contiguous pass in the batched kernel's form
     if (variant == 6) {
         if (log_n == 12) emu_whole<WholePlan12>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
         else if (log_n == 13) emu_whole<WholePlan13>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);

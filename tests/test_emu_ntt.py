@@ -156,3 +156,37 @@ def test_fp64_path_does_not_depend_on_the_contract_flag(cxx, tmp_path):
                 assert np.array_equal(got, c.nwt_forward(x.reshape(1, n), 1)[0])
                 assert L.emu_ntt(fcode, 0, 3, p(x), p(got), q, p(f(itw_p)), p(f1(ni)), p(f1(int(itw[1]))), p(z), p(z)) == 0
                 assert np.array_equal(got, c.nwt_backward(x.reshape(1, n), 1)[0])
+
+
+@pytest.mark.parametrize("log_n,variant", [(14, 3), (15, 3), (16, 11), (17, 3)])
+@pytest.mark.parametrize("bits", [43, 50, 60])
+def test_batched_kernel_form_of_the_contiguous_pass(emu, log_n, variant, bits):
+    """ntt_zloop_kernel (r04) runs the contiguous pass as: every round's twiddles requested once, then per polynomial the first round's
+    global loads (`prefetch`) and `run_prefetched` for each segment.  Bit 17 of the replay's code selects that form: forward and
+    inverse, both back ends, the product's plans (3 for N != 2^16, 10 for N = 2^16), must equal the oracle."""
+    n = 1 << log_n
+    q = int(O.get_primes(n, bits, 1)[0])
+    tw, tws, itw, itws, ni, nis = O.ntt_tables(log_n, q)
+    c = O.Ctx(log_n, [q], 0)
+    r = rng_for(log_n * 7 + bits)
+    z = np.zeros(2, dtype=np.uint64)
+    itw_p, itws_p = itw.copy(), itws.copy()
+    itw_p[1] = int(itw[1]) * n % q
+    itws_p[1] = O.compute_shoup(int(itw_p[1]), q)
+    twi = np.ascontiguousarray(np.stack([tw, tws], axis=1).reshape(-1))
+    itwi = np.ascontiguousarray(np.stack([itw_p, itws_p], axis=1).reshape(-1))
+    code = log_n | (variant << 8) | (1 << 17)
+    for x in (r.integers(0, q, n, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64)):
+        got = np.zeros(n, dtype=np.uint64)
+        assert emu.emu_ntt(code, 1, 1, p(x), p(got), q, p(twi), p(z), p(z), p(z), p(z)) == 0
+        assert np.array_equal(got, c.nwt_forward(x.reshape(1, n), 1)[0])
+        assert emu.emu_ntt(code, 0, 3, p(x), p(got), q, p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q)), p(z), p(z)) == 0
+        assert np.array_equal(got, c.nwt_backward(x.reshape(1, n), 1)[0])
+        if bits <= 50:
+            f = lambda w: np.ascontiguousarray(w.astype(np.float64)).view(np.uint64).copy()
+            f1 = lambda v: np.array([float(v), 0.0], dtype=np.float64).view(np.uint64).copy()
+            fcode = code | (1 << 16)
+            assert emu.emu_ntt(fcode, 1, 1, p(x), p(got), q, p(f(tw)), p(z), p(z), p(z), p(z)) == 0
+            assert np.array_equal(got, c.nwt_forward(x.reshape(1, n), 1)[0])
+            assert emu.emu_ntt(fcode, 0, 3, p(x), p(got), q, p(f(itw_p)), p(f1(ni)), p(f1(int(itw[1]))), p(z), p(z)) == 0
+            assert np.array_equal(got, c.nwt_backward(x.reshape(1, n), 1)[0])
