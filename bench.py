@@ -702,7 +702,7 @@ def main():
                          "frac": achieved / PEAK_HBM,
                          "traffic": (traffic or {}).get("ntt_batched_bytes_per_launch"),
                          "traffic_source": traffic,
-                         "kernel": "ntt_pass_kernel (strided pass, 64 x 64 tiles) + ntt_zloop_kernel (contiguous pass, 1024-point rows, twiddles resident "
+                         "kernel": "ntt_pass_kernel (strided pass, 64 x 32 tiles) + ntt_zloop_kernel (contiguous pass, 1024-point rows, twiddles resident "
                       "across the polynomials of the batch)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
                          "per_step_events": step_stats,
