@@ -596,7 +596,9 @@ static bool launch_zloop(const NttKArgs &k, hipStream_t s) {
     const size_t waves_per_poly = (size_t)tiles_per_limb * k.sel.count * (C::THREADS / 64);
     // resident wavefront slots at this kernel's register budget (4 per SIMD) x 3 generations
     const size_t want = (size_t)256 * 4 * 4 * 3;
-    uint32_t zper = k.batch;
+    // polynomials per workgroup: the gain saturates at 4-8 (r04 sweep: 4 / 8 / 16 per workgroup -> 274 / 275 / 290 us per 720-limb step),
+    // so at most 8, split evenly over the workgroups of a tile, fewer while the launch would not fill the device three times
+    uint32_t zper = (k.batch + ((k.batch + 7) / 8) - 1) / ((k.batch + 7) / 8);
     while (zper > 4 && waves_per_poly * ((k.batch + zper - 1) / zper) < want) zper = (zper + 1) / 2;
     if (waves_per_poly * ((k.batch + zper - 1) / zper) < want / 3) return false;   // too small a launch: the plain pass
 #if defined(PHA_X_KNOBS)
