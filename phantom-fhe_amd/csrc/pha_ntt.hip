@@ -217,8 +217,7 @@ __device__ __forceinline__ void exec_pass(const PassArgs &a, u64 *lds, int tid) 
 // polynomial-fastest block order has kept the rows there.  Here one workgroup owns tile t of limb j for `zper` polynomials in a
 // row: on the FP64 back end it requests ALL rounds' twiddles once (8 bytes per entry: two registers each) and then walks its
 // polynomials -- 26 loads, their address arithmetic and their waits leave the loop, which is what an issue-bound pass is short of
-// (720 limbs at N = 2^16: 300 -> 274 us per step with 4 polynomials per workgroup; requesting the next polynomial's coefficients
-// during the current transform, a second register set, measured 1-2 % SLOWER and is not built).  Integer-back-end limbs (60-bit primes: 16-byte twiddle pairs would need 100+ registers) take the plain pass, one
+// (720 limbs at N = 2^16: 300 -> 274 us per step with 4 polynomials per workgroup).  Integer-back-end limbs (60-bit primes: 16-byte twiddle pairs would need 100+ registers) take the plain pass, one
 // (tile, polynomial) per workgroup, at the head of the same grid.
 // Work map of one launch: a 1-D grid, the integer-back-end limbs FIRST (their tiles are the longest: one polynomial per workgroup, so that
 // they run side by side from the start), then the FP64 limbs with zper polynomials per workgroup.
@@ -254,19 +253,20 @@ __global__ __launch_bounds__(C::THREADS) void ntt_zloop_kernel(const NttKArgs k,
     a.fp = true;
     u64x2 twreg[C::TW_TOTAL];
     Prog::load_twiddles(a, tid, twreg);
-    u64 reg[C::EPT];
-    for (uint32_t z = z0; z < z1; z++) {
-        if (limb_excluded(k, twr, z)) continue;   // (uniform)
+    // Polynomial z + 1's coefficients are requested before polynomial z is transformed (a second register set: 126 registers, still
+    // four wavefronts per SIMD): with the twiddles out of the loop those 8 loads are the only ones inside it, so no wait for anything
+    // else drains them early.  Forward step +-0, inverse step 285 -> 272 us (its contiguous pass is the transform's first).
+    u64 regA[C::EPT], regB[C::EPT];
+    auto args_of = [&](uint32_t z) __attribute__((always_inline)) {
         PassArgs b = a;
-        if (k.batch > 1) {
-            const size_t dz = (size_t)(z - z0);
-            b.in += dz * k.in_stride;
-            b.out += dz * k.out_stride;
-            if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) b.aux += dz * k.aux_stride;
-            if (EPI == EPI_FWD_KSRESCALE) b.aux2 += dz * k.aux2_stride;
-        }
-        Prog::prefetch(b, tid, reg);             // (the first round's global loads)
-        __builtin_amdgcn_s_setprio(0);
+        const size_t dz = (size_t)(z - z0);
+        b.in += dz * k.in_stride;
+        b.out += dz * k.out_stride;
+        if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD || EPI == EPI_FWD_KSRESCALE) b.aux += dz * k.aux_stride;
+        if (EPI == EPI_FWD_KSRESCALE) b.aux2 += dz * k.aux2_stride;
+        return b;
+    };
+    auto transform = [&](const PassArgs &b, u64 *reg) __attribute__((always_inline)) {
         Prog::template run_prefetched<0>(b, lds, tid, reg, twreg);
         tile_sync<C>();
         Prog::template run_prefetched<1>(b, lds, tid, reg, twreg);
@@ -279,6 +279,26 @@ __global__ __launch_bounds__(C::THREADS) void ntt_zloop_kernel(const NttKArgs k,
             Prog::template run_prefetched<3>(b, lds, tid, reg, twreg);
         }
         tile_sync<C>();   // the next polynomial's first round writes the same LDS words
+    };
+    auto next = [&](uint32_t z) __attribute__((always_inline)) {   // (uniform) first polynomial >= z that transforms this limb (mod-up: a digit skips its own)
+        while (z < z1 && limb_excluded(k, twr, z)) z++;
+        return z;
+    };
+    uint32_t z = next(z0);
+    if (z >= z1) return;
+    Prog::prefetch(args_of(z), tid, regA);
+    __builtin_amdgcn_s_setprio(0);
+    for (;;) {
+        uint32_t zn = next(z + 1);
+        if (zn < z1) Prog::prefetch(args_of(zn), tid, regB);
+        transform(args_of(z), regA);
+        if (zn >= z1) break;
+        z = zn;
+        zn = next(z + 1);
+        if (zn < z1) Prog::prefetch(args_of(zn), tid, regA);
+        transform(args_of(z), regB);
+        if (zn >= z1) break;
+        z = zn;
     }
 }
 
