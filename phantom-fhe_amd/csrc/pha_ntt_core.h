@@ -337,10 +337,30 @@ PHA_HD void gs_round(u64 *v, const u64x2 *t, u64 q4, u64 nq, u64x2 ninv, u64x2 w
 }
 
 // value-only form: aux / accumulate operands are passed in (so the caller can fetch them with 16-byte loads)
+// Epilogues that the FP64 path computes on the doubles themselves (r04): the integer forms cost a Shoup multiply (~17 vector
+// instructions on 64-bit halves) per product on top of the conversion; here x arrives as the last round's lazy double (below 7.5 q),
+// the operands are canonical words below 2^50, every product is an exact fp_mulmod_light (inputs below 2.4 q), and one fp_to_canon
+// ends it -- the same residues, bit for bit.
+constexpr bool fp_epilogue(int epi) {
+    return epi == EPI_FWD_MODDOWN || epi == EPI_FWD_MODDOWN_ADD || epi == EPI_FWD_KSRESCALE || epi == EPI_INV_SCALE;
+}
+template <int EPI>
+PHA_HD u64 apply_epilogue_fp(u64 x, const PassArgs &a, u64 aux, u64 acc) {
+    const FpMod m = a.fpm;
+    if (EPI == EPI_INV_SCALE) return fp_to_canon(fp_mulmod_light(as_f64(x), fp_from_canon(a.scale.x), m), m);   // |x| < 8 q -> |.| < 3.5 q
+    const double t = fp_reduce(as_f64(x), m);                                   // NTT value, centred
+    if (EPI == EPI_FWD_KSRESCALE) {   // (ct + cx * PInv - t) * q_last^-1 ; acc carries the ct word
+        const double u = fp_from_canon(acc) + fp_mulmod_light(fp_from_canon(aux), fp_from_canon(a.scale2.x), m);   // < 1.9 q
+        return fp_to_canon(fp_mulmod_light(u - t, fp_from_canon(a.scale.x), m), m);
+    }
+    const double r = fp_mulmod_light(fp_from_canon(aux) - t, fp_from_canon(a.scale.x), m);   // (cx - t) * PInv, input < 1.6 q
+    return fp_to_canon(EPI == EPI_FWD_MODDOWN_ADD ? r + fp_from_canon(acc) : r, m);
+}
 template <int EPI>
 PHA_HD u64 apply_epilogue_v(u64 x, const PassArgs &a, u64 aux, u64 acc) {
     const u64 q = a.q;
-    // the FP64 path hands over canonical residues already (fp_to_canon); PHA_FPSEL(a) is uniform per workgroup
+    if (fp_epilogue(EPI) && PHA_FPSEL(a)) return apply_epilogue_fp<EPI>(x, a, aux, acc);   // (uniform)
+    // otherwise the FP64 path hands over canonical residues (fp_to_canon in fp_before_global_store); PHA_FPSEL(a) is uniform per workgroup
     if (EPI == EPI_FWD_CANON) return PHA_FPSEL(a) ? x : csub(csub(csub(x, q << 2), q << 1), q);
     if (EPI == EPI_FWD_MODDOWN || EPI == EPI_FWD_MODDOWN_ADD) {
         const u64 t = PHA_FPSEL(a) ? x : csub(csub(csub(x, q << 2), q << 1), q);
@@ -741,6 +761,7 @@ struct PassProgram {
     // FP64 path, last pass: doubles -> canonical integers (the integer epilogue then sees [0,q))
     PHA_HD static void fp_before_global_store(const PassArgs &a, u64 *reg) {
         if (!PHA_FPSEL(a) || !LAST_PASS) return;
+        if (fp_epilogue(EPI)) return;   // the epilogue takes the doubles as they are (apply_epilogue_fp)
 #pragma unroll
         for (int i = 0; i < C::EPT; i++) reg[i] = fp_to_canon(as_f64(reg[i]), a.fpm);
     }

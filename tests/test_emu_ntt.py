@@ -103,6 +103,11 @@ def test_thread_program_matches_oracle(emu, log_n, bits, variant):
         assert emu.emu_ntt(code, 1, 2, p(x), p(out), q, p(twi), p(z), p(z), p(pair(s, q)), p(cx)) == 0
         want = c.multiply_scalar(c.sub(cx.reshape(1, n), ref.reshape(1, n), 1), np.array([s], dtype=np.uint64), 1)[0]
         assert np.array_equal(out, want)
+        if bits <= 50:   # the FP64 path computes this epilogue on the doubles (apply_epilogue_fp): same words
+            fcode = code | (1 << 16)
+            ftw = np.ascontiguousarray(tw.astype(np.float64)).view(np.uint64).copy()
+            assert emu.emu_ntt(fcode, 1, 2, p(x), p(out), q, p(ftw), p(z), p(z), p(pair(s, q)), p(cx)) == 0
+            assert np.array_equal(out, want)
 
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
