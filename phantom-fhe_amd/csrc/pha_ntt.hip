@@ -878,11 +878,19 @@ __device__ __forceinline__ void modup_ip_body(const NttKArgs &k, const ModupIpAr
                 const u64x2 ka = *reinterpret_cast<const u64x2 *>(key + id + ip.qp_n);
                 const int i0 = gi * K + kk;
                 if (FP) {
+                    // r04: the lazy outputs of the last round are below M q (M from the pass's compile-time schedule; 2.13 for the
+                    // 8-8-4 rounds), so a LIGHT product is below q (0.5 + 0.375 M) and BETA of them stay exact integers below 8 q:
+                    // 6 instead of 9 operations per product where that holds (every plan at beta <= 3, all but N = 2^14 at beta = 4)
+                    constexpr double mlast = Prog::fp_sched().after[C::NR - 1];
+                    constexpr bool light = (0.5 + 0.375 * (mlast > 1.0 ? mlast : 1.0)) * BETA < 7.5;
                     const double x0 = as_f64(reg[i0]), x1 = as_f64(reg[i0 + 1]);
-                    accb[i0] = as_u64(as_f64(accb[i0]) + fp_mulmod(x0, fp_from_canon(kb.x), fm));
-                    accb[i0 + 1] = as_u64(as_f64(accb[i0 + 1]) + fp_mulmod(x1, fp_from_canon(kb.y), fm));
-                    acca[i0] = as_u64(as_f64(acca[i0]) + fp_mulmod(x0, fp_from_canon(ka.x), fm));
-                    acca[i0 + 1] = as_u64(as_f64(acca[i0 + 1]) + fp_mulmod(x1, fp_from_canon(ka.y), fm));
+                    auto prod = [&](double x, u64 kw) __attribute__((always_inline)) {
+                        return light ? fp_mulmod_light(x, fp_from_canon(kw), fm) : fp_mulmod(x, fp_from_canon(kw), fm);
+                    };
+                    accb[i0] = as_u64(as_f64(accb[i0]) + prod(x0, kb.x));
+                    accb[i0 + 1] = as_u64(as_f64(accb[i0 + 1]) + prod(x1, kb.y));
+                    acca[i0] = as_u64(as_f64(acca[i0]) + prod(x0, ka.x));
+                    acca[i0 + 1] = as_u64(as_f64(acca[i0 + 1]) + prod(x1, ka.y));
                 } else {
                     // (128-bit accumulators with one Barrett at the end, as inner_prod_kernel has them, cost 32 more VGPRs across the
                     //  transforms: 256+ registers, one wavefront per SIMD; measured r03)
