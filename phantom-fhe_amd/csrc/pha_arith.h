@@ -245,13 +245,6 @@ PHA_HD double fp_mulmod_light(double Y, double W, FpMod m) {
     const double c = __builtin_rint(h * m.qinv);
     return __builtin_fma(-c, m.q, h) + l;
 }
-// CT butterfly: (X, Y) -> (X + Y*W, X - Y*W); magnitudes grow by at most q/2 + 1 per stage
-PHA_HD void fp_ct_bfly(double &X, double &Y, double W, FpMod m) {
-    const double t = fp_mulmod(Y, W, m);
-    const double x = X;
-    X = x + t;
-    Y = x - t;
-}
 // GS butterfly: (X, Y) -> ((X + Y) mod q, (X - Y)*W mod q), both centred (inputs |.| <= 2q)
 PHA_HD void fp_gs_bfly(double &X, double &Y, double W, FpMod m) {
     const double s = X + Y, d = X - Y;

@@ -248,8 +248,10 @@ PHA_HD void ot_round_fp(u64 *v, const u64x2 *tc, const u64x2 *tr, FpMod m) {
     }
 }
 
-// FP64 forms of the two rounds (same twiddle order; t[i].x = W, t[i].y = W/q as doubles)
-template <int R, bool LIGHT>
+// FP64 form of the forward round (same twiddle order; t[i].x = W as a double): LIGHT butterflies for every prime below 2^50 -- the
+// registers are re-centred by the caller after the rounds PassProgram::fp_sched() names (r04; r01-r03 re-centred every product of
+// primes from 2^47 inside the butterfly, fp_ct_bfly)
+template <int R>
 PHA_HD void fp_ct_round(u64 *v, const u64x2 *t, FpMod m) {
 #pragma unroll
     for (int j = 0; j < R; j++) {
@@ -258,16 +260,9 @@ PHA_HD void fp_ct_round(u64 *v, const u64x2 *t, FpMod m) {
         for (int k = 0; k < (1 << R); k++) {
             if (k & dist) continue;
             const u64x2 w = t[(1 << j) - 1 + (k >> (R - j))];
-            double X = as_f64(v[k]), Y = as_f64(v[k + dist]);
-            if (LIGHT) {
-                const double tt = fp_mulmod_light(Y, as_f64(w.x), m), x = X;
-                X = x + tt;
-                Y = x - tt;
-            } else {
-                fp_ct_bfly(X, Y, as_f64(w.x), m);
-            }
-            v[k] = as_u64(X);
-            v[k + dist] = as_u64(Y);
+            const double X = as_f64(v[k]), tt = fp_mulmod_light(as_f64(v[k + dist]), as_f64(w.x), m);
+            v[k] = as_u64(X + tt);
+            v[k + dist] = as_u64(X - tt);
         }
     }
 }
@@ -582,7 +577,7 @@ PHA_HD void round_compute(const PassArgs &a, int tid, u64 *reg, const u64x2 *twr
             if (FWD) {
                 // light butterflies for every prime below 2^50: below 2^47 a whole pass stays exact without any re-centring
                 // (ct_light); from 2^47 the registers are re-centred after the rounds fp_sched() names
-                fp_ct_round<r, true>(rg, t, a.fpm);
+                fp_ct_round<r>(rg, t, a.fpm);
                 if (RECENTRE && !a.fpm.ct_light) {
 #pragma unroll
                     for (int k = 0; k < K; k++) rg[k] = as_u64(fp_reduce(as_f64(rg[k]), a.fpm));
