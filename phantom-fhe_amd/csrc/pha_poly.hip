@@ -19,6 +19,7 @@ struct EwArgs {
     const DModulus *mod;
     uint32_t n, limbs, mod_start;
     uint32_t poly_limbs;  // limbs between two polynomials of a ciphertext (0 = limbs)
+    size_t za, zb, zr, zr2;   // blockIdx.z (batched tensor product): elements between consecutive ciphertexts of a / b / r / r2
 };
 
 enum EwOp { EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_MULADD, EW_MULSCALAR, EW_TENSOR, EW_SQUARE };
@@ -58,8 +59,11 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
         const u64x2 w{k.s0[limb], k.s1[limb]};
         u64x2 x = ld2(k.a + idx);
         st2(k.r + idx, u64x2{shoup(x.x, w, q), shoup(x.y, w, q)});
-    } else if (OP == EW_TENSOR) {  // tensor_prod_2x2_rns_poly :463-496
-        u64x2 c00 = ld2(k.a + idx), c01 = ld2(k.a + idx + rc), c10 = ld2(k.b + idx), c11 = ld2(k.b + idx + rc);
+    } else if (OP == EW_TENSOR) {  // tensor_prod_2x2_rns_poly :463-496; blockIdx.z walks a batch of ciphertexts (r04: one launch)
+        const size_t z = blockIdx.z;
+        const u64 *ka = k.a + z * k.za, *kb = k.b + z * k.zb;
+        u64 *kr = k.r + z * k.zr, *kr2 = k.r2 ? k.r2 + z * k.zr2 : nullptr;
+        u64x2 c00 = ld2(ka + idx), c01 = ld2(ka + idx + rc), c10 = ld2(kb + idx), c11 = ld2(kb + idx + rc);
         u64x2 d0, d1, d2;
         d0.x = mul_mod(c00.x, c10.x, m); d0.y = mul_mod(c00.y, c10.y, m);
         d2.x = mul_mod(c01.x, c11.x, m); d2.y = mul_mod(c01.y, c11.y, m);
@@ -68,9 +72,9 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
         d1.y = mul_mod(c00.y + c01.y, c10.y + c11.y, m);
         d1.x = csub(csub(d1.x + 2 * q - d0.x - d2.x, q), q);
         d1.y = csub(csub(d1.y + 2 * q - d0.y - d2.y, q), q);
-        st2(k.r + idx, d0);
-        st2(k.r + idx + rc, d1);
-        st2(k.r2 ? k.r2 + idx : k.r + idx + 2 * rc, d2);
+        st2(kr + idx, d0);
+        st2(kr + idx + rc, d1);
+        st2(kr2 ? kr2 + idx : kr + idx + 2 * rc, d2);
     } else if (OP == EW_SQUARE) {  // tensor_square_2x2_rns_poly :500-529
         u64x2 c0 = ld2(k.a + idx), c1 = ld2(k.a + idx + rc);
         u64x2 d0, d1, d2;
@@ -88,14 +92,14 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
 }
 
 template <int OP>
-static void launch_ew(Context &c, EwArgs k, size_t limbs, size_t mod_start, hipStream_t s) {
-    if (limbs == 0) return;
+static void launch_ew(Context &c, EwArgs k, size_t limbs, size_t mod_start, hipStream_t s, size_t batch = 1) {
+    if (limbs == 0 || batch == 0) return;
     if (mod_start + limbs > c.size_qp) throw std::invalid_argument("modulus index out of range");
     k.mod = c.d_mod.p;
     k.n = (uint32_t)c.n;
     k.limbs = (uint32_t)limbs;
     k.mod_start = (uint32_t)mod_start;
-    dim3 grid((unsigned)(c.n / (kEwThreads * kEwPerThread)), (unsigned)limbs);
+    dim3 grid((unsigned)(c.n / (kEwThreads * kEwPerThread)), (unsigned)limbs, (unsigned)batch);
     hipLaunchKernelGGL((ew_kernel<OP>), grid, dim3(kEwThreads), 0, s, k);
     check_launch();
 }
@@ -202,11 +206,13 @@ int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *op1, const ui
     PHA_CTX_BEGIN(ctx)
     need(op1); need(op2); need(res01); need(res2);
     const size_t ln = cms * ctx->c.n;
-    for (size_t b = 0; b < batch; b++) {  // HBM-streaming kernel: one launch per ciphertext loses nothing
-        EwArgs k{};
-        k.a = op1 + b * 2 * ln; k.b = op2 + b * 2 * ln; k.r = res01 + b * 2 * ln; k.r2 = res2 + b * ln;
-        launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream));
-    }
+    if (batch > 65535) throw std::invalid_argument("batch out of range");
+    // one launch over the batch (blockIdx.z): r04 trace of 8 ciphertexts -- 8 launches of 35.7 us each against 30.7 us for a lone one
+    EwArgs k{};
+    k.a = op1; k.b = op2; k.r = res01; k.r2 = res2;
+    k.za = k.zb = k.zr = 2 * ln;
+    k.zr2 = ln;
+    launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream), batch);
     PHA_API_END
 }
 int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *op, uint64_t *res, size_t cms,
