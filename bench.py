@@ -44,8 +44,8 @@ C4_BITS = [60] + [50] * 29 + [60] * 15  # benchmark/keyswitch_bench.cu:25-34
 C4_BATCH = 64
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes (tools/traffic.sh)
 STAGES_FILE = os.path.join(ROOT, "profiles", "stages.json")     # per-kernel GPU times of one HomMul (tools/stage_table.py over a committed kernel trace)
-# BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block = 64 baby x 2 giant steps, four row blocks per
-# pass over the baby keys (tools/time_bsgs.py, ms per block alone / in groups: 16x8 4.22 / 4.09, 32x4 3.57 / 2.72, 64x2 4.33 / 2.04)
+# BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block = 64 baby x 2 giant steps, eight row blocks per
+# pass over the baby keys (tools/time_bsgs.py)
 C5_BABY, C5_GIANT = 64, 2
 C5_BLOCKS = 32                        # row blocks of the job (split over the ranks: 4 per GPU at 8 GPUs, so the key pass is shared everywhere)
 
@@ -652,7 +652,7 @@ def main():
         blocks5 = [[[pool5[(i * nbaby + j + b) % n_diag] for j in range(nbaby)] for i in range(ngiant)] for b in mine5]
         res5 = [None]
 
-        def c5_step():   # this rank's row blocks against the one ciphertext; the baby keys are streamed once per 8 / ngiant blocks
+        def c5_step():   # this rank's row blocks against the one ciphertext; the baby keys are streamed once per 16 / ngiant blocks
             res5[0] = W.diag_matvec_bsgs_blocks(ctx, size_q, ct5, baby_elts, baby_keys, giant_elts, giant_keys, blocks5,
                                                 P.scheme_type.ckks) if blocks5 else []
 

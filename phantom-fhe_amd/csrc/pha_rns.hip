@@ -750,6 +750,7 @@ struct BsgsArgs {
     const u64x2 *p_mod_q;             // [Ql] P mod q_j with its Shoup quotient
     uint32_t ql;
     size_t ql_n;
+    const FpInfo *fpinfo;             // [prime]: limbs below 2^50 accumulate in doubles (r04)
 };
 // The c0 / c1 terms ride in the same accumulators: on a data limb j the value added is P * x mod q_j, which the mod-down that
 // follows (it divides by P exactly: (cx_j - conv(cx_P)_j) P^-1) turns back into x, and on the P limbs P * x = 0 -- so
@@ -758,10 +759,84 @@ struct BsgsArgs {
 // entry) is issued before the first multiply: the first version branched per giant step on a null weight and looped over the
 // digits at run time, which serialised ~12 memory round trips per baby step (2.9 TB/s); missing weights now point at a zero
 // plane supplied by the driver.
+// r04: limbs whose prime is below 2^50 run the same sums in FP64 (pha_arith.h: residues as doubles with integer values, every
+// product an exact fp_mulmod_light).  A 128-bit multiply-accumulate costs ~12 vector instructions on 32-bit halves and the two
+// Barrett reductions per baby step ~55; here a product-and-add is 7 FP64 operations and there is nothing to reduce at the end of a
+// step but two re-centrings: ~210 instead of ~340 instructions per baby step at NG = 8, and 2 NG instead of 4 NG accumulator
+// register pairs.  Magnitudes: gathered digits, key words and weights are canonical (< q), so a digit product is below 0.875 q and
+// BETA + 1 of them below 4.4 q; s and t are re-centred (<= q/2), a weighted term is then below 0.69 q, and the accumulators are
+// re-centred every 8 baby steps (0.5 + 8 x 0.69 = 6.0 q < 8 q = 2^53): every value is an exact integer, the stored residues are
+// the ones the integer form stores.
 template <int NG, int BETA>
-__global__ __launch_bounds__(256) void hoist_bsgs_inner_prod_kernel(const BsgsArgs k) {
-    const uint32_t nid = blockIdx.y;
-    const uint32_t twr = k.qlp_prime[nid];
+__device__ __forceinline__ void hoist_bsgs_body_fp(const BsgsArgs &k, uint32_t nid, uint32_t twr, const FpInfo fi) {
+    const FpMod fm{fi.q, fi.qinv, false, false};
+    const size_t coeff = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t out_id = (size_t)nid * k.n + coeff;
+    const size_t evk_id = (size_t)twr * k.n + coeff;
+    const bool data_limb = nid < k.ql;          // uniform
+    const double pqd = data_limb ? fp_from_canon(k.p_mod_q[nid].x) : 0.0;
+    const u64 *cc0 = k.cc + (size_t)(data_limb ? nid : 0) * k.n;
+    double al[NG], bl[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) al[g] = bl[g] = 0.0;
+    uint32_t idx = k.tables[0][coeff];
+    for (uint32_t j = 0; j < k.nb; j++) {
+        const u64 *const *keys = k.keys[j];
+        const uint32_t idx_next = k.tables[j + 1 < k.nb ? j + 1 : j][coeff];
+        u64 wv[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) wv[g] = k.weights[(size_t)(k.g0 + g) * k.nb + j][out_id];
+        const u64 x0 = cc0[idx];
+        double s, t;
+        if (keys) {   // uniform
+            u64 v[BETA], kb[BETA], ka[BETA];
+#pragma unroll
+            for (int i = 0; i < BETA; i++) {
+                const u64 *key = keys[i];
+                v[i] = k.t_mod_up[(size_t)i * k.qlp_n + (size_t)nid * k.n + idx];
+                kb[i] = key[evk_id];
+                ka[i] = key[evk_id + k.qp_n];
+            }
+            s = data_limb ? fp_mulmod_light(fp_from_canon(x0), pqd, fm) : 0.0;   // + P * rot_j(c0)
+            t = 0.0;
+#pragma unroll
+            for (int i = 0; i < BETA; i++) {
+                const double vd = fp_from_canon(v[i]);
+                s += fp_mulmod_light(vd, fp_from_canon(kb[i]), fm);
+                t += fp_mulmod_light(vd, fp_from_canon(ka[i]), fm);
+            }
+        } else {      // identity baby step: (P c0, P c1) on the data limbs, nothing on the P limbs
+            s = data_limb ? fp_mulmod_light(fp_from_canon(x0), pqd, fm) : 0.0;
+            t = data_limb ? fp_mulmod_light(fp_from_canon(k.cc[k.ql_n + (size_t)nid * k.n + idx]), pqd, fm) : 0.0;
+        }
+        s = fp_reduce(s, fm);
+        t = fp_reduce(t, fm);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const double wd = fp_from_canon(wv[g]);
+            al[g] += fp_mulmod_light(s, wd, fm);
+            bl[g] += fp_mulmod_light(t, wd, fm);
+        }
+        if ((j & 7u) == 7u) {   // (uniform)
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                al[g] = fp_reduce(al[g], fm);
+                bl[g] = fp_reduce(bl[g], fm);
+            }
+        }
+        idx = idx_next;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        u64 *acc = k.acc + (size_t)(k.g0 + g) * 2 * k.qlp_n + out_id;
+        acc[0] = fp_to_canon(al[g], fm);
+        acc[k.qlp_n] = fp_to_canon(bl[g], fm);
+    }
+}
+
+// integer limbs: accumulators [goff, goff + NG) of the launch
+template <int NG, int BETA>
+__device__ __forceinline__ void hoist_bsgs_body_int(const BsgsArgs &k, uint32_t nid, uint32_t twr, uint32_t goff) {
     const DModulus m = k.mod[twr];
     const size_t coeff = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t out_id = (size_t)nid * k.n + coeff;
@@ -779,7 +854,7 @@ __global__ __launch_bounds__(256) void hoist_bsgs_inner_prod_kernel(const BsgsAr
         // loads first
         u64 wv[NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++) wv[g] = k.weights[(size_t)(k.g0 + g) * k.nb + j][out_id];
+        for (int g = 0; g < NG; g++) wv[g] = k.weights[(size_t)(k.g0 + goff + g) * k.nb + j][out_id];
         const u64 x0 = cc0[idx];
         u64 s, t;
         if (keys) {   // uniform
@@ -813,9 +888,31 @@ __global__ __launch_bounds__(256) void hoist_bsgs_inner_prod_kernel(const BsgsAr
     }
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        u64 *acc = k.acc + (size_t)(k.g0 + g) * 2 * k.qlp_n + out_id;
+        u64 *acc = k.acc + (size_t)(k.g0 + goff + g) * 2 * k.qlp_n + out_id;
         acc[0] = barrett128(al[g], ah[g], m);
         acc[k.qlp_n] = barrett128(bl[g], bh[g], m);
+    }
+}
+
+// NG accumulators per launch.  NG = 16 (r04): the FP64 limbs keep 16 (block, giant step) accumulators in 32 register pairs, so the
+// baby keys are streamed once per 16 / ng row blocks; an integer limb would need 64 pairs for that and walks its baby steps twice
+// with 8 accumulators each instead (16 of 60 limbs at the C3 set).
+template <int NG, int BETA>
+__global__ __launch_bounds__(256) void hoist_bsgs_inner_prod_kernel(const BsgsArgs k) {
+    const uint32_t nid = blockIdx.y;
+    const uint32_t twr = k.qlp_prime[nid];
+    if (k.fpinfo) {   // (uniform) FP64 limbs
+        const FpInfo fi = k.fpinfo[twr];
+        if (fi.ok) {
+            hoist_bsgs_body_fp<NG, BETA>(k, nid, twr, fi);
+            return;
+        }
+    }
+    if constexpr (NG > 8) {
+        hoist_bsgs_body_int<8, BETA>(k, nid, twr, 0);
+        hoist_bsgs_body_int<NG - 8, BETA>(k, nid, twr, 8);
+    } else {
+        hoist_bsgs_body_int<NG, BETA>(k, nid, twr, 0);
     }
 }
 
@@ -1842,6 +1939,7 @@ static void bsgs_core(Context &c, Tool &t, const u64 *ct_in, size_t blocks, cons
         k.qlp_prime = t.d_qlp_prime.p; k.n = (uint32_t)n; k.beta = t.beta; k.nb = (uint32_t)nb;
         k.qlp_n = qlp_n; k.qp_n = (size_t)c.size_qp * n;
         k.cc = cc; k.p_mod_q = t.p_mod_q2.p; k.ql = (uint32_t)size_Ql; k.ql_n = ql_n;
+        k.fpinfo = c.d_fpinfo.p;
         const dim3 grid((unsigned)(n / 256), t.size_qlp), block(256);
 #define PHA_BSGS_GO(NG)                                                                                                   \
     do {                                                                                                                  \
@@ -1855,7 +1953,8 @@ static void bsgs_core(Context &c, Tool &t, const u64 *ct_in, size_t blocks, cons
         for (size_t g0 = 0; g0 < G;) {
             const size_t left = G - g0;
             k.g0 = (uint32_t)g0;
-            if (left >= 8) { PHA_BSGS_GO(8); g0 += 8; }
+            if (left >= 16) { PHA_BSGS_GO(16); g0 += 16; }
+            else if (left >= 8) { PHA_BSGS_GO(8); g0 += 8; }
             else if (left >= 4) { PHA_BSGS_GO(4); g0 += 4; }
             else if (left >= 2) { PHA_BSGS_GO(2); g0 += 2; }
             else { PHA_BSGS_GO(1); g0 += 1; }

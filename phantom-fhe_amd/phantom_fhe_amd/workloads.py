@@ -87,14 +87,14 @@ def diag_matvec_bsgs(ctx, size_Ql, ct, baby_elts, baby_keys, giant_elts, giant_k
 
 def diag_matvec_bsgs_blocks(ctx, size_Ql, ct, baby_elts, baby_keys, giant_elts, giant_keys, blocks, scheme, per_call=0):
     """Several row blocks of the matrix against ONE encrypted vector (pha_hoisting_weighted_bsgs_blocks): blocks[r][i][j] as in
-    diag_matvec_bsgs.  `per_call` blocks go through one call (0: as many as make 8 (block, giant step) accumulators, the width of
+    diag_matvec_bsgs.  `per_call` blocks go through one call (0: as many as make 16 (block, giant step) accumulators, the width of
     the fused baby-step kernel, so that the baby keys are streamed once per that many blocks).  Returns [len(blocks)][2][Ql][N];
     every block equals its own diag_matvec_bsgs."""
     import torch
     nblk = len(blocks)
     out = torch.empty((nblk,) + tuple(ct.shape), dtype=ct.dtype, device=ct.device)
     if per_call <= 0:
-        per_call = max(1, 8 // max(1, len(giant_elts)))
+        per_call = max(1, 16 // max(1, len(giant_elts)))
     for r0 in range(0, nblk, per_call):
         ctx.hoisting_weighted_bsgs_blocks(size_Ql, ct, baby_elts, baby_keys, giant_elts, giant_keys, blocks[r0:r0 + per_call],
                                           out[r0:r0 + per_call], scheme)

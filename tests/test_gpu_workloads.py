@@ -389,3 +389,11 @@ def test_config5_bench_shape_64_by_2_four_row_blocks_per_call(gpu):
         ows = [[w_pool[pick(b, i, j)] for j in range(nb)] for i in range(ng)]
         want = tool.hoisting_weighted_bsgs(ct, baby, okb, giant, okg, ows, O.CKKS)
         assert np.array_equal(out[b], want), b
+    # r04: the bench now sends EIGHT row blocks through one call (16 (block, giant step) accumulators: the FP64 limbs keep all 16 in
+    # registers, the integer limbs walk the baby steps twice with 8 each).  Blocks 0..3 of such a call must equal the oracle-checked
+    # words above, blocks 4..7 their own four-block call.
+    d_blocks8 = d_blocks + [[[d_w_pool[pick(b, i, j)] for j in range(nb)] for i in range(ng)] for b in range(nblk, 2 * nblk)]
+    out8 = P.to_host(W.diag_matvec_bsgs_blocks(ctx, ql, d_ct, baby, d_bk, giant, d_gk, d_blocks8, O.CKKS, per_call=8))
+    assert np.array_equal(out8[:nblk], out)
+    tail4 = P.to_host(W.diag_matvec_bsgs_blocks(ctx, ql, d_ct, baby, d_bk, giant, d_gk, d_blocks8[nblk:], O.CKKS, per_call=4))
+    assert np.array_equal(out8[nblk:], tail4)

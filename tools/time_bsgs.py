@@ -49,5 +49,5 @@ for nb, ng in splits:
         out = W.diag_matvec_bsgs_blocks(ctx, size_q, ct, baby, bk, giant, gk, blocks, CK)
     torch.cuda.synchronize()
     ms8 = (time.perf_counter() - t0) / 3 * 1e3 / nblk
-    print(f"      the same, {nblk} row blocks per call sequence ({max(1, 8 // ng)} per pass over the keys): {ms8:7.3f} ms per block", flush=True)
+    print(f"      the same, {nblk} row blocks per call sequence ({max(1, 16 // ng)} per pass over the keys): {ms8:7.3f} ms per block", flush=True)
     del bk, gk, ws, blocks
