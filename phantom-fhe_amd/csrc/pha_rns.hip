@@ -442,6 +442,7 @@ struct InnerArgs {
     u64x2 fix_cst;           // P^-1 mod q_last
     const u64 *fix_ct;       // ct [2][Ql][N] of the (first) ciphertext
     size_t fix_ct_stride;    // Ql * N
+    const FpInfo *fpinfo;    // [prime]: limbs below 2^50 form their sums in FP64 (batched kernel, r04)
 };
 __device__ __forceinline__ void inner_fix(const InnerArgs &k, uint32_t nid, const DModulus &m, size_t coeff, uint32_t b,
                                           u64x2 &r0, u64x2 &r1) {
@@ -494,6 +495,38 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
         const u64 *key = k.evks[i];
         kb[i] = *reinterpret_cast<const u64x2 *>(key + evk_id);
         ka[i] = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
+    }
+    if (k.fpinfo && k.fpinfo[twr].ok) {   // (uniform) r04: limbs below 2^50 -- every product an exact fp_mulmod_light (digits and key
+        // words are canonical: a product is below 0.875 q, BETA <= 4 of them below 3.5 q), one fp_to_canon per sum: ~125 FP64
+        // operations per ciphertext and thread where four 128-bit accumulators and four Barrett reductions take ~260
+        const FpInfo fi = k.fpinfo[twr];
+        const FpMod fm{fi.q, fi.qinv, false, false};
+        double kbx[BETA], kby[BETA], kax[BETA], kay[BETA];
+#pragma unroll
+        for (int i = 0; i < BETA; i++) {
+            kbx[i] = fp_from_canon(kb[i].x); kby[i] = fp_from_canon(kb[i].y);
+            kax[i] = fp_from_canon(ka[i].x); kay[i] = fp_from_canon(ka[i].y);
+        }
+        for (uint32_t b = 0; b < batch; b++) {
+            const u64 *mu = k.t_mod_up + (size_t)b * BETA * k.qlp_n + c2_id;
+            u64 *cx = k.cx + (size_t)b * 2 * k.qlp_n + c2_id;
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < BETA; i++) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n);
+                const double vx = fp_from_canon(v.x), vy = fp_from_canon(v.y);
+                a0 += fp_mulmod_light(vx, kbx[i], fm);
+                a1 += fp_mulmod_light(vy, kby[i], fm);
+                b0 += fp_mulmod_light(vx, kax[i], fm);
+                b1 += fp_mulmod_light(vy, kay[i], fm);
+            }
+            u64x2 r0{fp_to_canon(a0, fm), fp_to_canon(a1, fm)};
+            u64x2 r1{fp_to_canon(b0, fm), fp_to_canon(b1, fm)};
+            inner_fix(k, nid, m, coeff, b, r0, r1);
+            *reinterpret_cast<u64x2 *>(cx) = r0;
+            *reinterpret_cast<u64x2 *>(cx + k.qlp_n) = r1;
+        }
+        return;
     }
     for (uint32_t b = 0; b < batch; b++) {
         const u64 *mu = k.t_mod_up + (size_t)b * BETA * k.qlp_n + c2_id;
@@ -1291,6 +1324,7 @@ static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const 
     k.cx = cx; k.t_mod_up = t_mod_up; k.evks = rlk; k.mod = c.d_mod.p; k.qlp_prime = t.d_qlp_prime.p;
     k.n = (uint32_t)c.n; k.beta = t.beta; k.qlp_n = (size_t)t.size_qlp * c.n; k.qp_n = (size_t)c.size_qp * c.n;
     k.fix_limb = 0xffffffffu;
+    k.fpinfo = c.d_fpinfo.p;
     if (fix_ct) {
         const u64 pinv_last = h_invmod_p(c, t.size_ql - 1);
         k.fix_limb = t.size_ql - 1;
