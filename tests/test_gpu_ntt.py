@@ -443,3 +443,38 @@ def test_batched_launches_in_both_block_orders(name, batch, gpu):
     assert np.array_equal(outs[0], outs[1])
     for z in range(batch):
         assert np.array_equal(outs[1][z], oc.nwt_forward(x[z], L, 0))
+
+
+def test_batched_transforms_replay_from_a_hip_graph(gpu):
+    """The batched twiddle-resident pass (r04) is a plain kernel launch with its work map passed by value: a forward + inverse batched
+    transform at N = 2^16 (8 polynomials x 45 limbs: integer and FP64 limbs in the one grid) captured into a hipGraph replays to
+    the eager result, twice."""
+    import torch
+    import phantom_fhe_amd as P
+    name, batch = "c3_ckks16", 8
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    ctx = _ctx(name, gpu)
+    L = len(primes) - size_p
+    x = np.stack([uniform_poly(rng_for(900 + z), primes[:L], n) for z in range(batch)])
+    d = P.to_device(x, gpu)
+    ctx.nwt_2d_radix8_forward_inplace_batched(d, L, 0, batch, L * n)
+    want = P.to_host(d)
+    ctx.nwt_2d_radix8_backward_inplace_batched(d, L, 0, batch, L * n)
+    assert np.array_equal(P.to_host(d), x)
+    side = torch.cuda.Stream(device=gpu)
+    fwd = P.to_device(x, gpu)
+    with torch.cuda.stream(side):
+        ctx.nwt_2d_radix8_forward_inplace_batched(fwd, L, 0, batch, L * n)     # warm-up on the capture stream
+        fwd.copy_(P.to_device(x, gpu))
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            ctx.nwt_2d_radix8_forward_inplace_batched(fwd, L, 0, batch, L * n)
+    for rep in range(2):
+        fwd.copy_(P.to_device(x, gpu))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(P.to_host(fwd), want), rep
