@@ -20,6 +20,7 @@ struct EwArgs {
     uint32_t n, limbs, mod_start;
     uint32_t poly_limbs;  // limbs between two polynomials of a ciphertext (0 = limbs)
     size_t za, zb, zr, zr2;   // blockIdx.z (batched tensor product): elements between consecutive ciphertexts of a / b / r / r2
+    const FpInfo *fpinfo;     // [prime]: limbs below 2^50 form the tensor product in FP64 (r04)
 };
 
 enum EwOp { EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_MULADD, EW_MULSCALAR, EW_TENSOR, EW_SQUARE };
@@ -65,6 +66,26 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
         u64 *kr = k.r + z * k.zr, *kr2 = k.r2 ? k.r2 + z * k.zr2 : nullptr;
         u64x2 c00 = ld2(ka + idx), c01 = ld2(ka + idx + rc), c10 = ld2(kb + idx), c11 = ld2(kb + idx + rc);
         u64x2 d0, d1, d2;
+        if (k.fpinfo && k.fpinfo[k.mod_start + limb].ok) {   // (uniform) r04: three exact FP64 products (pha_arith.h) instead of three Barrett-128
+            // multiplies on 32-bit halves (~115 vector instructions per coefficient -> ~50): the sums c0 + c1 are below 2 q, their
+            // product's light reduction below 2 q, d1 below 3.75 q before fp_to_canon; the same residues as :487-:494
+            const FpInfo fi = k.fpinfo[k.mod_start + limb];
+            const FpMod fm{fi.q, fi.qinv, false, false};
+            auto one = [&](u64 a0, u64 a1, u64 b0, u64 b1, u64 &o0, u64 &o1, u64 &o2) __attribute__((always_inline)) {
+                const double x0 = fp_from_canon(a0), x1 = fp_from_canon(a1), y0 = fp_from_canon(b0), y1 = fp_from_canon(b1);
+                const double e0 = fp_mulmod_light(x0, y0, fm), e2 = fp_mulmod_light(x1, y1, fm);
+                const double e1 = fp_mulmod_light(x0 + x1, y0 + y1, fm) - e0 - e2;
+                o0 = fp_to_canon(e0, fm);
+                o1 = fp_to_canon(e1, fm);
+                o2 = fp_to_canon(e2, fm);
+            };
+            one(c00.x, c01.x, c10.x, c11.x, d0.x, d1.x, d2.x);
+            one(c00.y, c01.y, c10.y, c11.y, d0.y, d1.y, d2.y);
+            st2(kr + idx, d0);
+            st2(kr + idx + rc, d1);
+            st2(kr2 ? kr2 + idx : kr + idx + 2 * rc, d2);
+            return;
+        }
         d0.x = mul_mod(c00.x, c10.x, m); d0.y = mul_mod(c00.y, c10.y, m);
         d2.x = mul_mod(c01.x, c11.x, m); d2.y = mul_mod(c01.y, c11.y, m);
         // (c0 + c1) is not reduced before the multiply (q < 2^61), exactly like :487
@@ -78,6 +99,22 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
     } else if (OP == EW_SQUARE) {  // tensor_square_2x2_rns_poly :500-529
         u64x2 c0 = ld2(k.a + idx), c1 = ld2(k.a + idx + rc);
         u64x2 d0, d1, d2;
+        if (k.fpinfo && k.fpinfo[k.mod_start + limb].ok) {   // (uniform) the FP64 form of the tensor product above: c0^2, 2 c0 c1, c1^2
+            const FpInfo fi = k.fpinfo[k.mod_start + limb];
+            const FpMod fm{fi.q, fi.qinv, false, false};
+            auto one = [&](u64 a0, u64 a1, u64 &o0, u64 &o1, u64 &o2) __attribute__((always_inline)) {
+                const double x0 = fp_from_canon(a0), x1 = fp_from_canon(a1);
+                o0 = fp_to_canon(fp_mulmod_light(x0, x0, fm), fm);
+                o1 = fp_to_canon(fp_mulmod_light(x0 + x0, x1, fm), fm);
+                o2 = fp_to_canon(fp_mulmod_light(x1, x1, fm), fm);
+            };
+            one(c0.x, c1.x, d0.x, d1.x, d2.x);
+            one(c0.y, c1.y, d0.y, d1.y, d2.y);
+            st2(k.r + idx, d0);
+            st2(k.r + idx + rc, d1);
+            st2(k.r + idx + 2 * rc, d2);
+            return;
+        }
         d0.x = mul_mod(c0.x, c0.x, m); d0.y = mul_mod(c0.y, c0.y, m);
         u64 lo, hi;
         mul128(c0.x, c1.x, lo, hi);
@@ -96,6 +133,7 @@ static void launch_ew(Context &c, EwArgs k, size_t limbs, size_t mod_start, hipS
     if (limbs == 0 || batch == 0) return;
     if (mod_start + limbs > c.size_qp) throw std::invalid_argument("modulus index out of range");
     k.mod = c.d_mod.p;
+    k.fpinfo = c.d_fpinfo.p;
     k.n = (uint32_t)c.n;
     k.limbs = (uint32_t)limbs;
     k.mod_start = (uint32_t)mod_start;

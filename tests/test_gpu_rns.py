@@ -56,6 +56,16 @@ def test_dyadic(name, gpu):
     buf = P.to_device(np.concatenate([mm, np.zeros((1, L, n), dtype=np.uint64)]), gpu)
     ctx.tensor_prod_2x2_rns_poly(buf, P.to_device(mm, gpu), buf, L)   # unreduced (c0+c1) at its maximum
     assert np.array_equal(P.to_host(buf), oc.tensor_prod_2x2(mm, mm, L))
+    buf = P.to_device(np.concatenate([mm, np.zeros((1, L, n), dtype=np.uint64)]), gpu)
+    ctx.tensor_square_2x2_rns_poly(buf, buf, L)                        # 2 c0 c1 at its maximum
+    assert np.array_equal(P.to_host(buf), oc.tensor_square_2x2(mm, L))
+    # mixed extremes: the FP64 form's quotient estimate at both ends of its range (limbs below 2^50)
+    ex = np.stack([np.stack([np.where(np.arange(n) % 3 == 0, 0, np.where(np.arange(n) % 3 == 1, 1, int(q) - 1)).astype(np.uint64)
+                             for q in primes[:L]]) for _ in range(2)])
+    ex[1] = ex[1][:, ::-1]
+    buf = P.to_device(np.concatenate([ex, np.zeros((1, L, n), dtype=np.uint64)]), gpu)
+    ctx.tensor_prod_2x2_rns_poly(buf, P.to_device(mm, gpu), buf, L)
+    assert np.array_equal(P.to_host(buf), oc.tensor_prod_2x2(ex, mm, L))
 
 
 def _keys(oc, rng, primes, n, size_q, size_p):
