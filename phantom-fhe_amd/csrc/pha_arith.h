@@ -258,6 +258,24 @@ PHA_HD u64 fp_to_canon(double x, FpMod m) {
     r = r < 0.0 ? r + m.q : r;               // [0, q)
     return as_u64(r + 4503599627370496.0) & 0x000fffffffffffffull;
 }
+// r04: the 2 x 2 tensor product / square of a limb below 2^50 on canonical residues (tensor_prod_2x2_rns_poly polymath.cu:463-496,
+// tensor_square_2x2_rns_poly :498-529): three light products.  The unreduced sums c0 + c1 are below 2 q, so the quotient estimate
+// of their product is off by at most 0.5 + 1.5 * 2 * 2 q 2^-52 <= 2 and its light reduction stays below 2 q + 2^48; with d0 and d2
+// below 0.875 q each, d1 is an exact integer below 3.75 q + 2^48 when fp_to_canon reduces it (tests/test_emu_fp.py).
+PHA_HD void fp_tensor_2x2(u64 a0, u64 a1, u64 b0, u64 b1, FpMod m, u64 &d0, u64 &d1, u64 &d2) {
+    const double x0 = fp_from_canon(a0), x1 = fp_from_canon(a1), y0 = fp_from_canon(b0), y1 = fp_from_canon(b1);
+    const double e0 = fp_mulmod_light(x0, y0, m), e2 = fp_mulmod_light(x1, y1, m);
+    const double e1 = fp_mulmod_light(x0 + x1, y0 + y1, m) - e0 - e2;
+    d0 = fp_to_canon(e0, m);
+    d1 = fp_to_canon(e1, m);
+    d2 = fp_to_canon(e2, m);
+}
+PHA_HD void fp_square_2x2(u64 a0, u64 a1, FpMod m, u64 &d0, u64 &d1, u64 &d2) {
+    const double x0 = fp_from_canon(a0), x1 = fp_from_canon(a1);
+    d0 = fp_to_canon(fp_mulmod_light(x0, x0, m), m);
+    d1 = fp_to_canon(fp_mulmod_light(x0 + x0, x1, m), m);
+    d2 = fp_to_canon(fp_mulmod_light(x1, x1, m), m);
+}
 
 // Harvey butterflies (include/butterfly.cuh:10-22 / :28-37). q2 = 2q.
 // CT: X,Y in [0,4q) -> X,Y in [0,4q)

@@ -66,21 +66,14 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
         u64 *kr = k.r + z * k.zr, *kr2 = k.r2 ? k.r2 + z * k.zr2 : nullptr;
         u64x2 c00 = ld2(ka + idx), c01 = ld2(ka + idx + rc), c10 = ld2(kb + idx), c11 = ld2(kb + idx + rc);
         u64x2 d0, d1, d2;
-        if (k.fpinfo && k.fpinfo[k.mod_start + limb].ok) {   // (uniform) r04: three exact FP64 products (pha_arith.h) instead of three Barrett-128
-            // multiplies on 32-bit halves (~115 vector instructions per coefficient -> ~50): the sums c0 + c1 are below 2 q, their
-            // product's light reduction below 2 q, d1 below 3.75 q before fp_to_canon; the same residues as :487-:494
+        if (k.fpinfo && k.fpinfo[k.mod_start + limb].ok) {   // (uniform) r04: three exact FP64 products (fp_tensor_2x2, pha_arith.h) instead of
+            // three Barrett-128 multiplies on 32-bit halves (~115 vector instructions per coefficient -> ~50); the same residues as :487-:494
             const FpInfo fi = k.fpinfo[k.mod_start + limb];
             const FpMod fm{fi.q, fi.qinv, false, false};
-            auto one = [&](u64 a0, u64 a1, u64 b0, u64 b1, u64 &o0, u64 &o1, u64 &o2) __attribute__((always_inline)) {
-                const double x0 = fp_from_canon(a0), x1 = fp_from_canon(a1), y0 = fp_from_canon(b0), y1 = fp_from_canon(b1);
-                const double e0 = fp_mulmod_light(x0, y0, fm), e2 = fp_mulmod_light(x1, y1, fm);
-                const double e1 = fp_mulmod_light(x0 + x1, y0 + y1, fm) - e0 - e2;
-                o0 = fp_to_canon(e0, fm);
-                o1 = fp_to_canon(e1, fm);
-                o2 = fp_to_canon(e2, fm);
-            };
-            one(c00.x, c01.x, c10.x, c11.x, d0.x, d1.x, d2.x);
-            one(c00.y, c01.y, c10.y, c11.y, d0.y, d1.y, d2.y);
+            u64 e[6];
+            fp_tensor_2x2(c00.x, c01.x, c10.x, c11.x, fm, e[0], e[1], e[2]);
+            fp_tensor_2x2(c00.y, c01.y, c10.y, c11.y, fm, e[3], e[4], e[5]);
+            d0 = u64x2{e[0], e[3]}; d1 = u64x2{e[1], e[4]}; d2 = u64x2{e[2], e[5]};
             st2(kr + idx, d0);
             st2(kr + idx + rc, d1);
             st2(kr2 ? kr2 + idx : kr + idx + 2 * rc, d2);
@@ -99,17 +92,13 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
     } else if (OP == EW_SQUARE) {  // tensor_square_2x2_rns_poly :500-529
         u64x2 c0 = ld2(k.a + idx), c1 = ld2(k.a + idx + rc);
         u64x2 d0, d1, d2;
-        if (k.fpinfo && k.fpinfo[k.mod_start + limb].ok) {   // (uniform) the FP64 form of the tensor product above: c0^2, 2 c0 c1, c1^2
+        if (k.fpinfo && k.fpinfo[k.mod_start + limb].ok) {   // (uniform) the FP64 form: c0^2, 2 c0 c1, c1^2 (fp_square_2x2)
             const FpInfo fi = k.fpinfo[k.mod_start + limb];
             const FpMod fm{fi.q, fi.qinv, false, false};
-            auto one = [&](u64 a0, u64 a1, u64 &o0, u64 &o1, u64 &o2) __attribute__((always_inline)) {
-                const double x0 = fp_from_canon(a0), x1 = fp_from_canon(a1);
-                o0 = fp_to_canon(fp_mulmod_light(x0, x0, fm), fm);
-                o1 = fp_to_canon(fp_mulmod_light(x0 + x0, x1, fm), fm);
-                o2 = fp_to_canon(fp_mulmod_light(x1, x1, fm), fm);
-            };
-            one(c0.x, c1.x, d0.x, d1.x, d2.x);
-            one(c0.y, c1.y, d0.y, d1.y, d2.y);
+            u64 e[6];
+            fp_square_2x2(c0.x, c1.x, fm, e[0], e[1], e[2]);
+            fp_square_2x2(c0.y, c1.y, fm, e[3], e[4], e[5]);
+            d0 = u64x2{e[0], e[3]}; d1 = u64x2{e[1], e[4]}; d2 = u64x2{e[2], e[5]};
             st2(k.r + idx, d0);
             st2(k.r + idx + rc, d1);
             st2(k.r + idx + 2 * rc, d2);
