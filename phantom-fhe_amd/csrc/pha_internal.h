@@ -330,6 +330,7 @@ struct NttExtra {
     size_t out_stride = 0, aux_stride = 0;               // same for out and aux (0 = poly_stride)
     size_t in_stride = 0;                                // polynomials of `in` when it is strided differently from mid (0 = poly_stride)
     bool first_pass_only = false;                        // forward: stop after the strided pass (the caller runs a fused second pass)
+    bool second_pass_only = false;                       // inverse: the contiguous pass already ran (folded into the fused mod-up, ModupIpArgs::inv_from)
     const u64 *pro_src = nullptr;                        // forward only: every limb of polynomial z transforms
     size_t pro_stride = 0;                               //   (pro_src + z * pro_stride) mod its own prime; `in` unused
     uint32_t excl_step = 0;                              // polynomial z skips [excl_start + z*step, min(+len, limit))
@@ -353,6 +354,13 @@ struct ModupIpArgs {
     u64x2 fix_cst;
     const u64 *fix_ct;
     size_t fix_ct_stride;
+    // r04: the limbs the mod-down transforms back first (the special limbs, and `inv_lead` -- the last data limb -- for the fused
+    // rescale) leave the kernel with the inverse transform's contiguous pass already applied to both sums: the wavefront holds the
+    // whole rows that pass works on, in its first round's register layout.  The caller then runs the inverse with
+    // NttExtra::second_pass_only.  inv_from: first such limb (selection-relative data index; 0xffffffff = off).
+    uint32_t inv_from = 0xffffffffu, inv_lead = 0xffffffffu;
+    const u64x2 *itw = nullptr;       // inverse twiddle tables [prime][n] (integer / FP64 back end)
+    const u64 *itwf = nullptr;
 };
 bool modup_ntt_inner_prod(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, uint32_t beta, const ModupIpArgs &ip,
                           hipStream_t s);

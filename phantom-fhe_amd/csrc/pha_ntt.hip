@@ -79,6 +79,7 @@ struct NttKArgs {
     size_t poly_stride, out_stride, aux_stride;
     size_t in_stride;        // elements between the polynomials of `in` (first pass; the second pass reads mid at poly_stride)
     bool first_pass_only;    // forward: the caller runs its own (fused) second pass
+    bool second_pass_only;   // inverse: the contiguous pass was folded into the producer of `mid`
     uint32_t excl_step, excl_limit, excl_mod;
     const u64 *pro_src;      // rescale prologue: every limb of polynomial z reads pro_src + z * pro_stride instead
     size_t pro_stride;
@@ -724,6 +725,11 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
 #else
     (void)fused;
 #endif
+    if (k.second_pass_only) {   // mid already holds the contiguous pass's output (T1 x T2 of this plan: choose_plan keeps the split of plan 3)
+        if (epi == EPI_INV_SCALE) launch_pass<P1, false, EPI_INV_SCALE, true>(k, s);
+        else launch_pass<P1, false, EPI_INV_CANON, true>(k, s);
+        return;
+    }
 #if !defined(PHA_NO_ZLOOP)
     if constexpr (VARIANT == 10 || VARIANT == 3 || VARIANT == 4) {   // batched launches: the contiguous pass with the twiddles resident (ntt_zloop_kernel)
         using Z2 = typename NttPlan<LOGN, VARIANT == 4 ? 3 : VARIANT>::P2;
@@ -767,6 +773,7 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.poly_stride = x.poly_stride;
     k.in_stride = x.in_stride ? x.in_stride : x.poly_stride;
     k.first_pass_only = fwd && x.first_pass_only;
+    k.second_pass_only = !fwd && x.second_pass_only;
     k.out_stride = x.out_stride ? x.out_stride : x.poly_stride;
     k.aux_stride = x.aux_stride ? x.aux_stride : x.poly_stride;
     k.excl_step = x.excl_step;
@@ -902,6 +909,8 @@ __device__ __forceinline__ void modup_ip_body(const NttKArgs &k, const ModupIpAr
             }
     }
     const bool fix = twr == ip.fix_limb;   // (uniform) pha_keyswitch_rescale: ct_last + cx_last * P^-1
+    // (uniform) this limb goes back to coefficient form next: run the inverse transform's contiguous pass here (ModupIpArgs::inv_from)
+    const bool inv = ip.inv_from != 0xffffffffu && (twr >= ip.inv_from || twr == ip.inv_lead);
 #pragma unroll
     for (int gi = 0; gi < G; gi++)
 #pragma unroll
@@ -924,9 +933,45 @@ __device__ __forceinline__ void modup_ip_body(const NttKArgs &k, const ModupIpAr
                 ra.x = add_mod(c1.x, shoup(ra.x, ip.fix_cst, q), q);
                 ra.y = add_mod(c1.y, shoup(ra.y, ip.fix_cst, q), q);
             }
-            *reinterpret_cast<u64x2 *>(ip.cx + id) = rb;
-            *reinterpret_cast<u64x2 *>(ip.cx + ip.qlp_n + id) = ra;
+            if (inv) {   // canonical residues, in the layout the inverse pass's first round loads
+                accb[i0] = rb.x; accb[i0 + 1] = rb.y;
+                acca[i0] = ra.x; acca[i0 + 1] = ra.y;
+            } else {
+                *reinterpret_cast<u64x2 *>(ip.cx + id) = rb;
+                *reinterpret_cast<u64x2 *>(ip.cx + ip.qlp_n + id) = ra;
+            }
         }
+    if (!inv) return;
+    // nwt_2d_radix8_backward's first pass (intt_2d.cu:9-104) on the rows this wavefront owns, from registers: the pass stores what the
+    // stand-alone launch would (lazy integers / centred doubles) and the caller launches the strided pass alone
+    using InvProg = PassProgram<C, false, EPI_NONE, false, 0, false>;
+    NttKArgs ki = k;
+    ki.tw = ip.itw;
+    ki.twf = ip.itwf;
+    ki.in = ki.out = ip.cx;
+    ki.batch = 2;
+    ki.in_stride = ki.out_stride = ip.qlp_n;
+    ki.pro_src = nullptr;
+    auto inverse_rows = [&](u64 *r, uint32_t z) __attribute__((always_inline)) {
+        PassArgs ai;
+        full_tile_args<C, false, EPI_NONE, false>(ki, twr, z, tile, ai);
+        ai.fp = FP;
+        u64x2 twreg[C::TW_TOTAL];
+        InvProg::template run_prefetched<0>(ai, lds, tid, r, twreg);
+        tile_sync<C>();
+        InvProg::template run_prefetched<1>(ai, lds, tid, r, twreg);
+        if constexpr (InvProg::NSEG >= 3) {
+            tile_sync<C>();
+            InvProg::template run_prefetched<2>(ai, lds, tid, r, twreg);
+        }
+        if constexpr (InvProg::NSEG == 4) {
+            tile_sync<C>();
+            InvProg::template run_prefetched<3>(ai, lds, tid, r, twreg);
+        }
+        tile_sync<C>();   // the second sum reuses the LDS words
+    };
+    inverse_rows(accb, 0);
+    inverse_rows(acca, 1);
 }
 
 // Limb order: blockIdx.y walks the special (P) limbs first -- 60-bit primes on the integer back end, the longest wavefronts of
@@ -1013,7 +1058,7 @@ static NttChoice choose_plan(Context &c, const LimbSel &sel, const NttExtra &x) 
     if (ch.v == 3 && c.log_n >= 14 && c.log_n <= 16 && limb_polys * (c.n >> 8) <= (size_t)PHA_EPT4_MAX_WAVES) ch.v = 5;
     // r04: N = 2^16 as 64 x 1024 for every launch that is not the first half of the fused mod-up (whose contiguous pass, with the key
     // inner product as its epilogue, is the 256-point one-wavefront pass of plan 3)
-    if (c.log_n == 16 && (ch.v == 3 || ch.v == 4) && !x.first_pass_only) {
+    if (c.log_n == 16 && (ch.v == 3 || ch.v == 4) && !x.first_pass_only && !x.second_pass_only) {
         if (has(vv, 4096)) ch.v = 10;
 #if defined(PHA_EXPERIMENTS)
         else if (has(vv, 8192)) ch.v = 12;
@@ -1030,6 +1075,11 @@ static NttChoice choose_plan(Context &c, const LimbSel &sel, const NttExtra &x) 
         (has(vv, 512) || tiles >= (size_t)g_fused_min_tiles.load(std::memory_order_relaxed)))
         ch.fused = &c;
 #endif
+    if (x.second_pass_only) {   // the other half ran in the fused mod-up: two launches' worth of plan, the split of plan 3
+        ch.whole = 0;
+        ch.fused = nullptr;
+        if (ch.v > 5) ch.v = 3;
+    }
     return ch;
 }
 

@@ -1296,12 +1296,15 @@ static u64 h_invmod_p(Context &c, uint32_t limb) {
 // mod-up + inner product of ONE ciphertext: the fused form where the shape has one, else the two steps.  fix_ct as in inner_prod.
 static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s, uint32_t batch = 1,
                        const u64 *fix_ct = nullptr);
-static void modup_inner_prod(Context &c, Tool &t, u64 *cx, u64 *t_mod_up, const u64 *c2, const u64 *const *rlk, int scheme, u64 *tmp,
-                             hipStream_t s, const u64 *fix_ct = nullptr) {
+// fold_inverse (ckks forms): the fused kernel also runs the contiguous pass of the mod-down's inverse transform on the special limbs
+// (and on the last data limb when fix_ct is given, the fused rescale); returns true when it did -- the caller then launches that
+// inverse with NttExtra::second_pass_only.
+static bool modup_inner_prod(Context &c, Tool &t, u64 *cx, u64 *t_mod_up, const u64 *c2, const u64 *const *rlk, int scheme, u64 *tmp,
+                             hipStream_t s, const u64 *fix_ct = nullptr, bool fold_inverse = false) {
     if (!fusable_ip(c, t)) {
         modup(c, t, t_mod_up, c2, scheme, tmp, s);
         inner_prod(c, t, cx, t_mod_up, rlk, s, 1, fix_ct);
-        return;
+        return false;
     }
     ModupIpArgs ip{};
     ip.cx = cx; ip.evks = rlk; ip.qlp_n = (size_t)t.size_qlp * c.n; ip.qp_n = (size_t)c.size_qp * c.n;
@@ -1313,7 +1316,14 @@ static void modup_inner_prod(Context &c, Tool &t, u64 *cx, u64 *t_mod_up, const 
         ip.fix_ct = fix_ct;
         ip.fix_ct_stride = (size_t)t.size_ql * c.n;
     }
+    if (fold_inverse) {
+        ip.inv_from = t.size_ql;
+        ip.inv_lead = fix_ct ? t.size_ql - 1 : 0xffffffffu;
+        ip.itw = c.d_itw.p;
+        ip.itwf = c.d_itwf.p;
+    }
     modup(c, t, t_mod_up, c2, scheme, tmp, s, 1, 0, &ip);
+    return ip.inv_from != 0xffffffffu;
 }
 
 // phantom::key_switch_inner_prod eval_key_switch.cu:71-92
@@ -1355,8 +1365,9 @@ static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const 
 // DRNSTool::moddown_from_NTT rns_bconv.cu:776-828 for `polys` polynomials cx + z*cx_stride at once.
 // accumulate = false: ct_z = result (the reference call).  accumulate = true: ct_z += result, i.e. the
 // add_to_ct_kernel of keyswitch_inplace (rns_bconv.cu:763-769) fused into the NTT epilogue.
+// folded (ckks): the special limbs of cx already went through the inverse transform's contiguous pass (modup_inner_prod).
 static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64 *cx, size_t cx_stride,
-                             uint32_t polys, int scheme, bool accumulate, u64 *delta, hipStream_t s) {
+                             uint32_t polys, int scheme, bool accumulate, u64 *delta, hipStream_t s, bool folded = false) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp;
     NttExtra xb;
@@ -1365,6 +1376,8 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
     // ckks, alpha > 1: bconv phase 1 (x phat_i^-1 mod p_i, bconv_mult_kernel rns_bconv.cu:22-33) rides on the
     // inverse NTT's last round, exactly as mod-up does (:558-559); the conversion then skips its own scaling
     const bool prescaled = scheme == PHA_SCHEME_CKKS && t.alpha > 1;
+    if (folded && scheme != PHA_SCHEME_CKKS) throw std::logic_error("folded inverse pass outside the ckks mod-down");
+    xb.second_pass_only = folded;
     if (prescaled) {
         xb.scale = t.p_hat_inv_by_limb.p;
         xb.scale_shoup = t.p_hat_inv_by_limb_shoup.p;
@@ -1478,8 +1491,9 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
                               u64 *base, hipStream_t s) {
     const size_t n = c.n, ql = t.size_ql, ql_n = ql * n, qlp_n = (size_t)t.size_qlp * n, nl = ql - 1;
     u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n;
+    bool folded = false;   // the inverse transform's contiguous pass already ran inside the fused mod-up
     if (B == 1) {
-        modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, PHA_SCHEME_CKKS, tmp, s, ct);   // cx_last <- ct_last + cx_last * P^-1
+        folded = modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, PHA_SCHEME_CKKS, tmp, s, ct, true);   // cx_last <- ct_last + cx_last * P^-1
     } else {
         modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B);
         inner_prod(c, t, cx, t_mod_up, rlk, s, B, ct);
@@ -1490,6 +1504,7 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
         xb.poly_stride = qlp_n;
         xb.scale = t.p_hat_inv_by_limb.p;
         xb.scale_shoup = t.p_hat_inv_by_limb_shoup.p;
+        xb.second_pass_only = folded;
         ntt_inverse(c, cx, cx, cx, special_sel(nl, c.size_p + 1, c.size_qp, c.size_p), EPI_INV_SCALE, xb, s);
     }
     {   // v_j = delta_j P^-1 + (c_last mod q_j)
@@ -1593,9 +1608,9 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     // scratch: t_cks / delta [2][Ql][N] | t_mod_up [beta][QlP][N] | cx [2][QlP][N]  (eval_key_switch.cu:151,155)
     u64 *base = c.scratch(stream, 2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n);
     u64 *tmp = base, *t_mod_up = base + 2 * ql_n, *cx = t_mod_up + (size_t)t.beta * qlp_n;
-    modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, scheme, tmp, s);
+    const bool folded = modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, scheme, tmp, s, nullptr, scheme == PHA_SCHEME_CKKS);
     // both polynomials at once; ct += moddown(cx) with the add fused into the NTT epilogue
-    moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2, scheme, true, tmp, s);
+    moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2, scheme, true, tmp, s, folded);
     PHA_API_END
 }
 

@@ -13,9 +13,11 @@ STAGES = [
     ("mod-up: inverse NTT x partQlHatInv", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * QL * W),
     ("mod-up: base conversion, 3 digits", ["bconv_kernel"], BETA * (ALPHA + QL) * W),             # in 15 + out 30 + 15 per digit
     # r03: the inner product is the epilogue of the forward transform's contiguous pass (modup_ip_kernel); algorithmic bytes of both
-    ("mod-up: forward NTT of the converted limbs + key inner product (fused)", ["ntt_pass_kernel", "modup_ip_kernel"],
-     2 * BETA * QL * W + QLP * (3 * BETA + 2) * W),
-    ("mod-down + rescale: inverse NTT of P and last limb, 2 polys", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * 2 * (ALPHA + 1) * W),
+    # r04: the fused kernel also runs the contiguous pass of the mod-down's inverse transform on the special limbs and the last data
+    # limb (ModupIpArgs::inv_from), so that inverse is ONE launch (the strided pass); its algorithmic bytes are split evenly
+    ("mod-up: forward NTT of the converted limbs + key inner product (fused; + contiguous pass of the inverse of P and last limb)",
+     ["ntt_pass_kernel", "modup_ip_kernel"], 2 * BETA * QL * W + QLP * (3 * BETA + 2) * W + 2 * (ALPHA + 1) * W),
+    ("mod-down + rescale: inverse NTT of P and last limb, 2 polys: strided pass", ["ntt_pass_kernel"], 2 * (ALPHA + 1) * W),
     ("mod-down + rescale: conversion + last-limb fold", ["bconv_rescale_kernel"], 2 * (ALPHA + 1 + QL - 1) * W),
     ("mod-down + rescale: ONE forward NTT, epilogue (ct + cx/P - .)/q_last", ["ntt_pass_kernel", "ntt_pass_kernel"], 2 * (QL - 1) * (2 + 2) * W),
 ]
