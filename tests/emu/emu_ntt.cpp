@@ -127,6 +127,90 @@ extern "C" int emu_plan_is_wave_local(int log_n, int variant) {   // bit 0: pass
     switch (log_n) { WLC(12) WLC(13) WLC(14) WLC(15) WLC(16) WLC(17) default: return -1; }
 }
 
+// ---- the fused mod-up kernel's hand-over (modup_ip_body, pha_ntt.hip): forward contiguous pass whose last round KEEPS its outputs
+// in registers (run_keep), canonical residues formed there, and the inverse transform's contiguous pass started from those
+// registers (run_prefetched) -- same calls, same order, one wavefront-sized tile at a time.  ntt_out receives the canonical forward
+// transform at the addresses the kernel uses for its key words (g0 + k), out the finished round trip.
+template <class F, class I, int SEG>
+static void keep_forward(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
+    if constexpr (SEG < F::NSEG - 1) {
+        for (int tid = 0; tid < F::THREADS; tid++) F::template run<SEG>(a, lds, tid, regs[tid], g_twregs[tid]);
+        keep_forward<F, I, SEG + 1>(a, lds, regs);
+    } else {
+        for (int tid = 0; tid < F::THREADS; tid++) F::template run_keep<SEG>(a, lds, tid, regs[tid], g_twregs[tid]);
+    }
+}
+template <class I, int SEG>
+static void inverse_from_registers(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
+    if constexpr (SEG < I::NSEG) {
+        for (int tid = 0; tid < I::THREADS; tid++) I::template run_prefetched<SEG>(a, lds, tid, regs[tid], g_twregs[tid]);
+        inverse_from_registers<I, SEG + 1>(a, lds, regs);
+    }
+}
+template <int LOGN, int VARIANT>
+static void emu_keep_inverse(const u64 *in, u64 *ntt_out, u64 *out, u64 q, const u64x2 *tw, const u64x2 *itw, u64x2 ninv, u64x2 w1ninv, bool fp) {
+    using P1 = typename NttPlan<LOGN, VARIANT>::P1;
+    using C = typename NttPlan<LOGN, VARIANT>::P2;
+    using F = PassProgram<C, true, EPI_NONE, false, 0, false>;
+    using I = PassProgram<C, false, EPI_NONE, false, 0, false>;
+    constexpr int RL = C::NR - 1, r = C::r(RL), K = 1 << r, G = C::EPT >> r;
+    const size_t n = (size_t)1 << LOGN;
+    PassArgs a{};
+    a.tw = tw; a.twd = reinterpret_cast<const u64 *>(tw); a.q = q; a.rho0 = P1::T; a.stride = C::T; a.fp = fp; a.fpm = make_fpmod(q);
+    a.in = in; a.out = out;
+    run_pass<P1, true, EPI_NONE, false>(a, n);       // strided pass: in -> out (the digits buffer of the kernel)
+    std::vector<u64> lds(C::LDS_WORDS);
+    static u64 regs[1024][16];
+    const u32 tiles = (u32)(n >> C::LOGTILE);
+    for (u32 t = 0; t < tiles; t++) {
+        PassArgs af = a;
+        af.in = out; af.tile = t;
+        keep_forward<F, I, 0>(af, lds.data(), regs);
+        for (int tid = 0; tid < C::THREADS; tid++)
+            for (int gi = 0; gi < G; gi++) {
+                int v, hi, lo;
+                decode_group<C, RL>(tid + C::THREADS * gi, v, hi, lo);
+                const size_t g0 = ((size_t)t * C::V + v) * C::T + ((size_t)hi << r);
+                for (int kk = 0; kk < K; kk++) {
+                    u64 &x = regs[tid][gi * K + kk];
+                    x = fp ? fp_to_canon(as_f64(x), a.fpm) : csub(csub(csub(x, q << 2), q << 1), q);
+                    ntt_out[g0 + kk] = x;
+                }
+            }
+        PassArgs ai = a;
+        ai.tw = itw; ai.twd = reinterpret_cast<const u64 *>(itw); ai.in = nullptr; ai.out = out; ai.tile = t;
+        inverse_from_registers<I, 0>(ai, lds.data(), regs);
+    }
+    a.tw = itw; a.twd = reinterpret_cast<const u64 *>(itw); a.ninv = ninv; a.w1ninv = w1ninv;
+    a.in = out; a.out = out;
+    run_pass<P1, false, EPI_INV_CANON, true>(a, n);   // the strided pass alone (NttExtra::second_pass_only)
+}
+extern "C" int emu_keep_then_inverse(int log_n, int variant, int fp, const uint64_t *in, uint64_t *ntt_out, uint64_t *out, uint64_t q,
+                                     const uint64_t *tw, const uint64_t *itw, const uint64_t *ninv, const uint64_t *w1ninv) {
+    const u64x2 *t = reinterpret_cast<const u64x2 *>(tw), *it = reinterpret_cast<const u64x2 *>(itw);
+    const u64x2 ni{ninv[0], ninv[1]}, w1{w1ninv[0], w1ninv[1]};
+    g_zloop_form = false;
+#define KI(N, V) emu_keep_inverse<N, V>(in, ntt_out, out, q, t, it, ni, w1, fp != 0)
+    if (variant == 3) {
+        switch (log_n) {
+            case 14: KI(14, 3); return 0;
+            case 15: KI(15, 3); return 0;
+            case 16: KI(16, 3); return 0;
+            case 17: KI(17, 3); return 0;
+            default: return -1;
+        }
+    }
+    if (variant == 5) {
+        switch (log_n) {
+            case 14: KI(14, 5); return 0;
+            case 15: KI(15, 5); return 0;
+            case 16: KI(16, 5); return 0;
+            default: return -1;
+        }
+    }
+    return -2;
+}
+
 // N = 4096 / 8192 as one pass (variant 6)
 template <class P>
 static void emu_whole(bool fwd, int epi, const u64 *in, u64 *out, u64 q, const u64x2 *tw, u64x2 ninv, u64x2 w1ninv,

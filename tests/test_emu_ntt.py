@@ -110,6 +110,43 @@ def test_thread_program_matches_oracle(emu, log_n, bits, variant):
             assert np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("log_n", [14, 15, 16, 17])
+@pytest.mark.parametrize("bits", [40, 47, 50, 60])
+def test_fused_modup_hands_its_registers_to_the_inverse_pass(emu, log_n, bits):
+    """modup_ip_body (pha_ntt.hip): the forward contiguous pass keeps its last round's outputs in registers; for the special limbs the
+    inverse transform's contiguous pass starts from those registers (ModupIpArgs::inv_from) and the caller launches the strided pass
+    alone.  Replay of exactly that call sequence: the values at the kernel's key addresses are the oracle's forward transform, and
+    the finished inverse is the input again -- integer and FP64 back ends, plan 3 (the product) and plan 5."""
+    n = 1 << log_n
+    q = int(O.get_primes(n, bits, 1)[0])
+    tw, tws, itw, itws, ni, nis = O.ntt_tables(log_n, q)
+    c = O.Ctx(log_n, [q], 0)
+    r = rng_for(log_n * 7 + bits)
+    x = r.integers(0, q, n, dtype=np.uint64)
+    if log_n == 15:
+        x[::3] = q - 1
+    ref = c.nwt_forward(x.reshape(1, n), 1)[0]
+    itw1 = int(itw[1]) * n % q
+    itw_p, itws_p = itw.copy(), itws.copy()
+    itw_p[1], itws_p[1] = itw1, O.compute_shoup(itw1, q)
+    twi = np.ascontiguousarray(np.stack([tw, tws], axis=1).reshape(-1))
+    itwi = np.ascontiguousarray(np.stack([itw_p, itws_p], axis=1).reshape(-1))
+    emu.emu_keep_then_inverse.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p, C.c_uint64] + [u64p] * 4
+    for variant in (3, 5):
+        if variant == 5 and log_n == 17:
+            continue
+        mid, back = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        assert emu.emu_keep_then_inverse(log_n, variant, 0, p(x), p(mid), p(back), q, p(twi), p(itwi), p(pair(ni, q)), p(pair(int(itw[1]), q))) == 0
+        assert np.array_equal(mid, ref) and np.array_equal(back, x), (variant, "integer")
+        if bits <= 50:
+            f = lambda w: np.ascontiguousarray(w.astype(np.float64)).view(np.uint64).copy()
+            f1 = lambda v: np.array([float(v), 0.0], dtype=np.float64).view(np.uint64).copy()
+            mid[:] = 0
+            back[:] = 0
+            assert emu.emu_keep_then_inverse(log_n, variant, 1, p(x), p(mid), p(back), q, p(f(tw)), p(f(itw_p)), p(f1(ni)), p(f1(int(itw[1])))) == 0
+            assert np.array_equal(mid, ref) and np.array_equal(back, x), (variant, "fp64")
+
+
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
 def test_barrier_free_plans_are_wave_local(emu, log_n):
     """The plans whose rounds hand over without a workgroup barrier (one-wavefront contiguous tiles) may only do so if no wavefront touches another wavefront's LDS words in any round."""
