@@ -357,7 +357,8 @@ struct ModupIpArgs {
     // r04: the limbs the mod-down transforms back first (the special limbs, and `inv_lead` -- the last data limb -- for the fused
     // rescale) leave the kernel with the inverse transform's contiguous pass already applied to both sums: the wavefront holds the
     // whole rows that pass works on, in its first round's register layout.  The caller then runs the inverse with
-    // NttExtra::second_pass_only.  inv_from: first such limb (selection-relative data index; 0xffffffff = off).
+    // NttExtra::second_pass_only.  inv_from: first such limb, inv_lead: the extra one (limb indices in the [Ql | P] buffer, as
+    // fix_limb; 0xffffffff = off / none).
     uint32_t inv_from = 0xffffffffu, inv_lead = 0xffffffffu;
     const u64x2 *itw = nullptr;       // inverse twiddle tables [prime][n] (integer / FP64 back end)
     const u64 *itwf = nullptr;
