@@ -84,6 +84,7 @@ KS_CASES = [
     ("c4_bfv15", O.BFV, [30]),
     ("c3_ckks16", O.CKKS, [45, 31]),
     ("hyb17_a2", O.CKKS, [4, 3]),        # N = 2^17 (3: a short last digit)
+    ("hyb14_a2", O.CKKS, [8, 7]),        # beta = 4 under the fused mod-up + inner product
     ("hyb12_a2", O.BGV, [6, 5, 1]),      # t-corrected mod-down (bgv_moddown_kernel rns_bconv.cu:636-652)
     ("hyb13_a3", O.BGV, [9, 7]),
     ("c1_bfv4096", O.BGV, [2]),
@@ -311,7 +312,7 @@ def test_hommul_relin_rescale_c3(gpu):
 # (config, live data limbs, batch): alpha = 2 / 3 / 15 incl. short last digits, the alpha = 1 fallback, both BASELINE sizes
 KSR_CASES = [("hyb12_a2", 6, 1), ("hyb12_a2", 5, 2), ("hyb12_a2", 2, 1), ("hyb13_a3", 9, 1), ("hyb13_a3", 7, 3), ("hyb13_a3", 4, 1),
              ("c1_bfv4096", 2, 2), ("c2_ckks14", 8, 2), ("hyb14_a4", 8, 1), ("hyb14_a4", 5, 2), ("c4_bfv15", 30, 2), ("c4_bfv15", 17, 1), ("c3_ckks16", 45, 1), ("c3_ckks16", 31, 2),
-             ("c3_ckks16", 45, 4), ("hyb17_a2", 4, 1), ("hyb17_a2", 3, 2)]   # 2 x 4 = 8 polynomials at N = 2^16: the twiddle-resident batched contiguous pass (r04) with the key switch + rescale epilogue
+             ("c3_ckks16", 45, 4), ("hyb17_a2", 4, 1), ("hyb17_a2", 3, 2), ("hyb14_a2", 8, 1)]   # 2 x 4 = 8 polynomials at N = 2^16: the twiddle-resident batched contiguous pass (r04) with the key switch + rescale epilogue
 
 
 @pytest.mark.parametrize("name,ql,batch", KSR_CASES)
