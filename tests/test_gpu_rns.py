@@ -354,6 +354,45 @@ def test_keyswitch_rescale_equals_keyswitch_then_rescale(name, ql, batch, gpu):
         ctx.keyswitch_rescale(ql, d_ct[0], d_c2[0], rlk.public_keys_ptr, d_ct[0])
 
 
+def test_keyswitch_rescale_replays_from_a_hip_graph(gpu):
+    """pha_keyswitch_rescale enqueues plain kernel launches on the caller's stream (arguments and work maps by value, scratch from the
+    stream's arena, no host synchronisation): captured into a hipGraph after one warm-up call on that stream, it replays on NEW inputs
+    to what the eager call gives -- the fused mod-up + inner product with the folded inverse pass included (N = 2^14, alpha 4)."""
+    import torch
+    import phantom_fhe_amd as P
+    name, ql = "hyb14_a4", 8
+    log_n, primes, size_p = primes_of(name)
+    n = 1 << log_n
+    size_q = len(primes) - size_p
+    oc, ctx = oracle_ctx(name), _ctx(name, gpu)
+    r = rng_for(733)
+    rlk = P.PhantomRelinKey.from_numpy(_keys(oc, r, primes, n, size_q, size_p), gpu)
+    ins = [(np.stack([uniform_poly(r, primes[:ql], n) for _ in range(2)]), uniform_poly(r, primes[:ql], n)) for _ in range(3)]
+    want = []
+    for ct, c2 in ins:
+        dst = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+        ctx.keyswitch_rescale(ql, P.to_device(ct, gpu), P.to_device(c2, gpu), rlk.public_keys_ptr, dst)
+        want.append(P.to_host(dst))
+    d_ct, d_c2 = P.to_device(ins[0][0], gpu), P.to_device(ins[0][1], gpu)
+    out = P.to_device(np.zeros((2, ql - 1, n), dtype=np.uint64), gpu)
+    side = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(side):
+        ctx.keyswitch_rescale(ql, d_ct, d_c2, rlk.public_keys_ptr, out)      # warm-up: the stream's scratch arena exists before the capture
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            ctx.keyswitch_rescale(ql, d_ct, d_c2, rlk.public_keys_ptr, out)
+    for i in (1, 2, 0):
+        d_ct.copy_(P.to_device(ins[i][0], gpu))
+        d_c2.copy_(P.to_device(ins[i][1], gpu))
+        out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(P.to_host(out), want[i]), i
+
+
 def _ternary_sk(oc, rng, primes, n):
     s_small = rng.integers(-1, 2, n)
     sk = np.stack([(s_small % int(q)).astype(np.uint64) for q in primes])
