@@ -43,6 +43,7 @@ C4_LOG_N = 15
 C4_BITS = [60] + [50] * 29 + [60] * 15  # benchmark/keyswitch_bench.cu:25-34
 C4_BATCH = 64
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes (tools/traffic.sh)
+STAGES_BATCHED_FILE = os.path.join(ROOT, "profiles", "stages_batched.json")   # the same for one op of a batch (tools/stage_table.py --batched)
 STAGES_FILE = os.path.join(ROOT, "profiles", "stages.json")     # per-kernel GPU times of one HomMul (tools/stage_table.py over a committed kernel trace)
 # BASELINE config 5: 128-slot encrypted mat-vec, one 128-diagonal block per row block = 64 baby x 2 giant steps, eight row blocks per
 # pass over the baby keys (tools/time_bsgs.py)
@@ -176,15 +177,91 @@ def load_traffic():
         return None
 
 
-def load_stages():
+def load_stages(path=None):
+    path = path or STAGES_FILE
     try:
-        raw = open(STAGES_FILE, "rb").read()
+        raw = open(path, "rb").read()
         t = json.loads(raw)
-        t["file"] = os.path.relpath(STAGES_FILE, ROOT)
+        t["file"] = os.path.relpath(path, ROOT)
         t["file_sha16"] = hashlib.sha256(raw).hexdigest()[:16]
         return t
     except (OSError, ValueError):
         return None
+
+
+def preflight(args, P, pdist, torch, dist, dev, world, rank, share, force_dist, comm):
+    """First-contact check of a multi-GPU run: nothing in this repository has ever executed on more than one
+    real RCCL rank, so the first 8-GPU run should fail HERE, with a reason, and not twelve GiB into the config-5 key broadcast.
+    Checks, per rank and then agreed over the group: visible devices >= world; distinct devices (PCI bus id / uuid) behind the ranks;
+    free device memory against the per-rank budget of the full bench (dominated by config 5: 12.1 GB of Galois keys + 4 GB of
+    plaintext diagonals + 6 GB of outputs and scratch, next to the headline's 0.4 GB batch and the table replicas); the RCCL
+    communicator (created by the caller: init_process_group + the all_gather above); a 64 MiB trial broadcast from rank 0 through
+    BOTH key-broadcast paths -- dist.broadcast and pha_broadcast_keys on the process group's own ncclComm_t (_comm_ptr()) -- each
+    checked word for word on every rank and timed.  Rank 0 prints ONE JSON line; the exit code is 0 only if every rank passed."""
+    import warnings
+    errors, notes = [], []
+    group = world > 1 or force_dist
+    n_vis = torch.cuda.device_count()
+    if not share and n_vis < world:
+        errors.append(f"{n_vis} HIP device(s) visible, {world} ranks")
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    need_b = int(26e9)   # see the docstring; measured peak of the full bench on one rank: 23.4 GB (torch.cuda.max_memory_allocated)
+    if free_b < need_b:
+        errors.append(f"rank {rank}: {free_b / 1e9:.1f} GB free on {dev}, the bench needs ~{need_b / 1e9:.0f} GB per rank (config 5)")
+    ids = [(i.get("pci_bus_id"), i.get("uuid")) for i in (comm or {}).get("per_rank", [])]
+    if group and not share and len(set(ids)) != len(ids):
+        errors.append(f"ranks share a device: {ids}")
+    trial = {}
+    if group:
+        words = (64 << 20) // 8
+        want = torch.arange(words, dtype=torch.int64, device=dev) * 0x9E3779B97F4A7C15 % (1 << 62)   # the pattern every rank can form itself
+        small_primes = [int(p) for p in P.coeff_modulus_create(4096, [50, 50, 60])]
+        pctx = P.PhantomContext(12, small_primes, 1, device=dev)
+        for path in ("dist.broadcast", "pha_broadcast_keys"):
+            if share and path == "pha_broadcast_keys":
+                trial[path] = {"skipped": "PHA_BENCH_SHARE_GPU: gloo group, no RCCL communicator"}
+                continue
+            buf = want.clone() if rank == 0 else torch.zeros(words, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            try:
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    if share:
+                        host = buf.cpu()
+                        calls = pdist.broadcast_keys([host], src=0)
+                        buf.copy_(host)
+                    else:
+                        calls = pdist.broadcast_keys([buf], src=0, ctx=pctx, direct=(path == "pha_broadcast_keys"))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                same = bool(torch.equal(buf, want))
+                took = pdist.LAST_BROADCAST_PATH
+                rec = {"ok": same and took == path, "path_taken": took, "calls": calls, "seconds": dt,
+                       "GBps": words * 8 / dt / 1e9, "fallback": pdist.LAST_BROADCAST_FALLBACK}
+                if not same:
+                    errors.append(f"rank {rank}: the {path} trial delivered different words")
+                if took != path:
+                    errors.append(f"rank {rank}: asked for {path}, got {took}: {pdist.LAST_BROADCAST_FALLBACK}")
+                trial[path] = rec
+            except Exception as e:   # noqa: BLE001 -- a preflight reports, it does not crash
+                errors.append(f"rank {rank}: {path} raised {type(e).__name__}: {e}")
+                trial[path] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+            del buf
+    else:
+        notes.append("one rank, no process group: nothing to broadcast (PHA_BENCH_FORCE_DIST=1 runs the RCCL checks on one device)")
+    mine = {"rank": rank, "errors": errors, "free_GB": free_b / 1e9, "total_GB": total_b / 1e9, "trial_broadcast": trial}
+    every = [mine]
+    if group:
+        every = [None] * dist.get_world_size()
+        dist.all_gather_object(every, mine)
+    ok = all(not e["errors"] for e in every)
+    if rank == 0:
+        print(json.dumps({"preflight": True, "ok": ok, "n_gpus": world, "devices_visible": n_vis,
+                          "backend": (comm or {}).get("backend"), "rccl": comm, "need_GB_per_rank": need_b / 1e9,
+                          "per_rank": every, "notes": notes,
+                          "errors": [x for e in every for x in e["errors"]]}), flush=True)
+    return ok
 
 
 def main():
@@ -197,6 +274,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue the K steps one by one from Python")
     ap.add_argument("--only-ntt", action="store_true", help="skip the HomMul and config-4 / config-5 legs (profiling runs)")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-5 leg (23 GB of Galois keys)")
+    ap.add_argument("--sustain", type=float, default=6.0,
+                    help="seconds of back-to-back headline steps AFTER the K timed ones (a sustained figure, and a GPU that the "
+                         "driver's utilisation sampler can see); 0 = off")
+    ap.add_argument("--preflight", action="store_true",
+                    help="first-contact check of an N-GPU run (devices, memory budget, RCCL init, a 64 MiB trial broadcast through "
+                         "both key-broadcast paths); prints one JSON line and exits")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -254,15 +337,36 @@ def main():
     n = 1 << LOG_N
     primes = [int(p) for p in P.coeff_modulus_create(n, BITS)]
     size_q = len(primes) - SIZE_P
-    ctx = P.PhantomContext(LOG_N, primes, SIZE_P, device=dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED0000 + 3 + rank)
     red_dev = None if share else dev
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1 or force_dist:
             dist.barrier()
+
+    if args.preflight:
+        ok = preflight(args, P, pdist, torch, dist, dev, world, rank, share, force_dist, comm)
+        if world > 1 or force_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
+
+    ctx = P.PhantomContext(LOG_N, primes, SIZE_P, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0000 + 3 + rank)
+
+    # ---- CPU baseline FIRST (r05): it needs idle host cores, not an idle GPU, and it is 13 of the run's ~30 s -- at the end it
+    #      left the GPU idle for the driver's utilisation sampler; at the start the GPU legs run back to back behind it.  Rank 0
+    #      times it (reported at N = 1 by contract; for N > 1 the other ranks wait at the barrier below, so that every rank ramps
+    #      its clocks at the same moment afterwards).
+    cpu_line = None
+    if rank == 0 and not args.no_cpu_baseline:
+        def gpu_forward(host_poly):   # the product path on the baseline's own input
+            d = P.to_device(host_poly, dev)
+            ctx.nwt_2d_radix8_forward_inplace(d, 45, 0)
+            return P.to_host(d)
+        cpu_line = cpu_baseline(primes, n, seconds=2.0 if small else 10.0, gpu_forward=gpu_forward)
+    barrier()
 
     direct_bcast = os.environ.get("PHA_BCAST_DIRECT") == "1"   # pha_broadcast_keys on the process group's own RCCL communicator
 
@@ -356,6 +460,31 @@ def main():
     kernel_ms = e0.elapsed_time(e1) / args.steps      # average duration of one launch pair inside the timed region
     ntt_per_s = world * args.steps * nb * size_q / elapsed
     step_stats = per_step_events(ntt_step, max(100, args.steps) if not small else 10)
+
+    # ---- sustained (r05): the same step back to back for --sustain seconds, in chunks of 100 steps enqueued by one library call
+    #      each, every chunk bracketed by events on the launch stream.  Reported beside the K timed steps (it is NOT `value`):
+    #      median / min / max per-step time over the chunks show what the part holds once clocks and temperature have settled.
+    sustained = None
+    sustain_s = 0.5 if small and args.sustain > 0 else args.sustain
+    if sustain_s > 0:
+        chunk = 20 if small else 100
+        chunk_ms = []
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < sustain_s:
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            ctx.repeat_forward_ntt_batched(polys, size_q, 0, nb, poly_stride, chunk)
+            b_.record()
+            b_.synchronize()
+            chunk_ms.append(a_.elapsed_time(b_) / chunk)
+        wall_s = time.perf_counter() - t_s
+        med = statistics.median(chunk_ms)
+        sustained = {"seconds": wall_s, "steps": chunk * len(chunk_ms), "steps_per_chunk": chunk,
+                     "median_ms_per_step": med, "min_ms_per_step": min(chunk_ms), "max_ms_per_step": max(chunk_ms),
+                     "first_chunk_ms_per_step": chunk_ms[0], "last_chunk_ms_per_step": chunk_ms[-1],
+                     "value": nb * size_q / (med * 1e-3), "unit": "NTT/s (this rank, median chunk)",
+                     "frac_of_peak": 16.0 * n * size_q * nb / (med * 1e-3) / PEAK_HBM,
+                     "gpu_busy_fraction": sum(chunk_ms) * chunk * 1e-3 / wall_s}
 
     # ---- informational: one 45-limb polynomial per launch pair (the r01 headline protocol) ------------------
     def single_inplace():
@@ -463,6 +592,28 @@ def main():
             batch_sweep.append({"batch": B, "ms_per_op": 1e3 * el / (B * hb_steps), "ops_per_s": world * B * hb_steps / el})
         best = min(batch_sweep, key=lambda e: e["ms_per_op"])
         B, hb_steps, hm_batched_elapsed = best["batch"], 1, best["ms_per_op"] * 1e-3 * best["batch"]
+        fixed = next((e for e in batch_sweep if e["batch"] == 8), None)   # the fixed-batch figure, comparable across rounds
+        # r05: the best batch again, back to back for ~--sustain / 2 seconds (each call = one op set of B ciphertext pairs between
+        # events): the sustained HomMul + relinearize + rescale rate; the sweep above times 3-10 calls per batch size
+        hm_sustained = None
+        if sustain_s > 0:
+            def hommul_best():
+                ctx.tensor_prod_2x2_batched(bt1, bt2, b01, b2, size_q, B)
+                ctx.keyswitch_rescale_batched(size_q, b01, b2, B, rlk.public_keys_ptr, bout)
+            per_call = []
+            t_s = time.perf_counter()
+            while time.perf_counter() - t_s < sustain_s / 2:
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                for _ in range(4):
+                    hommul_best()
+                b_.record()
+                b_.synchronize()
+                per_call.append(a_.elapsed_time(b_) / (4 * B))
+            med = statistics.median(per_call)
+            hm_sustained = {"batch": B, "seconds": time.perf_counter() - t_s, "ops": 4 * B * len(per_call),
+                            "median_ms_per_op": med, "min_ms_per_op": min(per_call), "max_ms_per_op": max(per_call),
+                            "value": 1e3 / med, "unit": "ops/s (this rank, median)", "frac_of_peak": 929.0 * (1 << 20) / (med * 1e-3) / PEAK_HBM}
         # minimal per-stage traffic of one HomMul + relinearize + rescale at C3: 929 MiB
         hm_alg_bytes = 929.0 * (1 << 20)
         hm = {"value": world * hm_steps / hm_elapsed, "unit": "ops/s", "ms_per_op": 1e3 * hm_elapsed / hm_steps,
@@ -475,7 +626,11 @@ def main():
                           "ms_per_op": 1e3 * hm_batched_elapsed / (B * hb_steps), "batch": B,
                           "frac_of_peak": hm_alg_bytes / (hm_batched_elapsed / (B * hb_steps)) / PEAK_HBM,
                           "sweep": batch_sweep,
-                          "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_rescale_batched; the best batch of the sweep"}}
+                          "fixed_batch_8": fixed,
+                          "sustained": hm_sustained,
+                          "note": "pha_tensor_prod_2x2_batched + pha_keyswitch_rescale_batched; value / ms_per_op = the best batch of "
+                                  "the sweep (3-10 timed calls per batch size); fixed_batch_8 = the B = 8 row of the same sweep (the "
+                                  "figure comparable across rounds); sustained = the best batch back to back for seconds"}}
         del ct1, ct2, buf, out, bt1, bt2, b01, b2, bout, rlk, evk
 
         # ---- BASELINE config 4: BFV relinearize + Galois rotate, N = 2^15, 30 + 15 limbs, batch 64 over the ranks ----
@@ -713,14 +868,16 @@ def main():
                                             "form of tools/stream_calib.hip that reaches the guide's float4-copy rate), best of default / "
                                             "nontemporal policy, (bytes read + bytes written) / time, this run; rmw = in-place "
                                             "read-modify-write, what an in-place pass does",
-                         "kernel_memory_floor_ms": 0.239,
-                         "kernel_memory_floor_note": "the two pass kernels with their butterflies compiled out (-DPHA_X_NOCOMPUTE build, "
+                         "sustained": sustained,
+                         "kernel_memory_floor_ms_offline": 0.239,
+                         "kernel_memory_floor_note": "OFFLINE figure, not measured in this run (profiles/r04j_bygrid_nocompute.csv, round 4): the two pass kernels with their butterflies compiled out (-DPHA_X_NOCOMPUTE build, "
                                                      "profiles/r04j_bygrid_nocompute.csv): strided 110 + contiguous 129 us per step = "
                                                      "0.395 of 8 TB/s; the FP64 work of the same step is ~84 operations per coefficient "
                                                      "= 131 us of pure issue at the 1.85 GHz the part holds under this load, so the "
                                                      "passes are issue- and memory-bound at once (profiles/r04_experiments.md)",
                          "torch_copy_GBps": copy_bps / 1e9, "guide_copy_GBps": 6290.0,
                          "ceiling_two_pass": ceiling, "frac_of_ceiling": achieved / PEAK_HBM / ceiling,
+                         "ceiling_two_pass_copy_rate": cal["copy_GBps"] * 1e9 / 2.0 / PEAK_HBM,
                          "ceiling_two_pass_guide": 6.29e12 / 2.0 / PEAK_HBM,
                          "frac_of_ceiling_guide": achieved / PEAK_HBM / (6.29e12 / 2.0 / PEAK_HBM),
                          "ceiling_note": "a two-pass transform moves every coefficient through the fabric twice in each "
@@ -751,19 +908,22 @@ def main():
         stages = load_stages()
         if hm is not None and stages:
             hm["stages"] = stages      # per-kernel us, algorithmic bytes and fraction of 8 TB/s from the committed kernel trace
-        if not args.no_cpu_baseline:      # rank 0 times it (for N > 1 the other ranks wait at the final barrier below)
-            def gpu_forward(host_poly):   # the product path on the baseline's own input
-                d = P.to_device(host_poly, dev)
-                ctx.nwt_2d_radix8_forward_inplace(d, 45, 0)
-                return P.to_host(d)
-            line["cpu_baseline"] = cpu_baseline(primes, n, seconds=2.0 if small else 10.0, gpu_forward=gpu_forward)
-        else:
-            line["cpu_baseline"] = None
+        # r05: the same two records for the BATCHED op (the throughput half of the metric): per-stage table of one op inside a batch
+        # of 8 and inside the best batch (tools/stage_table.py --batched over a kernel trace of tools/traffic_probe.py hommul_batched),
+        # PMC traffic per op (tools/traffic.sh)
+        bstages = load_stages(STAGES_BATCHED_FILE)
+        if hm is not None and bstages:
+            hm["batched"]["stages"] = bstages
+        if hm is not None and traffic and traffic.get("hommul_batched_bytes_per_op"):
+            hm["batched"]["traffic"] = traffic["hommul_batched_bytes_per_op"]
+            hm["batched"]["traffic_batch"] = traffic.get("hommul_batched_batch")
+            hm["batched"]["traffic_ratio"] = traffic["hommul_batched_bytes_per_op"] / hm["algorithmic_bytes_per_op"]
+        line["cpu_baseline"] = cpu_line    # timed first (see above); None with --no-cpu-baseline
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         if not share:
             torch.cuda.synchronize()
-        dist.barrier()                  # the other ranks leave only after rank 0 has printed the line (it times the CPU baseline last)
+        dist.barrier()                  # the other ranks leave only after rank 0 has printed the line
         dist.destroy_process_group()
 
 

@@ -650,6 +650,9 @@ static bool launch_zloop(const NttKArgs &k, hipStream_t s) {
     return true;
 }
 
+#ifndef PHA_IP_PLAN
+#define PHA_IP_PLAN 3    // NttPlan variant whose contiguous pass carries the inner product (3: 8 coefficients per thread; 5: 4)
+#endif
 template <int LOGN, int VARIANT>
 static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nullptr) {
     using P1 = typename NttPlan<LOGN, VARIANT>::P1;
@@ -726,6 +729,10 @@ static void inverse_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     (void)fused;
 #endif
     if (k.second_pass_only) {   // mid already holds the contiguous pass's output (T1 x T2 of this plan: choose_plan keeps the split of plan 3)
+        // the producer (modup_ip_kernel) ran the contiguous pass of the fused mod-up's plan: this strided pass must complete THAT split
+        using IpPlan = NttPlan<LOGN, (LOGN >= 14 && LOGN <= 16) ? PHA_IP_PLAN : 3>;
+        if (P1::LOGT + IpPlan::P2::LOGT != LOGN)
+            throw std::logic_error("second_pass_only: the chosen plan's strided pass does not complete the fused mod-up's contiguous pass");
         if (epi == EPI_INV_SCALE) launch_pass<P1, false, EPI_INV_SCALE, true>(k, s);
         else launch_pass<P1, false, EPI_INV_CANON, true>(k, s);
         return;
@@ -996,9 +1003,6 @@ __global__ PHA_IP_BOUNDS void modup_ip_kernel(const NttKArgs k, const ModupIpArg
     else modup_ip_body<C, BETA, false>(k, ip, twr, prime, tile, lds, threadIdx.x);
 }
 
-#ifndef PHA_IP_PLAN
-#define PHA_IP_PLAN 3    // NttPlan variant whose contiguous pass carries the inner product (3: 8 coefficients per thread; 5: 4)
-#endif
 template <int LOGN>
 static void launch_modup_ip(NttKArgs k, uint32_t beta, const ModupIpArgs &ip, hipStream_t s) {
     constexpr int V = (LOGN >= 14 && LOGN <= 16) ? PHA_IP_PLAN : 3;

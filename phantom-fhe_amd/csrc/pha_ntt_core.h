@@ -737,11 +737,19 @@ struct PassProgram {
     }
     static constexpr bool fp_sched_ok() {
         const FpSched sc = fp_sched();
-        for (int seg = 0; seg < C::NR; seg++)
+        for (int seg = 0; seg < C::NR; seg++) {
             if (sc.after[seg] > kFpLimit) return false;
+            // round_compute returns early for a round with on-the-fly twiddles and ignores RECENTRE / GSFULL there.  Going backward
+            // that is sound: the round's full butterflies leave centred values (ot_round_fp reduces every sum), which is what the
+            // schedule assumes when it restarts the bound at 1/2 behind it, and `full` is never set for such a round.  Going
+            // forward its outputs are NOT centred (M grows by 1/2 per stage), so the schedule must never ask it to re-centre:
+            // today it is the last round of the last pass, where the store canonicalises (fp_before_global_store).
+            const int ri = FWD ? seg : C::NR - 1 - seg;
+            if (C::ot_round(ri) && (sc.full[seg] || (FWD && sc.recentre[seg]))) return false;
+        }
         return true;
     }
-    static_assert(fp_sched_ok(), "FP64 path: a round would take the registers past 7.5 q (exactness needs < 8 q at 50 bits)");
+    static_assert(fp_sched_ok(), "FP64 path: a round would take the registers past 7.5 q (exactness needs < 8 q at 50 bits), or the schedule asks an on-the-fly-twiddle round to re-centre");
 
     // FP64 path: what just came from global memory becomes a small double.  First pass: canonical integers -> doubles; second
     // pass: the doubles of the first pass -- centred already when the forward pass re-centred them before its store (primes from

@@ -180,6 +180,11 @@ class PhantomContext:
         _lib.check(self._L.pha_nwt_2d_radix8_backward_scale(self._h, _ptr(out), _ptr(inp), cms, start,
                                                             _ptr(scale), _ptr(scale_shoup), _stream()))
 
+    def nwt_2d_radix8_backward_inplace_scale(self, inout, cms, start, scale, scale_shoup):
+        """include/ntt.cuh:217 (src/ntt/intt_2d.cu:759-794): inverse NTT in place, every output times the per-limb scale[i]."""
+        _lib.check(self._L.pha_nwt_2d_radix8_backward_inplace_scale(self._h, _ptr(inout), cms, start,
+                                                                    _ptr(scale), _ptr(scale_shoup), _stream()))
+
     def nwt_2d_radix8_backward_inplace_include_special_mod(self, inout, cms, start, size_QP, size_P):
         _lib.check(self._L.pha_nwt_2d_radix8_backward_inplace_include_special_mod(
             self._h, _ptr(inout), cms, start, size_QP, size_P, _stream()))

@@ -40,6 +40,26 @@ def _worker(rank, world, port, batch, q):
         pd.BROADCAST_CHUNK_BYTES = slab2[0].numel() * 8 * 2        # two keys per call: 5 keys -> 3 calls
         assert pd.broadcast_keys([slab2[k][d] for k in range(5) for d in range(3)], src=0) == 3
         key_sum += int(slab2.sum())
+        # direct=True without a reachable RCCL communicator (here: gloo, host tensors) falls back LOUDLY, with the reason
+        import warnings
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            assert pd.broadcast_keys(keys, src=0, ctx=object(), direct=True) == 2
+        assert pd.LAST_BROADCAST_PATH == "dist.broadcast"
+        assert pd.LAST_BROADCAST_FALLBACK and "HIP device" in pd.LAST_BROADCAST_FALLBACK
+        assert any("falling back to dist.broadcast" in str(w.message) and issubclass(w.category, RuntimeWarning) for w in caught)
+        assert pd.broadcast_keys(keys, src=0) == 2 and pd.LAST_BROADCAST_FALLBACK is None
+        comm, why = pd._raw_nccl_comm("cpu")
+        assert comm is None and "gloo" in why
+        # ranks that lay the same key set out differently (one slab here, separate tensors there) would issue different
+        # collective sequences: the call refuses on every rank instead of hanging
+        bad = [slab[0][0], slab[0][1]] if rank == 0 else [slab[0][0].clone(), slab[0][1].clone()]
+        try:
+            pd.broadcast_keys(bad, src=0)
+            refused = False
+        except RuntimeError as e:
+            refused = "different collective sequences" in str(e)
+        assert refused
         mine = list(pd.shard_range(batch, rank, world))
         # "process" the shard: a per-ciphertext function of the index and the key only (no cross-rank data)
         local = sum((i * 2654435761 + key_sum) % (1 << 40) for i in mine)

@@ -24,7 +24,7 @@ def _run(extra_args, **extra_env):
 
 
 def test_bench_line_contract(gpu):
-    d = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline"], PHA_BENCH_BATCHES="1,2")
+    d = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--sustain", "1.5"], PHA_BENCH_BATCHES="1,2")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -50,6 +50,31 @@ def test_bench_line_contract(gpu):
     for k in ("read_GBps", "write_GBps", "copy_GBps", "rmw_GBps"):
         assert 2000.0 < r[k] < 8000.0, (k, r[k])
     assert abs(r["ceiling_two_pass"] - r["rmw_GBps"] / 2 / 8000.0) < 1e-9
+    # r05: the sustained legs (the same step / the best batch back to back for seconds, medians over event-bracketed chunks)
+    su = r["sustained"]
+    assert su["seconds"] >= 1.5 and su["steps"] >= 100 and su["min_ms_per_step"] <= su["median_ms_per_step"] <= su["max_ms_per_step"]
+    assert 0.5 < su["gpu_busy_fraction"] <= 1.001 and abs(su["value"] - per_step / (su["median_ms_per_step"] * 1e-3)) / su["value"] < 1e-6
+    hs = hb["sustained"]
+    assert hs["batch"] == hb["batch"] and hs["seconds"] >= 0.75 and hs["median_ms_per_op"] > 0
+    assert hb["fixed_batch_8"] is None            # B = 8 is not in this run's sweep
+    assert "kernel_memory_floor_ms" not in r and r["kernel_memory_floor_ms_offline"] > 0   # an offline constant is named as one
+
+
+def test_bench_preflight(gpu):
+    """`bench.py --gpus N --preflight`: one JSON line, exit code 0, the trial broadcast through BOTH paths on a
+    one-rank RCCL group; without a group it says so; two ranks on one device (gloo) pass the dist.broadcast path and skip the other."""
+    one = _run(["--preflight"])
+    assert one["preflight"] is True and one["ok"] is True and one["n_gpus"] == 1 and one["notes"]
+    rccl = _run(["--preflight"], PHA_BENCH_FORCE_DIST="1")
+    assert rccl["ok"] is True and rccl["backend"] == "nccl" and rccl["errors"] == []
+    tb = rccl["per_rank"][0]["trial_broadcast"]
+    assert tb["dist.broadcast"]["ok"] and tb["dist.broadcast"]["path_taken"] == "dist.broadcast"
+    assert tb["pha_broadcast_keys"]["ok"] and tb["pha_broadcast_keys"]["path_taken"] == "pha_broadcast_keys"
+    assert rccl["per_rank"][0]["free_GB"] >= rccl["need_GB_per_rank"]
+    two = _run(["--gpus", "2", "--preflight"], PHA_BENCH_SHARE_GPU="1")
+    assert two["ok"] is True and two["n_gpus"] == 2 and [e["rank"] for e in two["per_rank"]] == [0, 1]
+    assert all(e["trial_broadcast"]["dist.broadcast"]["ok"] for e in two["per_rank"])
+    assert all("skipped" in e["trial_broadcast"]["pha_broadcast_keys"] for e in two["per_rank"])
 
 
 def test_bench_two_ranks_self_spawned_reproduce_one_rank(gpu):
@@ -75,7 +100,7 @@ def test_bench_two_ranks_self_spawned_reproduce_one_rank(gpu):
 
 def test_bench_two_ranks_keep_the_cpu_baseline_and_check_config4(gpu):
     """With the CPU baseline on (the default) a multi-rank line still carries `cpu_baseline` (rank 0 times it while the others
-    wait at the final barrier) and the config-4 leg states how many ciphertexts it compared with the oracle."""
+    wait at the barrier behind it) and the config-4 leg states how many ciphertexts it compared with the oracle."""
     two = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-graph", "--no-c5"], PHA_BENCH_SMALL="1", PHA_BENCH_SHARE_GPU="1")
     assert two["n_gpus"] == 2 and two["cpu_baseline"]["value"] > 0 and two["cpu_baseline"]["kind"] == "port"
     assert two["cpu_baseline"]["checked"].startswith("GPU forward NTT")

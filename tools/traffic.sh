@@ -6,18 +6,23 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for mode in ntt hommul; do
+HB=${HB:-8}    # batch of the batched HomMul pass
+for mode in ntt hommul hommul_batched; do
+  arg=$mode; [ $mode = hommul_batched ] && arg=hommul_batched:$HB
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 200 rocprofv3 --pmc $c --output-format csv -d $OUT/tr_${mode}_$c -o pmc -- python $R/tools/traffic_probe.py $mode > $OUT/tr_${mode}_$c.log 2>&1
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/tr_${mode}_$c -o pmc -- python $R/tools/traffic_probe.py $arg > $OUT/tr_${mode}_$c.log 2>&1
   done
 done
+export HB
 python - <<'PY'
 import csv, glob, json, os, collections, time
 out = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out"
 NTT_STEPS, HM_OPS = 6, 6
+HB = int(os.environ.get("HB", "8"))
+HB_SETS = 5
 res = {}
 detail = {}
-for mode, div in (("ntt", NTT_STEPS), ("hommul", HM_OPS)):
+for mode, div in (("ntt", NTT_STEPS), ("hommul", HM_OPS), ("hommul_batched", HB_SETS * HB)):
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         s = 0.0
@@ -34,7 +39,8 @@ for mode, div in (("ntt", NTT_STEPS), ("hommul", HM_OPS)):
     # FETCH_SIZE / WRITE_SIZE count in KiB (MI355X_MICROARCH.md: 1 unit = 1 KiB); gfx950 correction: FETCH_SIZE x 2
     res[mode] = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / div
 doc = {"ntt_batched_bytes_per_launch": res["ntt"], "hommul_bytes_per_op": res["hommul"],
-       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of tools/traffic_probe.py (6 steps / 6 ops), summed over "
+       "hommul_batched_bytes_per_op": res["hommul_batched"], "hommul_batched_batch": HB,
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of tools/traffic_probe.py (6 steps / 6 ops / 5 op sets of HB ciphertext pairs), summed over "
                  "the library's kernels, (2 x FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 correction of MI355X_MICROARCH.md",
        "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "detail": detail}
 json.dump(doc, open(out + "/traffic.json", "w"), indent=1)

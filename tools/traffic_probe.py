@@ -1,6 +1,7 @@
-"""Workload for the PMC traffic passes (tools/traffic.sh): nothing but NTT_STEPS forward NTT steps of the bench's headline
-batch (16 x 45 limbs, N = 2^16) and HM_OPS single HomMul + relinearize + rescale operations, so that the per-kernel
-FETCH_SIZE / WRITE_SIZE sums divide cleanly into bytes per step and bytes per op."""
+"""Workload for the PMC traffic passes (tools/traffic.sh) and the stage tables: nothing but NTT_STEPS forward NTT steps of the bench's
+headline batch (16 x 45 limbs, N = 2^16), HM_OPS single HomMul + relinearize + rescale operations, or (r05, mode hommul_batched[:B])
+5 op sets of B ciphertext pairs through the batched entry points -- so that the per-kernel FETCH_SIZE / WRITE_SIZE sums and kernel
+times divide cleanly into bytes / microseconds per step and per op."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "phantom-fhe_amd"))
@@ -34,4 +35,18 @@ if mode in ("hommul", "both"):
         ctx.tensor_prod_2x2_rns_poly(ct1, ct2, buf, size_q)
         ctx.keyswitch_rescale(size_q, buf, buf[2], rlk.public_keys_ptr, out)
     torch.cuda.synchronize()
+if mode.startswith("hommul_batched"):   # "hommul_batched[:B]": HB_SETS op sets of B ciphertext pairs through the batched entry points
+    B = int(mode.split(":")[1]) if ":" in mode else 8
+    HB_SETS = 5
+    rnd = lambda *s: torch.randint(0, 1 << 49, s, dtype=torch.int64, device=dev, generator=gen)   # below every prime of the set
+    rlk = P.PhantomRelinKey([rnd(2, len(primes), n) for _ in range(size_q // size_p)])
+    bt1, bt2 = rnd(B, 2, size_q, n), rnd(B, 2, size_q, n)
+    b01 = torch.zeros_like(bt1)
+    b2 = torch.zeros((B, size_q, n), dtype=torch.int64, device=dev)
+    bout = torch.zeros((B, 2, size_q - 1, n), dtype=torch.int64, device=dev)
+    for _ in range(HB_SETS):
+        ctx.tensor_prod_2x2_batched(bt1, bt2, b01, b2, size_q, B)
+        ctx.keyswitch_rescale_batched(size_q, b01, b2, B, rlk.public_keys_ptr, bout)
+    torch.cuda.synchronize()
+    print("probe done", HB_SETS, "sets of", B)
 print("probe done", NTT_STEPS, HM_OPS)
