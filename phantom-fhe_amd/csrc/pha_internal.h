@@ -331,6 +331,7 @@ struct NttExtra {
     size_t in_stride = 0;                                // polynomials of `in` when it is strided differently from mid (0 = poly_stride)
     bool first_pass_only = false;                        // forward: stop after the strided pass (the caller runs a fused second pass)
     bool second_pass_only = false;                       // inverse: the contiguous pass already ran (folded into the fused mod-up, ModupIpArgs::inv_from)
+    bool first_pass_done = false;                        // forward: the strided pass already ran (r05: fused into the mod-up's base conversion, modup_conv_strided)
     const u64 *pro_src = nullptr;                        // forward only: every limb of polynomial z transforms
     size_t pro_stride = 0;                               //   (pro_src + z * pro_stride) mod its own prime; `in` unused
     uint32_t excl_step = 0;                              // polynomial z skips [excl_start + z*step, min(+len, limit))
@@ -365,6 +366,25 @@ struct ModupIpArgs {
 };
 bool modup_ntt_inner_prod(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, uint32_t beta, const ModupIpArgs &ip,
                           hipStream_t s);
+
+// r05: the mod-up's base conversion fused with the STRIDED pass of the forward transform of the converted limbs ("from the
+// conversion side", pha_ntt.hip): a workgroup owns a tile of T1 rows x V adjacent columns of one digit, reads the digit's (scaled,
+// coefficient-form) input limbs for those coefficients ONCE, and for every output limb of the digit converts straight into the
+// registers the strided pass starts from, runs the pass and stores its output -- the converted digits are never written or read back
+// in coefficient form (src/rns_bconv.cu:455-485 + the first half of src/ntt/ntt_modup.cu:395-657).  `digits` [batch][QlP][N]
+// receives what ntt_forward(..., first_pass_only) would have left there; the caller then runs the transform with
+// NttExtra::first_pass_done.  Returns false (nothing launched) when the shape has no fused form.
+struct ModupConvArgs {
+    const BConvDev *convs;            // device array [beta]: the digit converters (Tool::d_digit_convs)
+    uint32_t beta;                    // polynomial z of the launch = digit z % beta of ciphertext z / beta
+    const u64 *src;                   // [ciphertexts][Ql][N]: c2 in coefficient form, scaled by partQlHatInv (the inverse transform's epilogue)
+    size_t src_group_stride;
+    const u64 *own;                   // NTT-form c2 for the verbatim copy of each digit's own limbs (modup_copy_partQl_kernel), or null
+    size_t own_group_stride;
+    uint32_t max_isz, max_osz;        // over the converters
+    bool mont_split;                  // every converter: 30 / 30 cuts, Montgomery rows (BConv::split_kind 1 with oninv)
+};
+bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, const ModupConvArgs &m, hipStream_t s);
 
 // shared launchers (pha_rns.hip / pha_poly.hip)
 // optional epilogue of a conversion: store dst_j (+)= (cx_j - converted_j) * cst_j instead of converted_j (BFV mod-down)

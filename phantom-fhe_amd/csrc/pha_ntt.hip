@@ -80,6 +80,7 @@ struct NttKArgs {
     size_t in_stride;        // elements between the polynomials of `in` (first pass; the second pass reads mid at poly_stride)
     bool first_pass_only;    // forward: the caller runs its own (fused) second pass
     bool second_pass_only;   // inverse: the contiguous pass was folded into the producer of `mid`
+    bool first_pass_done;    // forward: the strided pass was folded into the producer of `mid` (modup_conv_s1_kernel)
     uint32_t excl_step, excl_limit, excl_mod;
     const u64 *pro_src;      // rescale prologue: every limb of polynomial z reads pro_src + z * pro_stride instead
     size_t pro_stride;
@@ -671,7 +672,7 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     k.pro_src = nullptr;   // the rescale prologue belongs to the first pass
 #if defined(PHA_EXPERIMENTS)
     if constexpr (P1::THREADS == 512 && P1::LOGTILE == 12 && P2::THREADS == 64) {
-        if (fused && epi != EPI_FWD_KSRESCALE) {   // both passes in one launch
+        if (fused && epi != EPI_FWD_KSRESCALE && !k.first_pass_done) {   // both passes in one launch
             const bool done = epi == EPI_FWD_MODDOWN ? launch_fused<P1, P2, true, EPI_FWD_MODDOWN, false>(*fused, k1, k, s)
                               : epi == EPI_FWD_MODDOWN_ADD ? launch_fused<P1, P2, true, EPI_FWD_MODDOWN_ADD, false>(*fused, k1, k, s)
                                                            : launch_fused<P1, P2, true, EPI_FWD_CANON, false>(*fused, k1, k, s);
@@ -683,7 +684,7 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
 #endif
     // (the strided pass in the batched form measured SLOWER -- 720 limbs 282 -> 302 us: its twiddles are few and shared by a tile's columns,
     //  and a 512-thread workgroup that walks several polynomials keeps its barrier schedule for all of them)
-    launch_pass<P1, true, EPI_NONE, false>(k1, s);
+    if (!k.first_pass_done) launch_pass<P1, true, EPI_NONE, false>(k1, s);
     if (k.first_pass_only) return;
     // pass 1 ran in -> mid with the input stride; pass 2 reads mid and writes out with the output stride
 #if !defined(PHA_NO_ZLOOP)
@@ -781,6 +782,7 @@ static NttKArgs make_args(Context &c, const u64 *in, u64 *mid, u64 *out, const L
     k.in_stride = x.in_stride ? x.in_stride : x.poly_stride;
     k.first_pass_only = fwd && x.first_pass_only;
     k.second_pass_only = !fwd && x.second_pass_only;
+    k.first_pass_done = fwd && x.first_pass_done;
     k.out_stride = x.out_stride ? x.out_stride : x.poly_stride;
     k.aux_stride = x.aux_stride ? x.aux_stride : x.poly_stride;
     k.excl_step = x.excl_step;
@@ -1204,6 +1206,263 @@ bool modup_ntt_inner_prod(Context &c, u64 *digits, const LimbSel &sel, const Ntt
         default: launch_modup_ip<17>(k, beta, ip, s); break;
     }
     return true;
+}
+
+
+// ---- r05: the mod-up's base conversion fused with the strided pass of the forward transform -------------------
+// bconv_kernel (pha_rns.hip) writes beta x (l + alpha - alpha_b) converted limbs in coefficient form and the strided pass of the
+// forward transform reads them back: 67.5 + 67.5 MiB per key switch at C3, plus a launch.  Here the conversion is the LOAD of that
+// pass: a workgroup owns a strided-pass tile (T1 rows x V adjacent columns) of ONE digit polynomial, each thread reads the digit's
+// <= 16 scaled input residues of ITS coefficients once (the first round's register layout: EPT coefficients per thread, so the
+// inputs are EPT x isz words = 30 registers per coefficient as 30-bit halves -- hence four coefficients per thread and radix-4
+// rounds, where the stand-alone pass has eight and radix-8), and then walks the digit's output limbs: convert (the carry-free
+// 30 / 30 MAC against the LDS-staged Montgomery rows, REDC: the arithmetic of bconv_kernel, the same canonical residues), run
+// the pass from registers (PassProgram::run_prefetched), store the pass's output where the contiguous pass expects it.
+// Per output limb everything uniform (modulus, REDC constant, destination limb, table row, FP64 constants) comes from an LDS record
+// staged once per workgroup, so the loop has no dependent scalar-memory round trip.
+// LOGTILE 8: one wavefront per workgroup (64 rows x 4 columns: 32-byte runs, no workgroup barrier); 10: 64 x 16 (128-byte runs,
+// 256 threads); 11: 64 x 32.
+struct ConvLimbRec {      // 48 bytes; one per output limb of the digit
+    u64 p, oninv;
+    double fq, fqinv;
+    uint32_t jo, prime, fpok, pad;
+};
+constexpr int kMcsMaxOut = 64;
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ u64 uni64(u64 x) { return ((u64)uni32((uint32_t)(x >> 32)) << 32) | uni32((uint32_t)x); }
+
+#ifndef PHA_MCS_WAVES
+#define PHA_MCS_WAVES 2   // wavefronts per SIMD the register allocation aims at (inputs alone are 120 registers)
+#endif
+template <class C, int ISZ_PAD>
+__global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(PHA_MCS_WAVES, PHA_MCS_WAVES)))
+void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
+    static_assert(C::STRIDED && C::EPT == 4 && C::NR == 3 && C::r(0) == 2, "radix-4 strided pass, four coefficients per thread");
+    constexpr int K = 4, LOGD = C::LOGT - 2;
+// measured (profiles/r05_experiments.md, batched HomMul + relinearize + rescale, us per op at B = 8 / 32; separate kernels 279.5 / 275.0):
+// every round's twiddles requested before the conversion (HOIST 1), all four coefficients converted side by side (CHUNK 4: a matrix
+// row is read from LDS once) and 8 of the 15 input limbs in registers (226 registers, two 256-thread workgroups per CU with 76 KB
+// of LDS each): 275.1 / 275.2; 10 limbs in registers (252): 290 / 286; 7 (one workgroup per CU): 322; per-round twiddles: 284;
+// 64 x 4 tiles, one wavefront per workgroup: 365; 64 x 8: 295; 64 x 32: 292; one wavefront per SIMD, everything in registers: 339.
+#ifndef PHA_MCS_HOIST
+#define PHA_MCS_HOIST 1
+#endif
+#ifndef PHA_MCS_CHUNK
+#define PHA_MCS_CHUNK 4   // coefficients converted side by side (accumulator registers: 8 per coefficient)
+#endif
+#ifndef PHA_MCS_REGLIMBS
+#define PHA_MCS_REGLIMBS 8   // input limbs held in registers; the rest of the digit's inputs in LDS (16 = all in registers)
+#endif
+    using Prog = PassProgram<C, true, EPI_NONE, false, PHA_MCS_HOIST, false>;   // HOIST 1: a limb's twiddles are requested before its conversion; 2: the first round's only
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *lds = reinterpret_cast<u64 *>(smem);                                                  // the pass's tile
+    uint2 *s_rows = reinterpret_cast<uint2 *>(smem + (size_t)C::LDS_WORDS * sizeof(u64));      // [max_osz][kBcRowPad]
+    ConvLimbRec *s_rec = reinterpret_cast<ConvLimbRec *>(s_rows + m.max_osz * kBcRowPad);      // [max_osz]
+    const int tid = threadIdx.x;
+    const uint32_t z = blockIdx.z, tile = blockIdx.x;
+    const uint32_t ci = z % m.beta, grp = z / m.beta;
+    const BConvDev &d = m.convs[ci];
+    const uint32_t n = 1u << k.log_n, isz = d.isz, osz = d.osz, pitch = d.row_pad;
+    for (uint32_t e = tid; e < osz * kBcRowPad; e += C::THREADS) {
+        const uint32_t j = e / kBcRowPad, i = e % kBcRowPad;
+        s_rows[e] = i < pitch ? reinterpret_cast<const uint2 *>(d.mat30)[j * pitch + i] : uint2{0u, 0u};
+    }
+    for (uint32_t j = tid; j < osz; j += C::THREADS) {
+        ConvLimbRec r;
+        r.jo = j + (j >= d.pad_start ? d.pad_len : 0);                                   // limb of the [Ql | P] digit buffer
+        r.prime = r.jo >= k.sel.remap_from ? r.jo + k.sel.remap_add : r.jo;              // its row of the QP tables (= d.oprime[j])
+        r.p = k.mod[r.prime].value;
+        r.oninv = d.oninv[j];
+        r.fpok = 0; r.fq = 0.0; r.fqinv = 0.0; r.pad = 0;
+        if (k.fpinfo) {
+            const FpInfo fi = k.fpinfo[r.prime];
+            r.fpok = fi.ok; r.fq = fi.q; r.fqinv = fi.qinv;
+        }
+        s_rec[j] = r;
+    }
+    // this thread's coefficients: the first round's layout (round_load<C, 0>): rows lo + (kk << LOGD) of column tile * V + v
+    int v, hi, lo;
+    decode_group<C, 0>(tid, v, hi, lo);
+    uint32_t off[K];
+#pragma unroll
+    for (int kk = 0; kk < K; kk++) off[kk] = (uint32_t)(lo + (kk << LOGD)) * k.t2 + tile * C::V + (uint32_t)v;
+    const u64 *src = m.src + (size_t)grp * m.src_group_stride + (size_t)d.src_limb * n;
+    u64 *dig = k.out + (size_t)z * k.poly_stride;
+    // the first RL input limbs live in registers (8 per limb: four coefficients x two 30-bit halves), the others in LDS, [limb][kk][thread]
+    // as (lo, hi) pairs: conflict-free 8-byte reads.  All in registers is 120 + the pass's ~130: spills at two wavefronts per SIMD.
+    constexpr int RL = PHA_MCS_REGLIMBS < ISZ_PAD ? PHA_MCS_REGLIMBS : ISZ_PAD;
+    uint2 *s_in = reinterpret_cast<uint2 *>(s_rec + m.max_osz);                                // [ISZ_PAD - RL][K][THREADS]
+    u32 ylo[RL][K], yhi[RL][K];
+#pragma unroll
+    for (int i = 0; i < ISZ_PAD; i++)
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) {
+            const u64 y = i < (int)isz ? src[(size_t)i * n + off[kk]] : 0;
+            if (i < RL) {
+                ylo[i][kk] = (u32)y & 0x3fffffffu;
+                yhi[i][kk] = (u32)(y >> 30);
+            } else {
+                s_in[((i - RL) * K + kk) * C::THREADS + tid] = uint2{(u32)y & 0x3fffffffu, (u32)(y >> 30)};
+            }
+        }
+    if (d.copy_own && m.own) {   // modup_copy_partQl_kernel rns_bconv.cu:522-528
+        const u64 *own = m.own + (size_t)grp * m.own_group_stride + (size_t)d.src_limb * n;
+        for (uint32_t i = 0; i < isz; i++)
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) dig[(size_t)(d.src_limb + i) * n + off[kk]] = own[(size_t)i * n + off[kk]];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t e = 0; e < osz; e++) {
+        const ConvLimbRec rc = s_rec[e];
+        const u64 p = uni64(rc.p), oninv = uni64(rc.oninv);
+        const uint32_t jo = uni32(rc.jo), prime = uni32(rc.prime), fpok = uni32(rc.fpok);
+        PassArgs a;
+        a.in = nullptr;
+        a.out = dig + (size_t)jo * n;
+        a.tw = k.tw + (size_t)prime * n;
+        a.twd = k.twf + (size_t)prime * n;
+        a.q = p;
+        a.tile = tile;
+        a.rho0 = k.t1;
+        a.stride = k.t2;
+        a.aux = a.aux2 = nullptr;
+        a.pro_reduce = false;
+        a.pro_ratio1 = 0;
+        a.fp = fpok != 0;
+        a.fpm = FpMod{as_f64(uni64(as_u64(rc.fq))), as_f64(uni64(as_u64(rc.fqinv))), (fpok & 2) != 0, (fpok & 4) != 0};
+        u64 reg[K];
+        u64x2 twreg[C::TW_TOTAL];
+        // the pass's LDS / global offsets are functions of the thread index alone: recomputed per limb (a few dozen scalar-like
+        // vector instructions against ~2500) instead of living in ~40 registers next to the 120 of the inputs
+        int tid_e = threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        auto limb = [&](const PassArgs &pa) __attribute__((always_inline)) {
+            const int tid = tid_e;
+            Prog::load_twiddles(pa, tid, twreg);
+            // out_j = REDC(sum_i y_i * (qhat_i 2^64 mod p_j)) = sum_i y_i qhat_i mod p_j, canonical (bconv_kernel, SPLIT 30 / 30, mont)
+            const uint2 *row = s_rows + e * kBcRowPad;
+            constexpr int CH = PHA_MCS_CHUNK;
+#pragma unroll
+            for (int k0 = 0; k0 < K; k0 += CH) {
+                u64 ll[CH], lh[CH], hl[CH], hh[CH];
+#pragma unroll
+                for (int kk = 0; kk < CH; kk++) ll[kk] = lh[kk] = hl[kk] = hh[kk] = 0;
+#pragma unroll
+                for (int i = 0; i < ISZ_PAD; i++) {
+                    const uint2 mm = row[i];
+#pragma unroll
+                    for (int kk = 0; kk < CH; kk++) {
+                        u32 y0, y1;
+                        if (i < RL) {
+                            y0 = ylo[i < RL ? i : 0][k0 + kk];
+                            y1 = yhi[i < RL ? i : 0][k0 + kk];
+                        } else {
+                            const uint2 yy = s_in[((i - RL) * K + k0 + kk) * C::THREADS + threadIdx.x];
+                            y0 = yy.x;
+                            y1 = yy.y;
+                        }
+                        ll[kk] = (u64)y0 * mm.x + ll[kk];
+                        lh[kk] = (u64)y0 * mm.y + lh[kk];
+                        hl[kk] = (u64)y1 * mm.x + hl[kk];
+                        hh[kk] = (u64)y1 * mm.y + hh[kk];
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < CH; kk++) {
+                    const u64 mid = lh[kk] + hl[kk], mid_c = mid < lh[kk] ? 1 : 0;
+                    u64 rl = ll[kk], rh = 0;
+                    const u64 t1 = mid << 30;
+                    rl += t1;
+                    rh += (rl < t1) + (mid >> 34) + (mid_c << 30);
+                    const u64 t2 = hh[kk] << 60;
+                    rl += t2;
+                    rh += (rl < t2) + (hh[kk] >> 4);
+                    reg[k0 + kk] = mont_redc128(rl, rh, p, oninv);
+                }
+            }
+            Prog::template run_prefetched<0>(pa, lds, tid, reg, twreg);
+            tile_sync<C>();
+            Prog::template run_prefetched<1>(pa, lds, tid, reg, twreg);
+            tile_sync<C>();
+            Prog::template run_prefetched<2>(pa, lds, tid, reg, twreg);
+            tile_sync<C>();   // the next limb's first round writes the same LDS words
+        };
+        if (a.fp) {   // (uniform) one specialised body per butterfly back end, as exec_pass has them
+            PassArgs b = a;
+            b.fp = true;
+            limb(b);
+        } else {
+            PassArgs b = a;
+            b.fp = false;
+            limb(b);
+        }
+    }
+}
+
+#ifndef PHA_MCS_LOGTILE
+#define PHA_MCS_LOGTILE 10
+#endif
+#ifndef PHA_MODUP_CONV_FUSE
+#define PHA_MODUP_CONV_FUSE 1
+#endif
+#ifndef PHA_MCS_MIN_WORKGROUPS
+#if defined(PHA_EXPERIMENTS)
+#define PHA_MCS_MIN_WORKGROUPS 1      // the test-only library: every N = 2^16 mod-up takes the fused form, so that the key-switch parity tests reach it with ONE ciphertext (tests/test_gpu_ntt_variants.py)
+#else
+#define PHA_MCS_MIN_WORKGROUPS 1024
+#endif
+#endif
+bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, const ModupConvArgs &m, hipStream_t s) {
+#if !PHA_MODUP_CONV_FUSE
+    return false;
+#else
+    // the fused pass replaces the strided pass of NttPlan<16, 10> (64 rows x 1024-point rows): N = 2^16 launches that take that plan
+    if (c.log_n != 16 || !m.mont_split || m.max_isz > 16 || m.max_osz > (uint32_t)kMcsMaxOut || sel.count == 0 || sel.start != 0) return false;
+    NttExtra xd = x;
+    xd.first_pass_done = true;
+    const NttChoice ch = choose_plan(c, sel, xd);
+    if (ch.whole || ch.fused || ch.v != 10) return false;
+    using P1 = NttPlan<16, 10>::P1;
+    using P2 = NttPlan<16, 10>::P2;
+    using C = PassCfg<6, true, 2, 2, 2, 4, false, PHA_MCS_LOGTILE>;
+    static_assert(C::LOGT == P1::LOGT, "the fused pass is the strided pass of the plan whose contiguous pass follows");
+    check_sel(c, sel);
+    NttKArgs k = make_args(c, digits, digits, digits, sel, x, true);
+    k.t1 = P1::T;
+    k.t2 = P2::T;
+    const size_t lds_fixed = (size_t)C::LDS_WORDS * sizeof(u64) + (size_t)m.max_osz * kBcRowPad * sizeof(uint2) + (size_t)m.max_osz * sizeof(ConvLimbRec);
+    auto lds_for = [&](int isz_pad) {
+        const int in_lds = isz_pad > PHA_MCS_REGLIMBS ? isz_pad - PHA_MCS_REGLIMBS : 0;
+        return lds_fixed + (size_t)in_lds * 4 * C::THREADS * sizeof(uint2);
+    };
+    const dim3 grid((unsigned)(c.n >> C::LOGTILE), 1, k.batch), block(C::THREADS);
+    // a workgroup walks all output limbs of its tile (45 at the top level: ~200 us), so the form only pays when the launch fills the
+    // device several times over: two workgroups per CU are resident, four generations of them = batches of >= 6 ciphertexts at
+    // beta = 3 (measured: equal to the separate kernels at B = 32, 1.5 % ahead at B = 8; a single ciphertext would wait ~200 us for
+    // 192 workgroups where the separate kernels take 67)
+    if ((size_t)grid.x * grid.z < (size_t)PHA_MCS_MIN_WORKGROUPS) return false;
+    auto go = [&](auto kern, int isz_pad) {
+        const size_t lds_bytes = lds_for(isz_pad);
+        if (lds_bytes > 64 * 1024) {   // beyond the default dynamic LDS limit: raise it once per kernel and device
+            static std::atomic<uint64_t> raised[2] = {{0}, {0}};
+            int dev = 0;
+            PHA_HIP(hipGetDevice(&dev));
+            const uint64_t bit = 1ull << (dev & 63);
+            std::atomic<uint64_t> &r = raised[isz_pad == 15 ? 0 : 1];
+            if (!(r.load(std::memory_order_acquire) & bit)) {
+                PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                r.fetch_or(bit, std::memory_order_release);
+            }
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, k, m);
+    };
+    if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15>, 15);
+    else if (m.max_isz > 8) go(modup_conv_s1_kernel<C, 16>, 16);
+    else return false;
+    check_launch();
+    return true;
+#endif
 }
 
 }  // namespace pha

@@ -1253,17 +1253,6 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
                 hipLaunchKernelGGL(single_p_kernel, dim3((unsigned)(n / 256), qlp), dim3(256), 0, s, k);
                 check_launch();
             }
-    } else {
-        // own limbs are copied verbatim by the same kernel (modup_copy_partQl_kernel :522-528);
-        // BFV still needs the q-hat^-1 scaling (bconv_mult_kernel :603-607), ckks/bgv got it in the iNTT
-        uint32_t max_osz = 0;
-        for (const BConv &b : t.digit) max_osz = b.osz > max_osz ? b.osz : max_osz;
-        // (coefficient-form input: the conversion reads c2 itself, at its own stride; NTT form: the dense t_cks, and c2 only
-        //  for the verbatim copy of the digit's own limbs)
-        // (fused inner product, NTT-form input: the own limbs are read from c2 by the fused pass, no copy)
-        launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.modup_split, dst, (size_t)qlp * n,
-                     ntt_dom ? t_cks : cks, 0, (fused_ip && ntt_dom) ? nullptr : cks, !ntt_dom, s, batch > 1 ? t.beta : 0,
-                     ntt_dom ? (size_t)ql * n : cks_stride, nullptr, cks_stride);
     }
     LimbSel sel = special_sel(0, qlp, c.size_qp, c.size_p);
     NttExtra x;
@@ -1275,6 +1264,32 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         x.excl_step = alpha;
         x.excl_limit = ql;
         x.excl_mod = batch > 1 ? t.beta : 0;
+    }
+    if (alpha > 1) {
+        // own limbs are copied verbatim by the same kernel (modup_copy_partQl_kernel :522-528);
+        // BFV still needs the q-hat^-1 scaling (bconv_mult_kernel :603-607), ckks/bgv got it in the iNTT
+        uint32_t max_osz = 0;
+        bool mont_split = t.modup_split == 1;
+        for (const BConv &b : t.digit) {
+            max_osz = b.osz > max_osz ? b.osz : max_osz;
+            mont_split = mont_split && b.split_kind == 1 && b.mont && b.row_pad == (uint32_t)kBcRowPad;
+        }
+        // r05: NTT-form input, N = 2^16, the separate (batched) inner product: the conversion is the load of the forward
+        // transform's strided pass (modup_conv_strided, pha_ntt.hip); the transform then runs its contiguous pass only
+        if (ntt_dom && !fused_ip) {
+            const ModupConvArgs mc{t.d_digit_convs.p, t.beta, t_cks, (size_t)ql * n, cks, cks_stride, alpha, max_osz, mont_split};
+            if (modup_conv_strided(c, dst, sel, x, mc, s)) {
+                x.first_pass_done = true;
+                ntt_forward(c, dst, dst, dst, sel, EPI_FWD_CANON, x, s);
+                return;
+            }
+        }
+        // (coefficient-form input: the conversion reads c2 itself, at its own stride; NTT form: the dense t_cks, and c2 only
+        //  for the verbatim copy of the digit's own limbs)
+        // (fused inner product, NTT-form input: the own limbs are read from c2 by the fused pass, no copy)
+        launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.modup_split, dst, (size_t)qlp * n,
+                     ntt_dom ? t_cks : cks, 0, (fused_ip && ntt_dom) ? nullptr : cks, !ntt_dom, s, batch > 1 ? t.beta : 0,
+                     ntt_dom ? (size_t)ql * n : cks_stride, nullptr, cks_stride);
     }
     if (fused_ip) {
         ModupIpArgs ip = *fused_ip;

@@ -312,7 +312,10 @@ def test_hommul_relin_rescale_c3(gpu):
 # (config, live data limbs, batch): alpha = 2 / 3 / 15 incl. short last digits, the alpha = 1 fallback, both BASELINE sizes
 KSR_CASES = [("hyb12_a2", 6, 1), ("hyb12_a2", 5, 2), ("hyb12_a2", 2, 1), ("hyb13_a3", 9, 1), ("hyb13_a3", 7, 3), ("hyb13_a3", 4, 1),
              ("c1_bfv4096", 2, 2), ("c2_ckks14", 8, 2), ("hyb14_a4", 8, 1), ("hyb14_a4", 5, 2), ("c4_bfv15", 30, 2), ("c4_bfv15", 17, 1), ("c3_ckks16", 45, 1), ("c3_ckks16", 31, 2),
-             ("c3_ckks16", 45, 4), ("hyb17_a2", 4, 1), ("hyb17_a2", 3, 2), ("hyb14_a2", 8, 1)]   # 2 x 4 = 8 polynomials at N = 2^16: the twiddle-resident batched contiguous pass (r04) with the key switch + rescale epilogue
+             ("c3_ckks16", 45, 4), ("hyb17_a2", 4, 1), ("hyb17_a2", 3, 2), ("hyb14_a2", 8, 1),   # 2 x 4 = 8 polynomials at N = 2^16: the twiddle-resident batched contiguous pass (r04) with the key switch + rescale epilogue
+             # r05: batches whose mod-up launches >= 1024 workgroups take modup_conv_s1_kernel (base conversion fused with the forward
+             # transform's strided pass): 6 x 3 digits at the top level; 8 x 3 digits at level 31, whose last digit is ONE limb
+             ("c3_ckks16", 45, 6), ("c3_ckks16", 31, 8)]
 
 
 @pytest.mark.parametrize("name,ql,batch", KSR_CASES)
