@@ -13,6 +13,11 @@
  * All `uint64_t*` data arguments are DEVICE pointers owned by the caller, limb-major contiguous
  * `data[limb * N + coeff]`, values canonical in [0, q_limb).  No entry point
  * allocates caller-visible memory; scratch comes from a per-context, per-stream arena.
+ * PRECONDITION on every operand word, including caller-supplied constants (keys, plaintext diagonals / weights, scale and P^-1
+ * vectors): canonical, i.e. below its limb's modulus.  The reference's Barrett-128 kernels happen to tolerate lazy or unreduced
+ * words; this library does not promise to -- on limbs below 2^50 the dyadic, inner-product, hoisting and epilogue kernels compute in
+ * FP64 (exact only for words below 2^52), so a non-canonical word there gives wrong residues WITHOUT an error.  Every word the
+ * library writes is canonical, so chains of its own calls keep the precondition; tests/test_gpu_fuzz.py checks the inputs it feeds.
  * Capturing calls into a hipGraph: warm the same call up once first (same level and batch: an arena grows on demand, and growth is
  * an allocation), and capture on an EXPLICIT stream -- the arenas behind NULL / hipStreamPerThread belong to the calling host thread
  * and are released when that thread exits, so a graph captured on them must not be replayed after the thread is gone.
