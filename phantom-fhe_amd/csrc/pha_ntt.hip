@@ -11,6 +11,7 @@
 #include "pha_ntt_core.h"
 
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 namespace pha {
@@ -1425,8 +1426,9 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
     if (ch.whole || ch.fused || ch.v != 10) return false;
     using P1 = NttPlan<16, 10>::P1;
     using P2 = NttPlan<16, 10>::P2;
-    using C = PassCfg<6, true, 2, 2, 2, 4, false, PHA_MCS_LOGTILE>;
+    using C = PassCfg<6, true, 2, 2, 2, 4, false, PHA_MCS_LOGTILE>;    // = NttPlan<16, 13>::P1 at the default tile (the CPU replay runs that plan)
     static_assert(C::LOGT == P1::LOGT, "the fused pass is the strided pass of the plan whose contiguous pass follows");
+    static_assert(PHA_MCS_LOGTILE != 10 || std::is_same<C, NttPlan<16, 13>::P1>::value, "NttPlan<16, 13> names this pass");
     check_sel(c, sel);
     NttKArgs k = make_args(c, digits, digits, digits, sel, x, true);
     k.t1 = P1::T;

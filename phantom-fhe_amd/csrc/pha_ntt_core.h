@@ -922,6 +922,10 @@ template <> struct NttPlan<16, 9> { using P1 = PassCfg<7, true, 3, 2, 2, 8>;  us
 //  256-byte runs; measured 1-1.5 % ahead of 64 x 64 tiles on the 720-limb step and on one 45-limb polynomial)
 template <> struct NttPlan<16, 10> { using P1 = PassCfg<6, true, 3, 3, 0, 8, false, 11>;  using P2 = PassCfg<10, false, 3, 3, 2, 8, false, 10, false, 2>; };
 template <> struct NttPlan<16, 12> { using P1 = PassCfg<6, true, 3, 3, 0, 8>;  using P2 = PassCfg<10, false, 4, 3, 3, 16, false, 10>; };
+// VARIANT 13 (r05): plan 10 whose strided pass is the one modup_conv_s1_kernel (pha_ntt.hip) runs from the registers its base conversion
+// fills: FOUR coefficients per thread (the conversion's inputs are 30 registers per coefficient), radix-4 rounds 2-2-2, 64 rows x 16
+// columns (256 threads); the contiguous pass is plan 10's.  Not a plan choose_plan hands out: the CPU replay (tests/emu) runs it.
+template <> struct NttPlan<16, 13> { using P1 = PassCfg<6, true, 2, 2, 2, 4, false, 10>;  using P2 = NttPlan<16, 10>::P2; };
 // N = 4096: the whole transform in one 4096-coefficient tile (three radix-16 rounds, one launch, no intermediate)
 using WholePlan12 = PassCfg<12, false, 4, 4, 4, 16, false, 12, true>;
 // N = 8192: the same with a fourth (radix-2) round: one 8192-coefficient tile, 512 threads, 72 KiB of LDS

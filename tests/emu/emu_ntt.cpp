@@ -28,6 +28,9 @@ static void run_segments(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
 // the batched kernel's form of a pass (ntt_zloop_kernel): every round's twiddles requested once (HOIST 1), then per polynomial
 // prefetch (the first round's global loads) + run_prefetched
 static bool g_zloop_form = false;
+// r05: modup_conv_s1_kernel's form of the STRIDED pass: the first round's registers are filled before the pass starts (there by the base
+// conversion, here by the same global loads), every round's twiddles requested up front (HOIST 1), run_prefetched for each segment
+static bool g_prefetched_strided = false;
 template <class Prog, int SEG>
 static void run_segments_prefetched(const PassArgs &a, u64 *lds, u64 (*regs)[16]) {
     if constexpr (SEG == 0)
@@ -48,7 +51,7 @@ static void run_pass(PassArgs a, size_t n) {
     const u32 tiles = (u32)(n >> C::LOGTILE);
     for (u32 t = 0; t < tiles; t++) {
         a.tile = t;
-        if (g_zloop_form && !C::STRIDED) run_segments_prefetched<PassProgram<C, FWD, EPI, FOLD, 1>, 0>(a, lds.data(), regs);
+        if ((g_zloop_form && !C::STRIDED) || (g_prefetched_strided && C::STRIDED && FWD)) run_segments_prefetched<PassProgram<C, FWD, EPI, FOLD, 1>, 0>(a, lds.data(), regs);
         else run_segments<PassProgram<C, FWD, EPI, FOLD, 2>, 0>(a, lds.data(), regs);
     }
 }
@@ -255,12 +258,18 @@ extern "C" int emu_ntt(int log_n_and_variant, int fwd, int epi, const uint64_t *
         else EMU4(7);
         return 0;
     }
-    if (variant >= 9 && variant <= 12) {   // r04 experiment plans of N = 2^16: codes 9 / 10 -> plans 8 / 9 (128 x 512), 11 / 12 -> plans 10 / 12 (64 x 1024)
+    if (variant >= 9 && variant <= 13) {   // r04 experiment plans of N = 2^16: codes 9 / 10 -> plans 8 / 9 (128 x 512), 11 / 12 -> plans 10 / 12 (64 x 1024); r05: 13 -> plan 13
         if (log_n != 16) return -2;
         if (variant == 9) emu<16, 8>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
         else if (variant == 10) emu<16, 9>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
         else if (variant == 11) emu<16, 10>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
-        else emu<16, 12>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else if (variant == 12) emu<16, 12>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+        else {
+            if (!fwd) return -3;   // the fused conversion only exists in front of a forward transform
+            g_prefetched_strided = true;
+            emu<16, 13>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp);
+            g_prefetched_strided = false;
+        }
         return 0;
     }
 #define EMU_CASE(N) case N: if (variant == 4) emu<N, 4>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 3) emu<N, 3>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant == 2) emu<N, 2>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else if (variant) emu<N, 1>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); else emu<N, 0>(fwd, epi, i, o, q, tw, ni, w1, sc, ax, fp); break;

@@ -232,3 +232,30 @@ def test_batched_kernel_form_of_the_contiguous_pass(emu, log_n, variant, bits):
             assert np.array_equal(got, c.nwt_forward(x.reshape(1, n), 1)[0])
             assert emu.emu_ntt(fcode, 0, 3, p(x), p(got), q, p(f(itw_p)), p(f1(ni)), p(f1(int(itw[1]))), p(z), p(z)) == 0
             assert np.array_equal(got, c.nwt_backward(x.reshape(1, n), 1)[0])
+
+
+@pytest.mark.parametrize("bits", [43, 47, 50, 60])
+def test_strided_pass_of_the_fused_modup_conversion(emu, bits):
+    """r05: modup_conv_s1_kernel runs the forward transform's strided pass from registers that its base conversion fills: NttPlan<16, 13>::P1
+    (four coefficients per thread, radix-4 rounds 2-2-2, 64 x 16 tiles), every round's twiddles requested up front, `run_prefetched` for
+    each segment; plan 10's contiguous pass (in the batched kernel's form) finishes the transform.  Code 13 of the replay runs exactly
+    that pair: integer and FP64 back ends, random and extreme inputs, against the oracle's forward transform."""
+    log_n = 16
+    n = 1 << log_n
+    q = int(O.get_primes(n, bits, 1)[0])
+    tw, tws, itw, itws, ni, nis = O.ntt_tables(log_n, q)
+    c = O.Ctx(log_n, [q], 0)
+    r = rng_for(1300 + bits)
+    z = np.zeros(2, dtype=np.uint64)
+    twi = np.ascontiguousarray(np.stack([tw, tws], axis=1).reshape(-1))
+    code = log_n | (13 << 8) | (1 << 17)
+    for x in (r.integers(0, q, n, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64)):
+        want = c.nwt_forward(x.reshape(1, n), 1)[0]
+        got = np.zeros(n, dtype=np.uint64)
+        assert emu.emu_ntt(code, 1, 1, p(x), p(got), q, p(twi), p(z), p(z), p(z), p(z)) == 0
+        assert np.array_equal(got, want)
+        if bits <= 50:
+            f = lambda w: np.ascontiguousarray(w.astype(np.float64)).view(np.uint64).copy()
+            assert emu.emu_ntt(code | (1 << 16), 1, 1, p(x), p(got), q, p(f(tw)), p(z), p(z), p(z), p(z)) == 0
+            assert np.array_equal(got, want)
+    assert emu.emu_ntt(code, 0, 3, p(x), p(got), q, p(twi), p(z), p(z), p(z), p(z)) == -3     # forward only

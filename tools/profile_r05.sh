@@ -10,7 +10,6 @@ OUT=$R/gpurun_out
 TAG=${TAG:-r05}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -o trace -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-c5 > $OUT/prof_trace.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stage -o trace -- python $R/tools/traffic_probe.py hommul > $OUT/prof_stage.log 2>&1
 python $R/tools/stage_table.py $OUT/prof_stage $OUT/stages.json > $OUT/${TAG}_stages.txt 2>&1
@@ -31,4 +30,8 @@ fi
 python $R/tools/summarize_prof.py $OUT $TAG
 rm -rf $OUT/prof_trace $OUT/prof_stage $OUT/prof_hb8 $OUT/prof_hb32 $OUT/prof_pmc_sq $OUT/prof_pmc_lds
 bash $R/tools/traffic.sh > $OUT/${TAG}_traffic.txt 2>&1
+# the bench line LAST, with the records of THIS run in place: bench.py attaches profiles/{traffic,stages,stages_batched}.json with their sha, and
+# tools/collect_profiles.sh copies the same three files from gpurun_out/ into profiles/ of the build container afterwards
+cp $OUT/traffic.json $OUT/stages.json $OUT/stages_batched.json $R/profiles/ 2>/dev/null
+timeout 900 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 ls -la $OUT | grep -E "$TAG|traffic.json|stages.json|stages_batched.json"; du -sh $OUT

@@ -11,13 +11,19 @@ QLP = QL + ALPHA
 W = 8 * N   # bytes of one limb
 
 
-def stages_for(B):
+def stages_for(B, fused_conv):
     # (label, number of launches, name fragments any of which every launch must carry, algorithmic bytes PER OP)
+    if fused_conv:   # r05: modup_conv_s1_kernel = the conversion as the load of the forward transform's strided pass; then the contiguous pass
+        modup = [("mod-up: base conversion of 3 digits FUSED with the strided pass of the forward NTT of the converted limbs (+ own-limb copy)", 1,
+                  ("modup_conv_s1",), BETA * (ALPHA + QL) * W + BETA * QL * W),
+                 ("mod-up: forward NTT of the converted limbs, contiguous pass", 1, ("ntt_",), BETA * QL * W)]
+    else:
+        modup = [("mod-up: base conversion, 3 digits (+ verbatim copy of each digit's own limbs)", 1, ("bconv_kernel",), BETA * (ALPHA + QL) * W),
+                 ("mod-up: forward NTT of the converted limbs (strided pass, contiguous pass)", 2, ("ntt_",), 2 * BETA * QL * W)]
     return [
         ("tensor product (multiply), B ciphertext pairs in one launch", 1, ("ew_kernel", "tensor"), 7 * QL * W),
         ("mod-up: inverse NTT x partQlHatInv (contiguous pass, strided pass)", 2, ("ntt_",), 2 * QL * W),
-        ("mod-up: base conversion, 3 digits (+ verbatim copy of each digit's own limbs)", 1, ("bconv_kernel",), BETA * (ALPHA + QL) * W),
-        ("mod-up: forward NTT of the converted limbs (strided pass, contiguous pass)", 2, ("ntt_",), 2 * BETA * QL * W),
+    ] + modup + [
         ("key inner product (key limbs in registers across the batch)", 1, ("inner_prod",), QLP * (BETA + 2) * W + QLP * 2 * BETA * W // B),
         ("mod-down + rescale: inverse NTT of P and last limb, 2 polys (contiguous pass, strided pass)", 2, ("ntt_",), 2 * 2 * (ALPHA + 1) * W),
         ("mod-down + rescale: conversion + last-limb fold", 1, ("bconv_rescale_kernel",), 2 * (ALPHA + 1 + QL - 1) * W),
@@ -31,7 +37,7 @@ def table_for(B, trace_dir):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     lib = [r for r in rows if any(k in r["Kernel_Name"] for k in ("ntt_", "bconv", "inner_prod", "ew_kernel", "modup_ip", "modup_conv"))]
-    st = stages_for(B)
+    st = stages_for(B, any("modup_conv_s1" in r["Kernel_Name"] for r in lib))
     per_set = sum(cnt for _, cnt, _, _ in st)
     sets = len(lib) // per_set
     assert sets >= 2 and len(lib) % per_set == 0, f"{len(lib)} library kernels in the trace, {per_set} per op set expected: " + \
