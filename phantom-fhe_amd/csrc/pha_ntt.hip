@@ -1313,6 +1313,16 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
             for (int kk = 0; kk < K; kk++) dig[(size_t)(d.src_limb + i) * n + off[kk]] = own[(size_t)i * n + off[kk]];
     }
     __syncthreads();
+#if defined(PHA_MCS_STAGGER)   // r05 experiment: the two co-resident workgroups of a CU run their limbs in lockstep (conversion against conversion, rounds against
+    {                          // rounds); delay the one in the odd wave slot by about half a limb so that one's multiply-adds fill the other's FP64 latencies
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1u) __builtin_amdgcn_s_sleep(PHA_MCS_STAGGER);
+    }
+#endif
+#ifndef PHA_MCS_PRIO
+#define PHA_MCS_PRIO 0
+#endif
 #pragma unroll 1
     for (uint32_t e = 0; e < osz; e++) {
         const ConvLimbRec rc = s_rec[e];
@@ -1382,11 +1392,13 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
                     reg[k0 + kk] = mont_redc128(rl, rh, p, oninv);
                 }
             }
+            if (PHA_MCS_PRIO) __builtin_amdgcn_s_setprio(PHA_MCS_PRIO);   // (experiment) the rounds are latency-bound: let them issue ahead of the other wavefront's multiply-adds
             Prog::template run_prefetched<0>(pa, lds, tid, reg, twreg);
             tile_sync<C>();
             Prog::template run_prefetched<1>(pa, lds, tid, reg, twreg);
             tile_sync<C>();
             Prog::template run_prefetched<2>(pa, lds, tid, reg, twreg);
+            if (PHA_MCS_PRIO) __builtin_amdgcn_s_setprio(0);
             tile_sync<C>();   // the next limb's first round writes the same LDS words
         };
         if (a.fp) {   // (uniform) one specialised body per butterfly back end, as exec_pass has them
