@@ -28,12 +28,13 @@ def test_fused_conversion_and_strided_pass_in_the_experiments_library():
     """r05: modup_conv_s1_kernel (the mod-up's base conversion as the load of the forward transform's strided pass, N = 2^16).  The
     product takes it for launches of >= 1024 workgroups (batches of >= 6 ciphertexts at beta = 3); the experiments library takes it
     for EVERY N = 2^16 mod-up, so the key-switch parity tests of the C3 set -- per stage, whole key switch, key switch + rescale,
-    batches, every level with a short last digit that those tests hold -- reach it with one ciphertext."""
+    batches, every level with a short last digit that those tests hold, and the alpha = 12 set (the 16-input instantiation, BGV) -- reach it
+    with one or two ciphertexts."""
     import phantom_fhe_amd as P
     assert os.path.exists(P.EXP_LIB_PATH), "libphantom_amd_exp.so is not built (make -C phantom-fhe_amd/csrc)"
     env = dict(os.environ, PHA_LIB_OVERRIDE=P.EXP_LIB_PATH)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rns.py"), "-x", "-q", "-m", "gpu",
-                        "-k", "c3_ckks16 or hoist or galois", "-p", "no:cacheprovider"],
+                        "-k", "c3_ckks16 or hyb16_a12 or hoist or galois", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(r.stdout.splitlines()[-15:])
     assert r.returncode == 0, tail + "\n" + r.stderr[-2000:]

@@ -315,7 +315,8 @@ KSR_CASES = [("hyb12_a2", 6, 1), ("hyb12_a2", 5, 2), ("hyb12_a2", 2, 1), ("hyb13
              ("c3_ckks16", 45, 4), ("hyb17_a2", 4, 1), ("hyb17_a2", 3, 2), ("hyb14_a2", 8, 1),   # 2 x 4 = 8 polynomials at N = 2^16: the twiddle-resident batched contiguous pass (r04) with the key switch + rescale epilogue
              # r05: batches whose mod-up launches >= 1024 workgroups take modup_conv_s1_kernel (base conversion fused with the forward
              # transform's strided pass): 6 x 3 digits at the top level; 8 x 3 digits at level 31, whose last digit is ONE limb
-             ("c3_ckks16", 45, 6), ("c3_ckks16", 31, 8)]
+             ("c3_ckks16", 45, 6), ("c3_ckks16", 31, 8),
+             ("hyb16_a12", 24, 8)]    # alpha = 12: the 16-input instantiation, 8 x 2 digits = 1024 workgroups in the product library
 
 
 @pytest.mark.parametrize("name,ql,batch", KSR_CASES)
@@ -529,7 +530,10 @@ def test_extreme_residues_and_empty_calls(gpu):
 @pytest.mark.parametrize("name,scheme,ql,batch", [("hyb12_a2", O.CKKS, 6, 3), ("hyb12_a2", O.CKKS, 5, 2), ("hyb13_a3", O.CKKS, 7, 4),
                                                   ("hyb12_a2", O.BFV, 6, 2), ("hyb12_a2", O.BGV, 6, 2), ("c1_bfv4096", O.CKKS, 2, 3),
                                                   ("c4_bfv15", O.BFV, 30, 4), ("c3_ckks16", O.CKKS, 45, 2),
-                                                  ("c3_ckks16", O.CKKS, 45, 5)])   # 10 polynomials at N = 2^16: the r04 batched contiguous pass, mod-down epilogue
+                                                  ("c3_ckks16", O.CKKS, 45, 5),    # 10 polynomials at N = 2^16: the r04 batched contiguous pass, mod-down epilogue
+                                                  # r05: alpha = 12 at N = 2^16 -- in the experiments library (tests/test_gpu_ntt_variants.py) these take
+                                                  # modup_conv_s1_kernel<., 16>: full digits, a one-limb last digit, the BGV branch
+                                                  ("hyb16_a12", O.CKKS, 24, 2), ("hyb16_a12", O.CKKS, 13, 2), ("hyb16_a12", O.BGV, 24, 2)])
 def test_batched_keyswitch_and_tensor(name, scheme, ql, batch, gpu):
     """pha_keyswitch_inplace_batched / pha_tensor_prod_2x2_batched: every ciphertext of the batch must equal the
     single-ciphertext result (oracle), including short last digits and the alpha = 1 path."""

@@ -20,6 +20,7 @@ CONFIGS = {
     "hyb14_a4": (14, [60] + [50] * 7 + [60] * 4, 4),      # 8 data limbs in 2 digits of 4
     "hyb14_a2": (14, [60] + [50] * 7 + [60] * 2, 2),      # beta = 4 at N = 2^14: the one shape whose fused key products take the full (not the light) FP64 form
     "hyb17_a2": (17, [60, 50, 50, 50, 60, 60], 2),        # N = 2^17: the 256 x 512 plan under the fused mod-up + inner product (4 data limbs, beta 2)
+    "hyb16_a12": (16, [60] + [50] * 23 + [60] * 12, 12),  # N = 2^16 with alpha = 12 (beta = 2): the 16-input instantiation of the r05 fused mod-up conversion
     "wide_p33": (12, [36] * 6 + [37] * 33, 33),            # special base wider than the register-resident converters (alpha > 32)
     "wide_p20": (12, [45] * 24 + [46] * 20, 20),           # 17..32 special primes: the 30 / 31-bit split converter (two digits: 20 + 4 limbs)
     "p61_a2": (12, [50] * 6 + [61, 61], 2),               # 61-bit special primes: 30 / 31 cuts in mod-up, 31 / 30 in mod-down
