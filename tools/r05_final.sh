@@ -16,11 +16,12 @@ rm -f oracle/liboracle.so oracle/liboracle_native.so
 rm -f phantom-fhe_amd/phantom_fhe_amd/libphantom_amd_*.so        # experiment builds of earlier sessions (tools/build_variant.sh)
 rm -rf phantom-fhe_amd/csrc/var
 python -c "import __graft_entry__ as g; g.build()" > /tmp/r05_build.log 2>&1 || { tail -30 /tmp/r05_build.log; exit 1; }
+DIRTY=$(git status --short | grep -v '^??' | grep -v "profiles/${TAG}_" || true)      # (the evidence files of this tag are rewritten by this very run)
 {
   echo "# built by tools/r05_final.sh in the build container (hipcc --offload-arch=gfx950), $(date -u +%Y-%m-%dT%H:%M:%SZ)"
   echo "HEAD $(git rev-parse HEAD)"
-  echo "dirty-files $(git status --short | grep -v '^??' | wc -l)"
-  git status --short | grep -v '^??' | sed 's/^/  /' || true
+  echo "dirty-files $(printf '%s' "$DIRTY" | grep -c . || true)"
+  printf '%s\n' "$DIRTY" | sed '/^$/d; s/^/  /'
   sha256sum phantom-fhe_amd/phantom_fhe_amd/*.so oracle/*.so
 } > profiles/${TAG}_build.txt
 cat profiles/${TAG}_build.txt
