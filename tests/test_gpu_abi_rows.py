@@ -82,3 +82,42 @@ def test_backward_inplace_scale(name, cms, start, gpu):
     assert np.array_equal(got[start], inv[0])
     assert np.array_equal(got[start + cms - 1], oc.negate(inv[cms - 1:cms], 1, start + cms - 1)[0])
     assert total >= start + cms
+
+
+# (special-modulus size alpha, data limbs of the chain, live data limbs, batch): batches large enough for the product library to take
+# modup_conv_s1_kernel (>= 1024 workgroups = 16 digit polynomials): both instantiations (15 inputs, <= 16 inputs zero-padded), short
+# last digits (1, 2, 7 limbs), one digit only, the largest output count (45 + 15 - 1 = 59 limbs per digit)
+FUSED_SWEEP = [(15, 45, 45, 6), (15, 45, 46 - 15, 8), (15, 45, 16, 8), (15, 45, 15, 16), (9, 27, 27, 6), (9, 27, 20, 6),
+               (10, 30, 21, 6), (16, 32, 32, 8), (16, 32, 18, 8), (12, 24, 7, 16)]
+
+
+@pytest.mark.parametrize("alpha,size_q,ql,batch", FUSED_SWEEP)
+def test_batched_keyswitch_with_the_fused_conversion_equals_per_ciphertext_calls(alpha, size_q, ql, batch, gpu):
+    """r05: at N = 2^16 a batched key switch whose mod-up launches >= 1024 workgroups converts inside the forward transform's strided pass
+    (modup_conv_s1_kernel); one ciphertext at a time takes the separate conversion (inside the fused mod-up + inner product).  Both must
+    give the same words for every ciphertext -- GPU against GPU, so the sweep over alpha / level / batch costs no oracle time (the
+    oracle pins both paths at the C3 set and an alpha = 12 set in tests/test_gpu_rns.py)."""
+    import torch
+    import phantom_fhe_amd as P
+    log_n, n = 16, 1 << 16
+    primes = [int(p) for p in P.coeff_modulus_create(n, [60] + [50] * (size_q - 1) + [60] * alpha)]
+    ctx = P.PhantomContext(log_n, primes, alpha, device=gpu)
+    g = torch.Generator(device=gpu)
+    g.manual_seed(0x5EED0500 + alpha * 64 + ql)
+    rnd = lambda *s: torch.randint(0, 1 << 49, s, dtype=torch.int64, device=gpu, generator=g)   # below every prime of the set
+    dnum = size_q // alpha
+    rlk = P.PhantomRelinKey([rnd(2, len(primes), n) for _ in range(dnum)])
+    ct, c2 = rnd(batch, 2, ql, n), rnd(batch, ql, n)
+    want = ct.clone()
+    for b in range(batch):
+        ctx.keyswitch_inplace(ql, want[b], c2[b], rlk.public_keys_ptr, P.scheme_type.ckks)
+    got = ct.clone()
+    ctx.keyswitch_inplace_batched(ql, got, c2, batch, rlk.public_keys_ptr, P.scheme_type.ckks)
+    assert torch.equal(got, want)
+    if ql >= 2:      # ... and through the fused key switch + rescale
+        out_b = torch.zeros((batch, 2, ql - 1, n), dtype=torch.int64, device=gpu)
+        ctx.keyswitch_rescale_batched(ql, ct, c2, batch, rlk.public_keys_ptr, out_b)
+        out_1 = torch.zeros_like(out_b)
+        for b in range(batch):
+            ctx.keyswitch_rescale(ql, ct[b], c2[b], rlk.public_keys_ptr, out_1[b])
+        assert torch.equal(out_b, out_1)
