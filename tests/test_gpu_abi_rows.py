@@ -121,3 +121,43 @@ def test_batched_keyswitch_with_the_fused_conversion_equals_per_ciphertext_calls
         for b in range(batch):
             ctx.keyswitch_rescale(ql, ct[b], c2[b], rlk.public_keys_ptr, out_1[b])
         assert torch.equal(out_b, out_1)
+
+
+def test_batched_keyswitch_rescale_with_the_fused_conversion_replays_from_a_hip_graph(gpu):
+    """pha_keyswitch_rescale_batched at the C3 set with a batch that takes modup_conv_s1_kernel (76 KB of dynamic LDS: the launcher raises
+    the kernel's limit on first use, which is why the header asks for one warm-up call before a capture): captured on an explicit stream
+    after that warm-up, the graph replays on NEW inputs to what eager calls give."""
+    import torch
+    import phantom_fhe_amd as P
+    log_n, n, alpha, size_q, ql, batch = 16, 1 << 16, 15, 45, 45, 6
+    primes = [int(p) for p in P.coeff_modulus_create(n, [60] + [50] * (size_q - 1) + [60] * alpha)]
+    ctx = P.PhantomContext(log_n, primes, alpha, device=gpu)
+    g = torch.Generator(device=gpu)
+    g.manual_seed(0x5EED0600)
+    rnd = lambda *s: torch.randint(0, 1 << 49, s, dtype=torch.int64, device=gpu, generator=g)
+    rlk = P.PhantomRelinKey([rnd(2, len(primes), n) for _ in range(size_q // alpha)])
+    ins = [(rnd(batch, 2, ql, n), rnd(batch, ql, n)) for _ in range(3)]
+    want = []
+    for ct, c2 in ins:
+        out = torch.zeros((batch, 2, ql - 1, n), dtype=torch.int64, device=gpu)
+        ctx.keyswitch_rescale_batched(ql, ct, c2, batch, rlk.public_keys_ptr, out)
+        want.append(out)
+    d_ct, d_c2 = ins[0][0].clone(), ins[0][1].clone()
+    out = torch.zeros((batch, 2, ql - 1, n), dtype=torch.int64, device=gpu)
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ctx.keyswitch_rescale_batched(ql, d_ct, d_c2, batch, rlk.public_keys_ptr, out)    # warm-up on the capture stream
+    side.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(gr, stream=side):
+            ctx.keyswitch_rescale_batched(ql, d_ct, d_c2, batch, rlk.public_keys_ptr, out)
+    for i in (1, 2, 0):
+        d_ct.copy_(ins[i][0])
+        d_c2.copy_(ins[i][1])
+        out.zero_()
+        torch.cuda.synchronize()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want[i]), i
