@@ -24,7 +24,7 @@
 #define PHA_GEMM_VALU_PER_MFMA 4      // vector instructions the scheduler places after each MFMA (3: slower, 4-5: same, 8: slower)
 #endif
 #ifndef PHA_GEMM_X
-#define PHA_GEMM_X 0      // 5: phase stamps instead of the result (tools/gemm_stamps.py)
+#define PHA_GEMM_X 0      // 5: phase stamps instead of the result (profiles/HISTORY.md 4.9)
 #endif
 
 namespace pha {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kGemmWg, 1) void gemm_mfma_kernel(const GemmArgs g,
         take_frags(nextbuf);
         __builtin_amdgcn_sched_barrier(0);                           // the two steps of a pair are scheduled separately
     };
-#if PHA_GEMM_X == 5      // phase stamps (tools/gemm_stamps.py): s_memtime over C instead of the result
+#if PHA_GEMM_X == 5      // phase stamps (profiles/HISTORY.md 4.9): s_memtime over C instead of the result
     u64 stamp[8];
     int ns = 0;
 #define PHA_STAMP() do { __builtin_amdgcn_sched_barrier(0); if (ns < 8) stamp[ns++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)

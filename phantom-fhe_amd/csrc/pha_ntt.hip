@@ -356,7 +356,7 @@ __global__ PHA_PASS_BOUNDS PHA_PASS_ATTR void ntt_pass_kernel(const NttKArgs k) 
 
 #if defined(PHA_EXPERIMENTS)
 // ---- both passes in ONE launch, the intermediate handed over through the XCD's own L2 -------------------------------
-// (r02; tools/handoff_bench.hip is the memory-side experiment behind it: the two access patterns at 720 limbs take
+// (r02; profiles/HISTORY.md has the memory-side experiment behind it: the two access patterns at 720 limbs take
 // 286 us as two launches and 211 us in this form, because the intermediate never crosses the fabric a second time.)
 // Placement: the workgroups of a 1-D grid are dealt to the 8 XCDs round-robin, so all workgroups with the same
 // b % 8 (a "class") share one XCD -- XCD (b + r) % 8 with r = 0 for plain launches and some other constant under
@@ -661,6 +661,10 @@ static void forward_impl(NttKArgs k, int epi, hipStream_t s, Context *fused = nu
     using P2 = typename NttPlan<LOGN, VARIANT>::P2;
     k.t1 = P1::T;
     k.t2 = P2::T;
+    // the only producer that folds the strided pass away (modup_conv_s1_kernel) writes the 64 x 1024 split of NttPlan<16, 10>: a
+    // plan choice that disagrees with it would transform garbage silently (the inverse's second_pass_only has the same guard)
+    if (k.first_pass_done && !(LOGN == 16 && VARIANT == 10 && P1::LOGT == 6))
+        throw std::logic_error("ntt_forward: first_pass_done needs the 64 x 1024 plan the fused conversion wrote");
     u64 *const final_out = k.out;
     const size_t final_stride = k.out_stride;
     k.out = k.mid;
@@ -1059,8 +1063,8 @@ static NttChoice choose_plan(Context &c, const LimbSel &sel, const NttExtra &x) 
     const bool ot = has(vv, 16) || (has(vv, 32) && has(vv, 1) && tiles >= 1024 && !shared_tables), wave = has(vv, 64) && has(vv, 1);
     NttChoice ch{ot ? (wave ? 4 : 2) : wave ? 3 : has(vv, 1), 0, shared_tables, nullptr};
     // launches that fit ONE co-resident generation of 256-coefficient wavefronts: four coefficients per thread in the contiguous
-    // pass, i.e. twice the wavefronts with half the serial work each (r03; N = 2^14 .. 2^16).  Same-box A/B (tools/time_small_ntt.py,
-    // tools/ks_trace.sh): a win of 0.4-1.1 us per launch pair up to 8 wavefronts per SIMD (2^16: 1-24 limbs, the 2 x 16-limb
+    // pass, i.e. twice the wavefronts with half the serial work each (r03; N = 2^14 .. 2^16).  Same-box A/B (profiles/r03_experiments.md;
+    // kernel traces): a win of 0.4-1.1 us per launch pair up to 8 wavefronts per SIMD (2^16: 1-24 limbs, the 2 x 16-limb
     // inverse of key switch + rescale 14.9 -> 13.6 us; 2^15: every size up to 60 limbs), a loss of 1-2.5 us beyond (2^16: 40-60 limbs)
     if (ch.v == 3 && c.log_n >= 14 && c.log_n <= 16 && limb_polys * (c.n >> 8) <= (size_t)PHA_EPT4_MAX_WAVES) ch.v = 5;
     // r04: N = 2^16 as 64 x 1024 for every launch that is not the first half of the fused mod-up (whose contiguous pass, with the key
@@ -1232,29 +1236,21 @@ constexpr int kMcsMaxOut = 64;
 __device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ u64 uni64(u64 x) { return ((u64)uni32((uint32_t)(x >> 32)) << 32) | uni32((uint32_t)x); }
 
-#ifndef PHA_MCS_WAVES
-#define PHA_MCS_WAVES 2   // wavefronts per SIMD the register allocation aims at (inputs alone are 120 registers)
-#endif
+// The geometry below is the one kept out of the 12 that r05 measured (profiles/r05_experiments.md §2: batched HomMul + relinearize +
+// rescale, us per op at B = 8 / 32; separate kernels 279.5 / 275.0): every round's twiddles requested before the conversion, all four
+// coefficients converted side by side (a matrix row is read from LDS once), 8 of the 15 input limbs in registers (226 registers, two
+// 256-thread workgroups per CU with 76 KB of LDS each): 275.1 / 275.2.  The losers (10 limbs in registers 290 / 286; 7: 322;
+// per-round twiddles 284; 64 x 4 tiles 365; 64 x 8 295; 64 x 32 292; one wavefront per SIMD 339; staggered workgroups, raised
+// priority for the rounds: no gain) are in that log, not in this source.
+constexpr int kMcsWaves = 2;      // wavefronts per SIMD the register allocation aims at (the inputs alone are 120 registers)
+constexpr int kMcsRegLimbs = 8;   // input limbs held in registers; the rest of the digit's inputs in LDS
+constexpr int kMcsLogTile = 10;   // 64 rows x 16 columns: 128-byte runs, 256 threads
 template <class C, int ISZ_PAD>
-__global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(PHA_MCS_WAVES, PHA_MCS_WAVES)))
+__global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(kMcsWaves, kMcsWaves)))
 void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
     static_assert(C::STRIDED && C::EPT == 4 && C::NR == 3 && C::r(0) == 2, "radix-4 strided pass, four coefficients per thread");
     constexpr int K = 4, LOGD = C::LOGT - 2;
-// measured (profiles/r05_experiments.md, batched HomMul + relinearize + rescale, us per op at B = 8 / 32; separate kernels 279.5 / 275.0):
-// every round's twiddles requested before the conversion (HOIST 1), all four coefficients converted side by side (CHUNK 4: a matrix
-// row is read from LDS once) and 8 of the 15 input limbs in registers (226 registers, two 256-thread workgroups per CU with 76 KB
-// of LDS each): 275.1 / 275.2; 10 limbs in registers (252): 290 / 286; 7 (one workgroup per CU): 322; per-round twiddles: 284;
-// 64 x 4 tiles, one wavefront per workgroup: 365; 64 x 8: 295; 64 x 32: 292; one wavefront per SIMD, everything in registers: 339.
-#ifndef PHA_MCS_HOIST
-#define PHA_MCS_HOIST 1
-#endif
-#ifndef PHA_MCS_CHUNK
-#define PHA_MCS_CHUNK 4   // coefficients converted side by side (accumulator registers: 8 per coefficient)
-#endif
-#ifndef PHA_MCS_REGLIMBS
-#define PHA_MCS_REGLIMBS 8   // input limbs held in registers; the rest of the digit's inputs in LDS (16 = all in registers)
-#endif
-    using Prog = PassProgram<C, true, EPI_NONE, false, PHA_MCS_HOIST, false>;   // HOIST 1: a limb's twiddles are requested before its conversion; 2: the first round's only
+    using Prog = PassProgram<C, true, EPI_NONE, false, 1, false>;   // HOIST 1: a limb's twiddles are requested before its conversion
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *lds = reinterpret_cast<u64 *>(smem);                                                  // the pass's tile
     uint2 *s_rows = reinterpret_cast<uint2 *>(smem + (size_t)C::LDS_WORDS * sizeof(u64));      // [max_osz][kBcRowPad]
@@ -1291,7 +1287,7 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
     u64 *dig = k.out + (size_t)z * k.poly_stride;
     // the first RL input limbs live in registers (8 per limb: four coefficients x two 30-bit halves), the others in LDS, [limb][kk][thread]
     // as (lo, hi) pairs: conflict-free 8-byte reads.  All in registers is 120 + the pass's ~130: spills at two wavefronts per SIMD.
-    constexpr int RL = PHA_MCS_REGLIMBS < ISZ_PAD ? PHA_MCS_REGLIMBS : ISZ_PAD;
+    constexpr int RL = kMcsRegLimbs < ISZ_PAD ? kMcsRegLimbs : ISZ_PAD;
     uint2 *s_in = reinterpret_cast<uint2 *>(s_rec + m.max_osz);                                // [ISZ_PAD - RL][K][THREADS]
     u32 ylo[RL][K], yhi[RL][K];
 #pragma unroll
@@ -1313,16 +1309,6 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
             for (int kk = 0; kk < K; kk++) dig[(size_t)(d.src_limb + i) * n + off[kk]] = own[(size_t)i * n + off[kk]];
     }
     __syncthreads();
-#if defined(PHA_MCS_STAGGER)   // r05 experiment: the two co-resident workgroups of a CU run their limbs in lockstep (conversion against conversion, rounds against
-    {                          // rounds); delay the one in the odd wave slot by about half a limb so that one's multiply-adds fill the other's FP64 latencies
-        uint32_t hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (hwid & 1u) __builtin_amdgcn_s_sleep(PHA_MCS_STAGGER);
-    }
-#endif
-#ifndef PHA_MCS_PRIO
-#define PHA_MCS_PRIO 0
-#endif
 #pragma unroll 1
     for (uint32_t e = 0; e < osz; e++) {
         const ConvLimbRec rc = s_rec[e];
@@ -1353,7 +1339,7 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
             Prog::load_twiddles(pa, tid, twreg);
             // out_j = REDC(sum_i y_i * (qhat_i 2^64 mod p_j)) = sum_i y_i qhat_i mod p_j, canonical (bconv_kernel, SPLIT 30 / 30, mont)
             const uint2 *row = s_rows + e * kBcRowPad;
-            constexpr int CH = PHA_MCS_CHUNK;
+            constexpr int CH = K;   // all four coefficients side by side
 #pragma unroll
             for (int k0 = 0; k0 < K; k0 += CH) {
                 u64 ll[CH], lh[CH], hl[CH], hh[CH];
@@ -1392,13 +1378,11 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
                     reg[k0 + kk] = mont_redc128(rl, rh, p, oninv);
                 }
             }
-            if (PHA_MCS_PRIO) __builtin_amdgcn_s_setprio(PHA_MCS_PRIO);   // (experiment) the rounds are latency-bound: let them issue ahead of the other wavefront's multiply-adds
             Prog::template run_prefetched<0>(pa, lds, tid, reg, twreg);
             tile_sync<C>();
             Prog::template run_prefetched<1>(pa, lds, tid, reg, twreg);
             tile_sync<C>();
             Prog::template run_prefetched<2>(pa, lds, tid, reg, twreg);
-            if (PHA_MCS_PRIO) __builtin_amdgcn_s_setprio(0);
             tile_sync<C>();   // the next limb's first round writes the same LDS words
         };
         if (a.fp) {   // (uniform) one specialised body per butterfly back end, as exec_pass has them
@@ -1413,9 +1397,6 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
     }
 }
 
-#ifndef PHA_MCS_LOGTILE
-#define PHA_MCS_LOGTILE 10
-#endif
 #ifndef PHA_MODUP_CONV_FUSE
 #define PHA_MODUP_CONV_FUSE 1
 #endif
@@ -1438,17 +1419,17 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
     if (ch.whole || ch.fused || ch.v != 10) return false;
     using P1 = NttPlan<16, 10>::P1;
     using P2 = NttPlan<16, 10>::P2;
-    using C = PassCfg<6, true, 2, 2, 2, 4, false, PHA_MCS_LOGTILE>;    // = NttPlan<16, 13>::P1 at the default tile (the CPU replay runs that plan)
+    using C = PassCfg<6, true, 2, 2, 2, 4, false, kMcsLogTile>;    // = NttPlan<16, 13>::P1 (the CPU replay runs that plan)
     static_assert(C::LOGT == P1::LOGT, "the fused pass is the strided pass of the plan whose contiguous pass follows");
-    static_assert(PHA_MCS_LOGTILE != 10 || std::is_same<C, NttPlan<16, 13>::P1>::value, "NttPlan<16, 13> names this pass");
+    static_assert(std::is_same<C, NttPlan<16, 13>::P1>::value, "NttPlan<16, 13> names this pass");
     check_sel(c, sel);
     NttKArgs k = make_args(c, digits, digits, digits, sel, x, true);
     k.t1 = P1::T;
     k.t2 = P2::T;
-    const size_t lds_fixed = (size_t)C::LDS_WORDS * sizeof(u64) + (size_t)m.max_osz * kBcRowPad * sizeof(uint2) + (size_t)m.max_osz * sizeof(ConvLimbRec);
-    auto lds_for = [&](int isz_pad) {
-        const int in_lds = isz_pad > PHA_MCS_REGLIMBS ? isz_pad - PHA_MCS_REGLIMBS : 0;
-        return lds_fixed + (size_t)in_lds * 4 * C::THREADS * sizeof(uint2);
+    auto lds_for = [&](int isz_pad, uint32_t max_osz) {
+        const int in_lds = isz_pad > kMcsRegLimbs ? isz_pad - kMcsRegLimbs : 0;
+        return (size_t)C::LDS_WORDS * sizeof(u64) + (size_t)max_osz * kBcRowPad * sizeof(uint2) + (size_t)max_osz * sizeof(ConvLimbRec) +
+               (size_t)in_lds * 4 * C::THREADS * sizeof(uint2);
     };
     const dim3 grid((unsigned)(c.n >> C::LOGTILE), 1, k.batch), block(C::THREADS);
     // a workgroup walks all output limbs of its tile (45 at the top level: ~200 us), so the form only pays when the launch fills the
@@ -1457,15 +1438,20 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
     // 192 workgroups where the separate kernels take 67)
     if ((size_t)grid.x * grid.z < (size_t)PHA_MCS_MIN_WORKGROUPS) return false;
     auto go = [&](auto kern, int isz_pad) {
-        const size_t lds_bytes = lds_for(isz_pad);
-        if (lds_bytes > 64 * 1024) {   // beyond the default dynamic LDS limit: raise it once per kernel and device
+        // the request grows with the level's output-limb count (176 B per limb of max_osz), so the limit is raised ONCE per kernel and
+        // device to the WORST case (kMcsMaxOut output limbs), not to the first call's size (a later, larger level would
+        // otherwise ask for more than the recorded limit)
+        const size_t lds_bytes = lds_for(isz_pad, m.max_osz), lds_worst = lds_for(isz_pad, kMcsMaxOut);
+        static_assert(kMcsMaxOut <= 64, "worst-case LDS request must stay inside the CU's 160 KiB");
+        if (lds_worst > 160 * 1024) throw std::logic_error("modup_conv_strided: worst-case LDS request exceeds the CU");
+        if (lds_worst > 64 * 1024) {   // beyond the default dynamic LDS limit
             static std::atomic<uint64_t> raised[2] = {{0}, {0}};
             int dev = 0;
             PHA_HIP(hipGetDevice(&dev));
             const uint64_t bit = 1ull << (dev & 63);
             std::atomic<uint64_t> &r = raised[isz_pad == 15 ? 0 : 1];
             if (!(r.load(std::memory_order_acquire) & bit)) {
-                PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_worst));
                 r.fetch_or(bit, std::memory_order_release);
             }
         }

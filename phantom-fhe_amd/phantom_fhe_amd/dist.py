@@ -92,7 +92,11 @@ BROADCAST_CHUNK_BYTES = 1 << 31   # one collective call moves at most 2 GiB (a C
 def _check_same_layout(mine):
     """Every rank must issue the SAME sequence of collectives: compare a description of it (the (numel, dtype) list of the merged
     runs, or the (numel, count) list of the direct form) across the ranks before the first broadcast -- one small
-    all_gather_object per key set; a mismatch would otherwise hang the job."""
+    all_gather_object per key set; a mismatch would otherwise hang the job.
+
+    On an RCCL group all_gather_object runs on torch.cuda.current_device(): the caller must have called
+    torch.cuda.set_device(<this rank's device>) first (bench.py and workloads do), exactly as for any object collective;
+    `check_layout=False` skips the check (and its pickle + host round trip) for callers that time the broadcast."""
     every = [None] * dist.get_world_size()
     dist.all_gather_object(every, mine)
     for r, other in enumerate(every):

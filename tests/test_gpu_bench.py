@@ -11,16 +11,60 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra_args, **extra_env):
+LINE_LIMIT = 8000     # bytes; bench.py asserts the same (a 20 KB line left the driver's record unparsed)
+
+
+def _run(extra_args, full=True, **extra_env):
+    """The FULL record of a bench run (what r01-r05 printed), after checking the stdout contract: exactly one JSON line, at most
+    LINE_LIMIT bytes, naming the file the full record went to.  full=False returns the compact line itself."""
+    import tempfile
     env = dict(os.environ, **extra_env)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):   # never inherit a launcher's rendezvous
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args,
-                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stdout + out.stderr
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout + out.stderr
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "full.json")
+        pre = "--preflight" in extra_args
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args + ([] if pre else ["--full-out", path]),
+                             capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout + out.stderr
+        line = json.loads(lines[0])
+        if pre:
+            return line
+        assert len(lines[0]) <= LINE_LIMIT, len(lines[0])
+        assert line["full_record"] == path
+        record = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype"):   # same run, same numbers
+        assert line[k] == record[k] or abs(line[k] - record[k]) <= 1e-5 * abs(record[k]), k
+    return record if full else line
+
+
+def test_bench_compact_line(gpu):
+    """The line the driver parses: every contract key, `roofline` and `cpu_baseline` with their meaning intact, references (file +
+    sha) instead of the bodies of the offline records, and a size that fits the driver's parser several times over."""
+    d = _run(["--steps", "20", "--warmup", "5", "--sustain", "1.0"], full=False, PHA_BENCH_BATCHES="1,8")
+    assert len(json.dumps(d, separators=(",", ":"))) <= LINE_LIMIT
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["dtype"] == "u64" and "workload" in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "sustained", "traffic_source"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert set(r["traffic_source"]) == {"file", "sha16", "collected"} and r["traffic_source"]["file"] == "profiles/traffic.json"
+    assert r["traffic"] > r["algorithmic_bytes_per_launch"] and 1.0 < r["traffic_ratio"] < 4.0
+    assert abs(r["sustained"]["median_ms_per_step"] - d["ms_per_step"]) / d["ms_per_step"] < 0.25
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 100 and c["unit"] == "NTT/s" and c["sample"] and c["all_cores"] >= 1
+    hm = d["hommul_relin_rescale"]
+    assert hm["value"] > 0 and set(hm["batched"]["ms_per_op_by_batch"]) == {"1", "8"}
+    for ref in (hm["stages"], hm["batched"]["stages"]):     # references, never bodies
+        assert set(ref) <= {"file", "sha16", "collected", "batch", "per_op_us", "furthest_below_roofline", "frac"} and 0 < ref["frac"] < 1
+    assert d["keyswitch_c4"]["checked"].startswith("2 ciphertexts == oracle") and d["matvec_c5"]["value"] > 0
+    assert d["next_rows"]["modular_gemm"]["frac_of_i8_mfma_peak"] > 0.05
 
 
 def test_bench_line_contract(gpu):
@@ -58,6 +102,9 @@ def test_bench_line_contract(gpu):
     assert hs["batch"] == hb["batch"] and hs["seconds"] >= 0.75 and hs["median_ms_per_op"] > 0
     assert hb["fixed_batch_8"] is None            # B = 8 is not in this run's sweep
     assert "kernel_memory_floor_ms" not in r and r["kernel_memory_floor_ms_offline"] > 0   # an offline constant is named as one
+    # r06: offline records are referenced, not embedded
+    assert set(r["traffic_source"]) == {"file", "sha16", "collected"}
+    assert "stages" not in (d["hommul_relin_rescale"]["stages"] or {}) and "batches" not in (hb["stages"] or {})
 
 
 def test_bench_preflight(gpu):
