@@ -15,9 +15,12 @@
  * allocates caller-visible memory; scratch comes from a per-context, per-stream arena.
  * PRECONDITION on every operand word, including caller-supplied constants (keys, plaintext diagonals / weights, scale and P^-1
  * vectors): canonical, i.e. below its limb's modulus.  The reference's Barrett-128 kernels happen to tolerate lazy or unreduced
- * words; this library does not promise to -- on limbs below 2^50 the dyadic, inner-product, hoisting and epilogue kernels compute in
- * FP64 (exact only for words below 2^52), so a non-canonical word there gives wrong residues WITHOUT an error.  Every word the
- * library writes is canonical, so chains of its own calls keep the precondition; tests/test_gpu_fuzz.py checks the inputs it feeds.
+ * words (src/polymath.cu:463-496 multiplies an unreduced c0 + c1; include/uintmodmath.cuh:96-136 reduces any 128-bit value); this
+ * library does not -- on limbs below 2^50 the dyadic, inner-product, hoisting and epilogue kernels compute in FP64 (exact only for
+ * words below 2^52), so a non-canonical word there gives wrong residues WITHOUT an error.  Every word the library writes is
+ * canonical, so chains of its own calls keep the precondition.  It is CHECKABLE (r06): pha_check_canonical / _keys count the
+ * offending words of a buffer, and strict mode (PHA_STRICT=1 in the environment, or pha_set_strict) makes every entry point that
+ * takes caller-supplied operands count first and return status -1 naming the operand instead of computing.
  * Capturing calls into a hipGraph: warm the same call up once first (same level and batch: an arena grows on demand, and growth is
  * an allocation), and capture on an EXPLICIT stream -- the arenas behind NULL / hipStreamPerThread belong to the calling host thread
  * and are released when that thread exits, so a graph captured on them must not be replayed after the thread is gone.
@@ -42,6 +45,24 @@ enum { PHA_SCHEME_BFV = 1, PHA_SCHEME_CKKS = 2, PHA_SCHEME_BGV = 3 };
  * "HIP Runtime Error" -- mirrors include/cuda_wrapper.cuh:19-43). */
 const char *pha_last_error(void);
 
+/* ---- the canonical-operand precondition, checkable (csrc/pha_check.hip).  Both calls SYNCHRONISE the stream (they return a
+ *      count): debugging and input validation, not the hot path, not inside a stream capture.
+ * pha_check_canonical: data [polys][coeff_modulus_size][N] (polys spaced poly_stride words; 0 with polys = 1), limb i checked
+ *   (data points at the FIRST checked limb) against table row start_modulus_idx + i -- or, for the last size_P_tail limbs of a [Q_l || P] buffer, against the special rows
+ *   (the remap of nwt_2d_radix8_forward_inplace_include_special_mod, src/ntt/fntt_2d.cu:434-437); *bad_words = how many words are
+ *   >= their modulus.
+ * pha_check_canonical_keys: the limbs a key switch at level size_Ql READS of n_keys keys [2][size_QP][N] (rows 0 .. size_Ql - 1
+ *   and the special rows), keys = DEVICE array of device pointers (PhantomRelinKey::public_keys_ptr()).
+ * pha_set_strict(on): strict mode on / off for the process, returns the previous state.  Default: on iff PHA_STRICT=1 was in the
+ *   environment when the library was first used.  In strict mode the dyadic, tensor, mod-up / inner-product / mod-down, key-switch
+ *   and hoisting entries check ct / c2 / t_mod_up / keys / weights before they compute (one synchronising pass per operand) and
+ *   fail with status -1 ("PHA_STRICT: <operand> holds k word(s) >= their limb's modulus"); results are unchanged otherwise. ---- */
+int pha_check_canonical(pha_context_t ctx, const uint64_t *data, size_t coeff_modulus_size, size_t start_modulus_idx,
+                        size_t size_P_tail, size_t polys, size_t poly_stride, uint64_t *bad_words, void *stream);
+int pha_check_canonical_keys(pha_context_t ctx, size_t size_Ql, const uint64_t *const *keys, size_t n_keys, uint64_t *bad_words,
+                             void *stream);
+int pha_set_strict(int on);
+
 /* ---- host precompute (replaces src/host/modulus.cu:82-111 CoeffModulus::Create and the
  *      hard-coded default table src/host/globals.cu:30-120) ---- */
 int pha_coeff_modulus_create(uint64_t poly_modulus_degree, const int *bit_sizes, size_t count, uint64_t *out);
@@ -60,7 +81,9 @@ int pha_context_set_plain_modulus(pha_context_t ctx, uint64_t plain_modulus);
 uint32_t pha_context_log_n(pha_context_t ctx);
 uint32_t pha_context_size_qp(pha_context_t ctx);
 uint32_t pha_context_size_p(pha_context_t ctx);
-/* host copies of per-prime constants, for callers that mirror DNTTTable getters */
+/* host copies of per-prime constants, for callers that mirror DNTTTable getters; rows 0 .. size_QP - 1 are the chain, the rows
+ * after them the auxiliary BFV bases once they exist (first use of a BFV multiply entry or pha_tool_aux_sizes): Bsk then m_tilde
+ * (root 0: no tables), R.  An index past the last row is status -1. */
 int pha_context_prime_info(pha_context_t ctx, uint32_t prime_idx, uint64_t *value, uint64_t const_ratio[2],
                            uint64_t *root, uint64_t *n_inv);
 /* download one twiddle row (host buffers of N words): which = 0 twiddle, 1 twiddle_shoup,
@@ -165,6 +188,14 @@ int pha_tensor_prod_2x2_rns_poly(pha_context_t ctx, const uint64_t *operand1, co
                                  uint64_t *result, size_t coeff_mod_size, void *stream);
 int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *operand, uint64_t *result,
                                    size_t coeff_mod_size, void *stream);
+/* the same two kernels with the reference's `modulus` pointer argument as a first table row (polymath.cu:463-529 take
+ * `const DModulus *modulus`; bfv_multiply_behz / _hps run them over base Bsk and base R: src/evaluate.cu:489-497, :763-777):
+ * limb i uses row mod_start + i, which may be an auxiliary row (pha_context_prime_info lists them).  pha_add / sub / multiply /
+ * multiply_and_add / multiply_scalar_rns_poly accept auxiliary rows through their mod_start in the same way. */
+int pha_tensor_prod_2x2_rns_poly_at(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *res, size_t cms,
+                                    size_t mod_start, void *stream);
+int pha_tensor_square_2x2_rns_poly_at(pha_context_t ctx, const uint64_t *op, uint64_t *res, size_t cms, size_t mod_start,
+                                      void *stream);
 /* add_to_ct_kernel (src/rns_bconv.cu:763-769) */
 int pha_add_to_ct(pha_context_t ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, void *stream);
 
@@ -241,6 +272,18 @@ int pha_base_converter_create(pha_context_t ctx, const uint32_t *ibase, size_t i
 void pha_base_converter_destroy(pha_base_converter_t conv);
 int pha_bConv_BEHZ(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream);
 int pha_bConv_HPS(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream);
+/* DBaseConverter::bConv_BEHZ_var1 (include/rns_bconv.cuh:64, src/rns_bconv.cu:231-246; constants src/host/rns.cu:469-496): the
+ * quotient-style conversion dst[j] = sum_i (x_i * (-P qhat_i^-1) mod q_i) * (q_i^-1 mod p_j) mod p_j with P = prod(obase); callers
+ * src/evaluate.cu:747-749, :911-913.  The var1 constants are built on first use. */
+int pha_bConv_BEHZ_var1(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream);
+/* DBaseConverter::exact_convert_array (include/rns_bconv.cuh:68, src/rns_bconv.cu:374-431): src [ibase][N] -> dst [N] modulo the
+ * converter's ONE output modulus (status -1 "out base in exact_convert_array must be one." otherwise, as :423-425), exactly:
+ * inner product minus round(sum_i y_i / q_i) * (Q mod t).  The reference's only user converts to the plain modulus t, which is no
+ * row of the prime table: pha_base_converter_create_modulus makes a converter from table rows to ONE raw modulus (2 .. 2^61 - 1);
+ * such a converter serves exact_convert_array only. */
+int pha_base_converter_create_modulus(pha_context_t ctx, const uint32_t *ibase, size_t ibase_size, uint64_t out_modulus,
+                                      pha_base_converter_t *out);
+int pha_exact_convert_array(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream);
 /* DBaseConverter::bConv_BEHZ for base_P_to_Ql_conv (rns_bconv.cu:212-229): src [P][N] -> dst [Ql][N] */
 int pha_bconv_P_to_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
 /* DRNSTool::modup (rns_bconv.cu:530-627): cks [Ql][N] -> dst [beta][Ql+P][N] */
@@ -255,6 +298,10 @@ int pha_key_switch_inner_prod(pha_context_t ctx, size_t size_Ql, uint64_t *p_cx,
 int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint64_t *cx_i, int scheme,
                          void *stream);
 /* phantom::keyswitch_inplace (eval_key_switch.cu:95-182) on raw buffers: ct [2][Ql][N] += KS(c2) */
+/* DRNSTool::moddown (include/rns.cuh:159-160, src/rns_bconv.cu:712-761): cx_i [Ql + alpha][N] -> ct_i [Ql][N], the mod-down whose
+ * BFV input is ALREADY in coefficient form (moddown_from_NTT transforms it first); ckks / bgv inputs in NTT form as there.  cx_i
+ * is scratch afterwards (its P limbs are left in coefficient form, scaled for ckks with alpha > 1). */
+int pha_moddown(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint64_t *cx_i, int scheme, void *stream);
 int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
                           const uint64_t *const *rlk, int scheme, void *stream);
 /* Extension (the reference loops over ciphertexts): `batch` independent ciphertexts through ONE set of launches.
@@ -354,6 +401,28 @@ int pha_scaleAndRound_HPS_Q_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst,
 int pha_ExpandCRTBasis_Ql_Q(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
 int pha_keyswitch_inplace_bfv_leveled(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint64_t *c2,
                                       const uint64_t *const *rlk, void *stream);
+/* ---- the DRNSTool steps of the BFV multiplies, ONE polynomial per call (include/rns.cuh:167-200; callers bfv_multiply_behz
+ *      src/evaluate.cu:447-548, bfv_multiply_hps :674-818, bfv_mul_relin_hps :822-1027), so that code written against the
+ *      reference's DRNSTool links step by step.  All buffers in coefficient form, limb-major, canonical.  size_Ql names the
+ *      level's tool as everywhere else; the BEHZ base Bsk and the HPS base R exist at the top data level only (size_Ql = |Q|,
+ *      status -1 otherwise), the hps_overq base Rl at every level.  pha_tool_aux_sizes reports |Bsk|, |R|, |Rl| (0 where the
+ *      base does not exist at that level); each pointer may be NULL.
+ *   pha_fastbconv_m_tilde             rns.cu:1249-1278  src [Q][N]        -> dst [Bsk + 1][N]  (last limb modulo m_tilde = 2^32)
+ *   pha_sm_mrq                        rns.cu:1290-1338  src [Bsk + 1][N]  -> dst [Bsk][N]
+ *   pha_fast_floor                    rns.cu:1343-1419  (input_base_q [Q][N], input_base_Bsk [Bsk][N]) -> out_base_Bsk [Bsk][N]
+ *   pha_fastbconv_sk                  rns.cu:1421-1510  input_base_Bsk [Bsk][N] -> out_base_q [Q][N]
+ *   pha_scaleAndRound_HPS_QR_R        rns.cu:1700-1746  src [Q + R][N]    -> dst [R][N]
+ *   pha_scaleAndRound_HPS_QlRl_Ql     rns.cu:1748-1796  src [Ql + Rl][N]  -> dst [Ql][N]
+ *   pha_ExpandCRTBasis_Ql_Q_add_to_ct rns.cu:1838-1858  dst [Ql limbs] += src [Ql][N] * prod(dropped primes); size_Ql < |Q| */
+int pha_tool_aux_sizes(pha_context_t ctx, size_t size_Ql, uint32_t *size_Bsk, uint32_t *size_R, uint32_t *size_Rl);
+int pha_fastbconv_m_tilde(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
+int pha_sm_mrq(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
+int pha_fast_floor(pha_context_t ctx, size_t size_Ql, const uint64_t *input_base_q, const uint64_t *input_base_Bsk,
+                   uint64_t *out_base_Bsk, void *stream);
+int pha_fastbconv_sk(pha_context_t ctx, size_t size_Ql, const uint64_t *input_base_Bsk, uint64_t *out_base_q, void *stream);
+int pha_scaleAndRound_HPS_QR_R(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
+int pha_scaleAndRound_HPS_QlRl_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
+int pha_ExpandCRTBasis_Ql_Q_add_to_ct(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream);
 /* Batched modular GEMM (benchmark/matmul_bench.cu:215-541): for z in [0, batch): C[z] = A[z] * B[z] mod q, q = the
  * context prime mod_start_idx + z; row-major A [batch][m][lda], B [batch][k][ldb], C [batch][m][ldc], inputs
  * canonical (below q; q <= 60 bits).  Exact (the reference's benchmark kernels lose the carries of the low product word,

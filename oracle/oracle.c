@@ -9,6 +9,7 @@
  */
 #include "oracle.h"
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -469,6 +470,69 @@ void orc_bconv(const u64 *ibase, size_t isz, const u64 *obase, size_t osz, const
     bconv_free(&b);
 }
 
+/* bConv_BEHZ_var1 constants on top of an initialised converter (src/host/rns.cu:469-496): phase-1 factor
+ * negPQHatInvModq_i = q_i - (P mod q_i) * qhat_i^-1 mod q_i (P = product of the OUTPUT base), matrix QInvModp[j][i] = q_i^-1 mod p_j */
+static void bconv_make_var1(bconv_t *b) {
+    for (size_t i = 0; i < b->isz; i++) {
+        const u64 qi = b->ib[i];
+        u64 pm = 1 % qi;
+        for (size_t j = 0; j < b->osz; j++) pm = orc_mulmod(pm, b->ob[j] % qi, qi);
+        const u64 v = qi - orc_mulmod(pm, b->hat_inv[i], qi);
+        b->hat_inv[i] = v;
+        b->hat_inv_s[i] = orc_compute_shoup(v, qi);
+    }
+    for (size_t j = 0; j < b->osz; j++)
+        for (size_t i = 0; i < b->isz; i++) b->mat[j * b->isz + i] = orc_invmod(b->ib[i] % b->ob[j], b->ob[j]);
+}
+/* DBaseConverter::bConv_BEHZ_var1 src/rns_bconv.cu:231-246: bconv_mult with negPQHatInvModq, bconv_matmul with QInvModp.
+ * The output primes must be prime (q_i^-1 mod p_j by Fermat; the reference's try_invert_uint_mod accepts any coprime pair). */
+void orc_bconv_behz_var1(const u64 *ibase, size_t isz, const u64 *obase, size_t osz, const u64 *src, u64 *dst, size_t n) {
+    bconv_t b;
+    bconv_init(&b, ibase, isz, obase, osz);
+    bconv_make_var1(&b);
+    u64 *tmp = (u64 *)malloc(sizeof(u64) * isz * n);
+    bconv_mult(&b, src, tmp, n);
+    bconv_matmul(&b, tmp, dst, n, osz, 0);
+    free(tmp);
+    bconv_free(&b);
+}
+
+/* DBaseConverter::exact_convert_array src/rns_bconv.cu:374-431 (one output modulus t, any t >= 2): per coefficient
+ * y_i = x_i * qhat_i^-1 mod q_i; inner = sum_i y_i * (qhat_i mod t) in 128 bits (the mid-loop reduction of :393-396 never fires:
+ * `i && reduction_threshold == 0` with reduction_threshold = 15), reduced once; v = sum_i double(y_i) / double(q_i) by IEEE
+ * divisions and additions in limb order; Q mod t by Horner over the words of prod(ibase), most significant first (:399-400);
+ * dst = inner - round(v) * (Q mod t) mod t. */
+void orc_exact_convert_array(const u64 *ibase, size_t isz, u64 t, const u64 *src, u64 *dst, size_t n) {
+    bconv_t b;
+    bconv_init(&b, ibase, isz, &t, 1);
+    /* prod(ibase) as isz little-endian words (RNSBase::big_modulus, src/host/rns.cu:296-305) */
+    u64 *big = (u64 *)calloc(isz + 1, sizeof(u64));
+    size_t len = 1;
+    big[0] = 1;
+    for (size_t i = 0; i < isz; i++) {
+        u64 carry = 0;
+        for (size_t w = 0; w < len; w++) { u128 x = (u128)big[w] * ibase[i] + carry; big[w] = (u64)x; carry = (u64)(x >> 64); }
+        if (carry) big[len++] = carry;
+    }
+    for (size_t k = 0; k < n; k++) {
+        u128 inner = 0;
+        double v = 0.0;
+        u64 q_mod_t = 0;
+        for (size_t i = 0; i < isz; i++) {
+            const u64 yi = shoup(src[i * n + k], b.hat_inv[i], b.hat_inv_s[i], ibase[i]);
+            inner += (u128)yi * b.mat[i];
+            q_mod_t = barrett128(((u128)q_mod_t << 64) | big[isz - i - 1], t, b.omu[0]);
+            v += (double)yi / (double)ibase[i];
+        }
+        const u64 ip = barrett128(inner, t, b.omu[0]);
+        const u64 rounded = (u64)round(v);
+        const u64 corr = barrett128((u128)rounded * q_mod_t, t, b.omu[0]);   /* multiply_and_barrett_reduce_uint64 */
+        dst[k] = submod(ip, corr, t);
+    }
+    free(big);
+    bconv_free(&b);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * DRNSTool at one data level (src/rns.cu:11-200)
  * ---------------------------------------------------------------------------------------------- */
@@ -722,6 +786,44 @@ void orc_moddown_from_ntt(const orc_tool *t, u64 *ct, u64 *cx, int scheme) {
     free(delta);
 }
 
+void orc_moddown(const orc_tool *t, u64 *ct, u64 *cx, int scheme) {
+    /* DRNSTool::moddown rns_bconv.cu:712-761.  Differs from moddown_from_NTT (:776-828) in three ways: BFV input is already in
+     * coefficient form (no inverse transform, :722-730); alpha = 1 has no special kernel (always bConv_BEHZ, :733, :746); CKKS
+     * transforms delta forward and then runs the element-wise moddown_kernel (:748-757) instead of the fused epilogue. */
+    const orc_ctx *c = t->c;
+    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp;
+    u64 *delta = (u64 *)malloc(sizeof(u64) * ql * n);
+    u64 *tmp = (u64 *)calloc(t->size_p * n, sizeof(u64));
+    if (scheme == ORC_CKKS) orc_nwt_backward_map(c, cx + ql * n, t->qlp_idx + ql, t->size_p);     /* :722-725 */
+    else if (scheme == ORC_BGV) orc_nwt_backward_map(c, cx, t->qlp_idx, qlp);                      /* :726-730 */
+    bconv_mult(&t->p_to_ql, cx + ql * n, tmp, n);                                                  /* bConv_BEHZ :733 / :746 */
+    bconv_matmul(&t->p_to_ql, tmp, delta, n, ql, 0);
+    if (scheme == ORC_BGV) {   /* :732-744 */
+        const u64 pt = t->plain_t;
+        u64 *cp_t = (u64 *)malloc(sizeof(u64) * n);
+        bconv_mult(&t->p_to_t, cx + ql * n, tmp, n);
+        bconv_matmul(&t->p_to_t, tmp, cp_t, n, 1, 0);
+        for (size_t j = 0; j < ql; j++)
+            for (size_t k = 0; k < n; k++) {
+                u64 v = shoup(cp_t[k], t->pinv_mod_t, t->pinv_mod_t_s, pt);
+                u64 corr = shoup(v, t->p_mod_q[j], t->p_mod_q_s[j], c->q[j]);
+                u64 d = submod(cx[j * n + k], delta[j * n + k], c->q[j]);
+                d = addmod(d, corr, c->q[j]);
+                ct[j * n + k] = shoup(d, t->pinv[j], t->pinv_s[j], c->q[j]);
+            }
+        orc_nwt_forward(c, ct, ql, 0);
+        free(cp_t); free(tmp); free(delta);
+        return;
+    }
+    if (scheme == ORC_CKKS) orc_nwt_forward(c, delta, ql, 0);                                      /* :748-751 */
+    for (size_t j = 0; j < ql; j++)                                                                /* moddown_kernel :680-689 */
+        for (size_t k = 0; k < n; k++) {
+            u64 d = submod(cx[j * n + k], delta[j * n + k], c->q[j]);
+            ct[j * n + k] = shoup(d, t->pinv[j], t->pinv_s[j], c->q[j]);
+        }
+    free(tmp); free(delta);
+}
+
 void orc_keyswitch_inplace(const orc_tool *t, u64 *ct, const u64 *c2, const u64 *const *evks, int scheme) {
     /* keyswitch_inplace eval_key_switch.cu:95-182 (mul_tech != hps_overq_leveled) */
     const orc_ctx *c = t->c;
@@ -912,6 +1014,70 @@ void orc_behz_destroy(orc_behz *b) {
     free(b);
 }
 
+/* DRNSTool::fastbconv_m_tilde rns.cu:1249-1278: src [Q][N] -> dst [Bsk + 1][N] (last limb modulo m_tilde); ONE phase 1 with
+ * m_tilde * QHatInv (:1258-1263), then Q -> Bsk (:1265-1270) and Q -> {m_tilde} (:1272-1277) */
+void orc_behz_fastbconv_m_tilde(const orc_behz *b, const u64 *src, u64 *dst) {
+    const orc_ctx *c = b->c;
+    const size_t n = b->n, sq = b->size_q, sk = b->size_bsk;
+    u64 *y = (u64 *)malloc(sizeof(u64) * sq * n);
+    for (size_t i = 0; i < sq; i++)
+        for (size_t k = 0; k < n; k++) y[i * n + k] = shoup(src[i * n + k], b->mt_qhatinv[i], b->mt_qhatinv_s[i], c->q[i]);
+    bconv_matmul(&b->q_to_bsk, y, dst, n, sk, 0);
+    bconv_matmul(&b->q_to_mtilde, y, dst + sk * n, n, 1, 0);
+    free(y);
+}
+/* DRNSTool::sm_mrq rns.cu:1290-1338 (sm_mrq_kernel :1290-1320): src [Bsk + 1][N] -> dst [Bsk][N] */
+void orc_behz_sm_mrq(const orc_behz *b, const u64 *src, u64 *dst) {
+    const size_t n = b->n, sk = b->size_bsk;
+    const u64 mt = b->m_tilde;
+    for (size_t j = 0; j < sk; j++) {
+        const u64 p = b->bsk[j];
+        for (size_t k = 0; k < n; k++) {
+            u64 r = shoup(src[sk * n + k], b->neg_inv_prod_q_mod_mt, b->neg_inv_prod_q_mod_mt_s, mt);
+            if (r >= (mt >> 1)) r += p - mt;
+            u128 t = (u128)r * b->prod_q_mod_bsk[j] + src[j * n + k];
+            u64 v = barrett128(t, p, b->bsk_mu[j]);
+            dst[j * n + k] = shoup(v, b->inv_mt_mod_bsk[j], b->inv_mt_mod_bsk_s[j], p);
+        }
+    }
+}
+/* DRNSTool::fast_floor rns.cu:1394-1419 (bconv_fuse_sub_mul_unroll2_kernel :1343-1386): (x_Bsk - FastBconv(x_q, q -> Bsk)) *
+ * prod(q)^-1 mod Bsk; in_q [Q][N], in_bsk [Bsk][N] -> out_bsk [Bsk][N] */
+void orc_behz_fast_floor(const orc_behz *b, const u64 *in_q, const u64 *in_bsk, u64 *out_bsk) {
+    const size_t n = b->n, sq = b->size_q, sk = b->size_bsk;
+    u64 *y = (u64 *)calloc(sq * n, sizeof(u64)), *conv = (u64 *)malloc(sizeof(u64) * sk * n);
+    bconv_mult(&b->q_to_bsk, in_q, y, n);
+    bconv_matmul(&b->q_to_bsk, y, conv, n, sk, 0);
+    for (size_t j = 0; j < sk; j++)
+        for (size_t k = 0; k < n; k++) {
+            const u64 v = in_bsk[j * n + k] + (b->bsk[j] - conv[j * n + k]);   /* not reduced before the multiply (:1376-1378) */
+            out_bsk[j * n + k] = shoup(v, b->inv_prod_q_mod_bsk[j], b->inv_prod_q_mod_bsk_s[j], b->bsk[j]);
+        }
+    free(y); free(conv);
+}
+/* DRNSTool::fastbconv_sk rns.cu:1470-1510: in_bsk [Bsk][N] (B limbs then the m_sk limb) -> out_q [Q][N] */
+void orc_behz_fastbconv_sk(const orc_behz *b, const u64 *in_bsk, u64 *out_q) {
+    const orc_ctx *c = b->c;
+    const size_t n = b->n, sq = b->size_q, sb = b->size_b;
+    u64 *yb = (u64 *)calloc(sb * n, sizeof(u64)), *alpha = (u64 *)malloc(sizeof(u64) * n);
+    bconv_mult(&b->b_to_q, in_bsk, yb, n);                               /* :1484-1487 (phase 1 of base B, shared) */
+    bconv_matmul(&b->b_to_msk, yb, alpha, n, 1, 0);                      /* :1489-1494 with the fused (conv - x_msk) * B^-1 mod m_sk */
+    for (size_t k = 0; k < n; k++) {
+        const u64 v = alpha[k] + (b->m_sk - in_bsk[sb * n + k]);
+        alpha[k] = shoup(v, b->inv_prod_b_mod_msk, b->inv_prod_b_mod_msk_s, b->m_sk);
+    }
+    bconv_matmul(&b->b_to_q, yb, out_q, n, sq, 0);                       /* :1496-1500 */
+    for (size_t i = 0; i < sq; i++)   /* multiply_and_negated_add_rns_poly polymath.cu:606-634 (:1506-1510) */
+        for (size_t k = 0; k < n; k++) {
+            u64 op1 = alpha[k], pb = b->prod_b_mod_q[i];
+            if (op1 > (b->m_sk >> 1)) op1 = b->m_sk - op1;
+            else pb = c->q[i] - pb;
+            op1 = barrett128((u128)op1 * pb, c->q[i], c->mu[i]);
+            out_q[i * n + k] = addmod(out_q[i * n + k], op1, c->q[i]);
+        }
+    free(yb); free(alpha);
+}
+
 /* BEHZ_mul_1 evaluate.cu:404-441: one polynomial x [Q][N] (coefficient form) -> NTT(x) over q and the lifted,
  * Montgomery-reduced polynomial over Bsk in NTT form */
 static void behz_lift(const orc_behz *b, const u64 *x, u64 *out_q, u64 *out_bsk) {
@@ -919,27 +1085,11 @@ static void behz_lift(const orc_behz *b, const u64 *x, u64 *out_q, u64 *out_bsk)
     const size_t n = b->n, sq = b->size_q, sk = b->size_bsk;
     memcpy(out_q, x, sizeof(u64) * sq * n);
     orc_nwt_forward(c, out_q, sq, 0);
-    /* fastbconv_m_tilde rns.cu:1249-1278: phase 1 with m_tilde * QHatInv, then Q -> Bsk and Q -> {m_tilde} */
-    u64 *y = (u64 *)malloc(sizeof(u64) * sq * n);
     u64 *lift = (u64 *)malloc(sizeof(u64) * (sk + 1) * n);
-    for (size_t i = 0; i < sq; i++)
-        for (size_t k = 0; k < n; k++) y[i * n + k] = shoup(x[i * n + k], b->mt_qhatinv[i], b->mt_qhatinv_s[i], c->q[i]);
-    bconv_matmul(&b->q_to_bsk, y, lift, n, sk, 0);
-    bconv_matmul(&b->q_to_mtilde, y, lift + sk * n, n, 1, 0);
-    /* sm_mrq_kernel rns.cu:1290-1320 */
-    const u64 mt = b->m_tilde;
-    for (size_t j = 0; j < sk; j++) {
-        const u64 p = b->bsk[j];
-        for (size_t k = 0; k < n; k++) {
-            u64 r = shoup(lift[sk * n + k], b->neg_inv_prod_q_mod_mt, b->neg_inv_prod_q_mod_mt_s, mt);
-            if (r >= (mt >> 1)) r += p - mt;
-            u128 t = (u128)r * b->prod_q_mod_bsk[j] + lift[j * n + k];
-            u64 v = barrett128(t, p, b->bsk_mu[j]);
-            out_bsk[j * n + k] = shoup(v, b->inv_mt_mod_bsk[j], b->inv_mt_mod_bsk_s[j], p);
-        }
-        orc_ntt_forward(out_bsk + j * n, b->log_n, p, b->tw + j * n, b->tws + j * n);
-    }
-    free(y); free(lift);
+    orc_behz_fastbconv_m_tilde(b, x, lift);
+    orc_behz_sm_mrq(b, lift, out_bsk);
+    for (size_t j = 0; j < sk; j++) orc_ntt_forward(out_bsk + j * n, b->log_n, b->bsk[j], b->tw + j * n, b->tws + j * n);
+    free(lift);
 }
 static void tensor_generic(const u64 *a, const u64 *bb, u64 *r, const u64 *q, u64 (*const mu)[2], size_t limbs, size_t n) {
     /* tensor_prod_2x2_rns_poly polymath.cu:463-496 over an arbitrary base; r may alias a */
@@ -957,7 +1107,7 @@ static void tensor_generic(const u64 *a, const u64 *bb, u64 *r, const u64 *q, u6
 }
 void orc_bfv_multiply_behz(const orc_behz *b, const u64 *ct1, const u64 *ct2, u64 *dst) {
     const orc_ctx *c = b->c;
-    const size_t n = b->n, sq = b->size_q, sk = b->size_bsk, sb = b->size_b;
+    const size_t n = b->n, sq = b->size_q, sk = b->size_bsk;
     u64 *q1 = (u64 *)calloc(3 * sq * n, 8), *b1 = (u64 *)calloc(3 * sk * n, 8);
     u64 *q2 = (u64 *)calloc(2 * sq * n, 8), *b2 = (u64 *)calloc(2 * sk * n, 8);
     for (int p = 0; p < 2; p++) {
@@ -980,35 +1130,11 @@ void orc_bfv_multiply_behz(const orc_behz *b, const u64 *ct1, const u64 *ct2, u6
             const u64 ts = orc_compute_shoup(b->plain_t, b->bsk[j]);
             for (size_t k = 0; k < n; k++) xb[j * n + k] = shoup(xb[j * n + k], b->plain_t, ts, b->bsk[j]);
         }
-        /* step 7 fast_floor rns.cu:1394-1419: (x_Bsk - FastBconv(x_q, q -> Bsk)) * prod(q)^-1 mod Bsk */
-        u64 *y = (u64 *)malloc(sizeof(u64) * sq * n), *conv = (u64 *)malloc(sizeof(u64) * sk * n);
+        /* step 7 fast_floor rns.cu:1394-1419, step 8 fastbconv_sk rns.cu:1470-1510 */
         u64 *fl = (u64 *)malloc(sizeof(u64) * sk * n);
-        bconv_mult(&b->q_to_bsk, xq, y, n);
-        bconv_matmul(&b->q_to_bsk, y, conv, n, sk, 0);
-        for (size_t j = 0; j < sk; j++)
-            for (size_t k = 0; k < n; k++) {
-                const u64 v = xb[j * n + k] + (b->bsk[j] - conv[j * n + k]);   /* not reduced before the multiply (:1376-1378) */
-                fl[j * n + k] = shoup(v, b->inv_prod_q_mod_bsk[j], b->inv_prod_q_mod_bsk_s[j], b->bsk[j]);
-            }
-        /* step 8 fastbconv_sk rns.cu:1470-1510 */
-        u64 *yb = (u64 *)malloc(sizeof(u64) * sb * n), *alpha = (u64 *)malloc(sizeof(u64) * n);
-        u64 *out = dst + p * sq * n;
-        bconv_mult(&b->b_to_q, fl, yb, n);
-        bconv_matmul(&b->b_to_msk, yb, alpha, n, 1, 0);
-        for (size_t k = 0; k < n; k++) {
-            const u64 v = alpha[k] + (b->m_sk - fl[sb * n + k]);
-            alpha[k] = shoup(v, b->inv_prod_b_mod_msk, b->inv_prod_b_mod_msk_s, b->m_sk);
-        }
-        bconv_matmul(&b->b_to_q, yb, out, n, sq, 0);
-        for (size_t i = 0; i < sq; i++)   /* multiply_and_negated_add_rns_poly polymath.cu:606-634 */
-            for (size_t k = 0; k < n; k++) {
-                u64 op1 = alpha[k], pb = b->prod_b_mod_q[i];
-                if (op1 > (b->m_sk >> 1)) op1 = b->m_sk - op1;
-                else pb = c->q[i] - pb;
-                op1 = barrett128((u128)op1 * pb, c->q[i], c->mu[i]);
-                out[i * n + k] = addmod(out[i * n + k], op1, c->q[i]);
-            }
-        free(y); free(conv); free(fl); free(yb); free(alpha);
+        orc_behz_fast_floor(b, xq, xb, fl);
+        orc_behz_fastbconv_sk(b, fl, dst + p * sq * n);
+        free(fl);
     }
     free(q1); free(b1); free(q2); free(b2);
 }
@@ -1019,7 +1145,6 @@ void orc_bfv_multiply_behz(const orc_behz *b, const u64 *ct1, const u64 *ct2, u6
  * Floating point: the reference's kernels are built by nvcc with its default -fmad=true (no flag in its CMake
  * files), so `acc += double(x) * c` is ONE fused multiply-add per term; the same fma chain is restated here.
  * ---------------------------------------------------------------------------------------------- */
-#include <math.h>
 typedef struct { u64 *w; size_t len; } big_t;
 static big_t big_one(size_t cap) { big_t b; b.w = (u64 *)calloc(cap, sizeof(u64)); b.w[0] = 1; b.len = 1; return b; }
 static void big_mul_small(big_t *b, u64 m) {
@@ -1148,6 +1273,26 @@ void orc_hps_destroy(orc_hps *h) {
     free(h->r); free(h->qr); free(h->qr_mu); free(h->tw); free(h->tws); free(h->itw); free(h->itws); free(h->n_inv); free(h->n_inv_s);
     hpsconv_free(&h->q_to_r); hpsconv_free(&h->r_to_q); free(h->frac); free(h->div_mod_r); free(h);
 }
+/* DRNSTool::scaleAndRound_HPS_QR_R rns.cu:1700-1746: src [Q + R][N] coefficient form -> dst [R][N], scaled by t / Q and rounded;
+ * nu accumulates by fused multiply-adds (nvcc's default -fmad), alpha is reduced IN PLACE across the R limbs (:1733) */
+void orc_hps_scale_round_qr_r(const orc_hps *h, const u64 *x, u64 *dst) {
+    const size_t n = h->n, sq = h->size_q, sr = h->size_r;
+    for (size_t k = 0; k < n; k++) {
+        double nu = 0.5;
+        for (size_t i = 0; i < sq; i++) nu = fma((double)x[i * n + k], h->frac[i], nu);
+        u64 alpha = (u64)nu;
+        for (size_t j = 0; j < sr; j++) {
+            const u64 rj = h->qr[sq + j];
+            const u64 *tab = h->div_mod_r + j * (sq + 1);
+            u128 cur = 0;
+            for (size_t i = 0; i < sq; i++) cur += (u128)x[i * n + k] * tab[i];
+            cur += (u128)x[(sq + j) * n + k] * tab[sq];
+            const u64 v = barrett128(cur, rj, h->qr_mu[sq + j]);
+            alpha = barrett64(alpha, rj, h->qr_mu[sq + j][1]);
+            dst[j * n + k] = addmod(v, alpha, rj);
+        }
+    }
+}
 void orc_bfv_multiply_hps(const orc_hps *h, const u64 *ct1, const u64 *ct2, u64 *dst) {
     const size_t n = h->n, sq = h->size_q, sr = h->size_r, sqr = sq + sr;
     u64 *x1 = (u64 *)calloc(3 * sqr * n, 8), *x2 = (u64 *)calloc(2 * sqr * n, 8);
@@ -1167,22 +1312,7 @@ void orc_bfv_multiply_hps(const orc_hps *h, const u64 *ct1, const u64 *ct2, u64 
         u64 *x = x1 + p * sqr * n;
         for (size_t i = 0; i < sqr; i++)
             orc_ntt_inverse(x + i * n, h->log_n, h->qr[i], h->itw + i * n, h->itws + i * n, h->n_inv[i], h->n_inv_s[i]);
-        /* scaleAndRound_HPS_QR_R_kernel rns.cu:1700-1737 */
-        for (size_t k = 0; k < n; k++) {
-            double nu = 0.5;
-            for (size_t i = 0; i < sq; i++) nu = fma((double)x[i * n + k], h->frac[i], nu);
-            u64 alpha = (u64)nu;
-            for (size_t j = 0; j < sr; j++) {
-                const u64 rj = h->qr[sq + j];
-                const u64 *tab = h->div_mod_r + j * (sq + 1);
-                u128 cur = 0;
-                for (size_t i = 0; i < sq; i++) cur += (u128)x[i * n + k] * tab[i];
-                cur += (u128)x[(sq + j) * n + k] * tab[sq];
-                const u64 v = barrett128(cur, rj, h->qr_mu[sq + j]);
-                alpha = barrett64(alpha, rj, h->qr_mu[sq + j][1]);
-                tmp[j * n + k] = addmod(v, alpha, rj);
-            }
-        }
+        orc_hps_scale_round_qr_r(h, x, tmp);                                /* scaleAndRound_HPS_QR_R evaluate.cu:800-803 */
         hpsconv_apply(&h->r_to_q, tmp, dst + p * sq * n, n);                /* evaluate.cu:806 */
     }
     free(tmp); free(x1); free(x2);
@@ -1346,6 +1476,17 @@ void orc_hps_expand_ql_q(const orc_hpsq *h, const u64 *src, u64 *dst) {
         for (size_t k = 0; k < n; k++) dst[i * n + k] = orc_mulmod(src[i * n + k], h->drop_mod_q[i], h->qr[i]);
     memset(dst + sq * n, 0, sizeof(u64) * h->drop * n);
 }
+/* scaleAndRound_HPS_QlRl_Ql (rns.cu:1748-1796): src [Ql + Rl][N] -> dst [Ql][N], scaled by t / Rl and rounded */
+void orc_hpsq_scale_round_qlrl_ql(const orc_hpsq *h, const u64 *src, u64 *dst) {
+    hps_scale_round_to_ql(h, src, dst, h->frac, h->div_mod_q, h->size_r);
+}
+/* ExpandCRTBasis_Ql_Q_add_to_ct (rns.cu:1838-1858): dst[i] += src[i] * prod(dropped primes) on the Ql limbs */
+void orc_hpsq_expand_add_to_ct(const orc_hpsq *h, const u64 *src, u64 *dst) {
+    const size_t n = h->n, sq = h->size_q;
+    for (size_t i = 0; i < sq; i++)
+        for (size_t k = 0; k < n; k++)
+            dst[i * n + k] = addmod(orc_mulmod(src[i * n + k], h->drop_mod_q[i], h->qr[i]), dst[i * n + k], h->qr[i]);
+}
 /* bfv_multiply_hps with mul_tech hps_overq (h built at the top level) or hps_overq_leveled with levels dropped (h built at a
  * lower level: evaluate.cu:709-711, :747-748, :794-795).  Operands and result are over the FULL base Q: [.][Q][N]. */
 static void hpsq_multiply(const orc_hpsq *h, const u64 *ct1, const u64 *ct2, u64 *dst, int keep_c2_low) {
@@ -1369,7 +1510,7 @@ static void hpsq_multiply(const orc_hpsq *h, const u64 *ct1, const u64 *ct2, u64
         u64 *x = x1 + p * sqr * n, *out = dst + p * sqf * n;
         for (size_t i = 0; i < sqr; i++)
             orc_ntt_inverse(x + i * n, h->log_n, h->qr[i], h->itw + i * n, h->itws + i * n, h->n_inv[i], h->n_inv_s[i]);
-        hps_scale_round_to_ql(h, x, out, h->frac, h->div_mod_q, sr);           /* scaleAndRound_HPS_QlRl_Ql :790-792 */
+        orc_hpsq_scale_round_qlrl_ql(h, x, out);                               /* scaleAndRound_HPS_QlRl_Ql :790-792 */
         if (h->drop && !(keep_c2_low && p == 2)) orc_hps_expand_ql_q(h, out, out);   /* :794-795 (:957-958 leaves c2 at level l) */
     }
     free(x1); free(x2); free(y);
@@ -1380,8 +1521,7 @@ void orc_bfv_multiply_hps_overq(const orc_hpsq *h, const u64 *ct1, const u64 *ct
  * dst [2][Q][N]; t = the tool of level l. */
 void orc_bfv_mul_relin_hps_overq_leveled(const orc_tool *t, const orc_hpsq *h, const u64 *ct1, const u64 *ct2,
                                          const u64 *const *evks, u64 *dst) {
-    const orc_ctx *c = t->c;
-    const size_t n = t->n, ql = t->size_ql, qlp = t->size_qlp, sqf = h->size_q_full;
+    const size_t n = t->n, qlp = t->size_qlp, sqf = h->size_q_full;
     u64 *d3 = (u64 *)malloc(sizeof(u64) * 3 * sqf * n);
     u64 *mu = (u64 *)malloc(sizeof(u64) * t->beta * qlp * n);
     u64 *cx = (u64 *)malloc(sizeof(u64) * 2 * qlp * n);
@@ -1392,9 +1532,7 @@ void orc_bfv_mul_relin_hps_overq_leveled(const orc_tool *t, const orc_hpsq *h, c
     for (int i = 0; i < 2; i++) {
         u64 *cxi = cx + (size_t)i * qlp * n, *ct = dst + (size_t)i * sqf * n;
         orc_moddown_from_ntt(t, cxi, cxi, ORC_BFV);
-        for (size_t l = 0; l < ql; l++)
-            for (size_t k = 0; k < n; k++)
-                ct[l * n + k] = addmod(ct[l * n + k], orc_mulmod(cxi[l * n + k], h->drop_mod_q[l], c->q[l]), c->q[l]);
+        orc_hpsq_expand_add_to_ct(h, cxi, ct);                                 /* :1014-1016 */
     }
     free(d3); free(mu); free(cx);
 }

@@ -84,6 +84,12 @@ void orc_tensor_square_2x2(const orc_ctx *c, const uint64_t *op, uint64_t *res, 
 void orc_bconv(const uint64_t *ibase, size_t isz, const uint64_t *obase, size_t osz, const uint64_t *src,
                uint64_t *dst, size_t n);
 
+/* DBaseConverter::bConv_BEHZ_var1 (src/rns_bconv.cu:231-246; constants src/host/rns.cu:469-496): the quotient-style conversion */
+void orc_bconv_behz_var1(const uint64_t *ibase, size_t isz, const uint64_t *obase, size_t osz, const uint64_t *src,
+                         uint64_t *dst, size_t n);
+/* DBaseConverter::exact_convert_array (src/rns_bconv.cu:374-431): src [ibase][N] -> dst [N] modulo ONE output modulus t */
+void orc_exact_convert_array(const uint64_t *ibase, size_t isz, uint64_t t, const uint64_t *src, uint64_t *dst, size_t n);
+
 /* ---- DRNSTool at level size_ql (src/rns.cu:11-200) ---- */
 typedef struct orc_tool orc_tool;
 orc_tool *orc_tool_create(const orc_ctx *c, size_t size_ql);
@@ -99,6 +105,8 @@ void orc_modup(const orc_tool *t, uint64_t *dst, const uint64_t *cks, int scheme
 void orc_key_switch_inner_prod(const orc_tool *t, uint64_t *cx, const uint64_t *t_mod_up, const uint64_t *const *evks);
 /* DRNSTool::moddown_from_NTT rns_bconv.cu:776-828: cx [size_ql+alpha][N] (clobbered) -> ct [size_ql][N] */
 void orc_moddown_from_ntt(const orc_tool *t, uint64_t *ct, uint64_t *cx, int scheme);
+/* DRNSTool::moddown rns_bconv.cu:712-761: as above, but BFV input already in coefficient form and no alpha = 1 special case */
+void orc_moddown(const orc_tool *t, uint64_t *ct, uint64_t *cx, int scheme);
 /* keyswitch_inplace eval_key_switch.cu:95-182: ct=[2][size_ql][N] += KS(c2) */
 void orc_keyswitch_inplace(const orc_tool *t, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks, int scheme);
 /* hoisting_inplace evaluate.cu:1670-1866: ct=[2][size_ql][N] <- sum_e rotate_e(ct); glk[e][digit] = key [2][size_QP][N] */
@@ -120,6 +128,8 @@ void orc_bfv_mul_relin_hps_overq_leveled(const orc_tool *t, const orc_hpsq *h, c
                                          const uint64_t *const *evks, uint64_t *dst);
 /* BFV key switch with levels dropped (eval_key_switch.cu:142-147,170-175); t = orc_tool of that level */
 void orc_keyswitch_bfv_leveled(const orc_tool *t, const orc_hpsq *h, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks);
+void orc_hpsq_scale_round_qlrl_ql(const orc_hpsq *h, const uint64_t *src, uint64_t *dst);  /* scaleAndRound_HPS_QlRl_Ql rns.cu:1748-1796 */
+void orc_hpsq_expand_add_to_ct(const orc_hpsq *h, const uint64_t *src, uint64_t *dst);      /* ExpandCRTBasis_Ql_Q_add_to_ct rns.cu:1838-1858 */
 void orc_hpsq_destroy(orc_hpsq *h);
 size_t orc_hpsq_r_size(const orc_hpsq *h);
 void orc_hpsq_base(const orc_hpsq *h, uint64_t *out);
@@ -143,6 +153,11 @@ orc_behz *orc_behz_create(const orc_ctx *c, uint64_t plain_t);
 void orc_behz_destroy(orc_behz *b);
 size_t orc_behz_bsk_size(const orc_behz *b);
 void orc_behz_base(const orc_behz *b, uint64_t *bsk_out);  /* B primes then m_sk */
+/* the four DRNSTool steps of the multiply, one polynomial each (include/rns.cuh:186-200) */
+void orc_behz_fastbconv_m_tilde(const orc_behz *b, const uint64_t *src, uint64_t *dst);                       /* rns.cu:1249-1278: [Q][N] -> [Bsk+1][N] */
+void orc_behz_sm_mrq(const orc_behz *b, const uint64_t *src, uint64_t *dst);                                  /* rns.cu:1290-1338: [Bsk+1][N] -> [Bsk][N] */
+void orc_behz_fast_floor(const orc_behz *b, const uint64_t *in_q, const uint64_t *in_bsk, uint64_t *out_bsk); /* rns.cu:1343-1419 */
+void orc_behz_fastbconv_sk(const orc_behz *b, const uint64_t *in_bsk, uint64_t *out_q);                       /* rns.cu:1421-1510 */
 /* ct1, ct2 [2][Q][N] in coefficient form -> dst [3][Q][N] in coefficient form */
 void orc_bfv_multiply_behz(const orc_behz *b, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst);
 
@@ -152,6 +167,7 @@ orc_hps *orc_hps_create(const orc_ctx *c, uint64_t plain_t);
 void orc_hps_destroy(orc_hps *h);
 size_t orc_hps_r_size(const orc_hps *h);
 void orc_hps_base(const orc_hps *h, uint64_t *r_out);
+void orc_hps_scale_round_qr_r(const orc_hps *h, const uint64_t *src, uint64_t *dst);   /* scaleAndRound_HPS_QR_R rns.cu:1700-1746: [Q+R][N] -> [R][N] */
 void orc_bfv_multiply_hps(const orc_hps *h, const uint64_t *ct1, const uint64_t *ct2, uint64_t *dst);
 
 /* ---- batched modular GEMM (benchmark/matmul_bench.cu:215-541), one modulus: row-major A [m][k], B [k][n], C [m][n] ---- */

@@ -119,6 +119,13 @@ def lib(path=None):
     L.orc_behz_base.argtypes = [C.c_void_p, u64p]
     L.orc_bfv_multiply_behz.argtypes = [C.c_void_p, u64p, u64p, u64p]
     L.orc_set_threads.restype = None
+    L.orc_moddown.argtypes = [C.c_void_p, u64p, u64p, C.c_int]
+    L.orc_bconv_behz_var1.argtypes = [u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, C.c_size_t]
+    L.orc_exact_convert_array.argtypes = [u64p, C.c_size_t, C.c_uint64, u64p, u64p, C.c_size_t]
+    for f in ("orc_behz_fastbconv_m_tilde", "orc_behz_sm_mrq", "orc_behz_fastbconv_sk", "orc_hps_scale_round_qr_r",
+              "orc_hpsq_scale_round_qlrl_ql", "orc_hpsq_expand_add_to_ct"):
+        getattr(L, f).argtypes = [C.c_void_p, u64p, u64p]
+    L.orc_behz_fast_floor.argtypes = [C.c_void_p, u64p, u64p, u64p]
     L.orc_tool_set_plain_modulus.restype = C.c_int
     L.orc_tool_set_plain_modulus.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_mod_t_divide_q_last_ntt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
@@ -323,6 +330,25 @@ def bconv(ibase, obase, src, n):
     return dst.reshape(len(obase), n)
 
 
+def bconv_behz_var1(ibase, obase, src, n):
+    """DBaseConverter::bConv_BEHZ_var1 (src/rns_bconv.cu:231-246) for arbitrary bases (prime output moduli)."""
+    ib = np.array([int(q) for q in ibase], dtype=np.uint64)
+    ob = np.array([int(q) for q in obase], dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+    dst = np.zeros(len(ob) * n, dtype=np.uint64)
+    lib().orc_bconv_behz_var1(_p(ib), len(ib), _p(ob), len(ob), _p(src), _p(dst), n)
+    return dst.reshape(len(ob), n)
+
+
+def exact_convert_array(ibase, t, src, n):
+    """DBaseConverter::exact_convert_array (src/rns_bconv.cu:374-431): [ibase][N] -> [N] modulo t."""
+    ib = np.array([int(q) for q in ibase], dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+    dst = np.zeros(n, dtype=np.uint64)
+    lib().orc_exact_convert_array(_p(ib), len(ib), int(t), _p(src), _p(dst), n)
+    return dst
+
+
 def bconv_hps(ibase, obase, src, n):
     """DBaseConverter::bConv_HPS (src/rns_bconv.cu:248-372) for arbitrary bases."""
     ib = np.array([int(q) for q in ibase], dtype=np.uint64)
@@ -358,6 +384,32 @@ class Behz:
         out = np.zeros(3 * c.size_q * c.n, dtype=np.uint64)
         self.L.orc_bfv_multiply_behz(self.h, _p(a), _p(b), _p(out))
         return out.reshape(3, c.size_q, c.n)
+
+    def _step(self, fn, src, out_limbs):
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(out_limbs * self.ctx.n, dtype=np.uint64)
+        fn(self.h, _p(src), _p(dst))
+        return dst.reshape(out_limbs, self.ctx.n)
+
+    def fastbconv_m_tilde(self, src):
+        """DRNSTool::fastbconv_m_tilde (src/rns.cu:1249-1278): [Q][N] -> [Bsk + 1][N], last limb modulo m_tilde."""
+        return self._step(self.L.orc_behz_fastbconv_m_tilde, src, self.size_bsk + 1)
+
+    def sm_mrq(self, src):
+        """DRNSTool::sm_mrq (src/rns.cu:1290-1338): [Bsk + 1][N] -> [Bsk][N]."""
+        return self._step(self.L.orc_behz_sm_mrq, src, self.size_bsk)
+
+    def fast_floor(self, in_q, in_bsk):
+        """DRNSTool::fast_floor (src/rns.cu:1394-1419): ([Q][N], [Bsk][N]) -> [Bsk][N]."""
+        a = np.ascontiguousarray(in_q, dtype=np.uint64).reshape(-1)
+        b = np.ascontiguousarray(in_bsk, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(self.size_bsk * self.ctx.n, dtype=np.uint64)
+        self.L.orc_behz_fast_floor(self.h, _p(a), _p(b), _p(dst))
+        return dst.reshape(self.size_bsk, self.ctx.n)
+
+    def fastbconv_sk(self, in_bsk):
+        """DRNSTool::fastbconv_sk (src/rns.cu:1470-1510): [Bsk][N] -> [Q][N]."""
+        return self._step(self.L.orc_behz_fastbconv_sk, in_bsk, self.ctx.size_q)
 
 
 def gemm_mod(q, A, B, quirk=False):
@@ -398,6 +450,13 @@ class Hps:
         self.L.orc_bfv_multiply_hps(self.h, _p(a), _p(b), _p(out))
         return out.reshape(3, c.size_q, c.n)
 
+    def scale_round_qr_r(self, src):
+        """DRNSTool::scaleAndRound_HPS_QR_R (src/rns.cu:1700-1746): [Q + R][N] -> [R][N]."""
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(self.size_r * self.ctx.n, dtype=np.uint64)
+        self.L.orc_hps_scale_round_qr_r(self.h, _p(src), _p(dst))
+        return dst.reshape(self.size_r, self.ctx.n)
+
 
 class HpsOverQ:
     """BFV multiply, hps_overq variant (mul_tech_type::hps_overq; src/evaluate.cu:674-818), and with size_ql < size_Q
@@ -433,6 +492,20 @@ class HpsOverQ:
         src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
         dst = np.zeros(self.size_ql * self.ctx.n, dtype=np.uint64)
         self.L.orc_hps_scale_q_ql(self.h, _p(src), _p(dst))
+        return dst.reshape(self.size_ql, self.ctx.n)
+
+    def scale_round_qlrl_ql(self, src):
+        """DRNSTool::scaleAndRound_HPS_QlRl_Ql (src/rns.cu:1748-1796): [Ql + Rl][N] -> [Ql][N]."""
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        dst = np.zeros(self.size_ql * self.ctx.n, dtype=np.uint64)
+        self.L.orc_hpsq_scale_round_qlrl_ql(self.h, _p(src), _p(dst))
+        return dst.reshape(self.size_ql, self.ctx.n)
+
+    def expand_add_to_ct(self, dst, src):
+        """DRNSTool::ExpandCRTBasis_Ql_Q_add_to_ct (src/rns.cu:1838-1858): dst [Ql][N] += src [Ql][N] * prod(dropped primes)."""
+        dst = np.array(dst, dtype=np.uint64, copy=True).reshape(-1)
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1)
+        self.L.orc_hpsq_expand_add_to_ct(self.h, _p(src), _p(dst))
         return dst.reshape(self.size_ql, self.ctx.n)
 
     def expand_ql_q(self, src):
@@ -500,6 +573,13 @@ class Tool:
         cx = np.array(cx, dtype=np.uint64, copy=True).reshape(-1)
         ct = np.zeros(self.size_ql * self.n, dtype=np.uint64)
         self.L.orc_moddown_from_ntt(self.h, _p(ct), _p(cx), scheme)
+        return ct.reshape(self.size_ql, self.n)
+
+    def moddown(self, cx, scheme):
+        """DRNSTool::moddown (src/rns_bconv.cu:712-761): BFV input in coefficient form, CKKS / BGV in NTT form."""
+        cx = np.array(cx, dtype=np.uint64, copy=True).reshape(-1)
+        ct = np.zeros(self.size_ql * self.n, dtype=np.uint64)
+        self.L.orc_moddown(self.h, _p(ct), _p(cx), scheme)
         return ct.reshape(self.size_ql, self.n)
 
     def keyswitch_inplace(self, ct, c2, evks, scheme):

@@ -644,7 +644,93 @@ struct pha_base_converter {
     pha::DevBuf<double> inv;          // 1 / q_i of the input base (src/host/rns.cu:321-323)
     pha::DevBuf<pha::u64> alpha_mod;  // [isz + 1][osz] alpha * prod(ibase) mod p_j (:459-466)
     bool split_ok = true;
+    // bConv_BEHZ_var1 (negPQHatInvModq / QInvModp, src/host/rns.cu:469-496): built on first use
+    std::unique_ptr<pha::BConv> var1;
+    pha::DevBuf<pha::BConvDev> d_var1;
+    std::mutex var1_lock;
+    // exact_convert_array (src/rns_bconv.cu:374-431): ONE output modulus, which may be a raw value outside the prime table (the
+    // plain modulus t of base_q_to_t_conv_, src/rns.cu:283-284)
+    bool raw = false;                 // created by pha_base_converter_create_modulus: exact_convert_array only
+    pha::DModulus out_mod{};          // the output modulus when osz == 1
+    std::vector<uint32_t> irows;
+    pha::DevBuf<pha::u64x2> x_hat_inv;   // [isz] qhat_i^-1 mod q_i (+ Shoup)
+    pha::DevBuf<pha::u64> x_mat;         // [isz] qhat_i mod t
+    pha::DevBuf<pha::u64> x_big;         // [isz] words of prod(ibase), little-endian
+    pha::DevBuf<pha::u64> x_q;           // [isz] q_i
+    bool x_ready = false;
 };
+
+namespace pha {
+struct ExactArgs {
+    u64 *dst;
+    const u64 *src;
+    const u64x2 *hat_inv;
+    const u64 *mat, *big, *q;
+    DModulus t;
+    uint32_t isz, n;
+};
+// exact_convert_array_kernel src/rns_bconv.cu:374-414, one thread per coefficient.  The mid-loop reduction (:393-396) never
+// fires in the reference (`i && reduction_threshold == 0` with reduction_threshold = 15) and is absent here; v is a sum of IEEE
+// divisions in limb order; Q mod t by Horner over the words of prod(ibase), most significant first.
+__global__ __launch_bounds__(256) void exact_convert_kernel(const ExactArgs k) {
+    const uint32_t coeff = blockIdx.x * 256 + threadIdx.x;
+    u64 lo = 0, hi = 0, q_mod_t = 0;
+    double v = 0.0;
+    for (uint32_t i = 0; i < k.isz; i++) {
+        const u64 qi = k.q[i];
+        const u64 yi = shoup(k.src[(size_t)i * k.n + coeff], k.hat_inv[i], qi);
+        mac128(yi, k.mat[i], lo, hi);
+        q_mod_t = barrett128(k.big[k.isz - i - 1], q_mod_t, k.t);
+        v += (double)yi / (double)qi;
+    }
+    const u64 inner = barrett128(lo, hi, k.t);
+    const u64 rounded = (u64)round(v);
+    k.dst[coeff] = sub_mod(inner, mul_mod(rounded, q_mod_t, k.t), k.t.value);
+}
+}  // namespace pha
+
+// constants of exact_convert_array for (input rows, ONE output modulus): qhat_i^-1 mod q_i, qhat_i mod t, prod(ibase)
+static void build_exact(pha::Context &c, pha_base_converter &h) {
+    using namespace pha;
+    using u128 = unsigned __int128;
+    const size_t isz = h.irows.size();
+    std::vector<u64x2> hat_inv(isz);
+    std::vector<u64> mat(isz), q(isz), big(isz + 1, 0);
+    const u64 t = h.out_mod.value;
+    size_t len = 1;
+    big[0] = 1;
+    for (size_t i = 0; i < isz; i++) {
+        const u64 qi = c.primes[h.irows[i]];
+        q[i] = qi;
+        u64 hat_q = 1 % qi, hat_t = 1 % t;
+        for (size_t kx = 0; kx < isz; kx++)
+            if (kx != i) {
+                hat_q = (u64)((u128)hat_q * (c.primes[h.irows[kx]] % qi) % qi);
+                hat_t = (u64)((u128)hat_t * (c.primes[h.irows[kx]] % t) % t);
+            }
+        u64 inv = 1, base = hat_q, e = qi - 2;    // q_i is prime
+        while (e) {
+            if (e & 1) inv = (u64)((u128)inv * base % qi);
+            base = (u64)((u128)base * base % qi);
+            e >>= 1;
+        }
+        hat_inv[i] = u64x2{inv, (u64)(((u128)inv << 64) / qi)};
+        mat[i] = hat_t;
+        u64 carry = 0;
+        for (size_t w = 0; w < len; w++) {
+            const u128 x = (u128)big[w] * qi + carry;
+            big[w] = (u64)x;
+            carry = (u64)(x >> 64);
+        }
+        if (carry) big[len++] = carry;
+    }
+    big.resize(isz);
+    h.x_hat_inv.upload(hat_inv);
+    h.x_mat.upload(mat);
+    h.x_big.upload(big);
+    h.x_q.upload(q);
+    h.x_ready = true;
+}
 
 extern "C" {
 
@@ -682,6 +768,33 @@ int pha_base_converter_create(pha_context_t ctx, const uint32_t *ibase, size_t i
     }
     h->inv.upload(inv);
     h->alpha_mod.upload(am);
+    h->irows = ip;
+    if (op.size() == 1) h->out_mod = c.mods[op[0]];
+    *out = h.release();
+    PHA_API_END
+}
+
+int pha_base_converter_create_modulus(pha_context_t ctx, const uint32_t *ibase, size_t ibase_size, uint64_t out_modulus,
+                                      pha_base_converter_t *out) {
+    PHA_CTX_BEGIN(ctx)
+    if (!ctx || !ibase || !out) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (ibase_size == 0 || ibase_size > 64) throw std::invalid_argument("RNSBase is invalid");
+    if (out_modulus < 2 || (out_modulus >> 61)) throw std::invalid_argument("modulus is invalid");   // Modulus: 2 .. 61 bits
+    std::vector<uint32_t> ip(ibase, ibase + ibase_size);
+    for (size_t i = 0; i < ip.size(); i++) {
+        if (ip[i] >= c.rows) throw std::invalid_argument("modulus index out of range");
+        for (size_t k = 0; k < i; k++)
+            if (ip[k] == ip[i]) throw std::invalid_argument("RNSBase is not coprime");
+    }
+    PHA_HIP(hipSetDevice(c.device));
+    auto h = std::make_unique<pha_base_converter>();
+    h->ctx = ctx;
+    h->raw = true;
+    h->irows = ip;
+    h->out_mod = h_modulus(out_modulus);
+    h->conv.isz = (uint32_t)ip.size();
+    h->conv.osz = 1;
     *out = h.release();
     PHA_API_END
 }
@@ -696,6 +809,7 @@ void pha_base_converter_destroy(pha_base_converter_t conv) {
 int pha_bConv_BEHZ(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream) {
     PHA_API_BEGIN
     if (!conv || !dst || !src) throw std::invalid_argument("null pointer");
+    if (conv->raw) throw std::invalid_argument("a converter to a raw modulus supports exact_convert_array only");
     Context &c = conv->ctx->c;
     launch_bconv(c, conv->d_conv.p, 0, 1, conv->conv.isz, conv->conv.osz, conv->conv.split_kind, dst, 0, src, 0, nullptr, true,
                  as_stream(stream));
@@ -705,9 +819,163 @@ int pha_bConv_BEHZ(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src
 int pha_bConv_HPS(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream) {
     PHA_API_BEGIN
     if (!conv || !dst || !src) throw std::invalid_argument("null pointer");
+    if (conv->raw) throw std::invalid_argument("a converter to a raw modulus supports exact_convert_array only");
     Context &c = conv->ctx->c;
     u64 *y = c.scratch(stream, (size_t)conv->conv.isz * c.n);
     bconv_hps(c, conv->conv, conv->d_conv.p, conv->inv.p, conv->alpha_mod.p, dst, src, y, as_stream(stream));
+    PHA_API_END
+}
+
+// DBaseConverter::bConv_BEHZ_var1 (src/rns_bconv.cu:231-246): phase 1 with negPQHatInvModq, phase 2 with QInvModp
+int pha_bConv_BEHZ_var1(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_API_BEGIN
+    if (!conv || !dst || !src) throw std::invalid_argument("null pointer");
+    if (conv->raw) throw std::invalid_argument("a converter to a raw modulus supports exact_convert_array only");
+    Context &c = conv->ctx->c;
+    PHA_HIP(hipSetDevice(c.device));
+    {
+        std::lock_guard<std::mutex> g(conv->var1_lock);
+        if (!conv->var1) {
+            auto v = std::make_unique<BConv>();
+            build_bconv_var1(c, *v, conv->conv.iprime, conv->conv.oprime);
+            describe_conv(*v, conv->d_var1);
+            conv->var1 = std::move(v);
+        }
+    }
+    launch_bconv(c, conv->d_var1.p, 0, 1, conv->var1->isz, conv->var1->osz, conv->var1->split_kind, dst, 0, src, 0, nullptr, true,
+                 as_stream(stream));
+    PHA_API_END
+}
+
+// DBaseConverter::exact_convert_array (src/rns_bconv.cu:416-431): src [ibase][N] -> dst [N], the output base is ONE modulus
+int pha_exact_convert_array(pha_base_converter_t conv, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_API_BEGIN
+    if (!conv || !dst || !src) throw std::invalid_argument("null pointer");
+    if (conv->conv.osz != 1) throw std::invalid_argument("out base in exact_convert_array must be one.");   // :423-425
+    Context &c = conv->ctx->c;
+    PHA_HIP(hipSetDevice(c.device));
+    {
+        std::lock_guard<std::mutex> g(conv->var1_lock);
+        if (!conv->x_ready) build_exact(c, *conv);
+    }
+    ExactArgs k{dst, src, conv->x_hat_inv.p, conv->x_mat.p, conv->x_big.p, conv->x_q.p, conv->out_mod, (uint32_t)conv->irows.size(),
+                (uint32_t)c.n};
+    hipLaunchKernelGGL(exact_convert_kernel, dim3((unsigned)(c.n / 256)), dim3(256), 0, as_stream(stream), k);
+    check_launch();
+    PHA_API_END
+}
+
+// ---- the DRNSTool steps of the BFV multiplies as entry points of their own (include/rns.cuh:167-200), ONE polynomial per call,
+//      so that a caller written like bfv_multiply_behz / bfv_multiply_hps (src/evaluate.cu:447-548, :674-818) links against
+//      this library step by step.  The whole multiplies above run the same kernels on two or three polynomials per launch. ----
+static void need_top(Context &c, size_t size_Ql, const char *what) {
+    if (size_Ql != c.size_q) throw std::invalid_argument(std::string(what) + ": the auxiliary base exists at the top data level only");
+}
+
+int pha_tool_aux_sizes(pha_context_t ctx, size_t size_Ql, uint32_t *size_Bsk, uint32_t *size_R, uint32_t *size_Rl) {
+    PHA_CTX_BEGIN(ctx)
+    Context &c = ctx->c;
+    if (size_Ql < 1 || size_Ql > c.size_q) throw std::invalid_argument("RNSBase is invalid");
+    if (size_Bsk) *size_Bsk = size_Ql == c.size_q ? c.behz().size_bsk : 0;
+    if (size_R) *size_R = size_Ql == c.size_q ? c.hps().size_r : 0;
+    if (size_Rl) *size_Rl = c.hps_overq((uint32_t)size_Ql).size_r;
+    PHA_API_END
+}
+
+// DRNSTool::fastbconv_m_tilde src/rns.cu:1249-1278: src [Q][N] -> dst [Bsk + 1][N] (last limb modulo m_tilde)
+int pha_fastbconv_m_tilde(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    if (!dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    need_top(c, size_Ql, "fastbconv_m_tilde");
+    Behz &b = c.behz();
+    launch_bconv(c, b.d_q_to_bskmt.p, 0, 1, b.size_q, b.size_bsk + 1, b.q_to_bskmt.split_kind, dst, 0, src, 0, nullptr, true,
+                 as_stream(stream));
+    PHA_API_END
+}
+
+// DRNSTool::sm_mrq src/rns.cu:1326-1338 (kernel :1290-1320): src [Bsk + 1][N] -> dst [Bsk][N]
+int pha_sm_mrq(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    if (!dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    need_top(c, size_Ql, "sm_mrq");
+    Behz &b = c.behz();
+    MrqArgs ma{dst, src, c.d_mod.p, b.prod_q_mod_bsk.p, b.inv_mt_mod_bsk.p, b.neg_inv_prod_q_mod_mt, b.aux0, b.size_bsk, (uint32_t)c.n};
+    hipLaunchKernelGGL(sm_mrq_kernel, dim3((unsigned)(c.n / 256), b.size_bsk, 1), dim3(256), 0, as_stream(stream), ma);
+    check_launch();
+    PHA_API_END
+}
+
+// DRNSTool::fast_floor src/rns.cu:1394-1419: input_base_q [Q][N], input_base_Bsk [Bsk][N] -> out_base_Bsk [Bsk][N]
+int pha_fast_floor(pha_context_t ctx, size_t size_Ql, const uint64_t *input_base_q, const uint64_t *input_base_Bsk,
+                   uint64_t *out_base_Bsk, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    if (!input_base_q || !input_base_Bsk || !out_base_Bsk) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    need_top(c, size_Ql, "fast_floor");
+    Behz &b = c.behz();
+    hipStream_t s = as_stream(stream);
+    const uint32_t n = (uint32_t)c.n;
+    u64 *conv = c.scratch(stream, (size_t)b.size_bsk * n);
+    launch_bconv(c, b.d_q_to_bsk.p, 0, 1, b.size_q, b.size_bsk, b.q_to_bsk.split_kind, conv, 0, input_base_q, 0, nullptr, true, s);
+    FloorArgs fa{out_base_Bsk, input_base_Bsk, conv, c.d_mod.p, b.inv_prod_q_mod_bsk.p, b.aux0, n, 0, 0, 0};
+    hipLaunchKernelGGL(fast_floor_kernel, dim3(n / 256, b.size_bsk, 1), dim3(256), 0, s, fa);
+    check_launch();
+    PHA_API_END
+}
+
+// DRNSTool::fastbconv_sk src/rns.cu:1470-1510: input_base_Bsk [Bsk][N] (B limbs, then the m_sk limb) -> out_base_q [Q][N]
+int pha_fastbconv_sk(pha_context_t ctx, size_t size_Ql, const uint64_t *input_base_Bsk, uint64_t *out_base_q, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    if (!input_base_Bsk || !out_base_q) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    need_top(c, size_Ql, "fastbconv_sk");
+    Behz &b = c.behz();
+    hipStream_t s = as_stream(stream);
+    const uint32_t n = (uint32_t)c.n;
+    u64 *msk = c.scratch(stream, n);
+    launch_bconv(c, b.d_b_to_msk.p, 0, 1, b.size_b, 1, b.b_to_msk.split_kind, msk, 0, input_base_Bsk, 0, nullptr, true, s);
+    launch_bconv(c, b.d_b_to_q.p, 0, 1, b.size_b, b.size_q, b.b_to_q.split_kind, out_base_q, 0, input_base_Bsk, 0, nullptr, true, s);
+    SkArgs ka{out_base_q, msk, input_base_Bsk + (size_t)b.size_b * n, c.d_mod.p, b.prod_b_mod_q.p, b.inv_prod_b_mod_msk, b.m_sk, n, 0, 0, 0};
+    hipLaunchKernelGGL(sk_fix_kernel, dim3(n / 256, b.size_q, 1), dim3(256), 0, s, ka);
+    check_launch();
+    PHA_API_END
+}
+
+// DRNSTool::scaleAndRound_HPS_QR_R src/rns.cu:1739-1746 (kernel :1700-1737): src [Q + R][N] -> dst [R][N]
+int pha_scaleAndRound_HPS_QR_R(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    if (!dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    need_top(c, size_Ql, "scaleAndRound_HPS_QR_R");
+    Hps &h = c.hps();
+    ScaleRoundArgs ka{dst, src, h.frac.p, h.div_mod_r.p, c.d_mod.p, h.size_q, h.size_r, h.aux0, (uint32_t)c.n, 0, 0};
+    launch_scale_round(c, ka, as_stream(stream), 1);
+    PHA_API_END
+}
+
+// DRNSTool::scaleAndRound_HPS_QlRl_Ql src/rns.cu:1789-1796 (kernel :1749-1787): src [Ql + Rl][N] -> dst [Ql][N]
+int pha_scaleAndRound_HPS_QlRl_Ql(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    if (!dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (size_Ql < 1 || size_Ql > c.size_q) throw std::invalid_argument("RNSBase is invalid");
+    HpsQ &h = c.hps_overq((uint32_t)size_Ql);
+    launch_scale_round_q(c, dst, src, h.frac.p, h.div_mod_q.p, h.size_q, h.size_r, as_stream(stream));
+    PHA_API_END
+}
+
+// DRNSTool::ExpandCRTBasis_Ql_Q_add_to_ct src/rns.cu:1850-1858 (kernel :1838-1848): dst [Ql limbs] += src [Ql][N] * prod(dropped)
+int pha_ExpandCRTBasis_Ql_Q_add_to_ct(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *src, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    if (!dst || !src) throw std::invalid_argument("null pointer");
+    Context &c = ctx->c;
+    if (size_Ql < 1 || size_Ql >= c.size_q) throw std::invalid_argument("at least one level has to be dropped");
+    HpsQ &h = c.hps_overq((uint32_t)size_Ql);
+    ExpandArgs ka{dst, src, h.drop_mod_q.p, h.drop_mod_q_shoup.p, c.d_mod.p, h.size_q, (uint32_t)c.n};
+    hipLaunchKernelGGL(hps_expand_add_kernel, dim3((unsigned)(c.n / 256), h.size_q), dim3(256), 0, as_stream(stream), ka);
+    check_launch();
     PHA_API_END
 }
 

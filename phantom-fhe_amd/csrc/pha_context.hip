@@ -1129,7 +1129,8 @@ int pha_context_prime_info(pha_context_t ctx, uint32_t i, uint64_t *value, uint6
                            uint64_t *n_inv) {
     PHA_CTX_BEGIN(ctx)
     Context &c = ctx->c;
-    if (i >= c.size_qp) throw std::invalid_argument("prime index out of range");
+    std::lock_guard<std::mutex> lk(c.mu);   // the auxiliary rows (BFV bases) are appended on first use
+    if (i >= c.rows) throw std::invalid_argument("prime index out of range");
     if (value) *value = c.primes[i];
     if (ratio) { ratio[0] = c.mods[i].ratio0; ratio[1] = c.mods[i].ratio1; }
     if (root) *root = c.roots[i];

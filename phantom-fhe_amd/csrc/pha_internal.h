@@ -318,6 +318,22 @@ inline LimbSel special_sel(size_t start, size_t count, size_t size_QP, size_t si
     return s;
 }
 
+// pha_check.hip: the canonical-operand precondition, countable; strict_* are no-ops unless strict mode is on (PHA_STRICT=1 / pha_set_strict)
+struct Context;
+struct RowMap {          // limb y of a buffer (relative to the pointer handed over) -> row of the prime table
+    uint32_t row0, count, tail_from, tail_row0;   // y < tail_from: row0 + y; else tail_row0 + (y - tail_from)
+};
+inline RowMap rows_plain(size_t row0, size_t count) { return RowMap{(uint32_t)row0, (uint32_t)count, 0xffffffffu, 0}; }
+// a [Q_l || P] buffer: size_ql data rows, then the special rows [size_q, size_q + size_p)
+inline RowMap rows_qlp(size_t size_ql, size_t size_q, size_t size_p) {
+    return RowMap{0, (uint32_t)(size_ql + size_p), (uint32_t)size_ql, (uint32_t)size_q};
+}
+bool strict_mode();
+u64 count_noncanonical(Context &c, const u64 *data, const RowMap &rows, uint32_t polys, size_t poly_stride, hipStream_t s);
+u64 count_noncanonical_keys(Context &c, const u64 *const *keys, uint32_t n_keys, uint32_t size_Ql, hipStream_t s);
+void strict_operand(Context &c, const char *what, const u64 *data, const RowMap &rows, uint32_t polys, size_t poly_stride, hipStream_t s);
+void strict_keys(Context &c, const char *what, const u64 *const *keys, uint32_t n_keys, uint32_t size_Ql, hipStream_t s);
+
 // NTT drivers (pha_ntt.hip): pass 1 reads `in` and writes `mid`, pass 2 reads `mid` and writes `out`
 struct NttExtra {
     const u64 *scale = nullptr, *scale_shoup = nullptr;  // indexed by absolute limb

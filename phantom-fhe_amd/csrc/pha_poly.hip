@@ -120,7 +120,9 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
 template <int OP>
 static void launch_ew(Context &c, EwArgs k, size_t limbs, size_t mod_start, hipStream_t s, size_t batch = 1) {
     if (limbs == 0 || batch == 0) return;
-    if (mod_start + limbs > c.size_qp) throw std::invalid_argument("modulus index out of range");
+    // rows past size_qp are the auxiliary BFV bases (the reference's callers hand these kernels base_Bsk / base_Rl moduli,
+    // src/evaluate.cu:489-497); they exist once a BFV multiply entry or pha_tool_aux_sizes has built them
+    if (mod_start + limbs > c.rows) throw std::invalid_argument("modulus index out of range");
     k.mod = c.d_mod.p;
     k.fpinfo = c.d_fpinfo.p;
     k.n = (uint32_t)c.n;
@@ -170,6 +172,8 @@ int pha_add_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, ui
                      size_t mod_start, void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
+    strict_operand(ctx->c, "operand a", a, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
+    strict_operand(ctx->c, "operand b", b, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
     launch_add(ctx->c, a, b, r, cms, mod_start, as_stream(stream));
     PHA_API_END
 }
@@ -177,6 +181,8 @@ int pha_sub_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *b, ui
                      size_t mod_start, void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
+    strict_operand(ctx->c, "operand a", a, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
+    strict_operand(ctx->c, "operand b", b, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
     EwArgs k{};
     k.a = a; k.b = b; k.r = r;
     launch_ew<EW_SUB>(ctx->c, k, cms, mod_start, as_stream(stream));
@@ -186,6 +192,7 @@ int pha_negate_rns_poly(pha_context_t ctx, const uint64_t *a, uint64_t *r, size_
                         void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(a); need(r);
+    strict_operand(ctx->c, "operand a", a, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
     EwArgs k{};
     k.a = a; k.r = r;
     launch_ew<EW_NEG>(ctx->c, k, cms, mod_start, as_stream(stream));
@@ -195,6 +202,8 @@ int pha_multiply_rns_poly(pha_context_t ctx, const uint64_t *a, const uint64_t *
                           size_t mod_start, void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(r);
+    strict_operand(ctx->c, "operand a", a, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
+    strict_operand(ctx->c, "operand b", b, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
     EwArgs k{};
     k.a = a; k.b = b; k.r = r;
     launch_ew<EW_MUL>(ctx->c, k, cms, mod_start, as_stream(stream));
@@ -204,6 +213,9 @@ int pha_multiply_and_add_rns_poly(pha_context_t ctx, const uint64_t *a, const ui
                                   uint64_t *r, size_t cms, size_t mod_start, void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(a); need(b); need(d); need(r);
+    strict_operand(ctx->c, "operand a", a, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
+    strict_operand(ctx->c, "operand b", b, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
+    strict_operand(ctx->c, "operand d", d, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
     EwArgs k{};
     k.a = a; k.b = b; k.d = d; k.r = r;
     launch_ew<EW_MULADD>(ctx->c, k, cms, mod_start, as_stream(stream));
@@ -214,6 +226,7 @@ int pha_multiply_scalar_rns_poly(pha_context_t ctx, const uint64_t *a, const uin
                                  void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(a); need(scalar); need(scalar_shoup); need(r);
+    strict_operand(ctx->c, "operand a", a, rows_plain(mod_start, cms), 1, 0, as_stream(stream));
     EwArgs k{};
     k.a = a; k.s0 = scalar; k.s1 = scalar_shoup; k.r = r;
     launch_ew<EW_MULSCALAR>(ctx->c, k, cms, mod_start, as_stream(stream));
@@ -223,6 +236,8 @@ int pha_tensor_prod_2x2_rns_poly(pha_context_t ctx, const uint64_t *op1, const u
                                  size_t cms, void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(op1); need(op2); need(res);
+    strict_operand(ctx->c, "tensor_prod_2x2 operand1", op1, rows_plain(0, cms), 2, cms * ctx->c.n, as_stream(stream));
+    strict_operand(ctx->c, "tensor_prod_2x2 operand2", op2, rows_plain(0, cms), 2, cms * ctx->c.n, as_stream(stream));
     EwArgs k{};
     k.a = op1; k.b = op2; k.r = res;
     launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream));
@@ -234,6 +249,10 @@ int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *op1, const ui
     need(op1); need(op2); need(res01); need(res2);
     const size_t ln = cms * ctx->c.n;
     if (batch > 65535) throw std::invalid_argument("batch out of range");
+    if (2 * batch <= 65535) {
+        strict_operand(ctx->c, "tensor_prod_2x2 operand1", op1, rows_plain(0, cms), (uint32_t)(2 * batch), ln, as_stream(stream));
+        strict_operand(ctx->c, "tensor_prod_2x2 operand2", op2, rows_plain(0, cms), (uint32_t)(2 * batch), ln, as_stream(stream));
+    }
     // one launch over the batch (blockIdx.z): r04 trace of 8 ciphertexts -- 8 launches of 35.7 us each against 30.7 us for a lone one
     EwArgs k{};
     k.a = op1; k.b = op2; k.r = res01; k.r2 = res2;
@@ -246,14 +265,36 @@ int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *op, uint64
                                    void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(op); need(res);
+    strict_operand(ctx->c, "tensor_square_2x2 operand", op, rows_plain(0, cms), 2, cms * ctx->c.n, as_stream(stream));
     EwArgs k{};
     k.a = op; k.r = res;
     launch_ew<EW_SQUARE>(ctx->c, k, cms, 0, as_stream(stream));
     PHA_API_END
 }
+// tensor_prod_2x2_rns_poly / tensor_square_2x2_rns_poly with the reference's `modulus` pointer argument (polymath.cu:463-529) as a
+// first table row: the BEHZ / HPS callers run them over base Bsk and base R (src/evaluate.cu:489-497, :763-777)
+int pha_tensor_prod_2x2_rns_poly_at(pha_context_t ctx, const uint64_t *op1, const uint64_t *op2, uint64_t *res, size_t cms,
+                                    size_t mod_start, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(op1); need(op2); need(res);
+    strict_operand(ctx->c, "tensor_prod_2x2 operand1", op1, rows_plain(mod_start, cms), 2, cms * ctx->c.n, as_stream(stream));
+    strict_operand(ctx->c, "tensor_prod_2x2 operand2", op2, rows_plain(mod_start, cms), 2, cms * ctx->c.n, as_stream(stream));
+    launch_tensor(ctx->c, op1, op2, res, cms, mod_start, false, as_stream(stream), cms);
+    PHA_API_END
+}
+int pha_tensor_square_2x2_rns_poly_at(pha_context_t ctx, const uint64_t *op, uint64_t *res, size_t cms, size_t mod_start,
+                                      void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(op); need(res);
+    strict_operand(ctx->c, "tensor_square_2x2 operand", op, rows_plain(mod_start, cms), 2, cms * ctx->c.n, as_stream(stream));
+    launch_tensor(ctx->c, op, op, res, cms, mod_start, true, as_stream(stream), cms);
+    PHA_API_END
+}
 int pha_add_to_ct(pha_context_t ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, void *stream) {
     PHA_CTX_BEGIN(ctx)
     need(ct); need(cx);
+    strict_operand(ctx->c, "ct", ct, rows_plain(0, size_Ql), 1, 0, as_stream(stream));
+    strict_operand(ctx->c, "cx", cx, rows_plain(0, size_Ql), 1, 0, as_stream(stream));
     launch_add(ctx->c, ct, cx, ct, size_Ql, 0, as_stream(stream));  // add_to_ct_kernel rns_bconv.cu:763-769
     PHA_API_END
 }

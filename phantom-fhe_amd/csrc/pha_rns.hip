@@ -1381,8 +1381,10 @@ static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const 
 // accumulate = false: ct_z = result (the reference call).  accumulate = true: ct_z += result, i.e. the
 // add_to_ct_kernel of keyswitch_inplace (rns_bconv.cu:763-769) fused into the NTT epilogue.
 // folded (ckks): the special limbs of cx already went through the inverse transform's contiguous pass (modup_inner_prod).
+// coeff_input (bfv only): DRNSTool::moddown rns_bconv.cu:712-761 -- cx is already in coefficient form, no inverse transform.
 static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64 *cx, size_t cx_stride,
-                             uint32_t polys, int scheme, bool accumulate, u64 *delta, hipStream_t s, bool folded = false) {
+                             uint32_t polys, int scheme, bool accumulate, u64 *delta, hipStream_t s, bool folded = false,
+                             bool coeff_input = false) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp;
     NttExtra xb;
@@ -1399,10 +1401,13 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         ntt_inverse(c, cx, cx, cx, special_sel(ql, c.size_p, c.size_qp, c.size_p), EPI_INV_SCALE, xb, s);
     } else if (scheme == PHA_SCHEME_CKKS)
         ntt_inverse(c, cx, cx, cx, special_sel(ql, c.size_p, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
+    else if (scheme == PHA_SCHEME_BFV && coeff_input)
+        ;   // (rns_bconv.cu:722-730 transforms ckks and bgv only)
     else if (scheme == PHA_SCHEME_BFV || scheme == PHA_SCHEME_BGV)
         ntt_inverse(c, cx, cx, cx, special_sel(0, qlp, c.size_qp, c.size_p), EPI_INV_CANON, xb, s);
     else
         throw std::invalid_argument("unsupported scheme");
+    if (coeff_input && scheme != PHA_SCHEME_BFV) throw std::logic_error("coefficient-form mod-down input outside bfv");
     if (scheme == PHA_SCHEME_BGV && !t.bgv_ready)
         throw std::invalid_argument("bgv needs a plain modulus (pha_context_set_plain_modulus)");
     const size_t d_stride = (size_t)ql * n;
@@ -1584,6 +1589,7 @@ int pha_modup(pha_context_t ctx, size_t size_Ql, uint64_t *dst, const uint64_t *
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
+    strict_operand(c, "modup input", cks, rows_plain(0, size_Ql), 1, 0, as_stream(stream));
     u64 *t_cks = c.scratch(stream, size_Ql * c.n);
     modup(c, t, dst, cks, scheme, t_cks, as_stream(stream));
     PHA_API_END
@@ -1595,6 +1601,12 @@ int pha_key_switch_inner_prod(pha_context_t ctx, size_t size_Ql, uint64_t *p_cx,
     need(p_cx); need(p_t_mod_up); need(rlk);
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
+    {
+        Tool &ts = c.tool((uint32_t)size_Ql);
+        strict_operand(c, "key_switch_inner_prod t_mod_up", p_t_mod_up, rows_qlp(ts.size_ql, c.size_q, c.size_p), ts.beta,
+                       (size_t)ts.size_qlp * c.n, as_stream(stream));
+        strict_keys(c, "key_switch_inner_prod key", rlk, ts.beta, (uint32_t)size_Ql, as_stream(stream));
+    }
     inner_prod(c, c.tool((uint32_t)size_Ql), p_cx, p_t_mod_up, rlk, as_stream(stream));
     PHA_API_END
 }
@@ -1606,8 +1618,25 @@ int pha_moddown_from_NTT(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint
     Context &c = ctx->c;
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
+    strict_operand(c, "mod-down input", cx_i, rows_qlp(t.size_ql, c.size_q, c.size_p), 1, 0, as_stream(stream));
     u64 *delta = c.scratch(stream, size_Ql * c.n);
     moddown_from_ntt(c, t, ct_i, 0, cx_i, 0, 1, scheme, false, delta, as_stream(stream));
+    PHA_API_END
+}
+
+// DRNSTool::moddown rns_bconv.cu:712-761.  Against moddown_from_NTT (:776-828): bfv input is in coefficient form already; ckks
+// and bgv take the same steps (the reference's separate forward transform of delta + moddown_kernel :748-757 stores the same
+// canonical words as the fused epilogue; its alpha = 1 route through bConv_BEHZ :733 / :746 stores what the single-prime kernel
+// does: y = x for a one-prime base, then x mod q_j).
+int pha_moddown(pha_context_t ctx, size_t size_Ql, uint64_t *ct_i, uint64_t *cx_i, int scheme, void *stream) {
+    PHA_CTX_BEGIN(ctx)
+    need(ct_i); need(cx_i);
+    Context &c = ctx->c;
+    check_level(c, size_Ql, true);
+    Tool &t = c.tool((uint32_t)size_Ql);
+    strict_operand(c, "mod-down input", cx_i, rows_qlp(t.size_ql, c.size_q, c.size_p), 1, 0, as_stream(stream));
+    u64 *delta = c.scratch(stream, size_Ql * c.n);
+    moddown_from_ntt(c, t, ct_i, 0, cx_i, 0, 1, scheme, false, delta, as_stream(stream), false, scheme == PHA_SCHEME_BFV);
     PHA_API_END
 }
 
@@ -1619,6 +1648,9 @@ int pha_keyswitch_inplace(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
     hipStream_t s = as_stream(stream);
+    strict_operand(c, "keyswitch ct", ct, rows_plain(0, size_Ql), 2, size_Ql * c.n, s);
+    strict_operand(c, "keyswitch c2", c2, rows_plain(0, size_Ql), 1, 0, s);
+    strict_keys(c, "keyswitch key", rlk, t.beta, (uint32_t)size_Ql, s);
     const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
     // scratch: t_cks / delta [2][Ql][N] | t_mod_up [beta][QlP][N] | cx [2][QlP][N]  (eval_key_switch.cu:151,155)
     u64 *base = c.scratch(stream, 2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n);
@@ -1641,6 +1673,9 @@ int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *c
     if ((size_t)t.beta * batch > 65535 || 2 * batch > 65535) throw std::invalid_argument("batch out of range");
     hipStream_t s = as_stream(stream);
     const uint32_t B = (uint32_t)batch;
+    strict_operand(c, "keyswitch ct", ct, rows_plain(0, size_Ql), 2 * B, size_Ql * c.n, s);
+    strict_operand(c, "keyswitch c2", c2, rows_plain(0, size_Ql), B, size_Ql * c.n, s);
+    strict_keys(c, "keyswitch key", rlk, t.beta, (uint32_t)size_Ql, s);
     const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
     // scratch: t_cks / delta [B][2][Ql][N] | t_mod_up [B][beta][QlP][N] | cx [B][2][QlP][N]
     u64 *base = c.scratch(stream, B * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n));
@@ -1667,6 +1702,9 @@ int pha_keyswitch_rescale_batched(pha_context_t ctx, size_t size_Ql, const uint6
     if ((size_t)t.beta * batch > 65535 || 2 * batch > 65535) throw std::invalid_argument("batch out of range");
     hipStream_t s = as_stream(stream);
     const uint32_t B = (uint32_t)batch;
+    strict_operand(c, "keyswitch ct", ct, rows_plain(0, size_Ql), 2 * B, size_Ql * c.n, s);
+    strict_operand(c, "keyswitch c2", c2, rows_plain(0, size_Ql), B, size_Ql * c.n, s);
+    strict_keys(c, "keyswitch key", rlk, t.beta, (uint32_t)size_Ql, s);
     const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
     if (overlaps(dst, B * 2 * (size_Ql - 1) * n, ct, B * 2 * ql_n) || overlaps(dst, B * 2 * (size_Ql - 1) * n, c2, B * ql_n))
         throw std::invalid_argument("dst must not overlap ct or c2");
@@ -1782,6 +1820,11 @@ int pha_hoisting(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const uint32_t
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
     hipStream_t s = as_stream(stream);
+    if (strict_mode()) {
+        strict_operand(c, "hoisting ct", ct, rows_plain(0, size_Ql), 2, size_Ql * c.n, s);
+        for (size_t e = 0; e < n_elts; e++)
+            if (glk[e]) strict_keys(c, "hoisting Galois key", glk[e], t.beta, (uint32_t)size_Ql, s);
+    }
     const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
     const bool ntt_dom = ntt_domain_scheme(scheme);
     // per-element device tables: permutation tables and key pointer tables
@@ -1856,6 +1899,13 @@ int pha_hoisting_weighted(pha_context_t ctx, size_t size_Ql, uint64_t *ct, const
     check_level(c, size_Ql, true);
     Tool &t = c.tool((uint32_t)size_Ql);
     hipStream_t s = as_stream(stream);
+    if (strict_mode()) {
+        strict_operand(c, "hoisting ct", ct, rows_plain(0, size_Ql), 2, size_Ql * c.n, s);
+        for (size_t e = 0; e < n_elts; e++) {
+            if (glk[e]) strict_keys(c, "hoisting Galois key", glk[e], t.beta, (uint32_t)size_Ql, s);
+            if (weights[e]) strict_operand(c, "hoisting weight", weights[e], rows_qlp(t.size_ql, c.size_q, c.size_p), 1, 0, s);
+        }
+    }
     const size_t n = c.n, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n;
     // order the elements: key-switched ones first, main-diagonal ones (element 1, no key) last
     std::vector<const void *> tabs, keys, w_ks, w_all;
@@ -1927,6 +1977,15 @@ static void bsgs_core(Context &c, Tool &t, const u64 *ct_in, size_t blocks, cons
                       const uint64_t *const *const *giant_glk, const uint64_t *const *weights, u64 *out, int scheme, void *stream) {
     hipStream_t s = as_stream(stream);
     const size_t n = c.n, size_Ql = t.size_ql, ql_n = size_Ql * n, qlp_n = (size_t)t.size_qlp * n, G = blocks * ng;
+    if (strict_mode()) {
+        strict_operand(c, "hoisting ct", ct_in, rows_plain(0, size_Ql), 2, ql_n, s);
+        for (size_t j = 0; j < nb; j++)
+            if (baby_glk[j]) strict_keys(c, "baby-step Galois key", baby_glk[j], t.beta, (uint32_t)size_Ql, s);
+        for (size_t i = 0; i < ng; i++)
+            if (giant_glk[i]) strict_keys(c, "giant-step Galois key", giant_glk[i], t.beta, (uint32_t)size_Ql, s);
+        for (size_t i = 0; i < G * nb; i++)
+            if (weights[i]) strict_operand(c, "BSGS weight", weights[i], rows_qlp(t.size_ql, c.size_q, c.size_p), 1, 0, s);
+    }
     // 128-bit accumulators: every weighted term is below 2^122 (61-bit primes), 63 of them fit; the giant inner products are
     // plain products (2^120 each for 60-bit primes)
     size_t nbk = 0, nk = 0;

@@ -306,6 +306,11 @@ public:
     DBaseConverter(pha_context_t ctx, const std::vector<uint32_t> &ibase, const std::vector<uint32_t> &obase) {
         phantom::util::check_pha(pha_base_converter_create(ctx, ibase.data(), ibase.size(), obase.data(), obase.size(), &conv_));
     }
+    // a converter to ONE raw output modulus (base_q_to_t_conv_ of src/rns.cu:283-284: the plain modulus is no row of the table);
+    // it serves exact_convert_array only
+    DBaseConverter(pha_context_t ctx, const std::vector<uint32_t> &ibase, uint64_t out_modulus) {
+        phantom::util::check_pha(pha_base_converter_create_modulus(ctx, ibase.data(), ibase.size(), out_modulus, &conv_));
+    }
     DBaseConverter(const DBaseConverter &) = delete;
     DBaseConverter &operator=(const DBaseConverter &) = delete;
     DBaseConverter(DBaseConverter &&o) noexcept : conv_(o.conv_) { o.conv_ = nullptr; }
@@ -320,6 +325,12 @@ public:
     }
     void bConv_HPS(uint64_t *dst, const uint64_t *src, size_t /*n*/, const cudaStream_t &stream) const {
         phantom::util::check_pha(pha_bConv_HPS(conv_, dst, src, stream));
+    }
+    void bConv_BEHZ_var1(uint64_t *dst, const uint64_t *src, size_t /*n*/, const cudaStream_t &stream) const {   // rns_bconv.cuh:64
+        phantom::util::check_pha(pha_bConv_BEHZ_var1(conv_, dst, src, stream));
+    }
+    void exact_convert_array(uint64_t *dst, const uint64_t *src, uint64_t /*poly_degree*/, const cudaStream_t &stream) const {   // :68
+        phantom::util::check_pha(pha_exact_convert_array(conv_, dst, src, stream));
     }
 };
 
@@ -344,9 +355,38 @@ public:
     void modup(uint64_t *dst, const uint64_t *cks, const DNTTTable &, const scheme_type &scheme, const cudaStream_t &stream) const {
         util::check_pha(pha_modup(ctx_, size_Ql_, dst, cks, static_cast<int>(scheme), stream));
     }
+    void moddown(uint64_t *ct_i, uint64_t *cx_i, const DNTTTable &, const scheme_type &scheme, const cudaStream_t &stream) const {   // rns.cuh:159-160
+        util::check_pha(pha_moddown(ctx_, size_Ql_, ct_i, cx_i, static_cast<int>(scheme), stream));
+    }
     void moddown_from_NTT(uint64_t *ct_i, uint64_t *cx_i, const DNTTTable &, const scheme_type &scheme, const cudaStream_t &stream) const {
         util::check_pha(pha_moddown_from_NTT(ctx_, size_Ql_, ct_i, cx_i, static_cast<int>(scheme), stream));
     }
+    // the BFV multiply steps (include/rns.cuh:167-200; callers src/evaluate.cu:404-548, :674-818, :1014-1016)
+    void scaleAndRound_HPS_QR_R(uint64_t *dst, const uint64_t *src, const cudaStream_t &stream) const {
+        util::check_pha(pha_scaleAndRound_HPS_QR_R(ctx_, size_Ql_, dst, src, stream));
+    }
+    void scaleAndRound_HPS_QlRl_Ql(uint64_t *dst, const uint64_t *src, const cudaStream_t &stream) const {
+        util::check_pha(pha_scaleAndRound_HPS_QlRl_Ql(ctx_, size_Ql_, dst, src, stream));
+    }
+    void ExpandCRTBasis_Ql_Q_add_to_ct(uint64_t *dst, const uint64_t *src, const cudaStream_t &stream) const {
+        util::check_pha(pha_ExpandCRTBasis_Ql_Q_add_to_ct(ctx_, size_Ql_, dst, src, stream));
+    }
+    void fastbconv_m_tilde(uint64_t *dst, uint64_t *src, const cudaStream_t &stream) const {
+        util::check_pha(pha_fastbconv_m_tilde(ctx_, size_Ql_, dst, src, stream));
+    }
+    void sm_mrq(uint64_t *dst, const uint64_t *src, const cudaStream_t &stream) const {
+        util::check_pha(pha_sm_mrq(ctx_, size_Ql_, dst, src, stream));
+    }
+    void fast_floor(uint64_t *input_base_q, uint64_t *input_base_Bsk, uint64_t *out_base_Bsk, const cudaStream_t &stream) const {
+        util::check_pha(pha_fast_floor(ctx_, size_Ql_, input_base_q, input_base_Bsk, out_base_Bsk, stream));
+    }
+    void fastbconv_sk(uint64_t *input_base_Bsk, uint64_t *out_base_q, const cudaStream_t &stream) const {
+        util::check_pha(pha_fastbconv_sk(ctx_, size_Ql_, input_base_Bsk, out_base_q, stream));
+    }
+    // sizes of the auxiliary bases of this level's tool (base_Bsk().size(), base_Rl().size() of include/rns.cuh)
+    [[nodiscard]] size_t base_Bsk_size() const { uint32_t v = 0; util::check_pha(pha_tool_aux_sizes(ctx_, size_Ql_, &v, nullptr, nullptr)); return v; }
+    [[nodiscard]] size_t base_R_size() const { uint32_t v = 0; util::check_pha(pha_tool_aux_sizes(ctx_, size_Ql_, nullptr, &v, nullptr)); return v; }
+    [[nodiscard]] size_t base_Rl_size() const { uint32_t v = 0; util::check_pha(pha_tool_aux_sizes(ctx_, size_Ql_, nullptr, nullptr, &v)); return v; }
     void divide_and_round_q_last(const uint64_t *src, size_t cipher_size, uint64_t *dst, const cudaStream_t &stream) const {
         util::check_pha(pha_divide_and_round_q_last(ctx_, size_Ql_, src, cipher_size, dst, stream));
     }

@@ -78,6 +78,12 @@ def set_tuning(key, value):
     _lib.check(_lib.load().pha_set_tuning(int(key), int(value)))
 
 
+def set_strict(on):
+    """Strict mode of the library (pha_set_strict): entry points check caller-supplied operands for words >= their modulus and
+    raise ValueError instead of computing.  Returns the previous state.  Process-wide; default from PHA_STRICT=1."""
+    return bool(_lib.load().pha_set_strict(1 if on else 0))
+
+
 def coeff_modulus_create(poly_modulus_degree, bit_sizes):
     """CoeffModulus::Create (src/host/modulus.cu:82-111)."""
     L = _lib.load()
@@ -121,6 +127,19 @@ class PhantomContext:
         if h:
             self._L.pha_context_destroy(h)
             self._h = None
+
+    # -- the canonical-operand precondition, checkable (include/phantom_amd.h; csrc/pha_check.hip) --------------------
+    def check_canonical(self, data, cms, start=0, size_P_tail=0, polys=1, poly_stride=0):
+        """Number of words of data [polys][cms][N] that are >= their limb's modulus (synchronises the stream)."""
+        bad = C.c_uint64()
+        _lib.check(self._L.pha_check_canonical(self._h, _ptr(data), cms, start, size_P_tail, polys, poly_stride, C.byref(bad), _stream()))
+        return bad.value
+
+    def check_canonical_keys(self, size_Ql, keys_ptr, n_keys):
+        """The same for the limbs a key switch at level size_Ql reads of n_keys keys (keys_ptr: PhantomRelinKey.public_keys_ptr)."""
+        bad = C.c_uint64()
+        _lib.check(self._L.pha_check_canonical_keys(self._h, size_Ql, _ptr(keys_ptr), n_keys, C.byref(bad), _stream()))
+        return bad.value
 
     # -- table queries ------------------------------------------------------------------------
     def prime_info(self, idx):
@@ -267,6 +286,13 @@ class PhantomContext:
         """NTT of a plaintext modulo every q_i (the modup_fuse loop of src/evaluate.cu:1150-1154)."""
         _lib.check(self._L.pha_bgv_lift_plain(self._h, size_Ql, _ptr(plain), _ptr(out), _stream()))
 
+    def tensor_prod_2x2_rns_poly_at(self, op1, op2, result, cms, mod_start):
+        """tensor_prod_2x2_rns_poly over table rows mod_start .. (the reference's `modulus` pointer: base Bsk / base R callers)."""
+        _lib.check(self._L.pha_tensor_prod_2x2_rns_poly_at(self._h, _ptr(op1), _ptr(op2), _ptr(result), cms, mod_start, _stream()))
+
+    def tensor_square_2x2_rns_poly_at(self, op, result, cms, mod_start):
+        _lib.check(self._L.pha_tensor_square_2x2_rns_poly_at(self._h, _ptr(op), _ptr(result), cms, mod_start, _stream()))
+
     def tensor_prod_2x2_rns_poly(self, op1, op2, result, cms):
         _lib.check(self._L.pha_tensor_prod_2x2_rns_poly(self._h, _ptr(op1), _ptr(op2), _ptr(result), cms, _stream()))
 
@@ -333,6 +359,38 @@ class PhantomContext:
     def bfv_mul_relin_hps_overq_leveled(self, size_Ql, ct1, ct2, rlk_ptrs, dst):
         """bfv_mul_relin_hps with levels dropped (src/evaluate.cu:822-1027); dst [2][Q][N]."""
         _lib.check(self._L.pha_bfv_mul_relin_hps_overq_leveled(self._h, size_Ql, _ptr(ct1), _ptr(ct2), _ptr(rlk_ptrs), _ptr(dst), _stream()))
+
+    # ---- the DRNSTool steps of the BFV multiplies, one polynomial per call (include/rns.cuh:159-200) ----
+    def moddown(self, size_Ql, ct_i, cx_i, scheme):
+        """DRNSTool::moddown (src/rns_bconv.cu:712-761): BFV input in coefficient form."""
+        _lib.check(self._L.pha_moddown(self._h, size_Ql, _ptr(ct_i), _ptr(cx_i), int(scheme), _stream()))
+
+    def tool_aux_sizes(self, size_Ql):
+        """(|Bsk|, |R|, |Rl|) of the level's tool; 0 where the base does not exist at that level."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.pha_tool_aux_sizes(self._h, size_Ql, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def fastbconv_m_tilde(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_fastbconv_m_tilde(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
+
+    def sm_mrq(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_sm_mrq(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
+
+    def fast_floor(self, size_Ql, input_base_q, input_base_Bsk, out_base_Bsk):
+        _lib.check(self._L.pha_fast_floor(self._h, size_Ql, _ptr(input_base_q), _ptr(input_base_Bsk), _ptr(out_base_Bsk), _stream()))
+
+    def fastbconv_sk(self, size_Ql, input_base_Bsk, out_base_q):
+        _lib.check(self._L.pha_fastbconv_sk(self._h, size_Ql, _ptr(input_base_Bsk), _ptr(out_base_q), _stream()))
+
+    def scaleAndRound_HPS_QR_R(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_scaleAndRound_HPS_QR_R(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
+
+    def scaleAndRound_HPS_QlRl_Ql(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_scaleAndRound_HPS_QlRl_Ql(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
+
+    def ExpandCRTBasis_Ql_Q_add_to_ct(self, size_Ql, dst, src):
+        _lib.check(self._L.pha_ExpandCRTBasis_Ql_Q_add_to_ct(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
 
     def scaleAndRound_HPS_Q_Ql(self, size_Ql, dst, src):
         _lib.check(self._L.pha_scaleAndRound_HPS_Q_Ql(self._h, size_Ql, _ptr(dst), _ptr(src), _stream()))
@@ -481,13 +539,20 @@ class PhantomContext:
 class DBaseConverter:
     """DBaseConverter (include/rns_bconv.cuh:13-87) between two bases given as rows of the context's prime table."""
 
-    def __init__(self, ctx, ibase, obase):
+    def __init__(self, ctx, ibase, obase=None, out_modulus=None):
+        """obase: rows of the prime table; or out_modulus: ONE raw output modulus (the plain modulus t of base_q_to_t_conv_,
+        src/rns.cu:283-284) -- such a converter serves exact_convert_array only."""
         self._ctx, self._L = ctx, _lib.load()
-        self.ibase, self.obase = [int(i) for i in ibase], [int(o) for o in obase]
+        self.ibase = [int(i) for i in ibase]
         ib = (C.c_uint32 * len(self.ibase))(*self.ibase)
-        ob = (C.c_uint32 * len(self.obase))(*self.obase)
         h = C.c_void_p()
-        _lib.check(self._L.pha_base_converter_create(ctx._h, ib, len(self.ibase), ob, len(self.obase), C.byref(h)))
+        if out_modulus is not None:
+            self.obase = None
+            _lib.check(self._L.pha_base_converter_create_modulus(ctx._h, ib, len(self.ibase), int(out_modulus), C.byref(h)))
+        else:
+            self.obase = [int(o) for o in obase]
+            ob = (C.c_uint32 * len(self.obase))(*self.obase)
+            _lib.check(self._L.pha_base_converter_create(ctx._h, ib, len(self.ibase), ob, len(self.obase), C.byref(h)))
         self._h = h
 
     def __del__(self):
@@ -500,6 +565,14 @@ class DBaseConverter:
 
     def bConv_HPS(self, dst, src):
         _lib.check(self._L.pha_bConv_HPS(self._h, _ptr(dst), _ptr(src), _stream()))
+
+    def bConv_BEHZ_var1(self, dst, src):
+        """DBaseConverter::bConv_BEHZ_var1 (src/rns_bconv.cu:231-246)."""
+        _lib.check(self._L.pha_bConv_BEHZ_var1(self._h, _ptr(dst), _ptr(src), _stream()))
+
+    def exact_convert_array(self, dst, src):
+        """DBaseConverter::exact_convert_array (src/rns_bconv.cu:374-431): [ibase][N] -> [N] modulo the one output modulus."""
+        _lib.check(self._L.pha_exact_convert_array(self._h, _ptr(dst), _ptr(src), _stream()))
 
 
 class PhantomRelinKey:

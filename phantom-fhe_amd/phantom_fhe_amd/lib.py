@@ -43,6 +43,8 @@ _SIGS = {
     "pha_multiply_scalar_rns_poly": [vp, vp, vp, vp, vp, sz, sz, vp],
     "pha_tensor_prod_2x2_rns_poly": [vp, vp, vp, vp, sz, vp],
     "pha_tensor_square_2x2_rns_poly": [vp, vp, vp, sz, vp],
+    "pha_tensor_prod_2x2_rns_poly_at": [vp, vp, vp, vp, sz, sz, vp],
+    "pha_tensor_square_2x2_rns_poly_at": [vp, vp, vp, sz, sz, vp],
     "pha_add_to_ct": [vp, vp, vp, sz, vp],
     "pha_bconv_P_to_Ql": [vp, sz, vp, vp, vp],
     "pha_modup": [vp, sz, vp, vp, C.c_int, vp],
@@ -72,6 +74,20 @@ _SIGS = {
     "pha_base_converter_create": [vp, C.POINTER(C.c_uint32), sz, C.POINTER(C.c_uint32), sz, C.POINTER(vp)],
     "pha_bConv_BEHZ": [vp, vp, vp, vp],
     "pha_bConv_HPS": [vp, vp, vp, vp],
+    "pha_bConv_BEHZ_var1": [vp, vp, vp, vp],
+    "pha_base_converter_create_modulus": [vp, C.POINTER(C.c_uint32), sz, u64, C.POINTER(vp)],
+    "pha_exact_convert_array": [vp, vp, vp, vp],
+    "pha_moddown": [vp, sz, vp, vp, C.c_int, vp],
+    "pha_check_canonical": [vp, vp, sz, sz, sz, sz, sz, u64p, vp],
+    "pha_check_canonical_keys": [vp, sz, vp, sz, u64p, vp],
+    "pha_tool_aux_sizes": [vp, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+    "pha_fastbconv_m_tilde": [vp, sz, vp, vp, vp],
+    "pha_sm_mrq": [vp, sz, vp, vp, vp],
+    "pha_fast_floor": [vp, sz, vp, vp, vp, vp],
+    "pha_fastbconv_sk": [vp, sz, vp, vp, vp],
+    "pha_scaleAndRound_HPS_QR_R": [vp, sz, vp, vp, vp],
+    "pha_scaleAndRound_HPS_QlRl_Ql": [vp, sz, vp, vp, vp],
+    "pha_ExpandCRTBasis_Ql_Q_add_to_ct": [vp, sz, vp, vp, vp],
     "pha_bfv_add_plain": [vp, sz, vp, vp, C.c_int, vp],
     "pha_bfv_multiply_plain": [vp, sz, vp, sz, vp, vp],
     "pha_bgv_lift_plain": [vp, sz, vp, vp, vp],
@@ -124,6 +140,7 @@ _SPECIAL = {
     "pha_context_log_n": (C.c_uint32, [vp]),
     "pha_context_size_qp": (C.c_uint32, [vp]),
     "pha_context_size_p": (C.c_uint32, [vp]),
+    "pha_set_strict": (C.c_int, [C.c_int]),
 }
 
 EXPORTED = sorted(list(_SIGS) + list(_SPECIAL))

@@ -147,6 +147,45 @@ int main(int argc, char **argv) {
     orc_multiply_rns_poly(oc, a.data(), b.data(), o_prod.data(), size_Q, 0);
     REQUIRE(download(da.get(), a.size(), s) == o_prod);
 
+    // 5. r06: the launchers of rns.cuh / rns_bconv.cuh that had no entry of their own before -- DRNSTool::moddown with a BFV
+    //    input in coefficient form (include/rns.cuh:159-160, caller shape of src/evaluate.cu:1005-1012), bConv_BEHZ_var1
+    //    (include/rns_bconv.cuh:64) and exact_convert_array (:68), spelled as the reference spells them
+    {
+        std::vector<uint64_t> qlp(qp.begin(), qp.begin() + size_Ql);
+        qlp.insert(qlp.end(), qp.begin() + size_Q, qp.end());
+        auto cx_h = uniform(g, qlp, n);
+        auto cx_d = upload(cx_h, s);
+        auto ct_d = make_cuda_auto_ptr<uint64_t>(size_Ql * n, s);
+        rns_tool.moddown(ct_d.get(), cx_d.get(), context.gpu_rns_tables(), scheme_type::bfv, s);
+        std::vector<uint64_t> o_down(size_Ql * n);
+        orc_moddown(tool, o_down.data(), cx_h.data(), ORC_BFV);
+        REQUIRE(download(ct_d.get(), o_down.size(), s) == o_down);
+
+        const std::vector<uint32_t> ibase{0, 1, 2, 3}, obase{9, 10, 11};
+        std::vector<uint64_t> ip, op;
+        for (auto r : ibase) ip.push_back(qp[r]);
+        for (auto r : obase) op.push_back(qp[r]);
+        DBaseConverter conv(context.amd(), ibase, obase);
+        auto src_h = uniform(g, ip, n);
+        auto src_d = upload(src_h, s);
+        auto dst_d = make_cuda_auto_ptr<uint64_t>(op.size() * n, s);
+        conv.bConv_BEHZ_var1(dst_d.get(), src_d.get(), n, s);
+        std::vector<uint64_t> o_var1(op.size() * n);
+        orc_bconv_behz_var1(ip.data(), ip.size(), op.data(), op.size(), src_h.data(), o_var1.data(), n);
+        REQUIRE(download(dst_d.get(), o_var1.size(), s) == o_var1);
+
+        const uint64_t t = 1032193;
+        DBaseConverter to_t(context.amd(), ibase, t);            // base_q_to_t_conv_ (src/rns.cu:283-284)
+        auto one_d = make_cuda_auto_ptr<uint64_t>(n, s);
+        to_t.exact_convert_array(one_d.get(), src_d.get(), n, s);
+        std::vector<uint64_t> o_exact(n);
+        orc_exact_convert_array(ip.data(), ip.size(), t, src_h.data(), o_exact.data(), n);
+        REQUIRE(download(one_d.get(), n, s) == o_exact);
+        threw = false;
+        try { conv.exact_convert_array(one_d.get(), src_d.get(), n, s); } catch (const std::invalid_argument &) { threw = true; }
+        REQUIRE(threw);                                          // "out base in exact_convert_array must be one." (rns_bconv.cu:423-425)
+    }
+
     orc_tool_destroy(tool);
     orc_ctx_destroy(oc);
     std::printf("REF_SPELLING_OK\n");
