@@ -21,6 +21,22 @@ Sources restated (file:line under /root/reference):
   src/ntt/fntt_2d.cu:9-99 (inplace_fnwt_radix8_phase1), :101-198 (phase2), :620-653 (launcher)
   src/ntt/intt_2d.cu:9-104 (inplace_inwt_radix8_phase1), :106-207 (phase2), :724-757 (launcher)
   include/ntt.cuh:131-153 (SAMPLE_SIZE), include/common.h:23-30 (blockDimNTT = 128, per_block_pad = 4)
+
+r06 -- the kernels with INDEX MAPS, where an unpinned restatement could be wrong without a transform being wrong:
+  src/ntt/ntt_modup.cu:395-657   nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range: the grid-stride tid -> (data limb
+                                 twr_idx, table row twr_idx2) map of :421-425 / :521-525 (phase 2 walks the limbs backwards), the
+                                 `continue` over the digit's own range.  The per-limb bodies are token for token those of
+                                 fntt_2d.cu:9-198 apart from the row used for psi / modulus (checked with diff), so they are the
+                                 functions above, fed the remapped row.
+  src/ntt/ntt_moddown.cu:106-261 inplace_fnwt_radix8_phase2_fuse_moddown: phase 2 reads `delta`, never writes it back, and stores
+                                 sub_negate_const_mult(NTT(delta), cx, PInv) into ct (:203-208; uintmodmath.cuh:233-241).
+  src/rns_bconv.cu:455-485       bconv_matmul_padded_unroll2_kernel with base_convert_acc_unroll2 (include/rns_bconv.cuh:127-143): thread
+                                 tid -> (degree_idx = 2 (tid / obase), out_prime = tid % obase), 128-bit accumulation with carries,
+                                 Barrett-128 as the PTX of uintmodmath.cuh:108-126 spells it, the leap of the output limb index over
+                                 the digit's own range; :143-170 (bconv_matmul_unroll2_kernel) is the same without the leap; :22-29,
+                                 :522-528 (bconv_mult_kernel, modup_copy_partQl_kernel).
+  src/eval_key_switch.cu:14-69   key_switch_inner_prod_c2_and_evk: nid -> key limb twr (keys at full QP width, data at QlP), the dead
+                                 `i && reduction_threshold == 0` branch, one Barrett-128 per accumulator.
 """
 import numpy as np
 
@@ -333,3 +349,193 @@ def nwt_2d_radix8_backward_inplace(x, ipsi, ipsis, n_inv, n_inv_shoup, q):
     finally:
         np.seterr(**old)
     return d
+
+
+# ---- r06: kernels with index maps ------------------------------------------------------------------------------------------------------
+
+def _mul128(a, b):
+    """multiply_uint64_uint64 (uintmath.cuh): (lo, hi) of a * b on uint64 vectors."""
+    return a * b, _umul64hi(a, b)
+
+
+def _add128(alo, ahi, blo, bhi):
+    """add_uint128_uint128: 128-bit sum modulo 2^128 with the carry out of the low word."""
+    lo = alo + blo
+    return lo, ahi + bhi + (lo < alo).astype(U64)
+
+
+def _barrett128(lo, hi, q, mu0, mu1):
+    """barrett_reduce_uint128_uint64, the PTX sequence of uintmodmath.cuh:108-126 (mul.hi / mad.lo.cc / madc.hi ...), then csub_q (:135)."""
+    tmp = _umul64hi(lo, mu0)                       # mul.hi.u64 tmp, lo, ratio0
+    p = lo * mu1                                   # mad.lo.cc.u64 tmp, lo, ratio1, tmp
+    t2 = p + tmp
+    carry = (t2 < p).astype(U64)
+    r = _umul64hi(lo, mu1) + carry                 # madc.hi.u64 r, lo, ratio1, 0
+    p = hi * mu0                                   # mad.lo.cc.u64 tmp, hi, ratio0, tmp
+    t3 = p + t2
+    carry = (t3 < p).astype(U64)
+    r = _umul64hi(hi, mu0) + r + carry             # madc.hi.u64 r, hi, ratio0, r
+    r = hi * mu1 + r                               # mad.lo.u64 r, hi, ratio1, r
+    return _csub_q(lo - r * q, q)                  # mul.lo, sub, csub_q
+
+
+def _shoup(x, w, ws, q):
+    """multiply_and_reduce_shoup (uintmodmath.cuh:207-215): lazy product, then csub_q."""
+    return _csub_q(_shoup_lazy(x, w, ws, q), q)
+
+
+def _quiet(fn):
+    def run(*a, **k):
+        old = np.seterr(over="ignore")
+        try:
+            return fn(*a, **k)
+        finally:
+            np.seterr(**old)
+    run.__doc__ = fn.__doc__
+    return run
+
+
+@_quiet
+def nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(data, tw, tws, mod, n, cms, start, size_qp, size_p, ex_start, ex_end):
+    """The launcher of src/ntt/ntt_modup.cu:606-657 on data [.][n] (limb-major; rows `start .. start + cms` are visited), tw / tws / mod =
+    the DNTTTable rows ([size_QP][n] twiddles, [size_QP] moduli).  In place; returns the list of (phase, twr_idx, twr_idx2) visits."""
+    if ex_start < start or ex_end > start + cms:
+        raise ValueError("Excluded range in NTT is invalid.")       # :617-620
+    n1 = sample_size(n)
+    n2 = n // n1
+    visits = []
+    per_limb = n // 8
+    for phase in (1, 2):
+        # the grid-stride loop covers tid in [0, n / 8 * cms); tid / (n / 8) takes every value 0 .. cms - 1, all threads of a (virtual)
+        # block share it (n / 8 is a multiple of both block sizes), so the `continue` of :422 / :522 is block-uniform
+        for k in range(cms):
+            tid0 = k * per_limb
+            twr_idx = tid0 // per_limb + start if phase == 1 else cms - 1 - tid0 // per_limb + start     # :421 / :521
+            if ex_start <= twr_idx < ex_end:                                                                # :422 / :522
+                continue
+            twr_idx2 = size_qp - (start + cms - twr_idx) if twr_idx >= start + cms - size_p else twr_idx   # :423-425 / :523-525
+            visits.append((phase, twr_idx, twr_idx2))
+            limb = data[twr_idx]                                     # data_ptr = inout + twr_idx * n
+            if phase == 1:
+                fnwt_phase1(limb, tw[twr_idx2], tws[twr_idx2], mod[twr_idx2], n, n1, PER_BLOCK_PAD)
+            else:
+                fnwt_phase2(limb, tw[twr_idx2], tws[twr_idx2], mod[twr_idx2], n, n1, n2)
+    return visits
+
+
+@_quiet
+def nwt_2d_radix8_forward_inplace_fuse_moddown(ct, cx, pinv, pinv_shoup, delta, tw, tws, mod, n, cms, start):
+    """src/ntt/ntt_moddown.cu:222-261: phase 1 of the plain transform on delta (in place), then inplace_fnwt_radix8_phase2_fuse_moddown
+    (:106-210): the plain phase 2 reading delta, whose canonical outputs are NOT written back but go through
+    ct[...] = sub_negate_const_mult(sample, cx[...], PInv[twr], PInv_shoup[twr], q) (:203-208)."""
+    n1 = sample_size(n)
+    n2 = n // n1
+    for k in range(cms):
+        twr = k + start                                              # fntt_2d.cu:27
+        fnwt_phase1(delta[twr], tw[twr], tws[twr], mod[twr], n, n1, PER_BLOCK_PAD)
+    for k in range(cms):
+        twr = cms - 1 - k + start                                    # :130
+        q = U64(mod[twr])
+        out = delta[twr].copy()                                      # phase 2 on a scratch copy: the kernel keeps its results in registers
+        fnwt_phase2(out, tw[twr], tws[twr], mod[twr], n, n1, n2)     # ... :131-200 == fntt_2d.cu:101-193 (same statements)
+        temp = cx[twr] + q - out                                     # sub_negate_const_mult uintmodmath.cuh:233-241: op2 + modulus - op1
+        temp = _csub_q(temp, q)
+        ct[twr] = _shoup(temp, U64(pinv[twr]), U64(pinv_shoup[twr]), q)
+
+
+@_quiet
+def bconv_mult_kernel(src, scale, scale_shoup, base, n):
+    """src/rns_bconv.cu:22-29: dst[tid] = multiply_and_reduce_shoup(src[tid], scale[i], scale_shoup[i], base[i]), i = tid / n."""
+    isz = len(base)
+    tid = np.arange(n * isz, dtype=np.int64)
+    i = tid // n
+    flat = np.ascontiguousarray(src, dtype=U64).reshape(-1)
+    sc, ss, bq = (np.asarray(v, dtype=U64) for v in (scale, scale_shoup, base))
+    return _shoup(flat[tid], sc[i], ss[i], bq[i]).reshape(isz, n)
+
+
+@_quiet
+def bconv_matmul_padded_unroll2_kernel(dst, y, mat, obase, omu, isz, n, start_part_idx, size_part_ql):
+    """src/rns_bconv.cu:455-485 with base_convert_acc_unroll2 (include/rns_bconv.cuh:127-143).  dst [.][n] is written at the PADDED limb
+    index; y [isz][n] = x_i qhat_i^-1 mod q_i; mat [osz][isz] = QHatModp (row-major, as the shared copy of :461-464 holds it);
+    obase / omu = output moduli and their (ratio0, ratio1).  start_part_idx >= osz and size_part_ql = 0 give bconv_matmul_unroll2_kernel
+    (:143-170)."""
+    osz = len(obase)
+    yf = np.ascontiguousarray(y, dtype=U64).reshape(-1)
+    m = np.ascontiguousarray(mat, dtype=U64).reshape(-1)
+    ob = np.asarray(obase, dtype=U64)
+    mu = np.asarray(omu, dtype=U64).reshape(osz, 2)
+    tid = np.arange((n * osz + 1) // 2, dtype=np.int64)               # :467
+    degree_idx = 2 * (tid // osz)                                      # :469
+    out_prime_idx = tid % osz                                          # :470
+    xlo = np.zeros(len(tid), dtype=U64)
+    xhi, ylo, yhi = xlo.copy(), xlo.copy(), xlo.copy()
+    for i in range(isz):                                               # rns_bconv.cuh:131-141
+        op2 = m[out_prime_idx * isz + i]
+        op1_x = yf[i * n + degree_idx]                                 # ld_two_uint64(ptr + i * degree + degree_idx)
+        op1_y = yf[i * n + degree_idx + 1]
+        lo, hi = _mul128(op1_x, op2)
+        xlo, xhi = _add128(lo, hi, xlo, xhi)
+        lo, hi = _mul128(op1_y, op2)
+        ylo, yhi = _add128(lo, hi, ylo, yhi)
+    q, mu0, mu1 = ob[out_prime_idx], mu[out_prime_idx, 0], mu[out_prime_idx, 1]
+    padded = out_prime_idx + np.where(out_prime_idx >= start_part_idx, size_part_ql, 0)   # :479
+    out1 = _barrett128(xlo, xhi, q, mu0, mu1)
+    out2 = _barrett128(ylo, yhi, q, mu0, mu1)
+    dst[padded, degree_idx] = out1                                     # st_two_uint64(dst + padded * n + degree_idx, out, out2)
+    dst[padded, degree_idx + 1] = out2
+
+
+@_quiet
+def modup_copy_part_ql_kernel(t_mod_up, cks, size_ql, size_qlp, alpha, n):
+    """src/rns_bconv.cu:522-528: t_mod_up[beta_idx * size_QlP_n + tid] = cks[tid], beta_idx = tid / (alpha n); t_mod_up flat [beta][QlP][n]."""
+    tid = np.arange(size_ql * n, dtype=np.int64)
+    beta_idx = tid // (alpha * n)
+    t_mod_up.reshape(-1)[beta_idx * (size_qlp * n) + tid] = np.ascontiguousarray(cks, dtype=U64).reshape(-1)[tid]
+
+
+@_quiet
+def key_switch_inner_prod_c2_and_evk(c2, evks, mod, mu, n, size_qp, size_qlp, size_q, size_ql, beta, reduction_threshold=1 << 8):
+    """src/eval_key_switch.cu:14-69.  c2 flat [beta][QlP][n]; evks = list of beta flat keys [2][QP][n]; mod / mu = DModulus rows of the
+    QP table.  Returns dst flat [2][QlP][n]."""
+    size_qp_n, size_qlp_n = size_qp * n, size_qlp * n
+    c2 = np.ascontiguousarray(c2, dtype=U64).reshape(-1)
+    ev = [np.ascontiguousarray(e, dtype=U64).reshape(-1) for e in evks]
+    md = np.asarray(mod, dtype=U64)
+    ratio = np.asarray(mu, dtype=U64).reshape(-1, 2)
+    tid = np.arange(size_qlp_n, dtype=np.int64)
+    nid = tid // n                                                     # :20
+    twr = np.where(nid >= size_ql, size_q + (nid - size_ql), nid)      # :21
+    q, mu0, mu1 = md[twr], ratio[twr, 0], ratio[twr, 1]
+    evk_id = (tid % n) + twr * n                                       # :24
+    c2_id = (tid % n) + nid * n                                        # :25
+    a0lo, a0hi = _mul128(c2[c2_id], ev[0][evk_id])                     # :44
+    a1lo, a1hi = _mul128(c2[c2_id], ev[0][evk_id + size_qp_n])         # :46
+    for i in range(1, beta):
+        if i and reduction_threshold == 0:                             # :49-55 (never true for the threshold callers pass)
+            a0lo, a0hi = _barrett128(a0lo, a0hi, q, mu0, mu1), np.zeros_like(a0hi)
+            a1lo, a1hi = _barrett128(a1lo, a1hi, q, mu0, mu1), np.zeros_like(a1hi)
+        lo, hi = _mul128(c2[c2_id + i * size_qlp_n], ev[i][evk_id])
+        a0lo, a0hi = _add128(a0lo, a0hi, lo, hi)                       # :57-58
+        lo, hi = _mul128(c2[c2_id + i * size_qlp_n], ev[i][evk_id + size_qp_n])
+        a1lo, a1hi = _add128(a1lo, a1hi, lo, hi)                       # :60-61
+    dst = np.zeros(2 * size_qlp_n, dtype=U64)
+    dst[tid] = _barrett128(a0lo, a0hi, q, mu0, mu1)                    # :64-65
+    dst[tid + size_qlp_n] = _barrett128(a1lo, a1hi, q, mu0, mu1)       # :67-68
+    return dst
+
+
+@_quiet
+def nwt_2d_radix8_backward_inplace_include_special_mod(data, itw, itws, n_inv, n_inv_shoup, mod, n, cms, start, size_qp, size_p):
+    """src/ntt/intt_2d.cu:796-834 (kernels :411-617): the plain inverse kernels with the same twr_idx2 remap (:421, :494; diffed against
+    :9-207 -- only the row used for the tables differs), limbs twr_idx = tid / (n / 8) + start in both phases."""
+    n2 = sample_size(n)
+    n1 = n // n2
+    for k in range(cms):
+        twr_idx = k + start
+        twr_idx2 = size_qp - (start + cms - twr_idx) if twr_idx >= start + cms - size_p else twr_idx
+        inwt_phase1(data[twr_idx], itw[twr_idx2], itws[twr_idx2], mod[twr_idx2], n, n1, n2)
+    for k in range(cms):
+        twr_idx = k + start
+        twr_idx2 = size_qp - (start + cms - twr_idx) if twr_idx >= start + cms - size_p else twr_idx
+        inwt_phase2(data[twr_idx], itw[twr_idx2], itws[twr_idx2], n_inv[twr_idx2], n_inv_shoup[twr_idx2], mod[twr_idx2], n, n1, PER_BLOCK_PAD)
