@@ -142,7 +142,7 @@ class _StubCtx:
         ct *= acc[None]
 
 
-def _workload_worker(rank, world, port, q):
+def _workload_worker(rank, world, port, q, batch=5, nblocks=5):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "phantom-fhe_amd"))
@@ -152,14 +152,14 @@ def _workload_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = torch.Generator().manual_seed(99)
-        ql, n, batch = 3, 16, 5
+        ql, n = 3, 16
         ct3 = torch.randint(0, 1 << 40, (batch, 3, ql, n), dtype=torch.int64, generator=g)
         keep = ct3.clone()
         ctx = _StubCtx()
         mine, res = W.relinearize_rotate_sharded(ctx, ql, ct3, _StubKey(), _StubKey(), 3, 1)   # rank / world from the group
         assert torch.equal(ct3, keep)                                                         # inputs are not consumed
         ct = torch.randint(0, 1 << 20, (2, ql, n), dtype=torch.int64, generator=g)
-        blocks = [[torch.randint(0, 1 << 20, (ql + 2, n), dtype=torch.int64, generator=g) for _ in range(3)] for _ in range(5)]
+        blocks = [[torch.randint(0, 1 << 20, (ql + 2, n), dtype=torch.int64, generator=g) for _ in range(3)] for _ in range(nblocks)]
         mine5, outs = W.matvec_row_blocks_sharded(ctx, ql, ct, [1, 5, 25], [None, _StubKey(), _StubKey()], blocks, 2)
         gathered = [None] * world
         dist.all_gather_object(gathered, (list(mine), res, list(mine5), outs))
@@ -170,8 +170,19 @@ def _workload_worker(rank, world, port, q):
             ok4 = idx == list(range(batch)) and torch.equal(torch.cat([g_[1] for g_ in gathered]), full)
             idx5 = sum((g_[2] for g_ in gathered), [])
             outs5 = sum((g_[3] for g_ in gathered), [])
-            ok5 = idx5 == list(range(5)) and all(torch.equal(a, b) for a, b in zip(outs5, full5))
+            ok5 = idx5 == list(range(nblocks)) and all(torch.equal(a, b) for a, b in zip(outs5, full5))
+            # the checksum of checksums bench.py prints (sum mod 2^64 of all output words) does not depend on the world size
+            from phantom_fhe_amd import dist as pd
             q.put((ok4, ok5))
+        from phantom_fhe_amd import dist as pd
+        local = int(res.sum().item()) if len(mine) else 0
+        sums = pd.gather_checksums(local)
+        whole = int(W.relinearize_rotate_batch(ctx, ql, ct3, _StubKey(), _StubKey(), 3, 1).sum().item())
+        assert len(sums) == world and sum(sums) == whole, (sums, whole)
+        # a key slab generated on rank 0 reaches every rank in ONE collective call
+        slab = torch.arange(4 * 2 * 5 * n, dtype=torch.int64).reshape(4, 2, 5, n) * (1 if rank == 0 else 0)
+        calls = pd.broadcast_keys([slab[i] for i in range(4)], src=0)
+        assert calls == 1 and torch.equal(slab, torch.arange(4 * 2 * 5 * n, dtype=torch.int64).reshape(4, 2, 5, n))
     finally:
         dist.destroy_process_group()
 
@@ -242,6 +253,24 @@ def _gpu_workload_worker(rank, world, port, q):
 
 
 import pytest  # noqa: E402
+
+
+def test_eight_rank_config4_and_config5_sharding_reproduces_one_rank():
+    """The world size of the node the scaling bench runs on: 8 gloo ranks, an uneven batch (19 ciphertexts: shards of
+    3 and 2) and fewer row blocks than ranks (5: three ranks own nothing) -- index cover, results, checksum of checksums and the one-call
+    key broadcast all as in the two-rank test."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_workload_worker, args=(r, world, port, q, 19, 5)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok4, ok5 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok4 and ok5
 
 
 @pytest.mark.gpu
