@@ -825,6 +825,20 @@ def main():
             bfv[name + "_multiply_relinearize_ms"] = local_ms(mul_relin, reps)
         bfv["config"] = ("BFV N=2^15, 30 data limbs (+15 special for the relinearization), 61-bit auxiliary bases; bfv_multiply_behz / "
                          "bfv_multiply_hps, src/evaluate.cu:447-548, :674-818")
+        # r06: the rows' roofline figure.  Algorithmic bytes = the minimal per-stage traffic summed over the stages of
+        # the reference's own call sequence, in limb-polynomials of N x 8 B (every stage reads its inputs once and writes its outputs once):
+        #   BEHZ (src/evaluate.cu:404-548), Q limbs, |Bsk| = Q + 2: per input polynomial NTT over q (2Q), q -> Bsk u {m_tilde} (Q + Bsk + 1),
+        #     sm_mrq (2 Bsk + 1), NTT over Bsk (2 Bsk) -- x 4 polynomials; tensor 7 (Q + Bsk); inverse NTTs 3 x 2 (Q + Bsk); fast_floor
+        #     3 (Q + 2 Bsk); fastbconv_sk 3 (Bsk + Q)
+        #   HPS (:674-818), |R| = Q + 1: per input polynomial bConv_HPS q -> R (Q + R), NTT over Q u R (2 (Q + R)) -- x 4; tensor 7 (Q + R);
+        #     inverse 3 x 2 (Q + R); scaleAndRound_HPS_QR_R 3 (Q + 2 R); bConv_HPS R -> Q 3 (R + Q)
+        nq, nbsk, nr = q4, q4 + 2, q4 + 1
+        limb_bytes = 8.0 * n4
+        behz_units = 4 * (2 * nq + (nq + nbsk + 1) + (2 * nbsk + 1) + 2 * nbsk) + 7 * (nq + nbsk) + 6 * (nq + nbsk) + 3 * (nq + 2 * nbsk) + 3 * (nbsk + nq)
+        hps_units = 4 * ((nq + nr) + 2 * (nq + nr)) + 7 * (nq + nr) + 6 * (nq + nr) + 3 * (nq + 2 * nr) + 3 * (nr + nq)
+        for name, units in (("behz", behz_units), ("hps", hps_units)):
+            bfv[name + "_algorithmic_bytes"] = units * limb_bytes
+            bfv[name + "_frac_of_peak"] = units * limb_bytes / (bfv[name + "_multiply_ms"] * 1e-3) / PEAK_HBM
         gm = gn = gk = 256
         gbatch = 4 if small else 30
         gprimes = [int(p) for p in P.coeff_modulus_create(4096, [50] * gbatch)]
