@@ -17,7 +17,7 @@ def _latest_full_record():
     new = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06*_bench_full.json")))
     if new:
         return json.load(open(new[-1]))
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05z_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06z_bench.json")))
     _, ref = bench.load_record(bench.TRAFFIC_FILE)
     d["roofline"]["traffic_source"] = ref
     d["hommul_relin_rescale"]["stages"] = bench.stage_ref(bench.STAGES_FILE)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/collect_profiles.sh TAG: copy the tagged summaries of a tools/r05_final.sh run from gpurun_out/ (scratch) into profiles/
+# tools/collect_profiles.sh TAG: copy the tagged summaries of a tools/r06_final.sh run from gpurun_out/ (scratch) into profiles/
 # (tracked), plus stages.json / traffic.json, which bench.py reports with their sha.
 TAG=${1:?usage: collect_profiles.sh TAG}
 cd "$(dirname "$0")/.."

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 profile set, ONE command on the GPU box (TAG=r05x bash tools/profile_r05.sh): bench line, rocprofv3 kernel trace of the
+# Round-6 profile set (the r05 set + the driver's exact bench command with the line-size check), ONE command on the GPU box (TAG=r05x bash tools/profile_r06.sh): bench line, rocprofv3 kernel trace of the
 # same command (by kernel and by grid), the per-stage table of one HomMul (profiles/stages.json) and, r05, of one op INSIDE A BATCH of 8
 # and of 32 (profiles/stages_batched.json), PMC passes in their own runs (SQ / LDS counters over the two small workloads, FETCH_SIZE /
 # WRITE_SIZE traffic of the step, the single op and the batched op -> profiles/traffic.json).  Everything lands in
@@ -7,7 +7,7 @@
 # tree they were measured on -- bench.py prints the sha of traffic.json / stages.json so a stale file shows.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -o trace -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-c5 > $OUT/prof_trace.log 2>&1
@@ -33,5 +33,19 @@ bash $R/tools/traffic.sh > $OUT/${TAG}_traffic.txt 2>&1
 # the bench line LAST, with the records of THIS run in place: bench.py attaches profiles/{traffic,stages,stages_batched}.json with their sha, and
 # tools/collect_profiles.sh copies the same three files from gpurun_out/ into profiles/ of the build container afterwards
 cp $OUT/traffic.json $OUT/stages.json $OUT/stages_batched.json $R/profiles/ 2>/dev/null
-timeout 900 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# r06: the DRIVER'S OWN COMMAND; stdout must be ONE JSON line of at most 8000 bytes that json.loads; the full record
+# (what r01-r05 printed) goes to the file named in the line
+cd $R
+timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --full-out $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
+python3 - <<PY
+import json
+raw = open("$OUT/${TAG}_bench_line.json").read()
+lines = [l for l in raw.splitlines() if l.strip()]
+assert len(lines) == 1, f"{len(lines)} stdout lines"
+d = json.loads(lines[-1])
+assert len(lines[-1]) <= 8000, len(lines[-1])
+for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline"):
+    assert k in d, k
+print("bench line:", len(lines[-1]), "bytes; value", d["value"], d["unit"], "ms_per_step", d["ms_per_step"], "frac", d["roofline"]["frac"])
+PY
 ls -la $OUT | grep -E "$TAG|traffic.json|stages.json|stages_batched.json"; du -sh $OUT

@@ -1,8 +1,8 @@
 #!/bin/bash
-# The GPU-box half of tools/r05_final.sh (run it through that script: it builds first and records what it built).
+# The GPU-box half of tools/r06_final.sh (run it through that script: it builds first and records what it built).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${TAG:-r05z}
+TAG=${TAG:-r06z}
 mkdir -p $OUT
 cd $R
 # the libraries this box loads are the ones the build container recorded
@@ -17,7 +17,7 @@ T0=$(date +%s)
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py --preflight > $OUT/${TAG}_preflight.json 2>/dev/null
 PHA_BENCH_FORCE_DIST=1 python bench.py --preflight > $OUT/${TAG}_preflight_rccl1.json 2>/dev/null
-bash tools/profile_r05.sh
+bash tools/profile_r06.sh
 echo "profile seconds: $(( $(date +%s) - T0 ))"
 # the reference's benchmark shapes on the same tree (benchmark/ntt_bench.cu:104-117, keyswitch_bench.cu:16-34, ckks_bench.cu:168-205)
 T0=$(date +%s)
@@ -30,7 +30,7 @@ cat $OUT/${TAG}_stages_batched.txt
 tail -c 400 $OUT/${TAG}_bench.err
 python - <<PY
 import json
-d=json.load(open("gpurun_out/${TAG}_bench.json"))
+d=json.load(open("gpurun_out/${TAG}_bench_full.json"))
 r=d["roofline"]
 print("NTT/s", d["value"], "ms/step", d["ms_per_step"], "frac", r["frac"], "sustained", r["sustained"]["median_ms_per_step"], "own copy", r["calibrated_copy_GBps"], "ceil", r["ceiling_two_pass"], r["frac_of_ceiling"])
 print("traffic", r["traffic"], "single", d["single_polynomial"]["mall_resident"]["mean_ms"], d["single_polynomial"]["hbm_resident"]["mean_ms"])

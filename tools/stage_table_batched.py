@@ -69,7 +69,7 @@ def table_for(B, trace_dir):
 
 
 out = sys.argv[1]
-doc = {"source": "rocprofv3 --kernel-trace of tools/traffic_probe.py hommul_batched:B (tools/profile_r05.sh); under the profiler every launch "
+doc = {"source": "rocprofv3 --kernel-trace of tools/traffic_probe.py hommul_batched:B (tools/profile_r06.sh); under the profiler every launch "
                  "is serialised, so the per-op sum is a few per cent above the figure bench.py times without it",
        "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "batches": []}
 for arg in sys.argv[2:]:
