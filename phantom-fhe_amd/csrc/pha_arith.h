@@ -178,6 +178,35 @@ PHA_HD u64 mont_redc128(u64 lo, u64 hi, u64 p, u64 ninv) {
     return csub(t, p);
 }
 
+// r06: Montgomery reduction of the four carry-free split accumulators of a base conversion, word by word in base B = 2^30, without
+// first recombining them into a 128-bit value (22 vector instructions) for the 64-bit REDC above (18):
+//   V = ll + (lh + hl) B + hh B^2      ->      V * B^-3 mod p, canonical,
+// for odd p < 2^60 cut as p = p0 + p1 B, n30 = -p^-1 mod 2^30 (any upper bits of n30 are ignored), and accumulators of AT MOST 15
+// products of 30-bit halves: with H = 2^30 - 1 each of ll, lh, hl, hh is <= 15 H^2, and every sum below stays inside 64 bits:
+//   step 1  m1 = ll n30 mod B;  t = ll + m1 p0 <= 16 H^2 = 2^64 - 2^35 + 16 (low 30 bits zero);  u = lh + m1 p1 + (t >> 30)
+//           <= 16 H^2 + 2^34 - 32 < 2^64;                                   V / B   = u + hl + hh B
+//   step 2  m2 = (u + hl) n30 mod B;  w = hl + m2 p0 <= 16 H^2;  u + w < 2^65 (its carry is kept);  x = hh + m2 p1 + ((u + w) >> 30)
+//           <= 16 H^2 + 2^35 - 48 = 2^64 - 32;                               V / B^2 = x
+//   step 3  m3 = x n30 mod B;  r = (x + m3 p) >> 30 = (x >> 30) + m3 p1 + ((x mod B + m3 p0) >> 30) < 2^34 + 2^60 + 2^30
+// r = (V + (m1 + m2 B + m3 B^2) p) / B^3 < V / 2^90 + p, and V < 15 * 2^60 * p for rows below p, so r < 2p: one conditional subtract.
+// The rows of such a converter hold qhat_i * 2^90 mod p_j (BConv::r90, pha_context.hip).  A sixteenth term would overflow step 1:
+// converters with 16 inputs keep the 64-bit form.  Checked against big-integer arithmetic at the corners by tests/test_emu_fp.py.
+PHA_HD u64 mont_redc90_split(u64 ll, u64 lh, u64 hl, u64 hh, u64 p, u32 p0, u32 p1, u32 n30) {
+    constexpr u32 M = (1u << 30) - 1;
+    const u32 m1 = ((u32)ll * n30) & M;
+    const u64 t = mad_u64_u32(m1, p0, ll);
+    const u64 u = mad_u64_u32(m1, p1, lh) + (t >> 30);
+    const u32 m2 = (((u32)u + (u32)hl) * n30) & M;
+    const u64 w = mad_u64_u32(m2, p0, hl);
+    const u64 s = u + w;
+    const u64 c = s < u ? (u64)1 << 34 : 0;
+    const u64 x = mad_u64_u32(m2, p1, hh) + ((s >> 30) | c);
+    const u32 x0 = (u32)x & M;
+    const u32 m3 = (x0 * n30) & M;
+    const u64 r = mad_u64_u32(m3, p1, x >> 30) + (mad_u64_u32(m3, p0, (u64)x0) >> 30);
+    return csub(r, p);
+}
+
 // Butterflies on the [0,8q) / [0,4q) lazy ranges that shoup_lazy4 needs (q < 2^61). q4 = 4q.
 // CT: X,Y in [0,8q) -> [0,8q)
 PHA_HD void ct_bfly4(u64 &X, u64 &Y, u64x2 w, u64 q4, u64 nq) {

@@ -336,7 +336,7 @@ uint32_t Context::add_aux_moduli(const std::vector<u64> &ntt_primes, u64 table_l
 }
 
 void describe_conv(const BConv &b, DevBuf<BConvDev> &out) {
-    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz, 0xffffffffu, 0, 0, 0, b.row_pad}});
+    out.upload({BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz, 0xffffffffu, 0, 0, 0, b.row_pad, b.r90 ? 1u : 0u}});
 }
 
 // DRNSTool constructor, HPS multiply part (src/rns.cu:687-790; converters src/host/rns.cu:282-337,438-466).
@@ -684,6 +684,9 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
     for (uint32_t row : ip) sum_q += c.primes[row];
     b.mont = b.split_kind == 1 || (b.split_kind != 0 && (sum_q >> 64) == 0);
     for (uint32_t j = 0; j < b.osz; j++) b.mont = b.mont && (c.primes[op[j]] & 1);
+    // r06: with at most 15 inputs and the 30 / 30 cuts the kernels reduce word by word in base 2^30 straight from the four split
+    // accumulators (mont_redc90_split, pha_arith.h): the rows then carry 2^90.  A sixteenth term would overflow its first step.
+    b.r90 = b.mont && b.split_kind == 1 && widest <= 15;
     std::vector<u64> oninv(b.osz, 0);
     if (b.mont)
         for (uint32_t j = 0; j < b.osz; j++) {
@@ -700,6 +703,7 @@ static void upload_bconv(Context &c, BConv &b, const std::vector<uint32_t> &ip, 
                 if (b.mont) {
                     const u64 pj = c.primes[op[j]];
                     m = (u64)((((unsigned __int128)m) << 64) % pj);
+                    if (b.r90) m = (u64)((((unsigned __int128)m) << 26) % pj);   // 2^64 * 2^26 = 2^90
                 }
                 mat30[((size_t)j * b.row_pad + i) * 2] = (uint32_t)(m & ((1u << sm) - 1));
                 mat30[((size_t)j * b.row_pad + i) * 2 + 1] = (uint32_t)(m >> sm);
@@ -847,7 +851,7 @@ Tool &Context::tool(uint32_t size_ql) {
         // device descriptors for the batched launches
         auto describe = [](const BConv &b, uint32_t pad_start, uint32_t pad_len, uint32_t src_limb, uint32_t copy_own) {
             return BConvDev{b.hat_inv.p, b.d_iprime.p, b.d_oprime.p, b.mat.p, b.mat30.p, b.mont ? b.oninv.p : nullptr, b.isz, b.osz,
-                            pad_start, pad_len, src_limb, copy_own, b.row_pad};
+                            pad_start, pad_len, src_limb, copy_own, b.row_pad, b.r90 ? 1u : 0u};
         };
         std::vector<BConvDev> dd;
         for (uint32_t b = 0; b < t->beta; b++) {

@@ -120,6 +120,7 @@ struct BConvDev {
     uint32_t src_limb;           // first input limb inside the source polynomial
     uint32_t copy_own;           // mod-up: also copy the digit's own limbs [src_limb, src_limb+isz) verbatim
     uint32_t row_pad;            // row pitch (entries) of mat30: kBcRowPad, or 32 for 17..32 inputs (split kinds 2, 3)
+    uint32_t r90;                // r06: the Montgomery rows carry 2^90 instead of 2^64 (<= 15 inputs, 30 / 30 cuts): mont_redc90_split
 };
 
 
@@ -131,6 +132,7 @@ struct BConv {
     DevBuf<uint32_t> mat30;                // [osz][kBcRowPad][2] 30-bit halves of mat (Montgomery form when mont), zero-padded rows
     DevBuf<u64> oninv;                     // [osz] -p_j^-1 mod 2^64
     bool mont = false;                     // every output modulus is odd: the split kernel reduces with Montgomery
+    bool r90 = false;                      // r06: Montgomery radix 2^90, reduced word by word from the split accumulators (pha_arith.h mont_redc90_split)
     // which carry-free split the constants in mat30 were cut for (0: none): 1 = inputs and matrix entries in 30-bit halves
     // (<= 16 inputs, every prime <= 60 bits); 2 = inputs cut at 30 bits, entries at 31 (<= 32 inputs of <= 60 bits, outputs
     // <= 62 bits: Q -> Bsk / Q -> R of the BFV multiply, whose auxiliary primes are 61 bits wide); 3 = the mirror (31, 30)

@@ -1260,6 +1260,7 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
     const uint32_t ci = z % m.beta, grp = z / m.beta;
     const BConvDev &d = m.convs[ci];
     const uint32_t n = 1u << k.log_n, isz = d.isz, osz = d.osz, pitch = d.row_pad;
+    const bool r90 = uni32(d.r90) != 0;
     for (uint32_t e = tid; e < osz * kBcRowPad; e += C::THREADS) {
         const uint32_t j = e / kBcRowPad, i = e % kBcRowPad;
         s_rows[e] = i < pitch ? reinterpret_cast<const uint2 *>(d.mat30)[j * pitch + i] : uint2{0u, 0u};
@@ -1364,6 +1365,12 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
                         hl[kk] = (u64)y1 * mm.x + hl[kk];
                         hh[kk] = (u64)y1 * mm.y + hh[kk];
                     }
+                }
+                if (r90) {   // (uniform) rows carry 2^90: word-wise REDC from the accumulators (pha_arith.h)
+                    const u32 p0 = (u32)p & 0x3fffffffu, p1 = (u32)(p >> 30);
+#pragma unroll
+                    for (int kk = 0; kk < CH; kk++) reg[k0 + kk] = mont_redc90_split(ll[kk], lh[kk], hl[kk], hh[kk], p, p0, p1, (u32)oninv);
+                    continue;
                 }
 #pragma unroll
                 for (int kk = 0; kk < CH; kk++) {

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     const uint32_t j0 = blockIdx.y * L.out_per_block;
     const uint32_t j1 = min(j0 + L.out_per_block, osz);
     const bool mont = SPLIT && d.oninv != nullptr;
+    const bool r90 = mont && SY == 30 && SM == 30 && d.r90 != 0;   // (uniform) word-wise REDC from the split accumulators
     // Everything the output loop needs per output prime goes through LDS once per workgroup: the matrix rows (SPLIT:
     // out_per_block x 16 entries of two dwords, read back as broadcast ds_read_b64) and the prime's constants and
     // destination limb.  (r02: the loop used to fetch oprime[j] and then mod[oprime[j]] from global memory for every
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         const DModulus m = L.mod[d.oprime[j]];
         s_p[threadIdx.x] = m.value;
         s_c0[threadIdx.x] = mont ? d.oninv[j] : m.ratio0;   // Montgomery: -p^-1 mod 2^64; Barrett: floor(2^128 / p)
-        s_c1[threadIdx.x] = m.ratio1;
+        // r06 (2^90 rows): the 30-bit halves of p ride in the Barrett word the Montgomery branch does not use
+        s_c1[threadIdx.x] = r90 ? ((m.value >> 30) << 32) | (m.value & 0x3fffffffu) : m.ratio1;
         const uint32_t jo = j + (j >= d.pad_start ? d.pad_len : 0);
         s_jo[threadIdx.x] = jo;
         if (L.epi_cx) s_e[threadIdx.x] = L.epi_cst[jo];
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
     const uint32_t count = j1 - j0;
     const u64 *hps_row = L.hps_inv ? L.hps_alpha + (size_t)llround(hps_frac) * osz + j0 : nullptr;
     for (uint32_t e = 0; e < count; e++) {
-        u64 lo, hi;
+        u64 lo = 0, hi = 0, r = 0;
+        bool reduced = false;
         if (SPLIT) {
             // rows are zero-padded to ROWPAD entries, and y[i] = 0 beyond isz: no per-term branch
             const uint2 *row = s_rows + e * ROWPAD;
@@ -152,17 +155,23 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
                     hl = (u64)y1 * m0 + hl;
                     hh = (u64)y1 * m1 + hh;
                 }
-                // value = ll + (lh + hl) * 2^30 + hh * 2^60   (mid < 2^65: keep its carry)
-                const u64 mid = lh + hl;
-                const u64 mid_c = mid < lh ? 1 : 0;
-                lo = ll;
-                hi = 0;
-                const u64 t1 = mid << 30;
-                lo += t1;
-                hi += (lo < t1) + (mid >> 34) + (mid_c << 30);
-                const u64 t2 = hh << 60;
-                lo += t2;
-                hi += (lo < t2) + (hh >> 4);
+                if (r90) {   // rows carry 2^90: three 30-bit REDC steps on the accumulators as they stand
+                    const u64 pp = s_c1[e];
+                    r = mont_redc90_split(ll, lh, hl, hh, s_p[e], (u32)pp, (u32)(pp >> 32), (u32)s_c0[e]);
+                    reduced = true;
+                } else {
+                    // value = ll + (lh + hl) * 2^30 + hh * 2^60   (mid < 2^65: keep its carry)
+                    const u64 mid = lh + hl;
+                    const u64 mid_c = mid < lh ? 1 : 0;
+                    lo = ll;
+                    hi = 0;
+                    const u64 t1 = mid << 30;
+                    lo += t1;
+                    hi += (lo < t1) + (mid >> 34) + (mid_c << 30);
+                    const u64 t2 = hh << 60;
+                    lo += t2;
+                    hi += (lo < t2) + (hh >> 4);
+                }
             } else {
                 // halves of up to 30 / 31 bits: partial products below 2^61, so the four sums are folded into the 128-bit
                 // total every 8 terms: value += ll + lh * 2^SM + hl * 2^SY + hh * 2^(SY + SM)
@@ -205,8 +214,8 @@ __global__ __launch_bounds__(kBcThreads) void bconv_kernel(const BConvLaunch L) 
         // SPLIT rows are in Montgomery form when the converter has oninv (uniform): sum_i y_i * (qhat_i 2^64) < 16 * 2^60 * p
         // = 2^64 p, and REDC brings it to sum_i y_i * qhat_i mod p with a third of Barrett-128's multiplies
         const u64 p = s_p[e];
-        u64 r;
-        if (mont) r = mont_redc128(lo, hi, p, s_c0[e]);
+        if (reduced) {}
+        else if (mont) r = mont_redc128(lo, hi, p, s_c0[e]);
         else r = barrett128(lo, hi, DModulus{p, s_c0[e], s_c1[e]});
         if (hps_row) r = sub_mod(r, hps_row[e], p);
         const size_t id = (size_t)s_jo[e] * n + coeff;
@@ -349,6 +358,8 @@ __global__ __launch_bounds__(kBcThreads) void bconv_rescale_kernel(const BConvRe
     // rows / constants of this group's outputs, plus (slot out_per_block) those of the last data limb
     __shared__ uint2 s_rows[(kBcMaxOutPerBlock + 1) * kBcRowPad];
     __shared__ u64 s_p[kBcMaxOutPerBlock + 1], s_c0[kBcMaxOutPerBlock + 1], s_c1[kBcMaxOutPerBlock + 1];
+    __shared__ uint2 s_pp[kBcMaxOutPerBlock + 1];   // r06: the 30-bit halves of p (mont_redc90_split)
+    const bool r90 = d.r90 != 0;                    // (uniform) the rows carry 2^90
     for (uint32_t e = threadIdx.x; e < (L.out_per_block + 1) * kBcRowPad; e += kBcThreads) {
         const uint32_t slot = e / kBcRowPad, i = e % kBcRowPad;
         const uint32_t j = slot == L.out_per_block ? nl : j0 + slot;
@@ -361,6 +372,7 @@ __global__ __launch_bounds__(kBcThreads) void bconv_rescale_kernel(const BConvRe
             s_p[threadIdx.x] = m.value;
             s_c0[threadIdx.x] = d.oninv[j];
             s_c1[threadIdx.x] = m.ratio1;
+            s_pp[threadIdx.x] = uint2{(uint32_t)(m.value & 0x3fffffffu), (uint32_t)(m.value >> 30)};
         }
     }
     __syncthreads();
@@ -382,6 +394,10 @@ __global__ __launch_bounds__(kBcThreads) void bconv_rescale_kernel(const BConvRe
             lh = (u64)ylo[i] * mm.y + lh;
             hl = (u64)yhi[i] * mm.x + hl;
             hh = (u64)yhi[i] * mm.y + hh;
+        }
+        if (r90) {
+            const uint2 pp = s_pp[slot];
+            return mont_redc90_split(ll, lh, hl, hh, s_p[slot], pp.x, pp.y, (u32)s_c0[slot]);
         }
         const u64 mid = lh + hl, mid_c = mid < lh ? 1 : 0;
         u64 lo = ll, hi = 0;

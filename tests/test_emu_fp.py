@@ -28,6 +28,8 @@ def emu(tmp_path_factory):
     L.emu_fp_mulmod.argtypes = [C.c_uint64, C.c_size_t, u64p, u64p, C.c_int, C.c_int, u64p]
     L.emu_fp_light_bound.argtypes = [C.c_uint64, C.c_size_t, u64p, u64p, C.c_int]
     L.emu_fp_light_bound.restype = C.c_uint64
+    L.emu_redc90.argtypes = [C.c_uint64, C.c_size_t] + [u64p] * 5
+    L.emu_split_acc.argtypes = [C.c_size_t, C.c_size_t] + [u64p] * 6
     return L
 
 
@@ -90,3 +92,58 @@ def test_mulmod_forms_on_lazy_inputs(emu, bits, shift):
         worst = emu.emu_fp_light_bound(q, x.shape[1], p(x[0]), p(x[1]), shift) / 1048576.0
         m = max(abs(shift), abs(shift + 1))            # |Y| <= m q
         assert worst <= 0.5 + 1.5 * m * q / 2.0 ** 52 + 1e-5, (q, shift, worst)
+
+
+# ---- r06: mont_redc90_split, the word-wise Montgomery reduction of the base conversion's split accumulators ----------------------
+def _redc90_expect(ll, lh, hl, hh, q):
+    inv = pow(1 << 90, -1, q)
+    v = ll.astype(object) + ((lh.astype(object) + hl.astype(object)) << 30) + (hh.astype(object) << 60)
+    return v * inv % q
+
+
+REDC_PRIMES = [(1 << 60) - 93, 1152921504606584833, 1125899906826241, (1 << 50) - 27, (1 << 40) - 87, (1 << 31) - 1, 1073741827, 65537, 12289, 3]
+
+
+@pytest.mark.parametrize("q", REDC_PRIMES)
+@pytest.mark.parametrize("terms", [1, 2, 8, 14, 15])
+def test_redc90_on_conversion_sums(emu, q, terms):
+    """sum_i y_i * row_i accumulated as the kernels do (30-bit halves, four 64-bit sums), y_i below 2^60 (any input prime up to
+    60 bits), row_i in [0, q): the function returns sum * 2^-90 mod q, canonical -- for every modulus size the converters meet
+    (60-bit special primes, 50-bit data primes, a BFV plain modulus) and every corner of the inputs."""
+    r = rng_for(q % 1000003 + terms)
+    count = 20_000
+    top = (1 << 60) - 1
+    y = r.integers(0, 1 << 60, (terms, count), dtype=np.uint64)
+    y[:, 0] = top                                   # every half at its maximum
+    y[:, 1] = 0
+    y[:, 2] = (1 << 30) - 1
+    y[:, 3] = ((1 << 30) - 1) << 30
+    y[:, 4] = 1 << 30
+    y = np.ascontiguousarray(y)
+    for rows in ([q - 1] * terms, [1] * terms, [int(x) for x in r.integers(0, q, terms, dtype=np.uint64)],
+                 [q - 1 - int(x) for x in r.integers(0, min(q, 1 << 20), terms, dtype=np.uint64)]):
+        m = np.array(rows, dtype=np.uint64)
+        acc = [np.zeros(count, dtype=np.uint64) for _ in range(4)]
+        emu.emu_split_acc(terms, count, p(y), p(m), *[p(a) for a in acc])
+        out = np.zeros(count, dtype=np.uint64)
+        emu.emu_redc90(q, count, *[p(a) for a in acc], p(out))
+        want = (y.astype(object) * m.astype(object)[:, None]).sum(axis=0) * pow(1 << 90, -1, q) % q
+        assert np.array_equal(out.astype(object), want)
+        assert np.array_equal(out.astype(object), _redc90_expect(*acc, q))
+
+
+@pytest.mark.parametrize("q", [(1 << 60) - 93, 1152921504606584833, (1 << 59) + 21])
+def test_redc90_at_the_accumulator_bound(emu, q):
+    """The overflow argument in pha_arith.h: every accumulator at its ceiling 15 (2^30 - 1)^2 (no row below q reaches it; the
+    function must not wrap there all the same), neighbours of it, and random accumulators below it, with a 60-bit modulus
+    (V < 2^124 = 2^64 * 2^60 keeps the result below 2q)."""
+    assert q % 2 == 1
+    h2 = 15 * ((1 << 30) - 1) ** 2
+    r = rng_for(7)
+    cs = [h2, h2 - 1, h2 - ((1 << 30) - 1), h2 >> 1, (1 << 63) + 12345, 0, 1, (1 << 30) - 1, 1 << 30, (1 << 34) - 1]
+    grid = np.array(list(itertools.product(cs, repeat=4)), dtype=np.uint64)
+    rnd = r.integers(0, h2 + 1, (100_000, 4), dtype=np.uint64)
+    x = np.ascontiguousarray(np.concatenate([grid, rnd]).T)
+    out = np.zeros(x.shape[1], dtype=np.uint64)
+    emu.emu_redc90(q, x.shape[1], p(x[0]), p(x[1]), p(x[2]), p(x[3]), p(out))
+    assert np.array_equal(out.astype(object), _redc90_expect(x[0], x[1], x[2], x[3], q))
