@@ -23,10 +23,30 @@ struct EwArgs {
     const FpInfo *fpinfo;     // [prime]: limbs below 2^50 form the tensor product in FP64 (r04)
 };
 
-enum EwOp { EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_MULADD, EW_MULSCALAR, EW_TENSOR, EW_SQUARE };
+// EW_TENSOR_NT (r06): the tensor product of a BATCH of ciphertexts: every word is read once and written once and the batch is larger
+// than the MALL from two ciphertexts on (161 MB per pair at C3), so its loads and stores are nontemporal -- they stream past the L2 / MALL
+// contents the neighbouring kernels live on.  One box, batched HomMul + relinearize + rescale with this and the batched inner product's
+// streams nontemporal: 279.3 / 277.9 -> 275.5 / 274.8 us per op at B = 32, 283.8 / 281.7 -> 277.9 / 275.6 at B = 8
+// (profiles/r06_experiments.md section 7).  A single ciphertext keeps the default policy: its c2 is read back from the MALL right away.
+enum EwOp { EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_MULADD, EW_MULSCALAR, EW_TENSOR, EW_SQUARE, EW_TENSOR_NT };
 
-__device__ __forceinline__ u64x2 ld2(const u64 *p) { return *reinterpret_cast<const u64x2 *>(p); }
-__device__ __forceinline__ void st2(u64 *p, u64x2 v) { *reinterpret_cast<u64x2 *>(p) = v; }
+typedef unsigned long long ew_v2 __attribute__((ext_vector_type(2)));
+template <bool NT = false>
+__device__ __forceinline__ u64x2 ld2(const u64 *p) {
+    if (NT) {
+        const ew_v2 t = __builtin_nontemporal_load(reinterpret_cast<const ew_v2 *>(p));
+        return u64x2{t.x, t.y};
+    }
+    return *reinterpret_cast<const u64x2 *>(p);
+}
+template <bool NT = false>
+__device__ __forceinline__ void st2(u64 *p, u64x2 v) {
+    if (NT) {
+        __builtin_nontemporal_store(ew_v2{v.x, v.y}, reinterpret_cast<ew_v2 *>(p));
+        return;
+    }
+    *reinterpret_cast<u64x2 *>(p) = v;
+}
 
 template <int OP>
 __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
@@ -60,11 +80,12 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
         const u64x2 w{k.s0[limb], k.s1[limb]};
         u64x2 x = ld2(k.a + idx);
         st2(k.r + idx, u64x2{shoup(x.x, w, q), shoup(x.y, w, q)});
-    } else if (OP == EW_TENSOR) {  // tensor_prod_2x2_rns_poly :463-496; blockIdx.z walks a batch of ciphertexts (r04: one launch)
+    } else if (OP == EW_TENSOR || OP == EW_TENSOR_NT) {  // tensor_prod_2x2_rns_poly :463-496; blockIdx.z walks a batch of ciphertexts (r04: one launch)
         const size_t z = blockIdx.z;
         const u64 *ka = k.a + z * k.za, *kb = k.b + z * k.zb;
         u64 *kr = k.r + z * k.zr, *kr2 = k.r2 ? k.r2 + z * k.zr2 : nullptr;
-        u64x2 c00 = ld2(ka + idx), c01 = ld2(ka + idx + rc), c10 = ld2(kb + idx), c11 = ld2(kb + idx + rc);
+        constexpr bool NT = OP == EW_TENSOR_NT;
+        u64x2 c00 = ld2<NT>(ka + idx), c01 = ld2<NT>(ka + idx + rc), c10 = ld2<NT>(kb + idx), c11 = ld2<NT>(kb + idx + rc);
         u64x2 d0, d1, d2;
         if (k.fpinfo && k.fpinfo[k.mod_start + limb].ok) {   // (uniform) r04: three exact FP64 products (fp_tensor_2x2, pha_arith.h) instead of
             // three Barrett-128 multiplies on 32-bit halves (~115 vector instructions per coefficient -> ~50); the same residues as :487-:494
@@ -74,9 +95,9 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
             fp_tensor_2x2(c00.x, c01.x, c10.x, c11.x, fm, e[0], e[1], e[2]);
             fp_tensor_2x2(c00.y, c01.y, c10.y, c11.y, fm, e[3], e[4], e[5]);
             d0 = u64x2{e[0], e[3]}; d1 = u64x2{e[1], e[4]}; d2 = u64x2{e[2], e[5]};
-            st2(kr + idx, d0);
-            st2(kr + idx + rc, d1);
-            st2(kr2 ? kr2 + idx : kr + idx + 2 * rc, d2);
+            st2<NT>(kr + idx, d0);
+            st2<NT>(kr + idx + rc, d1);
+            st2<NT>(kr2 ? kr2 + idx : kr + idx + 2 * rc, d2);
             return;
         }
         d0.x = mul_mod(c00.x, c10.x, m); d0.y = mul_mod(c00.y, c10.y, m);
@@ -86,9 +107,9 @@ __global__ __launch_bounds__(kEwThreads) void ew_kernel(const EwArgs k) {
         d1.y = mul_mod(c00.y + c01.y, c10.y + c11.y, m);
         d1.x = csub(csub(d1.x + 2 * q - d0.x - d2.x, q), q);
         d1.y = csub(csub(d1.y + 2 * q - d0.y - d2.y, q), q);
-        st2(kr + idx, d0);
-        st2(kr + idx + rc, d1);
-        st2(kr2 ? kr2 + idx : kr + idx + 2 * rc, d2);
+        st2<NT>(kr + idx, d0);
+        st2<NT>(kr + idx + rc, d1);
+        st2<NT>(kr2 ? kr2 + idx : kr + idx + 2 * rc, d2);
     } else if (OP == EW_SQUARE) {  // tensor_square_2x2_rns_poly :500-529
         u64x2 c0 = ld2(k.a + idx), c1 = ld2(k.a + idx + rc);
         u64x2 d0, d1, d2;
@@ -258,7 +279,8 @@ int pha_tensor_prod_2x2_batched(pha_context_t ctx, const uint64_t *op1, const ui
     k.a = op1; k.b = op2; k.r = res01; k.r2 = res2;
     k.za = k.zb = k.zr = 2 * ln;
     k.zr2 = ln;
-    launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream), batch);
+    if (batch >= 2) launch_ew<EW_TENSOR_NT>(ctx->c, k, cms, 0, as_stream(stream), batch);
+    else launch_ew<EW_TENSOR>(ctx->c, k, cms, 0, as_stream(stream), batch);
     PHA_API_END
 }
 int pha_tensor_square_2x2_rns_poly(pha_context_t ctx, const uint64_t *op, uint64_t *res, size_t cms,

@@ -497,6 +497,8 @@ __global__ __launch_bounds__(256) void inner_prod_kernel(const InnerArgs k) {
 
 // Batch of ciphertexts against ONE key: the key limbs are read once and stay in registers while the kernel
 // walks the ciphertexts (the inner product is HBM-bound and 2/3 of its bytes are the key).
+// r06: the digits are read once and the sums written once, in a launch that moves 157 MB per ciphertext: nontemporal loads and
+// stores (33.6 -> 32.0 us per op at B = 32; see EW_TENSOR_NT in pha_poly.hip).
 template <int BETA>
 __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs k, uint32_t batch) {
     const uint32_t nid = blockIdx.y;
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
             double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
             for (int i = 0; i < BETA; i++) {
-                const u64x2 v = *reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n);
+                const u64x2 v = gload2<true>(reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n));
                 const double vx = fp_from_canon(v.x), vy = fp_from_canon(v.y);
                 a0 += fp_mulmod_light(vx, kbx[i], fm);
                 a1 += fp_mulmod_light(vy, kby[i], fm);
@@ -539,8 +541,8 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
             u64x2 r0{fp_to_canon(a0, fm), fp_to_canon(a1, fm)};
             u64x2 r1{fp_to_canon(b0, fm), fp_to_canon(b1, fm)};
             inner_fix(k, nid, m, coeff, b, r0, r1);
-            *reinterpret_cast<u64x2 *>(cx) = r0;
-            *reinterpret_cast<u64x2 *>(cx + k.qlp_n) = r1;
+            gstore2<true>(reinterpret_cast<u64x2 *>(cx), r0);
+            gstore2<true>(reinterpret_cast<u64x2 *>(cx + k.qlp_n), r1);
         }
         return;
     }
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
         u64 a0l = 0, a0h = 0, a1l = 0, a1h = 0, b0l = 0, b0h = 0, b1l = 0, b1h = 0;
 #pragma unroll
         for (int i = 0; i < BETA; i++) {
-            const u64x2 v = *reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n);
+            const u64x2 v = gload2<true>(reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n));
             mac128(v.x, kb[i].x, a0l, a0h);
             mac128(v.y, kb[i].y, a1l, a1h);
             mac128(v.x, ka[i].x, b0l, b0h);
@@ -559,8 +561,8 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
         u64x2 r0{barrett128(a0l, a0h, m), barrett128(a1l, a1h, m)};
         u64x2 r1{barrett128(b0l, b0h, m), barrett128(b1l, b1h, m)};
         inner_fix(k, nid, m, coeff, b, r0, r1);
-        *reinterpret_cast<u64x2 *>(cx) = r0;
-        *reinterpret_cast<u64x2 *>(cx + k.qlp_n) = r1;
+        gstore2<true>(reinterpret_cast<u64x2 *>(cx), r0);
+        gstore2<true>(reinterpret_cast<u64x2 *>(cx + k.qlp_n), r1);
     }
 }
 
