@@ -459,6 +459,12 @@ struct InnerArgs {
     const u64 *fix_ct;       // ct [2][Ql][N] of the (first) ciphertext
     size_t fix_ct_stride;    // Ql * N
     const FpInfo *fpinfo;    // [prime]: limbs below 2^50 form their sums in FP64 (batched kernel, r04)
+    // r06 (batched kernel, NTT-form schemes): digit i's own limbs [i * alpha, min((i + 1) * alpha, ql)) are read from c2 where they lie
+    // (own + b * own_stride) instead of from a verbatim copy inside t_mod_up, which the mod-up then does not make (modup's
+    // own_in_place): 2 x 22.5 MiB per ciphertext at C3 that only moved data.  null = the copy is there (pha_modup's callers).
+    const u64 *own;
+    size_t own_stride;
+    uint32_t alpha, ql;
 };
 __device__ __forceinline__ void inner_fix(const InnerArgs &k, uint32_t nid, const DModulus &m, size_t coeff, uint32_t b,
                                           u64x2 &r0, u64x2 &r1) {
@@ -514,6 +520,9 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
         kb[i] = *reinterpret_cast<const u64x2 *>(key + evk_id);
         ka[i] = *reinterpret_cast<const u64x2 *>(key + evk_id + k.qp_n);
     }
+    bool mine[BETA];   // (uniform) digit i holds this limb itself: its NTT form is c2's own
+#pragma unroll
+    for (int i = 0; i < BETA; i++) mine[i] = k.own != nullptr && nid < k.ql && nid >= (uint32_t)i * k.alpha && nid < ((uint32_t)i + 1) * k.alpha;
     if (k.fpinfo && k.fpinfo[twr].ok) {   // (uniform) r04: limbs below 2^50 -- every product an exact fp_mulmod_light (digits and key
         // words are canonical: a product is below 0.875 q, BETA <= 4 of them below 3.5 q), one fp_to_canon per sum: ~125 FP64
         // operations per ciphertext and thread where four 128-bit accumulators and four Barrett reductions take ~260
@@ -527,11 +536,12 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
         }
         for (uint32_t b = 0; b < batch; b++) {
             const u64 *mu = k.t_mod_up + (size_t)b * BETA * k.qlp_n + c2_id;
+            const u64 *own = k.own + (size_t)b * k.own_stride + c2_id;
             u64 *cx = k.cx + (size_t)b * 2 * k.qlp_n + c2_id;
             double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
             for (int i = 0; i < BETA; i++) {
-                const u64x2 v = gload2<true>(reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n));
+                const u64x2 v = gload2<true>(reinterpret_cast<const u64x2 *>(mine[i] ? own : mu + (size_t)i * k.qlp_n));
                 const double vx = fp_from_canon(v.x), vy = fp_from_canon(v.y);
                 a0 += fp_mulmod_light(vx, kbx[i], fm);
                 a1 += fp_mulmod_light(vy, kby[i], fm);
@@ -548,11 +558,12 @@ __global__ __launch_bounds__(256) void inner_prod_batched_kernel(const InnerArgs
     }
     for (uint32_t b = 0; b < batch; b++) {
         const u64 *mu = k.t_mod_up + (size_t)b * BETA * k.qlp_n + c2_id;
+        const u64 *own = k.own + (size_t)b * k.own_stride + c2_id;
         u64 *cx = k.cx + (size_t)b * 2 * k.qlp_n + c2_id;
         u64 a0l = 0, a0h = 0, a1l = 0, a1h = 0, b0l = 0, b0h = 0, b1l = 0, b1h = 0;
 #pragma unroll
         for (int i = 0; i < BETA; i++) {
-            const u64x2 v = gload2<true>(reinterpret_cast<const u64x2 *>(mu + (size_t)i * k.qlp_n));
+            const u64x2 v = gload2<true>(reinterpret_cast<const u64x2 *>(mine[i] ? own : mu + (size_t)i * k.qlp_n));
             mac128(v.x, kb[i].x, a0l, a0h);
             mac128(v.y, kb[i].y, a1l, a1h);
             mac128(v.x, ka[i].x, b0l, b0h);
@@ -1242,8 +1253,10 @@ static bool ntt_domain_scheme(int scheme) {
 // returns true; on false (shape without a fused form) nothing but the conversion has happened... the caller must not rely on
 // that: it passes fused_ip only when fusable_ip() says so.
 static bool fusable_ip(Context &c, Tool &t) { return t.alpha > 1 && c.log_n >= 14 && c.log_n <= 17 && t.beta <= 4; }
+// own_in_place (r06; NTT-form schemes, batched key switches): the digits' own limbs are NOT copied into dst -- the caller's inner product
+// reads them from cks (InnerArgs::own); dst's own-limb rows stay unwritten and nothing reads them (the forward transform skips them)
 static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64 *t_cks, hipStream_t s,
-                  uint32_t batch = 1, size_t cks_stride = 0, const ModupIpArgs *fused_ip = nullptr) {
+                  uint32_t batch = 1, size_t cks_stride = 0, const ModupIpArgs *fused_ip = nullptr, bool own_in_place = false) {
     const size_t n = c.n;
     const uint32_t ql = t.size_ql, qlp = t.size_qlp, alpha = t.alpha;
     const bool ntt_dom = ntt_domain_scheme(scheme);
@@ -1295,7 +1308,7 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         // r05: NTT-form input, N = 2^16, the separate (batched) inner product: the conversion is the load of the forward
         // transform's strided pass (modup_conv_strided, pha_ntt.hip); the transform then runs its contiguous pass only
         if (ntt_dom && !fused_ip) {
-            const ModupConvArgs mc{t.d_digit_convs.p, t.beta, t_cks, (size_t)ql * n, cks, cks_stride, alpha, max_osz, mont_split};
+            const ModupConvArgs mc{t.d_digit_convs.p, t.beta, t_cks, (size_t)ql * n, own_in_place ? nullptr : cks, cks_stride, alpha, max_osz, mont_split};
             if (modup_conv_strided(c, dst, sel, x, mc, s)) {
                 x.first_pass_done = true;
                 ntt_forward(c, dst, dst, dst, sel, EPI_FWD_CANON, x, s);
@@ -1306,7 +1319,7 @@ static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64
         //  for the verbatim copy of the digit's own limbs)
         // (fused inner product, NTT-form input: the own limbs are read from c2 by the fused pass, no copy)
         launch_bconv(c, t.d_digit_convs.p, 1, t.beta * batch, alpha, max_osz, t.modup_split, dst, (size_t)qlp * n,
-                     ntt_dom ? t_cks : cks, 0, (fused_ip && ntt_dom) ? nullptr : cks, !ntt_dom, s, batch > 1 ? t.beta : 0,
+                     ntt_dom ? t_cks : cks, 0, ((fused_ip || own_in_place) && ntt_dom) ? nullptr : cks, !ntt_dom, s, batch > 1 ? t.beta : 0,
                      ntt_dom ? (size_t)ql * n : cks_stride, nullptr, cks_stride);
     }
     if (fused_ip) {
@@ -1328,7 +1341,7 @@ static u64 h_invmod_p(Context &c, uint32_t limb) {
 
 // mod-up + inner product of ONE ciphertext: the fused form where the shape has one, else the two steps.  fix_ct as in inner_prod.
 static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s, uint32_t batch = 1,
-                       const u64 *fix_ct = nullptr);
+                       const u64 *fix_ct = nullptr, const u64 *own = nullptr, size_t own_stride = 0);
 // fold_inverse (ckks forms): the fused kernel also runs the contiguous pass of the mod-down's inverse transform on the special limbs
 // (and on the last data limb when fix_ct is given, the fused rescale); returns true when it did -- the caller then launches that
 // inverse with NttExtra::second_pass_only.
@@ -1362,12 +1375,14 @@ static bool modup_inner_prod(Context &c, Tool &t, u64 *cx, u64 *t_mod_up, const 
 // phantom::key_switch_inner_prod eval_key_switch.cu:71-92
 // fix_ct != null (pha_keyswitch_rescale): cx's last data limb receives ct_last + cx_last * P^-1 (see InnerArgs)
 static void inner_prod(Context &c, Tool &t, u64 *cx, const u64 *t_mod_up, const u64 *const *rlk, hipStream_t s,
-                       uint32_t batch, const u64 *fix_ct) {
+                       uint32_t batch, const u64 *fix_ct, const u64 *own, size_t own_stride) {
     InnerArgs k{};
     k.cx = cx; k.t_mod_up = t_mod_up; k.evks = rlk; k.mod = c.d_mod.p; k.qlp_prime = t.d_qlp_prime.p;
     k.n = (uint32_t)c.n; k.beta = t.beta; k.qlp_n = (size_t)t.size_qlp * c.n; k.qp_n = (size_t)c.size_qp * c.n;
     k.fix_limb = 0xffffffffu;
     k.fpinfo = c.d_fpinfo.p;
+    if (own && !(batch > 1 && t.beta <= 4)) throw std::logic_error("inner_prod: own limbs in place need the batched kernel");
+    k.own = own; k.own_stride = own_stride; k.alpha = t.alpha; k.ql = t.size_ql;
     if (fix_ct) {
         const u64 pinv_last = h_invmod_p(c, t.size_ql - 1);
         k.fix_limb = t.size_ql - 1;
@@ -1533,8 +1548,9 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
     if (B == 1) {
         folded = modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, PHA_SCHEME_CKKS, tmp, s, ct, true);   // cx_last <- ct_last + cx_last * P^-1
     } else {
-        modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B);
-        inner_prod(c, t, cx, t_mod_up, rlk, s, B, ct);
+        const bool in_place = t.alpha > 1 && t.beta <= 4;   // the batched inner product reads the digits' own limbs from c2
+        modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B, 0, nullptr, in_place);
+        inner_prod(c, t, cx, t_mod_up, rlk, s, B, ct, in_place ? c2 : nullptr, ql_n);
     }
     {   // coefficient form of the P limbs (x phat_i^-1, bconv phase 1) and of the last data limb, both polynomials, one launch pair
         NttExtra xb;
@@ -1698,8 +1714,10 @@ int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *c
     // scratch: t_cks / delta [B][2][Ql][N] | t_mod_up [B][beta][QlP][N] | cx [B][2][QlP][N]
     u64 *base = c.scratch(stream, B * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n));
     u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n;
-    modup(c, t, t_mod_up, c2, scheme, tmp, s, B);
-    inner_prod(c, t, cx, t_mod_up, rlk, s, B);
+    // (NTT-form schemes, B > 1: the batched inner product reads the digits' own limbs from c2, the mod-up does not copy them)
+    const bool in_place = ntt_domain_scheme(scheme) && B > 1 && t.alpha > 1 && t.beta <= 4;
+    modup(c, t, t_mod_up, c2, scheme, tmp, s, B, 0, nullptr, in_place);
+    inner_prod(c, t, cx, t_mod_up, rlk, s, B, nullptr, in_place ? c2 : nullptr, ql_n);
     // 2B polynomials: ct [B][2][Ql][N] and cx [B][2][QlP][N] are uniformly strided
     moddown_from_ntt(c, t, ct, ql_n, cx, qlp_n, 2 * B, scheme, true, tmp, s);
     PHA_API_END
