@@ -14,7 +14,7 @@ W = 8 * N   # bytes of one limb
 def stages_for(B, fused_conv):
     # (label, number of launches, name fragments any of which every launch must carry, algorithmic bytes PER OP)
     if fused_conv:   # r05: modup_conv_s1_kernel = the conversion as the load of the forward transform's strided pass; then the contiguous pass
-        modup = [("mod-up: base conversion of 3 digits FUSED with the strided pass of the forward NTT of the converted limbs (+ own-limb copy)", 1,
+        modup = [("mod-up: base conversion of 3 digits FUSED with the strided pass of the forward NTT of the converted limbs (r06: no own-limb copy, the inner product reads those limbs from c2)", 1,
                   ("modup_conv_s1",), BETA * (ALPHA + QL) * W + BETA * QL * W),
                  ("mod-up: forward NTT of the converted limbs, contiguous pass", 1, ("ntt_",), BETA * QL * W)]
     else:
