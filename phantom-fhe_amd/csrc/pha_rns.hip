@@ -1253,6 +1253,11 @@ static bool ntt_domain_scheme(int scheme) {
 // returns true; on false (shape without a fused form) nothing but the conversion has happened... the caller must not rely on
 // that: it passes fused_ip only when fusable_ip() says so.
 static bool fusable_ip(Context &c, Tool &t) { return t.alpha > 1 && c.log_n >= 14 && c.log_n <= 17 && t.beta <= 4; }
+// r06: batched key switches of the NTT-form schemes leave the digits' own limbs where they are (modup's own_in_place + InnerArgs::own):
+// the batched inner product kernel is the one that knows how to read them from c2
+static bool own_in_place_ok(const Tool &t, int scheme, uint32_t batch) {
+    return (scheme == PHA_SCHEME_CKKS || scheme == PHA_SCHEME_BGV) && batch > 1 && t.alpha > 1 && t.beta <= 4;
+}
 // own_in_place (r06; NTT-form schemes, batched key switches): the digits' own limbs are NOT copied into dst -- the caller's inner product
 // reads them from cks (InnerArgs::own); dst's own-limb rows stay unwritten and nothing reads them (the forward transform skips them)
 static void modup(Context &c, Tool &t, u64 *dst, const u64 *cks, int scheme, u64 *t_cks, hipStream_t s,
@@ -1548,7 +1553,7 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
     if (B == 1) {
         folded = modup_inner_prod(c, t, cx, t_mod_up, c2, rlk, PHA_SCHEME_CKKS, tmp, s, ct, true);   // cx_last <- ct_last + cx_last * P^-1
     } else {
-        const bool in_place = t.alpha > 1 && t.beta <= 4;   // the batched inner product reads the digits' own limbs from c2
+        const bool in_place = own_in_place_ok(t, PHA_SCHEME_CKKS, B);   // the batched inner product reads the digits' own limbs from c2
         modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B, 0, nullptr, in_place);
         inner_prod(c, t, cx, t_mod_up, rlk, s, B, ct, in_place ? c2 : nullptr, ql_n);
     }
@@ -1715,7 +1720,7 @@ int pha_keyswitch_inplace_batched(pha_context_t ctx, size_t size_Ql, uint64_t *c
     u64 *base = c.scratch(stream, B * (2 * ql_n + (size_t)t.beta * qlp_n + 2 * qlp_n));
     u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n;
     // (NTT-form schemes, B > 1: the batched inner product reads the digits' own limbs from c2, the mod-up does not copy them)
-    const bool in_place = ntt_domain_scheme(scheme) && B > 1 && t.alpha > 1 && t.beta <= 4;
+    const bool in_place = own_in_place_ok(t, scheme, B);
     modup(c, t, t_mod_up, c2, scheme, tmp, s, B, 0, nullptr, in_place);
     inner_prod(c, t, cx, t_mod_up, rlk, s, B, nullptr, in_place ? c2 : nullptr, ql_n);
     // 2B polynomials: ct [B][2][Ql][N] and cx [B][2][QlP][N] are uniformly strided
@@ -1752,8 +1757,9 @@ int pha_keyswitch_rescale_batched(pha_context_t ctx, size_t size_Ql, const uint6
         u64 *base = c.scratch(stream, words + B * 2 * ql_n);
         u64 *tmp = base, *t_mod_up = base + B * 2 * ql_n, *cx = t_mod_up + B * (size_t)t.beta * qlp_n, *work = base + words;
         PHA_HIP(hipMemcpyAsync(work, ct, B * 2 * ql_n * sizeof(u64), hipMemcpyDeviceToDevice, s));
-        modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B);
-        inner_prod(c, t, cx, t_mod_up, rlk, s, B);
+        const bool in_place = own_in_place_ok(t, PHA_SCHEME_CKKS, B);
+        modup(c, t, t_mod_up, c2, PHA_SCHEME_CKKS, tmp, s, B, 0, nullptr, in_place);
+        inner_prod(c, t, cx, t_mod_up, rlk, s, B, nullptr, in_place ? c2 : nullptr, ql_n);
         moddown_from_ntt(c, t, work, ql_n, cx, qlp_n, 2 * B, PHA_SCHEME_CKKS, true, tmp, s);
         rescale_ntt(c, t, work, 2 * B, dst, s);
     }
@@ -1807,15 +1813,16 @@ int pha_relinearize_rotate_batched(pha_context_t ctx, size_t size_Ql, const uint
         const u64 *in = ct3 + b0 * 3 * ql_n;
         u64 *o = out + b0 * 2 * ql_n;
         // relinearize: ks = keyswitch(c2), c2 read where it lies (every third polynomial)
-        modup(c, t, t_mod_up, in + 2 * ql_n, scheme, tmp, ls, B, 3 * ql_n);
-        inner_prod(c, t, cx, t_mod_up, rlk, ls, B);
+        const bool in_place = own_in_place_ok(t, scheme, B);   // (CKKS / BGV; the BFV mod-up transforms its own limbs in the digit buffers)
+        modup(c, t, t_mod_up, in + 2 * ql_n, scheme, tmp, ls, B, 3 * ql_n, nullptr, in_place);
+        inner_prod(c, t, cx, t_mod_up, rlk, ls, B, nullptr, in_place ? in + 2 * ql_n : nullptr, 3 * ql_n);
         moddown_from_ntt(c, t, ks, ql_n, cx, qlp_n, 2 * B, scheme, false, tmp, ls);
         // rotate: (galois(c0 + ks0), 0) and galois(c1 + ks1) in the layout of the second key switch (apply_galois_inplace)
         hipLaunchKernelGGL(galois_split_kernel, dim3((unsigned)(n / 256), (unsigned)size_Ql, 2 * B), dim3(256), 0, ls, o, g1, ks, tab,
                            c.d_mod.p, tab ? galois_elt : inv_mod_2n(galois_elt, n), (uint32_t)n, (uint32_t)size_Ql, in, 3u);
         check_launch();
-        modup(c, t, t_mod_up, g1, scheme, tmp, ls, B);
-        inner_prod(c, t, cx, t_mod_up, glk, ls, B);
+        modup(c, t, t_mod_up, g1, scheme, tmp, ls, B, 0, nullptr, in_place);
+        inner_prod(c, t, cx, t_mod_up, glk, ls, B, nullptr, in_place ? g1 : nullptr, ql_n);
         moddown_from_ntt(c, t, o, ql_n, cx, qlp_n, 2 * B, scheme, true, tmp, ls);
     };
     if (!two_lanes) {
