@@ -401,6 +401,10 @@ struct ModupConvArgs {
     size_t own_group_stride;
     uint32_t max_isz, max_osz;        // over the converters
     bool mont_split;                  // every converter: 30 / 30 cuts, Montgomery rows (BConv::split_kind 1 with oninv)
+    // r06, rescale form (beta = 1, ONE converter P -> Ql whose last row is the last data limb's; `src` = cx, the converter's src_limb
+    // points at its P limbs): the coefficient-form last data limb of polynomial z at resc_last + z * src_group_stride; the kernel
+    // forms v_j = convert(row j) + (c_last mod q_j), j < osz - 1 (bconv_rescale_kernel's arithmetic).  null = the mod-up form
+    const u64 *resc_last = nullptr;
 };
 bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, const ModupConvArgs &m, hipStream_t s);
 

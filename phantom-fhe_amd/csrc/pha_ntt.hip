@@ -1227,10 +1227,11 @@ bool modup_ntt_inner_prod(Context &c, u64 *digits, const LimbSel &sel, const Ntt
 // staged once per workgroup, so the loop has no dependent scalar-memory round trip.
 // LOGTILE 8: one wavefront per workgroup (64 rows x 4 columns: 32-byte runs, no workgroup barrier); 10: 64 x 16 (128-byte runs,
 // 256 threads); 11: 64 x 32.
-struct ConvLimbRec {      // 48 bytes; one per output limb of the digit
+struct ConvLimbRec {      // 56 bytes; one per output limb of the digit
     u64 p, oninv;
     double fq, fqinv;
     uint32_t jo, prime, fpok, pad;
+    u64 ratio1;           // floor(2^64 / p): the rescale form reduces c_last modulo this limb's prime (barrett64)
 };
 constexpr int kMcsMaxOut = 64;
 __device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
@@ -1244,8 +1245,17 @@ __device__ __forceinline__ u64 uni64(u64 x) { return ((u64)uni32((uint32_t)(x >>
 // priority for the rounds: no gain) are in that log, not in this source.
 constexpr int kMcsWaves = 2;      // wavefronts per SIMD the register allocation aims at (the inputs alone are 120 registers)
 constexpr int kMcsRegLimbs = 8;   // input limbs held in registers; the rest of the digit's inputs in LDS
+#ifndef PHA_RESC_REGLIMBS
+#define PHA_RESC_REGLIMBS 15   // r06: the rescale form has no copy loop and fewer live pointers (174 registers with 8 limbs in registers): all 15 inputs fit, no LDS input reads (B = 8: 256.6 -> 251.6 us per op, B = 32: 254.0 -> 252.0)
+#endif
+constexpr int mcs_reg_limbs(bool resc) { return resc ? PHA_RESC_REGLIMBS : kMcsRegLimbs; }
 constexpr int kMcsLogTile = 10;   // 64 rows x 16 columns: 128-byte runs, 256 threads
-template <class C, int ISZ_PAD>
+// RESC (r06): the same kernel as the load of the forward transform that ends key switch + rescale (pha_keyswitch_rescale_batched): the
+// conversion is bconv_rescale_kernel's (pha_rns.hip) -- inputs = the P limbs of cx in coefficient form (x phat_i^-1), ONE converter
+// (P -> Ql with P^-1 in its rows) whose LAST row belongs to the last data limb: c_last = t_last - convert(last row) mod q_last once per
+// coefficient, then v_j = convert(row j) + (c_last mod q_j) for j < Ql - 1 goes straight into the strided pass's registers.  The
+// 2 x (Ql - 1) limbs of v are then never written and read back in coefficient form (92 MB per ciphertext at C3) and one launch goes.
+template <class C, int ISZ_PAD, bool RESC = false>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(kMcsWaves, kMcsWaves)))
 void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
     static_assert(C::STRIDED && C::EPT == 4 && C::NR == 3 && C::r(0) == 2, "radix-4 strided pass, four coefficients per thread");
@@ -1272,6 +1282,7 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
         r.p = k.mod[r.prime].value;
         r.oninv = d.oninv[j];
         r.fpok = 0; r.fq = 0.0; r.fqinv = 0.0; r.pad = 0;
+        r.ratio1 = k.mod[r.prime].ratio1;
         if (k.fpinfo) {
             const FpInfo fi = k.fpinfo[r.prime];
             r.fpok = fi.ok; r.fq = fi.q; r.fqinv = fi.qinv;
@@ -1288,7 +1299,7 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
     u64 *dig = k.out + (size_t)z * k.poly_stride;
     // the first RL input limbs live in registers (8 per limb: four coefficients x two 30-bit halves), the others in LDS, [limb][kk][thread]
     // as (lo, hi) pairs: conflict-free 8-byte reads.  All in registers is 120 + the pass's ~130: spills at two wavefronts per SIMD.
-    constexpr int RL = kMcsRegLimbs < ISZ_PAD ? kMcsRegLimbs : ISZ_PAD;
+    constexpr int RL = mcs_reg_limbs(RESC) < ISZ_PAD ? mcs_reg_limbs(RESC) : ISZ_PAD;
     uint2 *s_in = reinterpret_cast<uint2 *>(s_rec + m.max_osz);                                // [ISZ_PAD - RL][K][THREADS]
     u32 ylo[RL][K], yhi[RL][K];
 #pragma unroll
@@ -1310,8 +1321,66 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
             for (int kk = 0; kk < K; kk++) dig[(size_t)(d.src_limb + i) * n + off[kk]] = own[(size_t)i * n + off[kk]];
     }
     __syncthreads();
+    // out[kk] = REDC(sum_i y_i[kk] * row_e[i]) for the thread's four coefficients: sum_i y_i qhat_i mod p, canonical (the arithmetic of
+    // bconv_kernel, SPLIT 30 / 30, Montgomery rows; all four coefficients side by side, so a matrix row is read from LDS once)
+    auto convert4 = [&](uint32_t e, u64 p, u64 oninv, u64 *out) __attribute__((always_inline)) {
+        const uint2 *row = s_rows + e * kBcRowPad;
+        u64 ll[K], lh[K], hl[K], hh[K];
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) ll[kk] = lh[kk] = hl[kk] = hh[kk] = 0;
+#pragma unroll
+        for (int i = 0; i < ISZ_PAD; i++) {
+            const uint2 mm = row[i];
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) {
+                u32 y0, y1;
+                if (i < RL) {
+                    y0 = ylo[i < RL ? i : 0][kk];
+                    y1 = yhi[i < RL ? i : 0][kk];
+                } else {
+                    const uint2 yy = s_in[((i - RL) * K + kk) * C::THREADS + threadIdx.x];
+                    y0 = yy.x;
+                    y1 = yy.y;
+                }
+                ll[kk] = (u64)y0 * mm.x + ll[kk];
+                lh[kk] = (u64)y0 * mm.y + lh[kk];
+                hl[kk] = (u64)y1 * mm.x + hl[kk];
+                hh[kk] = (u64)y1 * mm.y + hh[kk];
+            }
+        }
+        if (r90) {   // (uniform) rows carry 2^90: word-wise REDC from the accumulators (pha_arith.h)
+            const u32 p0 = (u32)p & 0x3fffffffu, p1 = (u32)(p >> 30);
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) out[kk] = mont_redc90_split(ll[kk], lh[kk], hl[kk], hh[kk], p, p0, p1, (u32)oninv);
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) {
+            const u64 mid = lh[kk] + hl[kk], mid_c = mid < lh[kk] ? 1 : 0;
+            u64 rl = ll[kk], rh = 0;
+            const u64 t1 = mid << 30;
+            rl += t1;
+            rh += (rl < t1) + (mid >> 34) + (mid_c << 30);
+            const u64 t2 = hh[kk] << 60;
+            rl += t2;
+            rh += (rl < t2) + (hh[kk] >> 4);
+            out[kk] = mont_redc128(rl, rh, p, oninv);
+        }
+    };
+    u64 c_last[K];                       // RESC: t_last - dP_last mod q_last of the thread's four coefficients
+    uint32_t n_out = osz;
+    if (RESC) {
+        n_out = osz - 1;                 // the converter's last row is the last data limb's
+        const ConvLimbRec rl = s_rec[n_out];
+        const u64 ql_ = uni64(rl.p);
+        u64 dl[K];
+        convert4(n_out, ql_, uni64(rl.oninv), dl);
+        const u64 *last = m.resc_last + (size_t)grp * m.src_group_stride;
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) c_last[kk] = sub_mod(last[off[kk]], dl[kk], ql_);
+    }
 #pragma unroll 1
-    for (uint32_t e = 0; e < osz; e++) {
+    for (uint32_t e = 0; e < n_out; e++) {
         const ConvLimbRec rc = s_rec[e];
         const u64 p = uni64(rc.p), oninv = uni64(rc.oninv);
         const uint32_t jo = uni32(rc.jo), prime = uni32(rc.prime), fpok = uni32(rc.fpok);
@@ -1338,52 +1407,11 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
         auto limb = [&](const PassArgs &pa) __attribute__((always_inline)) {
             const int tid = tid_e;
             Prog::load_twiddles(pa, tid, twreg);
-            // out_j = REDC(sum_i y_i * (qhat_i 2^64 mod p_j)) = sum_i y_i qhat_i mod p_j, canonical (bconv_kernel, SPLIT 30 / 30, mont)
-            const uint2 *row = s_rows + e * kBcRowPad;
-            constexpr int CH = K;   // all four coefficients side by side
+            convert4(e, p, oninv, reg);
+            if (RESC) {   // v_j = dP_j + (c_last mod q_j)   (bconv_rescale_kernel; divide_and_round_reduce_q_last_kernel rns.cu:1128-1139)
+                const u64 ratio1 = uni64(rc.ratio1);
 #pragma unroll
-            for (int k0 = 0; k0 < K; k0 += CH) {
-                u64 ll[CH], lh[CH], hl[CH], hh[CH];
-#pragma unroll
-                for (int kk = 0; kk < CH; kk++) ll[kk] = lh[kk] = hl[kk] = hh[kk] = 0;
-#pragma unroll
-                for (int i = 0; i < ISZ_PAD; i++) {
-                    const uint2 mm = row[i];
-#pragma unroll
-                    for (int kk = 0; kk < CH; kk++) {
-                        u32 y0, y1;
-                        if (i < RL) {
-                            y0 = ylo[i < RL ? i : 0][k0 + kk];
-                            y1 = yhi[i < RL ? i : 0][k0 + kk];
-                        } else {
-                            const uint2 yy = s_in[((i - RL) * K + k0 + kk) * C::THREADS + threadIdx.x];
-                            y0 = yy.x;
-                            y1 = yy.y;
-                        }
-                        ll[kk] = (u64)y0 * mm.x + ll[kk];
-                        lh[kk] = (u64)y0 * mm.y + lh[kk];
-                        hl[kk] = (u64)y1 * mm.x + hl[kk];
-                        hh[kk] = (u64)y1 * mm.y + hh[kk];
-                    }
-                }
-                if (r90) {   // (uniform) rows carry 2^90: word-wise REDC from the accumulators (pha_arith.h)
-                    const u32 p0 = (u32)p & 0x3fffffffu, p1 = (u32)(p >> 30);
-#pragma unroll
-                    for (int kk = 0; kk < CH; kk++) reg[k0 + kk] = mont_redc90_split(ll[kk], lh[kk], hl[kk], hh[kk], p, p0, p1, (u32)oninv);
-                    continue;
-                }
-#pragma unroll
-                for (int kk = 0; kk < CH; kk++) {
-                    const u64 mid = lh[kk] + hl[kk], mid_c = mid < lh[kk] ? 1 : 0;
-                    u64 rl = ll[kk], rh = 0;
-                    const u64 t1 = mid << 30;
-                    rl += t1;
-                    rh += (rl < t1) + (mid >> 34) + (mid_c << 30);
-                    const u64 t2 = hh[kk] << 60;
-                    rl += t2;
-                    rh += (rl < t2) + (hh[kk] >> 4);
-                    reg[k0 + kk] = mont_redc128(rl, rh, p, oninv);
-                }
+                for (int kk = 0; kk < K; kk++) reg[kk] = add_mod(reg[kk], barrett64(c_last[kk], p, ratio1), p);
             }
             Prog::template run_prefetched<0>(pa, lds, tid, reg, twreg);
             tile_sync<C>();
@@ -1434,7 +1462,7 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
     k.t1 = P1::T;
     k.t2 = P2::T;
     auto lds_for = [&](int isz_pad, uint32_t max_osz) {
-        const int in_lds = isz_pad > kMcsRegLimbs ? isz_pad - kMcsRegLimbs : 0;
+        const int rl = mcs_reg_limbs(m.resc_last != nullptr), in_lds = isz_pad > rl ? isz_pad - rl : 0;
         return (size_t)C::LDS_WORDS * sizeof(u64) + (size_t)max_osz * kBcRowPad * sizeof(uint2) + (size_t)max_osz * sizeof(ConvLimbRec) +
                (size_t)in_lds * 4 * C::THREADS * sizeof(uint2);
     };
@@ -1452,11 +1480,11 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
         static_assert(kMcsMaxOut <= 64, "worst-case LDS request must stay inside the CU's 160 KiB");
         if (lds_worst > 160 * 1024) throw std::logic_error("modup_conv_strided: worst-case LDS request exceeds the CU");
         if (lds_worst > 64 * 1024) {   // beyond the default dynamic LDS limit
-            static std::atomic<uint64_t> raised[2] = {{0}, {0}};
+            static std::atomic<uint64_t> raised[4] = {{0}, {0}, {0}, {0}};
             int dev = 0;
             PHA_HIP(hipGetDevice(&dev));
             const uint64_t bit = 1ull << (dev & 63);
-            std::atomic<uint64_t> &r = raised[isz_pad == 15 ? 0 : 1];
+            std::atomic<uint64_t> &r = raised[(isz_pad == 15 ? 0 : 1) + (m.resc_last ? 2 : 0)];
             if (!(r.load(std::memory_order_acquire) & bit)) {
                 PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_worst));
                 r.fetch_or(bit, std::memory_order_release);
@@ -1464,7 +1492,12 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
         }
         hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, k, m);
     };
-    if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15>, 15);
+    if (m.resc_last) {   // rescale form: one converter, its last row is the last data limb's (and yields no output limb)
+        if (m.beta != 1 || sel.count + 1 != m.max_osz) throw std::logic_error("modup_conv_strided: rescale form needs the P -> Ql converter of this level");
+        if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15, true>, 15);
+        else if (m.max_isz > 8) go(modup_conv_s1_kernel<C, 16, true>, 16);
+        else return false;
+    } else if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15>, 15);
     else if (m.max_isz > 8) go(modup_conv_s1_kernel<C, 16>, 16);
     else return false;
     check_launch();

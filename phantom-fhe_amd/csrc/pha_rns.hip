@@ -1566,7 +1566,25 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
         xb.second_pass_only = folded;
         ntt_inverse(c, cx, cx, cx, special_sel(nl, c.size_p + 1, c.size_qp, c.size_p), EPI_INV_SCALE, xb, s);
     }
-    {   // v_j = delta_j P^-1 + (c_last mod q_j)
+    NttExtra x;   // out_j = (ct_j + cx_j P^-1 - NTT(v)_j) q_last^-1
+    x.scale = t.inv_q_last.p;
+    x.scale_shoup = t.inv_q_last_shoup.p;
+    x.scale2 = t.pinv.p;
+    x.scale2_shoup = t.pinv_shoup.p;
+    x.aux = cx;
+    x.aux2 = ct;
+    x.batch = 2 * B;
+    x.poly_stride = ql_n;
+    x.out_stride = nl * n;
+    x.aux_stride = qlp_n;
+    x.aux2_stride = ql_n;
+    // r06, batches at N = 2^16: the conversion (+ last-limb fold) is the LOAD of that transform's strided pass (modup_conv_s1_kernel's
+    // rescale form, pha_ntt.hip): v is never written in coefficient form
+    if (B > 1) {
+        const ModupConvArgs mc{t.d_p_to_ql_pinv_conv.p, 1, cx, qlp_n, nullptr, 0, t.alpha, (uint32_t)ql, true, cx + nl * n};
+        x.first_pass_done = modup_conv_strided(c, tmp, plain_sel(0, nl), x, mc, s);
+    }
+    if (!x.first_pass_done) {   // v_j = delta_j P^-1 + (c_last mod q_j)
         BConvRescaleLaunch L{};
         L.conv = t.d_p_to_ql_pinv_conv.p; L.dst = tmp; L.cx = cx; L.dst_stride = ql_n; L.cx_stride = qlp_n;
         L.mod = c.d_mod.p; L.n = (uint32_t)n; L.ql = (uint32_t)ql;
@@ -1580,18 +1598,6 @@ static void keyswitch_rescale(Context &c, Tool &t, const u64 *ct, const u64 *c2,
         else hipLaunchKernelGGL(bconv_rescale_kernel<16>, grid, block, 0, s, L);
         check_launch();
     }
-    NttExtra x;   // out_j = (ct_j + cx_j P^-1 - NTT(v)_j) q_last^-1
-    x.scale = t.inv_q_last.p;
-    x.scale_shoup = t.inv_q_last_shoup.p;
-    x.scale2 = t.pinv.p;
-    x.scale2_shoup = t.pinv_shoup.p;
-    x.aux = cx;
-    x.aux2 = ct;
-    x.batch = 2 * B;
-    x.poly_stride = ql_n;
-    x.out_stride = nl * n;
-    x.aux_stride = qlp_n;
-    x.aux2_stride = ql_n;
     ntt_forward(c, tmp, tmp, dst, plain_sel(0, nl), EPI_FWD_KSRESCALE, x, s);
 }
 
