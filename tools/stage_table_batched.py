@@ -11,7 +11,7 @@ QLP = QL + ALPHA
 W = 8 * N   # bytes of one limb
 
 
-def stages_for(B, fused_conv):
+def stages_for(B, fused_conv, fused_resc=False):
     # (label, number of launches, name fragments any of which every launch must carry, algorithmic bytes PER OP)
     if fused_conv:   # r05: modup_conv_s1_kernel = the conversion as the load of the forward transform's strided pass; then the contiguous pass
         modup = [("mod-up: base conversion of 3 digits FUSED with the strided pass of the forward NTT of the converted limbs (r06: no own-limb copy, the inner product reads those limbs from c2)", 1,
@@ -26,9 +26,14 @@ def stages_for(B, fused_conv):
     ] + modup + [
         ("key inner product (key limbs in registers across the batch)", 1, ("inner_prod",), QLP * (BETA + 2) * W + QLP * 2 * BETA * W // B),
         ("mod-down + rescale: inverse NTT of P and last limb, 2 polys (contiguous pass, strided pass)", 2, ("ntt_",), 2 * 2 * (ALPHA + 1) * W),
+    ] + ([   # r06: the conversion as the load of the final forward transform's strided pass (rescale form of modup_conv_s1_kernel)
+        ("mod-down + rescale: conversion + last-limb fold FUSED with the strided pass of the ONE forward NTT", 1, ("modup_conv_s1",),
+         2 * (ALPHA + 1 + QL - 1) * W + 2 * (QL - 1) * W),
+        ("mod-down + rescale: contiguous pass of that forward NTT, epilogue (ct + cx/P - .)/q_last", 1, ("ntt_",), 2 * (QL - 1) * (1 + 2) * W),
+    ] if fused_resc else [
         ("mod-down + rescale: conversion + last-limb fold", 1, ("bconv_rescale_kernel",), 2 * (ALPHA + 1 + QL - 1) * W),
         ("mod-down + rescale: ONE forward NTT, epilogue (ct + cx/P - .)/q_last (strided pass, contiguous pass)", 2, ("ntt_",), 2 * (QL - 1) * (2 + 2) * W),
-    ]
+    ])
 
 
 def table_for(B, trace_dir):
@@ -37,7 +42,8 @@ def table_for(B, trace_dir):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     lib = [r for r in rows if any(k in r["Kernel_Name"] for k in ("ntt_", "bconv", "inner_prod", "ew_kernel", "modup_ip", "modup_conv"))]
-    st = stages_for(B, any("modup_conv_s1" in r["Kernel_Name"] for r in lib))
+    fused_conv = any("modup_conv_s1" in r["Kernel_Name"] for r in lib)
+    st = stages_for(B, fused_conv, fused_conv and not any("bconv_rescale_kernel" in r["Kernel_Name"] for r in lib))
     per_set = sum(cnt for _, cnt, _, _ in st)
     sets = len(lib) // per_set
     assert sets >= 2 and len(lib) % per_set == 0, f"{len(lib)} library kernels in the trace, {per_set} per op set expected: " + \
