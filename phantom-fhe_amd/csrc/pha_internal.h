@@ -405,6 +405,7 @@ struct ModupConvArgs {
     // points at its P limbs): the coefficient-form last data limb of polynomial z at resc_last + z * src_group_stride; the kernel
     // forms v_j = convert(row j) + (c_last mod q_j), j < osz - 1 (bconv_rescale_kernel's arithmetic).  null = the mod-up form
     const u64 *resc_last = nullptr;
+    bool moddown = false;             // r06, plain mod-down form: as the rescale form without the last-limb fold (every row is an output limb)
 };
 bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttExtra &x, const ModupConvArgs &m, hipStream_t s);
 

@@ -1248,16 +1248,22 @@ constexpr int kMcsRegLimbs = 8;   // input limbs held in registers; the rest of 
 #ifndef PHA_RESC_REGLIMBS
 #define PHA_RESC_REGLIMBS 15   // r06: the rescale form has no copy loop and fewer live pointers (174 registers with 8 limbs in registers): all 15 inputs fit, no LDS input reads (B = 8: 256.6 -> 251.6 us per op, B = 32: 254.0 -> 252.0)
 #endif
-constexpr int mcs_reg_limbs(bool resc) { return resc ? PHA_RESC_REGLIMBS : kMcsRegLimbs; }
+#ifndef PHA_DOWN_REGLIMBS
+#define PHA_DOWN_REGLIMBS 8    // the plain mod-down form spills at 12 (76 bytes of scratch) and 15 (260 bytes: 280 instead of 230 us per key switch)
+#endif
+constexpr int mcs_reg_limbs(int form) { return form == 1 ? PHA_RESC_REGLIMBS : form == 2 ? PHA_DOWN_REGLIMBS : kMcsRegLimbs; }
 constexpr int kMcsLogTile = 10;   // 64 rows x 16 columns: 128-byte runs, 256 threads
 // RESC (r06): the same kernel as the load of the forward transform that ends key switch + rescale (pha_keyswitch_rescale_batched): the
 // conversion is bconv_rescale_kernel's (pha_rns.hip) -- inputs = the P limbs of cx in coefficient form (x phat_i^-1), ONE converter
 // (P -> Ql with P^-1 in its rows) whose LAST row belongs to the last data limb: c_last = t_last - convert(last row) mod q_last once per
 // coefficient, then v_j = convert(row j) + (c_last mod q_j) for j < Ql - 1 goes straight into the strided pass's registers.  The
 // 2 x (Ql - 1) limbs of v are then never written and read back in coefficient form (92 MB per ciphertext at C3) and one launch goes.
-template <class C, int ISZ_PAD, bool RESC = false>
+// FORM 2 (r06): the plain mod-down form -- the same without the last-limb fold: every row of the P -> Ql converter is an output limb (the CKKS
+// mod-down of a batched key switch WITHOUT rescale; the transform's contiguous pass then carries the (cx - NTT delta) P^-1 epilogue)
+template <class C, int ISZ_PAD, int FORM = 0>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(kMcsWaves, kMcsWaves)))
 void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
+    constexpr bool RESC = FORM == 1;
     static_assert(C::STRIDED && C::EPT == 4 && C::NR == 3 && C::r(0) == 2, "radix-4 strided pass, four coefficients per thread");
     constexpr int K = 4, LOGD = C::LOGT - 2;
     using Prog = PassProgram<C, true, EPI_NONE, false, 1, false>;   // HOIST 1: a limb's twiddles are requested before its conversion
@@ -1299,7 +1305,7 @@ void modup_conv_s1_kernel(const NttKArgs k, const ModupConvArgs m) {
     u64 *dig = k.out + (size_t)z * k.poly_stride;
     // the first RL input limbs live in registers (8 per limb: four coefficients x two 30-bit halves), the others in LDS, [limb][kk][thread]
     // as (lo, hi) pairs: conflict-free 8-byte reads.  All in registers is 120 + the pass's ~130: spills at two wavefronts per SIMD.
-    constexpr int RL = mcs_reg_limbs(RESC) < ISZ_PAD ? mcs_reg_limbs(RESC) : ISZ_PAD;
+    constexpr int RL = mcs_reg_limbs(FORM) < ISZ_PAD ? mcs_reg_limbs(FORM) : ISZ_PAD;
     uint2 *s_in = reinterpret_cast<uint2 *>(s_rec + m.max_osz);                                // [ISZ_PAD - RL][K][THREADS]
     u32 ylo[RL][K], yhi[RL][K];
 #pragma unroll
@@ -1462,7 +1468,7 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
     k.t1 = P1::T;
     k.t2 = P2::T;
     auto lds_for = [&](int isz_pad, uint32_t max_osz) {
-        const int rl = mcs_reg_limbs(m.resc_last != nullptr), in_lds = isz_pad > rl ? isz_pad - rl : 0;
+        const int rl = mcs_reg_limbs(m.resc_last ? 1 : m.moddown ? 2 : 0), in_lds = isz_pad > rl ? isz_pad - rl : 0;
         return (size_t)C::LDS_WORDS * sizeof(u64) + (size_t)max_osz * kBcRowPad * sizeof(uint2) + (size_t)max_osz * sizeof(ConvLimbRec) +
                (size_t)in_lds * 4 * C::THREADS * sizeof(uint2);
     };
@@ -1480,11 +1486,11 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
         static_assert(kMcsMaxOut <= 64, "worst-case LDS request must stay inside the CU's 160 KiB");
         if (lds_worst > 160 * 1024) throw std::logic_error("modup_conv_strided: worst-case LDS request exceeds the CU");
         if (lds_worst > 64 * 1024) {   // beyond the default dynamic LDS limit
-            static std::atomic<uint64_t> raised[4] = {{0}, {0}, {0}, {0}};
+            static std::atomic<uint64_t> raised[6] = {{0}, {0}, {0}, {0}, {0}, {0}};
             int dev = 0;
             PHA_HIP(hipGetDevice(&dev));
             const uint64_t bit = 1ull << (dev & 63);
-            std::atomic<uint64_t> &r = raised[(isz_pad == 15 ? 0 : 1) + (m.resc_last ? 2 : 0)];
+            std::atomic<uint64_t> &r = raised[(isz_pad == 15 ? 0 : 1) + (m.resc_last ? 2 : m.moddown ? 4 : 0)];
             if (!(r.load(std::memory_order_acquire) & bit)) {
                 PHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_worst));
                 r.fetch_or(bit, std::memory_order_release);
@@ -1494,8 +1500,13 @@ bool modup_conv_strided(Context &c, u64 *digits, const LimbSel &sel, const NttEx
     };
     if (m.resc_last) {   // rescale form: one converter, its last row is the last data limb's (and yields no output limb)
         if (m.beta != 1 || sel.count + 1 != m.max_osz) throw std::logic_error("modup_conv_strided: rescale form needs the P -> Ql converter of this level");
-        if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15, true>, 15);
-        else if (m.max_isz > 8) go(modup_conv_s1_kernel<C, 16, true>, 16);
+        if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15, 1>, 15);
+        else if (m.max_isz > 8) go(modup_conv_s1_kernel<C, 16, 1>, 16);
+        else return false;
+    } else if (m.moddown) {   // plain mod-down form: one converter, every row an output limb
+        if (m.beta != 1 || sel.count != m.max_osz) throw std::logic_error("modup_conv_strided: mod-down form needs the P -> Ql converter of this level");
+        if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15, 2>, 15);
+        else if (m.max_isz > 8) go(modup_conv_s1_kernel<C, 16, 2>, 16);
         else return false;
     } else if (m.max_isz == 15) go(modup_conv_s1_kernel<C, 15>, 15);
     else if (m.max_isz > 8) go(modup_conv_s1_kernel<C, 16>, 16);

@@ -1449,8 +1449,19 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
     if (scheme == PHA_SCHEME_BGV && !t.bgv_ready)
         throw std::invalid_argument("bgv needs a plain modulus (pha_context_set_plain_modulus)");
     const size_t d_stride = (size_t)ql * n;
-    bool bfv_epilogue_fused = false;
-    if (t.alpha == 1) {
+    bool bfv_epilogue_fused = false, ckks_conv_fused = false;
+    // r06, CKKS batches at N = 2^16 with the prescaled inputs: the P -> Ql conversion is the LOAD of the forward transform's strided
+    // pass (mod-down form of modup_conv_s1_kernel, pha_ntt.hip): delta is never written in coefficient form
+    if (prescaled && polys > 1 && t.p_to_ql.split_kind == 1 && t.p_to_ql.mont && t.p_to_ql.row_pad == (uint32_t)kBcRowPad) {
+        NttExtra xf;
+        xf.batch = polys;
+        xf.poly_stride = d_stride;
+        ModupConvArgs mc{t.d_p_to_ql_conv.p, 1, cx, cx_stride, nullptr, 0, t.alpha, ql, true, nullptr};
+        mc.moddown = true;
+        ckks_conv_fused = modup_conv_strided(c, delta, plain_sel(0, ql), xf, mc, s);
+    }
+    if (ckks_conv_fused) {
+    } else if (t.alpha == 1) {
         for (uint32_t z = 0; z < polys; z++) {
             SinglePArgs k{delta + z * d_stride, nullptr, cx + z * cx_stride + (size_t)ql * n, c.d_mod.p,
                           t.d_qlp_prime.p, ql, (uint32_t)n};
@@ -1497,6 +1508,7 @@ static void moddown_from_ntt(Context &c, Tool &t, u64 *ct, size_t ct_stride, u64
         x.poly_stride = d_stride;
         x.out_stride = ct_stride;
         x.aux_stride = cx_stride;
+        x.first_pass_done = ckks_conv_fused;   // the conversion already ran as the load of this transform's strided pass
         ntt_forward(c, delta, delta, ct, plain_sel(0, ql), accumulate ? EPI_FWD_MODDOWN_ADD : EPI_FWD_MODDOWN, x, s);
     } else if (!bfv_epilogue_fused) {
         // BFV, alpha = 1 or alpha > 32 (moddown_kernel rns_bconv.cu:680-689): every polynomial in ONE launch,
