@@ -315,7 +315,10 @@ KSR_CASES = [("hyb12_a2", 6, 1), ("hyb12_a2", 5, 2), ("hyb12_a2", 2, 1), ("hyb13
              ("c3_ckks16", 45, 4), ("hyb17_a2", 4, 1), ("hyb17_a2", 3, 2), ("hyb14_a2", 8, 1),   # 2 x 4 = 8 polynomials at N = 2^16: the twiddle-resident batched contiguous pass (r04) with the key switch + rescale epilogue
              # r05: batches whose mod-up launches >= 1024 workgroups take modup_conv_s1_kernel (base conversion fused with the forward
              # transform's strided pass): 6 x 3 digits at the top level; 8 x 3 digits at level 31, whose last digit is ONE limb
-             ("c3_ckks16", 45, 6), ("c3_ckks16", 31, 8),
+             # r06: from 8 ciphertexts on (16 polynomials = 1024 workgroups) the rescale's / mod-down's P -> Ql conversion is the load of the
+             # final transform's strided pass too (the kernel's FORM 1 / 2), and the inner product reads the digits' own limbs from c2:
+             # the top level runs the 15-input instantiations of all three forms in the PRODUCT library
+             ("c3_ckks16", 45, 8), ("c3_ckks16", 31, 8),
              ("hyb16_a12", 24, 8)]    # alpha = 12: the 16-input instantiation, 8 x 2 digits = 1024 workgroups in the product library
 
 
